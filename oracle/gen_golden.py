@@ -1,0 +1,309 @@
+"""oracle/gen_golden.py -- freeze golden vectors under tests/golden/.
+
+Run ONLY in the build container (needs /root/reference):
+
+    PYTHONDONTWRITEBYTECODE=1 python -m oracle.gen_golden
+
+Every expected output below is produced by the reference's OWN modules
+(pyramid.py, stack.py, stack_framework.py, core/framework.py) imported through
+oracle/ref_import.py, with oracle.py's cv2 primitives as the shim.  The script
+also asserts that oracle.RefShaped and oracle.StreamingOracle reproduce those
+outputs bit for bit before writing anything, so a fixture on disk certifies
+reference control flow == both restatements.
+
+Fixtures are data only (inputs + expected outputs); no reference source text.
+"""
+import io
+import json
+import os
+import shutil
+import sys
+import types
+import zlib
+
+import numpy as np
+
+from . import oracle as orc
+from . import ref_import as ri
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def _save(name, **arrays):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"  wrote {name}.npz  {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+def _check_restatements(frames, out_ref, det, use_fma=True, **kw):
+    """RefShaped and StreamingOracle must equal the reference run."""
+    rs = orc.RefShaped(use_fma=use_fma, **kw)
+    out_rs, d = rs.stack(frames, want_detail=True)
+    assert np.array_equal(out_rs, out_ref), "RefShaped final != reference"
+    for a, b in zip(d["fused"], det["fused"]):
+        assert np.array_equal(a, b), "RefShaped fused pyramid != reference"
+    h, w = frames[0].shape[:2]
+    so = orc.StreamingOracle(h, w, frames[0].dtype, use_fma=use_fma,
+                             min_size=kw.get("min_size", 32),
+                             kernel_size=kw.get("kernel_size", 5),
+                             gen_kernel=kw.get("gen_kernel", 0.4))
+    gs = [so.push_frame(f) for f in frames]
+    assert so.levels == len(det["fused"]) - 1
+    assert np.array_equal(so.finish(), out_ref), "StreamingOracle final != reference"
+    for lv in range(so.levels):
+        assert np.array_equal(so.best_lap[lv], det["fused"][lv])
+        assert np.array_equal(so.best_idx[lv], d["best"][lv])
+    assert np.array_equal(so.fused_base(), det["fused"][-1])
+    return d, so, gs
+
+
+def fusion_case(name, frames, store_pyramids=False, use_fma=True, **kw):
+    out_ref, det = ri.reference_stack(frames, use_fma=use_fma, exact_log=True, **kw)
+    d, so, gs = _check_restatements(frames, out_ref, det, use_fma, **kw)
+    arrays = {"frames": np.stack(frames), "final": out_ref, "collapsed": det["collapsed"],
+              "params": np.array(json.dumps({"use_fma": use_fma, **kw}))}
+    nl = len(det["fused"]) - 1
+    arrays["levels"] = np.array(nl)
+    for lv in range(nl):
+        arrays[f"fused_{lv}"] = det["fused"][lv]
+        arrays[f"best_{lv}"] = d["best"][lv].astype(np.int16)
+        arrays[f"energy_{lv}"] = d["energy"][lv]
+    arrays["fused_base"] = det["fused"][-1]
+    arrays["base_idx_e"] = d["be"].astype(np.int16)
+    arrays["base_idx_d"] = d["bd"].astype(np.int16)
+    arrays["base_ent"] = d["ent"]
+    arrays["base_dev"] = d["dev"]
+    if store_pyramids:
+        for f, pyr in enumerate(det["pyramids"]):
+            for lv, a in enumerate(pyr):
+                arrays[f"lap_f{f}_l{lv}"] = a
+            for lv in range(1, nl + 1):
+                arrays[f"gauss_f{f}_l{lv}"] = gs[f][lv]
+    _save(name, **arrays)
+    return out_ref
+
+
+def primitive_cases():
+    """G5: border behaviour of reduce / expand on impulse images, through the
+    reference's reduce_layer / expand_layer."""
+    mod = ri.load_pyramid_module()
+    algo = mod.PyramidStack()
+    arrays = {}
+    for (h, w) in [(8, 8), (9, 7), (6, 11)]:
+        for (py, px) in [(0, 0), (h - 1, w - 1), (1, w - 2), (h // 2, w // 2)]:
+            img = np.zeros((h, w, 3), np.float32)
+            img[py, px] = (1.0, 2.0, 3.0)
+            key = f"{h}x{w}_{py}_{px}"
+            arrays["in_" + key] = img
+            arrays["reduce_" + key] = algo.reduce_layer(img)
+            arrays["expand_" + key] = algo.expand_layer(img)
+    rng = np.random.default_rng(5)
+    img = (rng.random((13, 10, 3)) * 255).astype(np.float32)
+    arrays["in_rand"] = img
+    arrays["reduce_rand"] = algo.reduce_layer(img)
+    arrays["expand_rand"] = algo.expand_layer(img)
+    # both restatements agree with the reference functions
+    k = orc.k25_f32()
+    for key in [k_[3:] for k_ in arrays if k_.startswith("in_")]:
+        src = np.ascontiguousarray(arrays["in_" + key])
+        h, w = src.shape[:2]
+        red = np.empty(((h + 1) // 2, (w + 1) // 2, 3), np.float32)
+        orc.lib().orc_reduce_f32(src, h, w, 3, k, red, 1)
+        assert np.array_equal(red, arrays["reduce_" + key]), key
+        ex = np.empty((2 * h, 2 * w, 3), np.float32)
+        orc.lib().orc_expand_f32(src, h, w, 3, k, 2 * h, 2 * w, ex, 1)
+        assert np.array_equal(ex, arrays["expand_" + key]), key
+    _save("g5_primitives", **arrays)
+
+
+def base_case():
+    """G7: the base-level rule on hand-checkable sizes, several window sizes."""
+    rng = np.random.default_rng(7)
+    arrays = {}
+    for ks in (3, 5, 7):
+        for dtype, hi in ((np.uint8, 256), (np.uint16, 65536)):
+            mod = ri.load_pyramid_module(exact_log=True)
+            algo = mod.PyramidStack(kernel_size=ks)
+            algo.dtype = dtype
+            algo.num_pixel_values = hi
+            imgs = (rng.random((3, 7, 9, 3)) * (hi - 1)).astype(np.float32)
+            if dtype == np.uint8:
+                imgs[1] = np.round(imgs[1] / 16) * 16  # few distinct levels, ties
+            fused = algo.get_fused_base(imgs)
+            tag = f"k{ks}_{np.dtype(dtype).name}"
+            arrays["in_" + tag] = imgs
+            arrays["fused_" + tag] = fused
+            rs = orc.RefShaped(kernel_size=ks)
+            f2, be, bd, ent, dev = rs.fuse_base(list(imgs), dtype)
+            assert np.array_equal(f2, fused), tag
+            arrays["ent_" + tag] = ent
+            arrays["dev_" + tag] = dev
+            # C restatement
+            for i in range(3):
+                e = np.empty((7, 9), np.float32)
+                d = np.empty((7, 9), np.float32)
+                orc.lib().orc_base_features_f32(np.ascontiguousarray(imgs[i]), 7, 9, hi,
+                                                (ks - 1) // 2, e, d, 1)
+                assert np.array_equal(e, ent[i]) and np.array_equal(d, dev[i]), (tag, i)
+    _save("g7_base", **arrays)
+
+
+# ---------------------------------------------------------------------------
+# config-1 plumbing: the reference's StackJob / FocusStack / FocusStackBunch on
+# real image content (a crop of examples/input/img-jpg, frozen as PNG).
+# ---------------------------------------------------------------------------
+def _install_io_shim(cv2):
+    from PIL import Image
+
+    def imread(path, flags=None):
+        im = Image.open(path)
+        a = np.array(im)
+        if a.ndim == 3:
+            a = a[:, :, ::-1]  # RGB -> BGR like cv2
+        return np.ascontiguousarray(a)
+
+    def imwrite(path, img, params=None):
+        a = img[:, :, ::-1] if img.ndim == 3 else img
+        Image.fromarray(np.ascontiguousarray(a)).save(path)
+        return True
+
+    cv2.imread = imread
+    cv2.imwrite = imwrite
+
+
+def make_crop_inputs():
+    from PIL import Image
+    src_dir = "/root/reference/examples/input/img-jpg"
+    dst_dir = os.path.join(OUT, "img_jpg_crop")
+    os.makedirs(dst_dir, exist_ok=True)
+    names = sorted(os.listdir(src_dir))
+    for n in names:
+        im = Image.open(os.path.join(src_dir, n))
+        a = np.array(im)
+        y0, x0 = 500, 800
+        crop = a[y0:y0 + 256, x0:x0 + 384]
+        Image.fromarray(crop).save(os.path.join(dst_dir, n.replace(".jpg", ".png")),
+                                   optimize=True)
+    return dst_dir, [n.replace(".jpg", ".png") for n in names]
+
+
+def plumbing_case():
+    dst_dir, names = make_crop_inputs()
+    ri.load_pyramid_module(exact_log=True)
+    cv2 = sys.modules["cv2"]
+    _install_io_shim(cv2)
+    for stub in ("shinestacker.algorithms.exif", "shinestacker.algorithms.denoise"):
+        m = types.ModuleType(stub)
+        m.copy_exif_from_file_to_file = lambda *a, **k: None
+        m.denoise = lambda img, *a, **k: img
+        sys.modules[stub] = m
+    import importlib
+    cfg = importlib.import_module("shinestacker.config.config").config
+    try:
+        cfg.init(DISABLE_TQDM=True)
+    except Exception:
+        pass
+    sf = importlib.import_module("shinestacker.algorithms.stack_framework")
+    st = importlib.import_module("shinestacker.algorithms.stack")
+    pyr = sys.modules["shinestacker.algorithms.pyramid"]
+
+    work = "/tmp/_golden_work"
+    shutil.rmtree(work, ignore_errors=True)
+    os.makedirs(os.path.join(work, "input"))
+    for n in names:
+        shutil.copy(os.path.join(dst_dir, n), os.path.join(work, "input", n))
+
+    trace = []
+
+    def cb(key):
+        def _f(*args):
+            trace.append([key] + [a if isinstance(a, (int, str)) else str(a) for a in args])
+            return None
+        return _f
+    callbacks = {k: cb(k) for k in ("before_action", "after_action", "step_counts",
+                                    "begin_steps", "end_steps", "after_step", "save_plot",
+                                    "check_running")}
+    job = sf.StackJob("job", work, input_path="input", callbacks=callbacks)
+    job.add_action(st.FocusStack("stack-pyramid", pyr.PyramidStack(), output_path="out-stack",
+                                 prefix="pyr_"))
+    job.run()
+    out_files = sorted(os.listdir(os.path.join(work, "out-stack")))
+    from PIL import Image
+    stack_img = np.array(Image.open(os.path.join(work, "out-stack", out_files[0])))[:, :, ::-1]
+    trace_stack = list(trace)
+    trace.clear()
+
+    job = sf.StackJob("job", work, input_path="input", callbacks=callbacks)
+    job.add_action(st.FocusStackBunch("bunches", pyr.PyramidStack(), output_path="out-bunch",
+                                      frames=3))
+    job.run()
+    bunch_files = sorted(os.listdir(os.path.join(work, "out-bunch")))
+    bunch_imgs = [np.array(Image.open(os.path.join(work, "out-bunch", f)))[:, :, ::-1]
+                  for f in bunch_files]
+    trace_bunch = list(trace)
+
+    # the in-memory oracle agrees with what the reference job wrote
+    frames = [cv2.imread(os.path.join(work, "input", n)) for n in names]
+    rs = orc.RefShaped()
+    assert np.array_equal(rs.stack(frames), stack_img)
+
+    bunches = {f"{n}_{fr}_{ov}": st.get_bunches(list(range(n)), fr, ov)
+               for (n, fr, ov) in [(6, 3, 2), (1024, 10, 2), (10, 10, 2), (3, 10, 2), (7, 4, 1)]}
+    with open(os.path.join(OUT, "plumbing.json"), "w") as fh:
+        json.dump({"input_names": names, "stack_out_files": out_files,
+                   "bunch_out_files": bunch_files, "trace_stack": trace_stack,
+                   "trace_bunch": trace_bunch, "get_bunches": bunches,
+                   "levels": {"4000x6000": int(np.log2(4000 / 32)),
+                              "5760x8640": int(np.log2(5760 / 32)),
+                              "1300x2000": int(np.log2(1300 / 32)),
+                              "825x1280": int(np.log2(825 / 32))}}, fh, indent=1)
+    _save("plumbing_outputs", stack=np.ascontiguousarray(stack_img),
+          **{f"bunch_{i}": np.ascontiguousarray(b) for i, b in enumerate(bunch_imgs)})
+    shutil.rmtree(work, ignore_errors=True)
+
+
+def main():
+    assert ri.available(), "needs /root/reference"
+    os.makedirs(OUT, exist_ok=True)
+    orc.build()
+    rng = np.random.default_rng(20250824)
+    print("G1 u8 odd sizes")
+    fusion_case("g1_u8", [rng.integers(0, 256, (67, 101, 3), dtype=np.uint8) for _ in range(4)],
+                store_pyramids=True, min_size=8)
+    print("G2 u16")
+    fusion_case("g2_u16", [rng.integers(0, 65536, (45, 70, 3), dtype=np.uint16)
+                           for _ in range(3)], min_size=8)
+    print("G3 ties")
+    const = np.full((40, 48, 3), 77, np.uint8)
+    a = rng.integers(0, 256, (40, 48, 3), dtype=np.uint8)
+    fusion_case("g3_ties", [const, a, a.copy(), const.copy()], min_size=8)
+    print("G1b non-fma arithmetic, gen_kernel 0.3, kernel_size 3")
+    fusion_case("g1b_nofma", [rng.integers(0, 256, (50, 37, 3), dtype=np.uint8)
+                              for _ in range(3)], use_fma=False, min_size=8, gen_kernel=0.3,
+                kernel_size=3)
+    print("G1c smooth content (near-tie energies), default min_size")
+    yy, xx = np.mgrid[0:96, 0:130]
+    smooth = []
+    for f in range(5):
+        blur = 1.0 + 3.0 * abs(f - 2)
+        img = 128 + 100 * np.sin(xx / blur / 2.0) * np.cos(yy / blur / 3.0)
+        smooth.append(np.repeat(img[:, :, None], 3, 2).clip(0, 255).astype(np.uint8))
+    fusion_case("g1c_smooth", smooth)
+    print("G5 primitives")
+    primitive_cases()
+    print("G7 base")
+    base_case()
+    print("config-1 plumbing")
+    plumbing_case()
+    crcs = {}
+    for f in (0, 127, 255):
+        fr = orc.synth_frame_numpy(64, 96, f, 256)
+        assert np.array_equal(fr, orc.synth_frame_u8(64, 96, f, 256))
+        crcs[str(f)] = zlib.crc32(fr.tobytes())
+    with open(os.path.join(OUT, "synth_crc.json"), "w") as fh:
+        json.dump({"h": 64, "w": 96, "n": 256, "seed": 20250824, "crc32": crcs}, fh)
+    print("done")
+
+
+if __name__ == "__main__":
+    main()

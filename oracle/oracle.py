@@ -1,0 +1,398 @@
+"""oracle/oracle.py -- CPU checker for the HIP focus-stacking path.
+
+TEST INFRASTRUCTURE ONLY.  Importable from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg; never from shinestacker_amd/.
+
+Two restatements of /root/reference/src/shinestacker/algorithms/pyramid.py:
+
+* ``ref_shaped_*``  -- NumPy code that keeps the reference's *shape*: per-channel
+  full-resolution 25-tap filter then ``[::2, ::2]`` (pyramid.py:27-32), zero-stuff
+  then ``4*filter`` (:34-46), all frames' Laplacians resident, ``np.argmax`` over
+  the frame axis and ``sum(where(best == i, lap_i, 0))`` (:48-55), collapse
+  (:57-64), base-level entropy/deviation rule (:66-111), truncating cast (:179).
+  Its only non-NumPy ingredients are the three cv2 primitives, taken from
+  liboracle.so (pyramid_oracle.c).  gen_golden.py proves it equal, bit for bit,
+  to the reference's own pyramid.py run with the same primitives as a cv2 shim.
+
+* ``StreamingOracle`` -- the decimated/polyphase, O(1)-memory C implementation
+  (same arithmetic, running first-max).  Fast enough for multi-megapixel checks
+  and used as the ``cpu_baseline`` ("port") in bench.py.
+
+PARITY STATUS: the cv2 primitives themselves are "parity unpinned" -- see the
+header of pyramid_oracle.c.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "liboracle.so")
+
+
+def build(force=False):
+    """Compile liboracle.so with gcc (oracle/Makefile)."""
+    src = os.path.join(_HERE, "pyramid_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _SO
+
+
+_lib = None
+_f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+_f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+_i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+_u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+_u16p = np.ctypeslib.ndpointer(np.uint16, flags="C_CONTIGUOUS")
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        L = C.CDLL(_SO)
+        L.orc_num_threads.restype = C.c_int
+        L.orc_filter2d_f32.argtypes = [_f32p, C.c_int, C.c_int, _f32p, _f32p, C.c_int]
+        L.orc_filter2d_f64.argtypes = [_f64p, C.c_int, C.c_int, _f64p, _f64p, C.c_int]
+        L.orc_bgr2gray_f32.argtypes = [_f32p, C.c_size_t, _f32p, C.c_int]
+        L.orc_reduce_f32.argtypes = [_f32p, C.c_int, C.c_int, C.c_int, _f32p, _f32p, C.c_int]
+        L.orc_expand_f32.argtypes = [_f32p, C.c_int, C.c_int, C.c_int, _f32p, C.c_int, C.c_int,
+                                     _f32p, C.c_int]
+        L.orc_level_select_f32.argtypes = [_f32p, C.c_int, C.c_int, _f32p, C.c_int, C.c_int,
+                                           _f32p, C.c_int, C.c_int, _f32p, _f32p, _i32p, _f32p,
+                                           C.c_int]
+        L.orc_collapse_level_f32.argtypes = [_f32p, C.c_int, C.c_int, _f32p, _f32p, C.c_int,
+                                             C.c_int, _f32p, C.c_int]
+        L.orc_finalize_u8.argtypes = [_f32p, C.c_size_t, _u8p]
+        L.orc_finalize_u16.argtypes = [_f32p, C.c_size_t, _u16p]
+        L.orc_np_sum_f32.argtypes = [_f32p, C.c_int]
+        L.orc_np_sum_f32.restype = C.c_float
+        L.orc_base_features_f32.argtypes = [_f32p, C.c_int, C.c_int, C.c_int, C.c_int, _f32p,
+                                            _f32p, C.c_int]
+        L.orc_base_select_f32.argtypes = [_f32p, _f32p, C.c_size_t, C.c_int, C.c_int, _f32p,
+                                          _f32p, _i32p, _i32p]
+        L.orc_base_fuse_f32.argtypes = [_f32p, C.c_size_t, _i32p, _i32p, _f32p]
+        L.orc_synth_frame_u8.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32]
+        _lib = L
+    return _lib
+
+
+# --------------------------------------------------------------------------
+# constants of the path
+# --------------------------------------------------------------------------
+def gen_kernel_1d(a=0.4):
+    """pyramid.py:19-20 -- the Burt-Adelson generating kernel, float64."""
+    return np.array([0.25 - a / 2.0, 0.25, a, 0.25, 0.25 - a / 2.0])
+
+
+def gen_kernel_2d(a=0.4):
+    """pyramid.py:21 -- np.outer in float64 (what the reference hands cv2)."""
+    k = gen_kernel_1d(a)
+    return np.outer(k, k)
+
+
+def k25_f32(a=0.4):
+    """float32 taps as OpenCV uses them for a CV_32F image [from memory]."""
+    return np.ascontiguousarray(gen_kernel_2d(a).astype(np.float32).ravel())
+
+
+def num_levels(h, w, min_size=32):
+    """pyramid.py:165 (requested levels) + :129-130 (early stop when a side < 4)."""
+    req = int(np.log2(min(h, w) / min_size))
+    n = 0
+    for _ in range(req):
+        h, w = (h + 1) // 2, (w + 1) // 2
+        if min(h, w) < 4:
+            break
+        n += 1
+    return n
+
+
+def level_shapes(h, w, levels):
+    out = [(h, w)]
+    for _ in range(levels):
+        h, w = (h + 1) // 2, (w + 1) // 2
+        out.append((h, w))
+    return out
+
+
+# --------------------------------------------------------------------------
+# cv2 primitives (the three functions the reference's pyramid path calls)
+# --------------------------------------------------------------------------
+def filter2D(img, kernel2d, use_fma=True):
+    """cv2.filter2D(img, -1, kernel, borderType=BORDER_REFLECT101), 2-D single channel."""
+    assert img.ndim == 2
+    h, w = img.shape
+    if img.dtype == np.float32:
+        src = np.ascontiguousarray(img)
+        dst = np.empty_like(src)
+        k = np.ascontiguousarray(np.asarray(kernel2d).astype(np.float32).ravel())
+        lib().orc_filter2d_f32(src, h, w, k, dst, int(use_fma))
+        return dst
+    if img.dtype == np.float64:
+        src = np.ascontiguousarray(img)
+        dst = np.empty_like(src)
+        k = np.ascontiguousarray(np.asarray(kernel2d, dtype=np.float64).ravel())
+        lib().orc_filter2d_f64(src, h, w, k, dst, int(use_fma))
+        return dst
+    raise TypeError(f"filter2D oracle: unsupported dtype {img.dtype}")
+
+
+def bgr2gray_f32(img, use_fma=True):
+    """cv2.cvtColor(img.astype(float32), COLOR_BGR2GRAY)."""
+    assert img.dtype == np.float32 and img.shape[-1] == 3
+    src = np.ascontiguousarray(img)
+    out = np.empty(img.shape[:-1], np.float32)
+    lib().orc_bgr2gray_f32(src, out.size, out, int(use_fma))
+    return out
+
+
+def pad_reflect101(img, pad):
+    """cv2.copyMakeBorder(img, pad, pad, pad, pad, BORDER_REFLECT101)."""
+    return np.pad(img, pad, mode="reflect")
+
+
+# --------------------------------------------------------------------------
+# reference-shaped restatement
+# --------------------------------------------------------------------------
+class RefShaped:
+    """Keeps the reference's structure; see module docstring."""
+
+    def __init__(self, min_size=32, kernel_size=5, gen_kernel=0.4, float_type=np.float32,
+                 use_fma=True):
+        self.min_size = min_size
+        self.pad = (kernel_size - 1) // 2
+        self.k2d = gen_kernel_2d(gen_kernel)
+        self.ft = float_type
+        self.use_fma = use_fma
+
+    def conv(self, plane):
+        return filter2D(plane, self.k2d, self.use_fma)
+
+    def reduce(self, layer):
+        chans = [self.conv(np.ascontiguousarray(layer[:, :, c]))[::2, ::2]
+                 for c in range(layer.shape[2])]
+        return np.stack(chans, axis=-1)
+
+    def expand(self, layer):
+        h, w, nc = layer.shape
+        out = np.zeros((2 * h, 2 * w, nc), layer.dtype)
+        for c in range(nc):
+            z = np.zeros((2 * h, 2 * w), layer.dtype)
+            z[::2, ::2] = layer[:, :, c]
+            out[:, :, c] = 4.0 * self.conv(z)
+        return out
+
+    def laplacian_pyramid(self, img, levels):
+        gauss = [img.astype(self.ft)]
+        for _ in range(levels):
+            nxt = self.reduce(gauss[-1])
+            if min(nxt.shape[:2]) < 4:
+                break
+            gauss.append(nxt)
+        pyr = []
+        for lev in range(len(gauss) - 1):
+            h, w = gauss[lev].shape[:2]
+            pyr.append(gauss[lev] - self.expand(gauss[lev + 1])[:h, :w])
+        pyr.append(gauss[-1])
+        return pyr, gauss
+
+    def energy(self, lap):
+        g = bgr2gray_f32(lap.astype(np.float32), self.use_fma)
+        return self.conv(np.square(g))
+
+    def fuse_level(self, laps):
+        """laps: (N, h, w, 3). Returns fused, best, energies."""
+        e = np.stack([self.energy(l) for l in laps])
+        best = np.argmax(e, axis=0)
+        fused = np.zeros_like(laps[0])
+        for i, l in enumerate(laps):
+            fused += np.where(best[:, :, None] == i, l, 0)
+        return fused, best, e
+
+    # -- base level ------------------------------------------------------
+    def base_features(self, base, dtype):
+        nlev = 256 if dtype == np.uint8 else 65536
+        gray = bgr2gray_f32(base.astype(np.float32), self.use_fma).astype(dtype)
+        levels, counts = np.unique(gray, return_counts=True)
+        p = np.zeros(nlev, self.ft)
+        p[levels] = counts.astype(self.ft) / counts.sum()
+        # correctly rounded float32 log (see pyramid_oracle.c: orc_base_features_f32)
+        logp = np.zeros(nlev, np.float32)
+        nz = p > 0
+        logp[nz] = np.log(p[nz].astype(np.float64)).astype(np.float32)
+        pad = self.pad
+        padded = pad_reflect101(gray, pad)
+        hb, wb = gray.shape
+        ent = np.empty((hb, wb), np.float32)
+        dev = np.empty((hb, wb), np.float32)
+        n = (2 * pad + 1) ** 2
+        for y in range(hb):
+            for x in range(wb):
+                area = padded[y:y + 2 * pad + 1, x:x + 2 * pad + 1]
+                lv = area.flatten()
+                ent[y, x] = np.float32(-1.0 * (lv * logp[lv]).sum())
+                mean = np.average(area).astype(np.float32)
+                dev[y, x] = np.square(area - mean).sum() / n
+        return ent, dev
+
+    def fuse_base(self, bases, dtype):
+        feats = [self.base_features(b, dtype) for b in bases]
+        ent = np.stack([f[0] for f in feats])
+        dev = np.stack([f[1] for f in feats])
+        be, bd = np.argmax(ent, axis=0), np.argmax(dev, axis=0)
+        fused = np.zeros(bases[0].shape, self.ft)
+        for i, b in enumerate(bases):
+            fused += np.where(be[:, :, None] == i, b, 0)
+            fused += np.where(bd[:, :, None] == i, b, 0)
+        return (fused / 2).astype(bases[0].dtype), be, bd, ent, dev
+
+    def collapse(self, pyr, max_value):
+        img = pyr[-1]
+        for lap in pyr[-2::-1]:
+            up = self.expand(img)[:lap.shape[0], :lap.shape[1]]
+            img = up + lap
+        return np.clip(np.abs(img), 0, max_value)
+
+    def stack(self, frames, want_detail=False):
+        """frames: list of HxWx3 uint8/uint16 arrays (BGR). Returns the fused image."""
+        dtype = frames[0].dtype
+        maxv = 255 if dtype == np.uint8 else 65535
+        h, w = frames[0].shape[:2]
+        levels = int(np.log2(min(h, w) / self.min_size))
+        pyrs = [self.laplacian_pyramid(f, levels)[0] for f in frames]
+        nl = len(pyrs[0]) - 1
+        base, be, bd, ent, dev = self.fuse_base([p[-1] for p in pyrs], dtype)
+        fused = [None] * nl + [base]
+        detail = {"best": [None] * nl, "energy": [None] * nl, "be": be, "bd": bd,
+                  "ent": ent, "dev": dev}
+        for lev in range(nl - 1, -1, -1):
+            fl, best, e = self.fuse_level(np.stack([p[lev] for p in pyrs]))
+            fused[lev] = fl
+            detail["best"][lev] = best
+            detail["energy"][lev] = e.max(axis=0)
+        img = self.collapse(fused, maxv)
+        out = img.astype(dtype)
+        if want_detail:
+            detail.update(fused=fused, collapsed=img, pyramids=pyrs)
+            return out, detail
+        return out
+
+
+# --------------------------------------------------------------------------
+# streaming C restatement
+# --------------------------------------------------------------------------
+class StreamingOracle:
+    """push_frame()/finish() over liboracle.so; O(1) memory in the frame count
+    apart from the per-frame base images (tiny)."""
+
+    def __init__(self, h, w, dtype=np.uint8, min_size=32, kernel_size=5, gen_kernel=0.4,
+                 use_fma=True, levels=None):
+        self.h, self.w, self.dtype = h, w, np.dtype(dtype)
+        self.levels = num_levels(h, w, min_size) if levels is None else levels
+        self.shapes = level_shapes(h, w, self.levels)
+        self.k = k25_f32(gen_kernel)
+        self.pad = (kernel_size - 1) // 2
+        self.fma = int(use_fma)
+        self.n = 0
+        L = self.levels
+        self.best_e = [np.zeros(s, np.float32) for s in self.shapes[:L]]
+        self.best_idx = [np.zeros(s, np.int32) for s in self.shapes[:L]]
+        self.best_lap = [np.zeros(s + (3,), np.float32) for s in self.shapes[:L]]
+        hb, wb = self.shapes[L]
+        self.b_ent = np.zeros((hb, wb), np.float32)
+        self.b_dev = np.zeros((hb, wb), np.float32)
+        self.idx_e = np.zeros((hb, wb), np.int32)
+        self.idx_d = np.zeros((hb, wb), np.int32)
+        self.bases = []
+        self._scratch = np.empty(h * w * 4, np.float32)
+
+    def gaussians(self, frame):
+        g = [np.ascontiguousarray(frame.astype(np.float32))]
+        for lv in range(self.levels):
+            h, w = self.shapes[lv]
+            out = np.empty(self.shapes[lv + 1] + (3,), np.float32)
+            lib().orc_reduce_f32(g[-1], h, w, 3, self.k, out, self.fma)
+            g.append(out)
+        return g
+
+    def push_frame(self, frame):
+        assert frame.shape == (self.h, self.w, 3)
+        g = self.gaussians(frame)
+        first = int(self.n == 0)
+        for lv in range(self.levels):
+            h, w = self.shapes[lv]
+            hs, ws = self.shapes[lv + 1]
+            lib().orc_level_select_f32(g[lv], h, w, g[lv + 1], hs, ws, self.k, self.n, first,
+                                       self.best_e[lv], self.best_lap[lv], self.best_idx[lv],
+                                       self._scratch, self.fma)
+        hb, wb = self.shapes[self.levels]
+        ent = np.empty((hb, wb), np.float32)
+        dev = np.empty((hb, wb), np.float32)
+        nlev = 256 if self.dtype == np.uint8 else 65536
+        lib().orc_base_features_f32(g[-1], hb, wb, nlev, self.pad, ent, dev, self.fma)
+        lib().orc_base_select_f32(ent, dev, hb * wb, self.n, first, self.b_ent, self.b_dev,
+                                  self.idx_e, self.idx_d)
+        self.bases.append(g[-1])
+        self.n += 1
+        return g
+
+    def fused_base(self):
+        hb, wb = self.shapes[self.levels]
+        bases = np.ascontiguousarray(np.stack(self.bases))
+        out = np.empty((hb, wb, 3), np.float32)
+        lib().orc_base_fuse_f32(bases, hb * wb, self.idx_e, self.idx_d, out)
+        return out
+
+    def collapse(self):
+        img = self.fused_base()
+        for lv in range(self.levels - 1, -1, -1):
+            h, w = self.shapes[lv]
+            hs, ws = self.shapes[lv + 1]
+            out = np.empty((h, w, 3), np.float32)
+            lib().orc_collapse_level_f32(img, hs, ws, self.k, self.best_lap[lv], h, w, out,
+                                         self.fma)
+            img = out
+        return img
+
+    def finish(self):
+        img = self.collapse()
+        out = np.empty((self.h, self.w, 3), self.dtype)
+        if self.dtype == np.uint8:
+            lib().orc_finalize_u8(img, img.size, out)
+        else:
+            lib().orc_finalize_u16(img, img.size, out)
+        return out
+
+
+def synth_frame_u8(h, w, f, n, seed=20250824):
+    """SURVEY.md 8(d) config-2 generator (C version)."""
+    out = np.empty((h, w, 3), np.uint8)
+    lib().orc_synth_frame_u8(out, h, w, f, n, seed)
+    return out
+
+
+def synth_frame_numpy(h, w, f, n, seed=20250824, dtype=np.uint8):
+    """Same generator in NumPy integer arithmetic (no libm), for cross-checks."""
+    y = np.arange(h, dtype=np.uint32)[:, None, None]
+    x = np.arange(w, dtype=np.uint32)[None, :, None]
+    c = np.arange(3, dtype=np.uint32)[None, None, :]
+    with np.errstate(over="ignore"):
+        hsh = (np.uint32(seed) ^ (np.uint32(f) * np.uint32(0x9E3779B1)) ^
+               (y * np.uint32(0x85EBCA77)) ^ (x * np.uint32(0xC2B2AE3D)) ^ c)
+        hsh ^= hsh >> 16
+        hsh *= np.uint32(0x7feb352d)
+        hsh ^= hsh >> 15
+        hsh *= np.uint32(0x846ca68b)
+        hsh ^= hsh >> 16
+    noise = (hsh >> 24).astype(np.int32) - 128
+    band = (np.arange(h, dtype=np.int64) * n // h).astype(np.int32)[:, None, None]
+    d = np.abs(band - f)
+    amp = 64 >> np.minimum(d, 6)
+    base = ((3 * x.astype(np.int32) + 5 * y.astype(np.int32) + 17 * c.astype(np.int32)) & 127) + 64
+    v = np.clip(base + ((noise * amp) >> 7), 0, 255)
+    if np.dtype(dtype) == np.uint16:
+        return (v * 257).astype(np.uint16)
+    return v.astype(np.uint8)

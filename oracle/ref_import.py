@@ -1,0 +1,136 @@
+"""oracle/ref_import.py -- load the reference's OWN hot-path modules in this container.
+
+Only usable where /root/reference exists (the build container); never on the GPU
+box, never from the product.  Used by gen_golden.py to pin oracle.py's
+reference-shaped restatement against the reference's NumPy control flow.
+
+`import shinestacker` fails here (generated _version.py missing; cv2, tifffile,
+psdtags not installed), so the parent packages are pre-seeded as empty modules
+whose __path__ points at the real directories -- their __init__ never runs --
+and a `cv2` shim supplies exactly the symbols pyramid.py / utils.py touch at
+import or run time.  The shim's three numeric primitives are oracle.py's
+(liboracle.so): that is what "parity unpinned for the cv2 primitives, pinned
+for the control flow" means.
+"""
+import importlib
+import os
+import sys
+import types
+
+import numpy as np
+
+from . import oracle as orc
+
+REF_SRC = "/root/reference/src"
+
+
+def available():
+    return os.path.isdir(os.path.join(REF_SRC, "shinestacker", "algorithms"))
+
+
+def make_cv2_shim(use_fma=True):
+    cv2 = types.ModuleType("cv2")
+    cv2.BORDER_REFLECT101 = 4
+    cv2.BORDER_REFLECT_101 = 4
+    cv2.BORDER_CONSTANT = 0
+    cv2.BORDER_REPLICATE = 1
+    cv2.COLOR_BGR2GRAY = 6
+    cv2.COLOR_BGR2RGB = 4
+    cv2.INTER_AREA = 3
+    cv2.IMREAD_UNCHANGED = -1
+    cv2.IMWRITE_JPEG_QUALITY = 1
+    cv2.IMWRITE_TIFF_COMPRESSION = 259
+    cv2.RANSAC = 8
+    cv2.LMEDS = 4
+    cv2.NORM_HAMMING = 6
+
+    def filter2D(img, ddepth, kernel, borderType=None, **_kw):
+        assert ddepth == -1 and borderType == cv2.BORDER_REFLECT101
+        return orc.filter2D(np.ascontiguousarray(img), kernel, use_fma)
+
+    def cvtColor(img, code):
+        assert code == cv2.COLOR_BGR2GRAY
+        return orc.bgr2gray_f32(np.ascontiguousarray(img), use_fma)
+
+    def copyMakeBorder(img, t, b, l, r, borderType):
+        assert borderType == cv2.BORDER_REFLECT101 and t == b == l == r
+        return orc.pad_reflect101(img, t)
+
+    def _unavailable(*_a, **_k):
+        raise RuntimeError("cv2 shim: function not available in the oracle container")
+
+    cv2.filter2D = filter2D
+    cv2.cvtColor = cvtColor
+    cv2.copyMakeBorder = copyMakeBorder
+    for name in ("imread", "imwrite", "resize", "warpAffine", "warpPerspective", "GaussianBlur",
+                 "SIFT_create", "ORB_create", "AKAZE_create", "BRISK_create",
+                 "FastFeatureDetector_create", "FlannBasedMatcher", "BFMatcher",
+                 "findHomography", "estimateAffinePartial2D", "getPerspectiveTransform",
+                 "drawMatches", "fastNlMeansDenoisingColored"):
+        setattr(cv2, name, _unavailable)
+    return cv2
+
+
+class _NumpyWithExactLog:
+    """Proxy for the `np` name inside the reference module: identical to numpy
+    except float32 log is the correctly rounded one the oracle uses (NumPy's
+    SIMD float32 log is CPU-dispatch dependent, so it cannot be a parity target)."""
+
+    def __getattr__(self, name):
+        return getattr(np, name)
+
+    @staticmethod
+    def log(x):
+        x = np.asarray(x)
+        if x.dtype == np.float32:
+            return np.log(x.astype(np.float64)).astype(np.float32)
+        return np.log(x)
+
+
+def load_pyramid_module(use_fma=True, exact_log=False):
+    """Returns the reference's shinestacker.algorithms.pyramid module object."""
+    if not available():
+        raise RuntimeError("reference tree not present")
+    sys.dont_write_bytecode = True
+    for name in [m for m in sys.modules if m == "cv2" or m.startswith("shinestacker")]:
+        del sys.modules[name]
+    for pkg in ("shinestacker", "shinestacker.algorithms", "shinestacker.core",
+                "shinestacker.config"):
+        mod = types.ModuleType(pkg)
+        mod.__path__ = [os.path.join(REF_SRC, *pkg.split("."))]
+        sys.modules[pkg] = mod
+    sys.modules["cv2"] = make_cv2_shim(use_fma)
+    mod = importlib.import_module("shinestacker.algorithms.pyramid")
+    if exact_log:
+        mod.np = _NumpyWithExactLog()
+    return mod
+
+
+class FakeProcess:
+    """Stand-in for the owning action, as tests/test_0061_depth_map.py:43-48 does."""
+    id = 0
+    name = "oracle"
+
+    def callback(self, *_a):
+        return True
+
+    def sub_message_r(self, *_a, **_k):
+        pass
+
+
+def reference_stack(frames, use_fma=True, exact_log=False, **algo_kwargs):
+    """Run the reference's PyramidStack on in-memory frames (list of HxWx3 arrays).
+    Mirrors focus_stack (pyramid.py:150-179) minus file I/O.  Returns (out, detail)."""
+    mod = load_pyramid_module(use_fma, exact_log)
+    algo = mod.PyramidStack(**algo_kwargs)
+    algo.process = FakeProcess()
+    first = frames[0]
+    algo.dtype = first.dtype
+    algo.num_pixel_values = 256 if first.dtype == np.uint8 else 65536
+    algo.max_pixel_value = 255 if first.dtype == np.uint8 else 65535
+    levels = int(np.log2(min(first.shape[:2]) / algo.min_size))
+    pyrs = [algo.process_single_image(f, levels) for f in frames]
+    fused = algo.fuse_pyramids(pyrs)
+    collapsed = algo.collapse(fused)
+    out = collapsed.astype(algo.dtype)
+    return out, {"pyramids": pyrs, "fused": fused, "collapsed": collapsed, "algo": algo}
