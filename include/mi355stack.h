@@ -1,0 +1,165 @@
+/*
+ * mi355stack.h -- C ABI of libmi355stack.so: the MI355X (gfx950) focus-stacking
+ * hot path behind shinestacker's PyramidStack / align_images.
+ *
+ * Plain pointers and sizes only; no exceptions cross this boundary: every entry
+ * point returns an MI_* status and mi_last_error() gives the thread-local text
+ * (the Python shim maps codes to shinestacker's exception types,
+ * reference core/exceptions.py:2-52).
+ *
+ * Reference interfaces replaced (paths under /root/reference/src/shinestacker):
+ *   mi_stack_create / _reset / _destroy   PyramidStack.__init__ + per-stack state,
+ *                                         algorithms/pyramid.py:114-123, :150-165
+ *   mi_stack_push_frame[_device]          process_single_image per frame,
+ *                                         pyramid.py:125-139 (called at :173), fused with
+ *                                         the per-level selection of fuse_laplacian :48-55
+ *                                         and the base features of get_fused_base :95-102
+ *                                         as a running first-max (frames in index order)
+ *   mi_stack_finish[_device]              fuse_pyramids tail + collapse + cast,
+ *                                         pyramid.py:103-111, :57-64, :178-179
+ *   mi_stack_get_level                    debug/parity taps (no reference counterpart)
+ *   mi_stack_state / _set_first_index     hooks for the frame-sharded multi-GPU combine
+ *   mi_warp_affine                        cv2.warpAffine + mask + border blur composite,
+ *                                         algorithms/align.py:238-251
+ *
+ * Ownership: the caller owns every host buffer it passes and every device
+ * buffer obtained from mi_device_malloc; the library owns all device memory
+ * inside a handle; nothing returned by pointer outlives mi_stack_destroy.
+ * Threading: one thread at a time per handle; any thread may call (the device
+ * is selected per call).  The library never calls back into the host language.
+ */
+#ifndef MI355STACK_H
+#define MI355STACK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI_ABI_VERSION 1
+#define MI_API __attribute__((visibility("default")))
+
+/* status codes */
+enum {
+    MI_OK = 0,
+    MI_ERR_INVALID = 1,   /* bad argument / option            -> InvalidOptionError / ValueError */
+    MI_ERR_NO_DEVICE = 2, /* no HIP device visible            -> RuntimeError                    */
+    MI_ERR_HIP = 3,       /* a HIP runtime call failed        -> RuntimeError                    */
+    MI_ERR_STATE = 4,     /* call order (finish before push)  -> RuntimeError                    */
+    MI_ERR_NOMEM = 5,     /* device allocation failed         -> MemoryError                     */
+    MI_ERR_UNSUPPORTED = 6
+};
+
+/* pixel / arithmetic types */
+enum { MI_U8 = 0, MI_U16 = 1, MI_F32 = 2, MI_F64 = 3 };
+
+/* mi_stack_get_level selectors */
+enum {
+    MI_TAP_GAUSS = 0,      /* G_l of the most recently pushed frame, h x w x 3 f32 (l >= 1)   */
+    MI_TAP_FUSED_LAP = 1,  /* running fused Laplacian of level l, h x w x 3 f32               */
+    MI_TAP_ENERGY = 2,     /* running max energy of level l, h x w f32                        */
+    MI_TAP_INDEX = 3,      /* running arg-max (global frame index), h x w i32                 */
+    MI_TAP_FUSED_BASE = 4, /* fused base (level == levels), hb x wb x 3 f32; valid after finish */
+    MI_TAP_BASE_IDX_E = 5, /* hb x wb i32 */
+    MI_TAP_BASE_IDX_D = 6, /* hb x wb i32 */
+    MI_TAP_COLLAPSED = 7,  /* clip(abs(collapse)), H x W x 3 f32; valid after finish            */
+    MI_TAP_BASE_ENT = 8,   /* running max entropy, hb x wb f32 */
+    MI_TAP_BASE_DEV = 9    /* running max deviation, hb x wb f32 */
+};
+
+/* implementation selector (both give bit-identical results) */
+enum {
+    MI_IMPL_AUTO = 0,
+    MI_IMPL_SIMPLE = 1, /* one thread per output, global-memory taps: the on-GPU cross-check */
+    MI_IMPL_TILED = 2   /* LDS-tiled fused level kernels: the production path                */
+};
+
+typedef struct mi_stack mi_stack_t;
+
+typedef struct mi_stack_params {
+    int32_t height, width; /* frame geometry; channels fixed at 3, BGR interleaved            */
+    int32_t in_dtype;      /* MI_U8 / MI_U16 / MI_F32 (f32 frames hold integer pixel values)  */
+    int32_t out_dtype;     /* MI_U8 / MI_U16: dtype of the fused image (pyramid.py:159-164)   */
+    int32_t min_size;      /* pyramid.py:115,165  default 32                                  */
+    int32_t kernel_size;   /* pyramid.py:116,18   base-level window only; default 5           */
+    double gen_kernel;     /* pyramid.py:117,19   default 0.4                                 */
+    int32_t float_type;    /* MI_F32 (MI_F64 -> MI_ERR_UNSUPPORTED in this round)             */
+    int32_t use_fma;       /* 1: fma chain (OpenCV AVX2 path) 0: mul+add (SSE baseline path)  */
+    int32_t device;        /* HIP device ordinal                                              */
+    int32_t impl;          /* MI_IMPL_*                                                       */
+    int32_t batch_frames;  /* frames consumed per fused launch (tiled impl); 0 = default      */
+    int32_t reserved[5];
+} mi_stack_params_t;
+
+/* ---- library ---- */
+MI_API int mi_abi_version(void);
+MI_API const char* mi_last_error(void);
+MI_API int mi_device_count(int* count);
+MI_API int mi_device_name(int device, char* buf, size_t buflen);
+MI_API void mi_stack_default_params(mi_stack_params_t* p);
+
+/* ---- device memory helpers (so a host language needs no other GPU binding) ---- */
+MI_API int mi_device_malloc(int device, size_t bytes, void** dev_ptr);
+MI_API int mi_device_free(int device, void* dev_ptr);
+MI_API int mi_memcpy_h2d(int device, void* dev_dst, const void* host_src, size_t bytes);
+MI_API int mi_memcpy_d2h(int device, void* host_dst, const void* dev_src, size_t bytes);
+MI_API int mi_device_synchronize(int device);
+
+/* ---- stacker handle ---- */
+MI_API int mi_stack_create(mi_stack_t** out, const mi_stack_params_t* params);
+MI_API void mi_stack_destroy(mi_stack_t* s);
+MI_API int mi_stack_reset(mi_stack_t* s);
+MI_API int mi_stack_levels(const mi_stack_t* s, int* levels);
+MI_API int mi_stack_level_shape(const mi_stack_t* s, int level, int* h, int* w);
+MI_API int mi_stack_frames_pushed(const mi_stack_t* s, int* n);
+/* global index of this handle's first frame (multi-GPU frame sharding); default 0 */
+MI_API int mi_stack_set_first_index(mi_stack_t* s, int first_global_index);
+
+/* One frame from host memory (H rows of row_stride_bytes; 0 = tightly packed).
+ * Returns after the work is enqueued; the host buffer may be reused on return. */
+MI_API int mi_stack_push_frame(mi_stack_t* s, const void* host_bgr, size_t row_stride_bytes);
+/* n frames already resident in device memory (tightly packed rows, frames
+ * frame_stride_bytes apart), dtype = params.in_dtype. */
+MI_API int mi_stack_push_frames_device(mi_stack_t* s, const void* dev_frames, int n,
+                                size_t frame_stride_bytes);
+/* wait for everything enqueued so far */
+MI_API int mi_stack_sync(mi_stack_t* s);
+
+/* base fusion + collapse + abs/clip/truncating cast.  The handle stays valid
+ * (taps readable) until reset/destroy.  host_out: H x W x 3 of out_dtype. */
+MI_API int mi_stack_finish(mi_stack_t* s, void* host_out, size_t row_stride_bytes);
+MI_API int mi_stack_finish_device(mi_stack_t* s, void* dev_out);
+
+MI_API int mi_stack_get_level(mi_stack_t* s, int level, int what, void* host_out, size_t out_bytes);
+
+/* Device pointers of the running selection state of one level (level ==
+ * levels addresses the base: energy -> entropy max, lap -> base_e; the
+ * deviation twin comes from level == levels + 1).  For the cross-GPU combine. */
+MI_API int mi_stack_state(mi_stack_t* s, int level, void** dev_energy, void** dev_lap, void** dev_index,
+                   size_t* npixels);
+/* the HIP stream the handle launches on (hipStream_t as void*) */
+MI_API int mi_stack_stream(mi_stack_t* s, void** stream);
+
+/* ---- per-kernel timing (hipEvent pairs on the handle's stream) ---- */
+enum { MI_PROF_LEVEL = 0, MI_PROF_BASE = 1, MI_PROF_COLLAPSE = 2, MI_PROF_KINDS = 3 };
+MI_API int mi_stack_profile(mi_stack_t* s, int enable);
+/* sums since the last reset; algorithmic_bytes follows SURVEY.md 8(d) */
+MI_API int mi_stack_profile_get(mi_stack_t* s, int kind, double* total_ms, int64_t* launches,
+                         double* algorithmic_bytes);
+
+/* ---- cross-GPU combine kernels (local parts of the frame-sharded reduce) ---- */
+/* cand_e: [n][npix] f32, cand_lap: [n][npix*3] f32, candidates in ascending
+ * global-frame order; writes the first-max winner's energy / lap to out_*. */
+MI_API int mi_combine_select(int device, void* stream, int n, const void* cand_e, const void* cand_lap,
+                      size_t npix, void* out_e, void* out_lap);
+
+/* ---- synthetic stack generator, device side ---- */
+MI_API int mi_synth_frames_device(int device, void* dev_out, int dtype, int height, int width,
+                           int first_frame, int n_frames, int stack_size, uint32_t seed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355STACK_H */

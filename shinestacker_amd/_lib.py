@@ -1,0 +1,312 @@
+"""ctypes binding of libmi355stack.so (include/mi355stack.h).
+
+There is no CPU fallback: if the shared object is missing or no HIP device is
+visible, every compute entry point raises DeviceError.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .errors import DeviceError, InvalidOptionError
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmi355stack.so")
+
+# enums of mi355stack.h
+MI_OK, MI_ERR_INVALID, MI_ERR_NO_DEVICE, MI_ERR_HIP, MI_ERR_STATE, MI_ERR_NOMEM, \
+    MI_ERR_UNSUPPORTED = range(7)
+MI_U8, MI_U16, MI_F32, MI_F64 = range(4)
+(TAP_GAUSS, TAP_FUSED_LAP, TAP_ENERGY, TAP_INDEX, TAP_FUSED_BASE, TAP_BASE_IDX_E,
+ TAP_BASE_IDX_D, TAP_COLLAPSED, TAP_BASE_ENT, TAP_BASE_DEV) = range(10)
+IMPL_AUTO, IMPL_SIMPLE, IMPL_TILED = range(3)
+PROF_LEVEL, PROF_BASE, PROF_COLLAPSE = range(3)
+
+DTYPE_CODE = {np.dtype(np.uint8): MI_U8, np.dtype(np.uint16): MI_U16,
+              np.dtype(np.float32): MI_F32}
+CODE_DTYPE = {v: k for k, v in DTYPE_CODE.items()}
+
+
+class StackParams(C.Structure):
+    _fields_ = [("height", C.c_int32), ("width", C.c_int32), ("in_dtype", C.c_int32),
+                ("out_dtype", C.c_int32), ("min_size", C.c_int32), ("kernel_size", C.c_int32),
+                ("gen_kernel", C.c_double), ("float_type", C.c_int32), ("use_fma", C.c_int32),
+                ("device", C.c_int32), ("impl", C.c_int32), ("batch_frames", C.c_int32),
+                ("reserved", C.c_int32 * 5)]
+
+
+# name -> (restype, argtypes); also the list the symbol-export test walks
+SIGNATURES = {
+    "mi_abi_version": (C.c_int, []),
+    "mi_last_error": (C.c_char_p, []),
+    "mi_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "mi_device_name": (C.c_int, [C.c_int, C.c_char_p, C.c_size_t]),
+    "mi_stack_default_params": (None, [C.POINTER(StackParams)]),
+    "mi_device_malloc": (C.c_int, [C.c_int, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "mi_device_free": (C.c_int, [C.c_int, C.c_void_p]),
+    "mi_memcpy_h2d": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "mi_memcpy_d2h": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "mi_device_synchronize": (C.c_int, [C.c_int]),
+    "mi_stack_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(StackParams)]),
+    "mi_stack_destroy": (None, [C.c_void_p]),
+    "mi_stack_reset": (C.c_int, [C.c_void_p]),
+    "mi_stack_levels": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    "mi_stack_level_shape": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int),
+                                       C.POINTER(C.c_int)]),
+    "mi_stack_frames_pushed": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    "mi_stack_set_first_index": (C.c_int, [C.c_void_p, C.c_int]),
+    "mi_stack_push_frame": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "mi_stack_push_frames_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t]),
+    "mi_stack_sync": (C.c_int, [C.c_void_p]),
+    "mi_stack_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "mi_stack_finish_device": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mi_stack_get_level": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]),
+    "mi_stack_state": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p),
+                                 C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                 C.POINTER(C.c_size_t)]),
+    "mi_stack_stream": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "mi_stack_profile": (C.c_int, [C.c_void_p, C.c_int]),
+    "mi_stack_profile_get": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double),
+                                       C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+    "mi_combine_select": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                    C.c_size_t, C.c_void_p, C.c_void_p]),
+    "mi_synth_frames_device": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                         C.c_int, C.c_int, C.c_uint32]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen the library and declare every prototype. Raises DeviceError if absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DeviceError(
+                f"{LIB_PATH} not found: build it with `python -m shinestacker_amd.build` "
+                "(there is no CPU fallback)")
+        try:
+            lib = C.CDLL(LIB_PATH)
+        except OSError as e:
+            raise DeviceError(f"cannot load {LIB_PATH}: {e}") from e
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        if lib.mi_abi_version() != 1:
+            raise DeviceError("libmi355stack.so ABI version mismatch")
+        _lib = lib
+    return _lib
+
+
+def last_error():
+    return load().mi_last_error().decode("utf-8", "replace")
+
+
+def check(rc):
+    """Map an MI_* status to the exception types of the boundary."""
+    if rc == MI_OK:
+        return
+    msg = last_error()
+    if rc == MI_ERR_INVALID:
+        raise ValueError(msg)
+    if rc == MI_ERR_NOMEM:
+        raise MemoryError(msg)
+    if rc == MI_ERR_UNSUPPORTED:
+        raise InvalidOptionError("hip", "unsupported", msg)
+    raise DeviceError(msg)
+
+
+def device_count():
+    n = C.c_int(0)
+    rc = load().mi_device_count(C.byref(n))
+    return n.value if rc == MI_OK else 0
+
+
+def require_device():
+    if device_count() < 1:
+        raise DeviceError("no HIP device visible: the MI355X path cannot run "
+                          "(there is no CPU fallback)")
+
+
+def device_name(device=0):
+    buf = C.create_string_buffer(256)
+    check(load().mi_device_name(device, buf, 256))
+    return buf.value.decode()
+
+
+class DeviceBuffer:
+    """Owning wrapper of a mi_device_malloc allocation."""
+
+    def __init__(self, nbytes, device=0):
+        self.device, self.nbytes = device, int(nbytes)
+        p = C.c_void_p()
+        check(load().mi_device_malloc(device, self.nbytes, C.byref(p)))
+        self.ptr = p.value
+
+    def upload(self, arr, offset=0):
+        a = np.ascontiguousarray(arr)
+        assert offset + a.nbytes <= self.nbytes
+        check(load().mi_memcpy_h2d(self.device, self.ptr + offset, a.ctypes.data, a.nbytes))
+
+    def download(self, shape, dtype, offset=0):
+        out = np.empty(shape, dtype)
+        assert offset + out.nbytes <= self.nbytes
+        check(load().mi_memcpy_d2h(self.device, out.ctypes.data, self.ptr + offset, out.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            load().mi_device_free(self.device, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+class Stack:
+    """Thin object wrapper over an mi_stack_t handle."""
+
+    def __init__(self, height, width, in_dtype=np.uint8, out_dtype=None, min_size=32,
+                 kernel_size=5, gen_kernel=0.4, use_fma=True, device=0, impl=IMPL_AUTO,
+                 batch_frames=0, float_type=MI_F32):
+        lib = load()
+        require_device()
+        p = StackParams()
+        lib.mi_stack_default_params(C.byref(p))
+        in_dtype = np.dtype(in_dtype)
+        out_dtype = np.dtype(out_dtype if out_dtype is not None else
+                             (np.uint8 if in_dtype == np.float32 else in_dtype))
+        p.height, p.width = int(height), int(width)
+        p.in_dtype, p.out_dtype = DTYPE_CODE[in_dtype], DTYPE_CODE[out_dtype]
+        p.min_size, p.kernel_size, p.gen_kernel = int(min_size), int(kernel_size), float(gen_kernel)
+        p.float_type, p.use_fma, p.device = float_type, int(bool(use_fma)), int(device)
+        p.impl, p.batch_frames = int(impl), int(batch_frames)
+        self.params = p
+        self.in_dtype, self.out_dtype = in_dtype, out_dtype
+        self.height, self.width, self.device = p.height, p.width, p.device
+        h = C.c_void_p()
+        check(lib.mi_stack_create(C.byref(h), C.byref(p)))
+        self._h = h
+        n = C.c_int()
+        check(lib.mi_stack_levels(self._h, C.byref(n)))
+        self.levels = n.value
+        self.shapes = [self.level_shape(l) for l in range(self.levels + 1)]
+
+    # -- lifecycle
+    def close(self):
+        if getattr(self, "_h", None):
+            load().mi_stack_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def reset(self):
+        check(load().mi_stack_reset(self._h))
+
+    # -- geometry
+    def level_shape(self, level):
+        h, w = C.c_int(), C.c_int()
+        check(load().mi_stack_level_shape(self._h, level, C.byref(h), C.byref(w)))
+        return h.value, w.value
+
+    @property
+    def frames_pushed(self):
+        n = C.c_int()
+        check(load().mi_stack_frames_pushed(self._h, C.byref(n)))
+        return n.value
+
+    def set_first_index(self, idx):
+        check(load().mi_stack_set_first_index(self._h, int(idx)))
+
+    # -- data path
+    def push_frame(self, frame):
+        a = np.asarray(frame)
+        if a.shape != (self.height, self.width, 3):
+            raise ValueError(f"frame shape {a.shape} != {(self.height, self.width, 3)}")
+        if a.dtype != self.in_dtype:
+            raise ValueError(f"frame dtype {a.dtype} != {self.in_dtype}")
+        if not a.flags.c_contiguous:
+            if a.strides[1:] == (3 * a.itemsize, a.itemsize) and a.strides[0] > 0:
+                check(load().mi_stack_push_frame(self._h, a.ctypes.data, a.strides[0]))
+                return
+            a = np.ascontiguousarray(a)
+        check(load().mi_stack_push_frame(self._h, a.ctypes.data, 0))
+
+    def push_frames_device(self, dev_ptr, n, frame_stride_bytes=0):
+        check(load().mi_stack_push_frames_device(self._h, dev_ptr, int(n),
+                                                 int(frame_stride_bytes)))
+
+    def sync(self):
+        check(load().mi_stack_sync(self._h))
+
+    def finish(self):
+        out = np.empty((self.height, self.width, 3), self.out_dtype)
+        check(load().mi_stack_finish(self._h, out.ctypes.data, 0))
+        return out
+
+    def finish_device(self, dev_ptr=None):
+        check(load().mi_stack_finish_device(self._h, dev_ptr))
+
+    # -- taps
+    def tap(self, what, level=0):
+        L = self.levels
+        if what in (TAP_GAUSS, TAP_FUSED_LAP):
+            shape, dt = self.shapes[level] + (3,), np.float32
+        elif what == TAP_ENERGY:
+            shape, dt = self.shapes[level], np.float32
+        elif what == TAP_INDEX:
+            shape, dt = self.shapes[level], np.int32
+        elif what == TAP_FUSED_BASE:
+            shape, dt, level = self.shapes[L] + (3,), np.float32, L
+        elif what in (TAP_BASE_IDX_E, TAP_BASE_IDX_D):
+            shape, dt, level = self.shapes[L], np.int32, L
+        elif what in (TAP_BASE_ENT, TAP_BASE_DEV):
+            shape, dt, level = self.shapes[L], np.float32, L
+        elif what == TAP_COLLAPSED:
+            shape, dt, level = (self.height, self.width, 3), np.float32, 0
+        else:
+            raise ValueError(f"unknown tap {what}")
+        out = np.empty(shape, dt)
+        check(load().mi_stack_get_level(self._h, level, what, out.ctypes.data, out.nbytes))
+        return out
+
+    def state_ptrs(self, level):
+        e, l, i, n = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_size_t()
+        check(load().mi_stack_state(self._h, level, C.byref(e), C.byref(l), C.byref(i),
+                                    C.byref(n)))
+        return e.value, l.value, i.value, n.value
+
+    @property
+    def stream(self):
+        s = C.c_void_p()
+        check(load().mi_stack_stream(self._h, C.byref(s)))
+        return s.value
+
+    # -- timing
+    def profile(self, enable=True):
+        check(load().mi_stack_profile(self._h, int(enable)))
+
+    def profile_get(self, kind):
+        ms, n, b = C.c_double(), C.c_int64(), C.c_double()
+        check(load().mi_stack_profile_get(self._h, kind, C.byref(ms), C.byref(n), C.byref(b)))
+        return ms.value, n.value, b.value
+
+
+def synth_frames_device(dev_ptr, dtype, height, width, first_frame, n_frames, stack_size,
+                        seed=20250824, device=0):
+    check(load().mi_synth_frames_device(device, dev_ptr, DTYPE_CODE[np.dtype(dtype)], height,
+                                        width, first_frame, n_frames, stack_size, seed))

@@ -1,0 +1,51 @@
+"""Build libmi355stack.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+
+    python -m shinestacker_amd.build [--force]
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+ROOT = os.path.dirname(HERE)
+LIB = os.path.join(CSRC, "libmi355stack.so")
+SOURCES = ["capi.hip"]
+DEPS = ["capi.hip", "common.hpp", "kernels_simple.hpp", "kernels_tiled.hpp", "tiled_host.hpp",
+        os.path.join(ROOT, "include", "mi355stack.h")]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
+               "-fno-fast-math", "-shared", "-fPIC", "-fvisibility=hidden",
+               "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc():
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    return "hipcc"
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    for d in DEPS:
+        p = d if os.path.isabs(d) else os.path.join(CSRC, d)
+        if os.path.exists(p) and os.path.getmtime(p) > t:
+            return True
+    return False
+
+
+def build_extension(force=False, verbose=False):
+    if not force and not needs_build():
+        return LIB
+    cmd = [_hipcc(), *HIPCC_FLAGS, "-I", os.path.join(ROOT, "include"),
+           *[os.path.join(CSRC, s) for s in SOURCES], "-o", LIB]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_extension(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,732 @@
+// capi.hip -- C ABI of libmi355stack.so (declared in include/mi355stack.h).
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -shared -fPIC
+#include <stdarg.h>
+
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "common.hpp"
+#include "kernels_simple.hpp"
+#include "kernels_tiled.hpp"
+
+using namespace mi;
+
+struct mi_stack;
+namespace mi {
+// LDS-tiled production path + host-frame staging (tiled_host.hpp)
+bool tiled_available();
+int tiled_create(mi_stack* s);
+void tiled_destroy(mi_stack* s);
+int tiled_reset(mi_stack* s);
+int tiled_pending(const mi_stack* s);
+int tiled_push(mi_stack* s, const void* dev_frames, int n, size_t stride);
+int tiled_push_host(mi_stack* s, const void* host_bgr, size_t row_stride_bytes);
+int tiled_flush(mi_stack* s);
+const float* tiled_last_gauss(mi_stack* s, int level);
+int dispatch_push(mi_stack* s, const void* dev_frames, int n, size_t stride);
+}  // namespace mi
+
+namespace {
+
+size_t dtype_size(int dt) {
+    switch (dt) {
+        case MI_U8: return 1;
+        case MI_U16: return 2;
+        case MI_F32: return 4;
+        case MI_F64: return 8;
+    }
+    return 0;
+}
+
+struct ProfRec {
+    int kind;
+    hipEvent_t a, b;
+    double bytes;
+};
+
+}  // namespace
+
+struct mi_stack {
+    mi_stack_params_t p{};
+    int L = 0;                // number of Laplacian levels; base is level L
+    std::vector<int> lh, lw;  // level shapes, 0..L
+    K25 K{};
+    int pad = 2;
+    int nlevels_hist = 256;
+    float maxv = 255.f;
+    hipStream_t stream = nullptr;
+
+    void* frame_dev = nullptr;  // staging for host-pushed frames (in_dtype)
+    std::vector<float*> G;      // G[l], l = 1..L, of the frame being processed
+    float* lap_tmp = nullptr;   // simple impl scratch
+    float* q_tmp = nullptr;
+    std::vector<float*> bestE, bestLap;
+    std::vector<int32_t*> bestIdx;
+
+    int32_t* lev = nullptr;
+    uint32_t* cnt = nullptr;
+    float* logp = nullptr;
+    float *bEnt = nullptr, *bDev = nullptr, *baseE = nullptr, *baseD = nullptr;
+    int32_t *idxE = nullptr, *idxD = nullptr;
+    float* fusedBase = nullptr;
+
+    float *colA = nullptr, *colB = nullptr, *clipped = nullptr;
+    void* out_dev = nullptr;
+
+    int n_pushed = 0;
+    int first_index = 0;
+    bool finished = false;
+
+    bool prof = false;
+    std::vector<ProfRec> recs;
+    std::vector<hipEvent_t> ev_pool;
+    double prof_ms[MI_PROF_KINDS] = {0, 0, 0};
+    int64_t prof_n[MI_PROF_KINDS] = {0, 0, 0};
+    double prof_bytes[MI_PROF_KINDS] = {0, 0, 0};
+
+    std::vector<void*> allocs;
+};
+
+namespace {
+
+int dev_alloc(mi_stack* s, void** p, size_t bytes) {
+    MI_HIP(hipMalloc(p, bytes ? bytes : 1));
+    s->allocs.push_back(*p);
+    return MI_OK;
+}
+template <typename T>
+int dev_alloc_t(mi_stack* s, T** p, size_t count) {
+    return dev_alloc(s, (void**)p, count * sizeof(T));
+}
+
+hipEvent_t get_event(mi_stack* s) {
+    if (!s->ev_pool.empty()) {
+        hipEvent_t e = s->ev_pool.back();
+        s->ev_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
+struct ProfScope {
+    mi_stack* s;
+    ProfRec r{};
+    bool on;
+    ProfScope(mi_stack* s_, int kind, double bytes) : s(s_), on(s_->prof) {
+        if (!on) return;
+        r.kind = kind;
+        r.bytes = bytes;
+        r.a = get_event(s);
+        r.b = get_event(s);
+        if (!r.a || !r.b) { on = false; return; }
+        (void)hipEventRecord(r.a, s->stream);
+    }
+    ~ProfScope() {
+        if (!on) return;
+        (void)hipEventRecord(r.b, s->stream);
+        s->recs.push_back(r);
+    }
+};
+
+int prof_drain(mi_stack* s) {
+    if (s->recs.empty()) return MI_OK;
+    MI_HIP(hipStreamSynchronize(s->stream));
+    for (auto& r : s->recs) {
+        float ms = 0.f;
+        MI_HIP(hipEventElapsedTime(&ms, r.a, r.b));
+        s->prof_ms[r.kind] += ms;
+        s->prof_n[r.kind] += 1;
+        s->prof_bytes[r.kind] += r.bytes;
+        s->ev_pool.push_back(r.a);
+        s->ev_pool.push_back(r.b);
+    }
+    s->recs.clear();
+    return MI_OK;
+}
+
+// algorithmic bytes of one frame's pyramid build + select:
+// read level 0 once, write each G_l (l>=1) once and read it twice.
+double algorithmic_bytes_per_frame(const mi_stack* s) {
+    double b = (double)dtype_size(s->p.in_dtype) * 3.0 * s->lh[0] * s->lw[0];
+    for (int l = 1; l <= s->L; ++l) b += 36.0 * s->lh[l] * s->lw[l];
+    return b;
+}
+
+inline dim3 grid2d(int w, int h, dim3 blk) { return dim3(cdiv(w, blk.x), cdiv(h, blk.y)); }
+
+// ------------------------------------------------------------------ simple implementation
+template <typename TIn, bool FMA>
+int process_frame_simple(mi_stack* s, const TIn* frame) {
+    const dim3 blk(64, 4);
+    const int idx = s->first_index + s->n_pushed;
+    const int first = s->n_pushed == 0;
+    {
+        ProfScope ps(s, MI_PROF_LEVEL, algorithmic_bytes_per_frame(s));
+        // Gaussian pyramid
+        hipLaunchKernelGGL((reduce_simple<TIn, FMA>), grid2d(s->lw[1], s->lh[1], blk), blk, 0,
+                           s->stream, frame, s->lh[0], s->lw[0], s->G[1], s->lh[1], s->lw[1],
+                           s->K);
+        for (int l = 1; l < s->L; ++l)
+            hipLaunchKernelGGL((reduce_simple<float, FMA>),
+                               grid2d(s->lw[l + 1], s->lh[l + 1], blk), blk, 0, s->stream,
+                               s->G[l], s->lh[l], s->lw[l], s->G[l + 1], s->lh[l + 1],
+                               s->lw[l + 1], s->K);
+        // Laplacian levels + selection
+        for (int l = 0; l < s->L; ++l) {
+            dim3 g = grid2d(s->lw[l], s->lh[l], blk);
+            if (l == 0)
+                hipLaunchKernelGGL((lapq_simple<TIn, FMA>), g, blk, 0, s->stream, frame,
+                                   s->lh[0], s->lw[0], s->G[1], s->lh[1], s->lw[1], s->lap_tmp,
+                                   s->q_tmp, s->K);
+            else
+                hipLaunchKernelGGL((lapq_simple<float, FMA>), g, blk, 0, s->stream, s->G[l],
+                                   s->lh[l], s->lw[l], s->G[l + 1], s->lh[l + 1], s->lw[l + 1],
+                                   s->lap_tmp, s->q_tmp, s->K);
+            hipLaunchKernelGGL((select_simple<FMA>), g, blk, 0, s->stream, s->q_tmp, s->lap_tmp,
+                               s->lh[l], s->lw[l], idx, first, s->bestE[l], s->bestLap[l],
+                               s->bestIdx[l], s->K);
+        }
+    }
+    MI_HIP(hipGetLastError());
+    return MI_OK;
+}
+
+// base-level features of the frame whose G_L sits in s->G[L] (or `base` for L == 0)
+template <bool FMA>
+int process_base(mi_stack* s, const float* base) {
+    ProfScope ps(s, MI_PROF_BASE, 0.0);
+    const int hb = s->lh[s->L], wb = s->lw[s->L], npix = hb * wb;
+    const int idx = s->first_index + s->n_pushed;
+    const int first = s->n_pushed == 0;
+    MI_HIP(hipMemsetAsync(s->cnt, 0, sizeof(uint32_t) * s->nlevels_hist, s->stream));
+    hipLaunchKernelGGL((base_gray_hist<FMA>), dim3(cdiv(npix, 256)), dim3(256), 0, s->stream, base,
+                       npix, s->nlevels_hist, s->lev, s->cnt);
+    hipLaunchKernelGGL(base_logp, dim3(cdiv(s->nlevels_hist, 256)), dim3(256), 0, s->stream,
+                       s->cnt, s->nlevels_hist, npix, s->logp);
+    const dim3 blk(32, 8);
+    hipLaunchKernelGGL(base_feat_select, grid2d(wb, hb, blk), blk, 0, s->stream, s->lev, s->logp,
+                       base, hb, wb, s->pad, idx, first, s->bEnt, s->bDev, s->idxE, s->idxD,
+                       s->baseE, s->baseD);
+    MI_HIP(hipGetLastError());
+    return MI_OK;
+}
+
+template <typename TIn, bool FMA>
+int push_device_frames(mi_stack* s, const void* dev_frames, int n, size_t stride) {
+    for (int f = 0; f < n; ++f) {
+        const TIn* fr = (const TIn*)((const char*)dev_frames + (size_t)f * stride);
+        int rc;
+        if (s->L == 0) {
+            return fail(MI_ERR_UNSUPPORTED, "frames smaller than 2*min_size have no pyramid levels");
+        }
+        rc = process_frame_simple<TIn, FMA>(s, fr);
+        if (rc) return rc;
+        rc = process_base<FMA>(s, s->G[s->L]);
+        if (rc) return rc;
+        s->n_pushed++;
+    }
+    return MI_OK;
+}
+
+}  // namespace
+int mi::dispatch_push(mi_stack* s, const void* dev_frames, int n, size_t stride) {
+    const bool fma = s->p.use_fma != 0;
+    if (s->p.impl == MI_IMPL_TILED) return tiled_push(s, dev_frames, n, stride);
+    switch (s->p.in_dtype) {
+        case MI_U8:
+            return fma ? push_device_frames<uint8_t, true>(s, dev_frames, n, stride)
+                       : push_device_frames<uint8_t, false>(s, dev_frames, n, stride);
+        case MI_U16:
+            return fma ? push_device_frames<uint16_t, true>(s, dev_frames, n, stride)
+                       : push_device_frames<uint16_t, false>(s, dev_frames, n, stride);
+        case MI_F32:
+            return fma ? push_device_frames<float, true>(s, dev_frames, n, stride)
+                       : push_device_frames<float, false>(s, dev_frames, n, stride);
+    }
+    return fail(MI_ERR_INVALID, "bad in_dtype %d", s->p.in_dtype);
+}
+namespace {
+
+template <bool FMA>
+int finish_impl(mi_stack* s) {
+    ProfScope ps(s, MI_PROF_COLLAPSE, 0.0);
+    const int L = s->L;
+    size_t nb = (size_t)s->lh[L] * s->lw[L] * 3;
+    hipLaunchKernelGGL(base_fuse, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, s->stream,
+                       s->baseE, s->baseD, nb, s->fusedBase);
+    const float* up = s->fusedBase;
+    float* bufs[2] = {s->colA, s->colB};
+    const dim3 blk(64, 4);
+    for (int l = L - 1; l >= 0; --l) {
+        float* out = bufs[l & 1];
+        hipLaunchKernelGGL((collapse_simple<FMA>), grid2d(s->lw[l], s->lh[l], blk), blk, 0,
+                           s->stream, up, s->lh[l + 1], s->lw[l + 1], s->bestLap[l], s->lh[l],
+                           s->lw[l], out, s->K);
+        up = out;
+    }
+    size_t n = (size_t)s->lh[0] * s->lw[0] * 3;
+    dim3 g((unsigned)((n + 255) / 256));
+    if (s->p.out_dtype == MI_U8)
+        hipLaunchKernelGGL((finalize_cast<uint8_t>), g, dim3(256), 0, s->stream, up, n, s->maxv,
+                           s->clipped, (uint8_t*)s->out_dev);
+    else
+        hipLaunchKernelGGL((finalize_cast<uint16_t>), g, dim3(256), 0, s->stream, up, n, s->maxv,
+                           s->clipped, (uint16_t*)s->out_dev);
+    MI_HIP(hipGetLastError());
+    return MI_OK;
+}
+
+int check_handle(const mi_stack* s) {
+    if (!s) return fail(MI_ERR_INVALID, "null handle");
+    return MI_OK;
+}
+
+}  // namespace
+
+// tiled implementation hooks (kernels_tiled.hpp) need the handle layout
+#include "tiled_host.hpp"
+
+extern "C" {
+
+int mi_abi_version(void) { return MI_ABI_VERSION; }
+
+const char* mi_last_error(void) { return last_error().c_str(); }
+
+int mi_device_count(int* count) {
+    if (!count) return fail(MI_ERR_INVALID, "null count");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return fail(MI_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    }
+    *count = n;
+    return MI_OK;
+}
+
+int mi_device_name(int device, char* buf, size_t buflen) {
+    if (!buf || !buflen) return fail(MI_ERR_INVALID, "null buffer");
+    hipDeviceProp_t prop;
+    MI_HIP(hipGetDeviceProperties(&prop, device));
+    snprintf(buf, buflen, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    return MI_OK;
+}
+
+void mi_stack_default_params(mi_stack_params_t* p) {
+    if (!p) return;
+    memset(p, 0, sizeof *p);
+    p->in_dtype = MI_U8;
+    p->out_dtype = MI_U8;
+    p->min_size = 32;
+    p->kernel_size = 5;
+    p->gen_kernel = 0.4;
+    p->float_type = MI_F32;
+    p->use_fma = 1;
+    p->device = 0;
+    p->impl = MI_IMPL_AUTO;
+    p->batch_frames = 0;
+}
+
+int mi_device_malloc(int device, size_t bytes, void** dev_ptr) {
+    if (!dev_ptr) return fail(MI_ERR_INVALID, "null out pointer");
+    MI_HIP(hipSetDevice(device));
+    MI_HIP(hipMalloc(dev_ptr, bytes ? bytes : 1));
+    return MI_OK;
+}
+int mi_device_free(int device, void* dev_ptr) {
+    MI_HIP(hipSetDevice(device));
+    MI_HIP(hipFree(dev_ptr));
+    return MI_OK;
+}
+int mi_memcpy_h2d(int device, void* dev_dst, const void* host_src, size_t bytes) {
+    MI_HIP(hipSetDevice(device));
+    MI_HIP(hipMemcpy(dev_dst, host_src, bytes, hipMemcpyHostToDevice));
+    return MI_OK;
+}
+int mi_memcpy_d2h(int device, void* host_dst, const void* dev_src, size_t bytes) {
+    MI_HIP(hipSetDevice(device));
+    MI_HIP(hipMemcpy(host_dst, dev_src, bytes, hipMemcpyDeviceToHost));
+    return MI_OK;
+}
+int mi_device_synchronize(int device) {
+    MI_HIP(hipSetDevice(device));
+    MI_HIP(hipDeviceSynchronize());
+    return MI_OK;
+}
+
+int mi_stack_create(mi_stack_t** out, const mi_stack_params_t* params) {
+    if (!out || !params) return fail(MI_ERR_INVALID, "null argument");
+    *out = nullptr;
+    const mi_stack_params_t& p = *params;
+    if (p.height < 1 || p.width < 1) return fail(MI_ERR_INVALID, "bad frame size %dx%d", p.width, p.height);
+    if (p.in_dtype != MI_U8 && p.in_dtype != MI_U16 && p.in_dtype != MI_F32)
+        return fail(MI_ERR_INVALID, "in_dtype must be MI_U8, MI_U16 or MI_F32");
+    if (p.out_dtype != MI_U8 && p.out_dtype != MI_U16)
+        return fail(MI_ERR_INVALID, "out_dtype must be MI_U8 or MI_U16");
+    if (p.float_type == MI_F64)
+        return fail(MI_ERR_UNSUPPORTED, "float_type float-64 is not implemented on the HIP path yet");
+    if (p.float_type != MI_F32) return fail(MI_ERR_INVALID, "bad float_type %d", p.float_type);
+    if (p.min_size < 1) return fail(MI_ERR_INVALID, "min_size must be >= 1");
+    if (p.kernel_size < 1 || p.kernel_size > 12)
+        return fail(MI_ERR_INVALID, "kernel_size must be in [1, 12] (base window <= 11x11)");
+    if (p.impl < MI_IMPL_AUTO || p.impl > MI_IMPL_TILED) return fail(MI_ERR_INVALID, "bad impl %d", p.impl);
+    int ndev = 0;
+    int rc = mi_device_count(&ndev);
+    if (rc) return rc;
+    if (ndev == 0) return fail(MI_ERR_NO_DEVICE, "no HIP device visible");
+    if (p.device < 0 || p.device >= ndev) return fail(MI_ERR_INVALID, "device %d out of range (have %d)", p.device, ndev);
+    MI_HIP(hipSetDevice(p.device));
+
+    mi_stack* s = new mi_stack();
+    s->p = p;
+    if (s->p.impl == MI_IMPL_AUTO) s->p.impl = tiled_available() ? MI_IMPL_TILED : MI_IMPL_SIMPLE;
+    // levels = int(log2(min(h,w)/min_size)), pyramid.py:165; stop when a side < 4, :129-130
+    {
+        double r = (double)(p.height < p.width ? p.height : p.width) / (double)p.min_size;
+        int req = r >= 1.0 ? (int)std::log2(r) : 0;
+        // guard against log2 rounding at exact powers of two (np.log2 is exact there)
+        while (req > 0 && (double)(1 << req) > r) --req;
+        while ((double)(1 << (req + 1)) <= r) ++req;
+        int h = p.height, w = p.width;
+        s->lh.push_back(h);
+        s->lw.push_back(w);
+        for (int i = 0; i < req; ++i) {
+            h = (h + 1) / 2;
+            w = (w + 1) / 2;
+            if ((h < w ? h : w) < 4) break;
+            s->lh.push_back(h);
+            s->lw.push_back(w);
+        }
+        s->L = (int)s->lh.size() - 1;
+    }
+    {
+        double a = p.gen_kernel;
+        double k[5] = {0.25 - a / 2.0, 0.25, a, 0.25, 0.25 - a / 2.0};
+        for (int i = 0; i < 5; ++i)
+            for (int j = 0; j < 5; ++j) s->K.k[i * 5 + j] = (float)(k[i] * k[j]);
+    }
+    s->pad = (p.kernel_size - 1) / 2;
+    s->nlevels_hist = p.out_dtype == MI_U8 ? 256 : 65536;
+    s->maxv = p.out_dtype == MI_U8 ? 255.f : 65535.f;
+
+#define TRY(x)                     \
+    do {                           \
+        rc = (x);                  \
+        if (rc) {                  \
+            mi_stack_destroy(s);   \
+            return rc;             \
+        }                          \
+    } while (0)
+    hipError_t he = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
+    if (he != hipSuccess) {
+        delete s;
+        return fail(MI_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(he));
+    }
+    const int L = s->L;
+    const size_t P0 = (size_t)p.height * p.width;
+    TRY(dev_alloc(s, &s->frame_dev, P0 * 3 * dtype_size(p.in_dtype)));
+    s->G.assign(L + 1, nullptr);
+    s->bestE.assign(L, nullptr);
+    s->bestLap.assign(L, nullptr);
+    s->bestIdx.assign(L, nullptr);
+    for (int l = 1; l <= L; ++l) TRY(dev_alloc_t(s, &s->G[l], (size_t)s->lh[l] * s->lw[l] * 3));
+    for (int l = 0; l < L; ++l) {
+        size_t np = (size_t)s->lh[l] * s->lw[l];
+        TRY(dev_alloc_t(s, &s->bestE[l], np));
+        TRY(dev_alloc_t(s, &s->bestLap[l], np * 3));
+        TRY(dev_alloc_t(s, &s->bestIdx[l], np));
+    }
+    if (s->p.impl == MI_IMPL_SIMPLE) {
+        TRY(dev_alloc_t(s, &s->lap_tmp, P0 * 3));
+        TRY(dev_alloc_t(s, &s->q_tmp, P0));
+    }
+    {
+        size_t nb = (size_t)s->lh[L] * s->lw[L];
+        TRY(dev_alloc_t(s, &s->lev, nb));
+        TRY(dev_alloc_t(s, &s->cnt, (size_t)s->nlevels_hist));
+        TRY(dev_alloc_t(s, &s->logp, (size_t)s->nlevels_hist));
+        TRY(dev_alloc_t(s, &s->bEnt, nb));
+        TRY(dev_alloc_t(s, &s->bDev, nb));
+        TRY(dev_alloc_t(s, &s->idxE, nb));
+        TRY(dev_alloc_t(s, &s->idxD, nb));
+        TRY(dev_alloc_t(s, &s->baseE, nb * 3));
+        TRY(dev_alloc_t(s, &s->baseD, nb * 3));
+        TRY(dev_alloc_t(s, &s->fusedBase, nb * 3));
+    }
+    TRY(dev_alloc_t(s, &s->colA, P0 * 3));
+    TRY(dev_alloc_t(s, &s->colB, L >= 2 ? (size_t)s->lh[1] * s->lw[1] * 3 : 1));
+    TRY(dev_alloc_t(s, &s->clipped, P0 * 3));
+    TRY(dev_alloc(s, &s->out_dev, P0 * 3 * dtype_size(p.out_dtype)));
+    TRY(tiled_create(s));
+#undef TRY
+    *out = s;
+    return MI_OK;
+}
+
+void mi_stack_destroy(mi_stack_t* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->p.device);
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    tiled_destroy(s);
+    for (auto& r : s->recs) {
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    for (auto e : s->ev_pool) (void)hipEventDestroy(e);
+    for (void* p : s->allocs) (void)hipFree(p);
+    if (s->stream) (void)hipStreamDestroy(s->stream);
+    delete s;
+}
+
+int mi_stack_reset(mi_stack_t* s) {
+    int rc = check_handle(s);
+    if (rc) return rc;
+    MI_HIP(hipSetDevice(s->p.device));
+    MI_HIP(hipStreamSynchronize(s->stream));
+    rc = prof_drain(s);
+    if (rc) return rc;
+    for (int k = 0; k < MI_PROF_KINDS; ++k) {
+        s->prof_ms[k] = 0;
+        s->prof_n[k] = 0;
+        s->prof_bytes[k] = 0;
+    }
+    s->n_pushed = 0;
+    s->finished = false;
+    return tiled_reset(s);
+}
+
+int mi_stack_levels(const mi_stack_t* s, int* levels) {
+    int rc = check_handle(s);
+    if (rc) return rc;
+    if (!levels) return fail(MI_ERR_INVALID, "null levels");
+    *levels = s->L;
+    return MI_OK;
+}
+
+int mi_stack_level_shape(const mi_stack_t* s, int level, int* h, int* w) {
+    int rc = check_handle(s);
+    if (rc) return rc;
+    if (level < 0 || level > s->L || !h || !w) return fail(MI_ERR_INVALID, "bad level %d", level);
+    *h = s->lh[level];
+    *w = s->lw[level];
+    return MI_OK;
+}
+
+int mi_stack_frames_pushed(const mi_stack_t* s, int* n) {
+    int rc = check_handle(s);
+    if (rc) return rc;
+    if (!n) return fail(MI_ERR_INVALID, "null n");
+    *n = s->n_pushed + tiled_pending(s);
+    return MI_OK;
+}
+
+int mi_stack_set_first_index(mi_stack_t* s, int first_global_index) {
+    int rc = check_handle(s);
+    if (rc) return rc;
+    if (s->n_pushed + tiled_pending(s) != 0) return fail(MI_ERR_STATE, "set_first_index after frames were pushed");
+    s->first_index = first_global_index;
+    return MI_OK;
+}
+
+int mi_stack_push_frames_device(mi_stack_t* s, const void* dev_frames, int n, size_t frame_stride_bytes) {
+    int rc = check_handle(s);
+    if (rc) return rc;
+    if (!dev_frames || n < 0) return fail(MI_ERR_INVALID, "bad frames argument");
+    if (s->finished) return fail(MI_ERR_STATE, "push after finish; call mi_stack_reset first");
+    size_t fb = (size_t)s->p.height * s->p.width * 3 * dtype_size(s->p.in_dtype);
+    if (frame_stride_bytes == 0) frame_stride_bytes = fb;
+    if (frame_stride_bytes < fb) return fail(MI_ERR_INVALID, "frame stride smaller than a frame");
+    MI_HIP(hipSetDevice(s->p.device));
+    return dispatch_push(s, dev_frames, n, frame_stride_bytes);
+}
+
+int mi_stack_push_frame(mi_stack_t* s, const void* host_bgr, size_t row_stride_bytes) {
+    int rc = check_handle(s);
+    if (rc) return rc;
+    if (!host_bgr) return fail(MI_ERR_INVALID, "null frame");
+    if (s->finished) return fail(MI_ERR_STATE, "push after finish; call mi_stack_reset first");
+    MI_HIP(hipSetDevice(s->p.device));
+    return tiled_push_host(s, host_bgr, row_stride_bytes);
+}
+
+int mi_stack_sync(mi_stack_t* s) {
+    int rc = check_handle(s);
+    if (rc) return rc;
+    MI_HIP(hipSetDevice(s->p.device));
+    MI_HIP(hipStreamSynchronize(s->stream));
+    return MI_OK;
+}
+
+int mi_stack_finish_device(mi_stack_t* s, void* dev_out) {
+    int rc = check_handle(s);
+    if (rc) return rc;
+    MI_HIP(hipSetDevice(s->p.device));
+    rc = tiled_flush(s);
+    if (rc) return rc;
+    if (s->n_pushed == 0) return fail(MI_ERR_STATE, "finish with no frames pushed");
+    rc = s->p.use_fma ? finish_impl<true>(s) : finish_impl<false>(s);
+    if (rc) return rc;
+    s->finished = true;
+    if (dev_out) {
+        size_t nb = (size_t)s->p.height * s->p.width * 3 * dtype_size(s->p.out_dtype);
+        MI_HIP(hipMemcpyAsync(dev_out, s->out_dev, nb, hipMemcpyDeviceToDevice, s->stream));
+    }
+    return MI_OK;
+}
+
+int mi_stack_finish(mi_stack_t* s, void* host_out, size_t row_stride_bytes) {
+    int rc = mi_stack_finish_device(s, nullptr);
+    if (rc) return rc;
+    if (!host_out) return fail(MI_ERR_INVALID, "null output buffer");
+    size_t rb = (size_t)s->p.width * 3 * dtype_size(s->p.out_dtype);
+    if (row_stride_bytes == 0) row_stride_bytes = rb;
+    if (row_stride_bytes < rb) return fail(MI_ERR_INVALID, "row stride smaller than a row");
+    MI_HIP(hipMemcpy2DAsync(host_out, row_stride_bytes, s->out_dev, rb, rb, s->p.height,
+                            hipMemcpyDeviceToHost, s->stream));
+    MI_HIP(hipStreamSynchronize(s->stream));
+    return MI_OK;
+}
+
+int mi_stack_get_level(mi_stack_t* s, int level, int what, void* host_out, size_t out_bytes) {
+    int rc = check_handle(s);
+    if (rc) return rc;
+    if (!host_out) return fail(MI_ERR_INVALID, "null output");
+    MI_HIP(hipSetDevice(s->p.device));
+    rc = tiled_flush(s);
+    if (rc) return rc;
+    const int L = s->L;
+    const void* src = nullptr;
+    size_t bytes = 0;
+    auto np = [&](int l) { return (size_t)s->lh[l] * s->lw[l]; };
+    switch (what) {
+        case MI_TAP_GAUSS:
+            if (level < 1 || level > L) return fail(MI_ERR_INVALID, "MI_TAP_GAUSS: level in [1, %d]", L);
+            src = tiled_last_gauss(s, level);
+            bytes = np(level) * 12;
+            break;
+        case MI_TAP_FUSED_LAP:
+            if (level < 0 || level >= L) return fail(MI_ERR_INVALID, "bad level %d", level);
+            src = s->bestLap[level]; bytes = np(level) * 12; break;
+        case MI_TAP_ENERGY:
+            if (level < 0 || level >= L) return fail(MI_ERR_INVALID, "bad level %d", level);
+            src = s->bestE[level]; bytes = np(level) * 4; break;
+        case MI_TAP_INDEX:
+            if (level < 0 || level >= L) return fail(MI_ERR_INVALID, "bad level %d", level);
+            src = s->bestIdx[level]; bytes = np(level) * 4; break;
+        case MI_TAP_FUSED_BASE:
+            if (!s->finished) return fail(MI_ERR_STATE, "fused base is available after finish");
+            src = s->fusedBase; bytes = np(L) * 12; break;
+        case MI_TAP_BASE_IDX_E: src = s->idxE; bytes = np(L) * 4; break;
+        case MI_TAP_BASE_IDX_D: src = s->idxD; bytes = np(L) * 4; break;
+        case MI_TAP_BASE_ENT: src = s->bEnt; bytes = np(L) * 4; break;
+        case MI_TAP_BASE_DEV: src = s->bDev; bytes = np(L) * 4; break;
+        case MI_TAP_COLLAPSED:
+            if (!s->finished) return fail(MI_ERR_STATE, "collapsed image is available after finish");
+            src = s->clipped; bytes = np(0) * 12; break;
+        default: return fail(MI_ERR_INVALID, "unknown tap %d", what);
+    }
+    if (out_bytes < bytes) return fail(MI_ERR_INVALID, "output buffer too small: need %zu bytes", bytes);
+    MI_HIP(hipMemcpyAsync(host_out, src, bytes, hipMemcpyDeviceToHost, s->stream));
+    MI_HIP(hipStreamSynchronize(s->stream));
+    return MI_OK;
+}
+
+int mi_stack_state(mi_stack_t* s, int level, void** dev_energy, void** dev_lap, void** dev_index, size_t* npixels) {
+    int rc = check_handle(s);
+    if (rc) return rc;
+    MI_HIP(hipSetDevice(s->p.device));
+    rc = tiled_flush(s);
+    if (rc) return rc;
+    const int L = s->L;
+    void *e = nullptr, *l = nullptr, *i = nullptr;
+    size_t n = 0;
+    if (level >= 0 && level < L) {
+        e = s->bestE[level]; l = s->bestLap[level]; i = s->bestIdx[level];
+        n = (size_t)s->lh[level] * s->lw[level];
+    } else if (level == L) {
+        e = s->bEnt; l = s->baseE; i = s->idxE; n = (size_t)s->lh[L] * s->lw[L];
+    } else if (level == L + 1) {
+        e = s->bDev; l = s->baseD; i = s->idxD; n = (size_t)s->lh[L] * s->lw[L];
+    } else
+        return fail(MI_ERR_INVALID, "bad level %d", level);
+    if (dev_energy) *dev_energy = e;
+    if (dev_lap) *dev_lap = l;
+    if (dev_index) *dev_index = i;
+    if (npixels) *npixels = n;
+    return MI_OK;
+}
+
+int mi_stack_stream(mi_stack_t* s, void** stream) {
+    int rc = check_handle(s);
+    if (rc) return rc;
+    if (!stream) return fail(MI_ERR_INVALID, "null stream out");
+    *stream = (void*)s->stream;
+    return MI_OK;
+}
+
+int mi_stack_profile(mi_stack_t* s, int enable) {
+    int rc = check_handle(s);
+    if (rc) return rc;
+    s->prof = enable != 0;
+    return MI_OK;
+}
+
+int mi_stack_profile_get(mi_stack_t* s, int kind, double* total_ms, int64_t* launches, double* algorithmic_bytes) {
+    int rc = check_handle(s);
+    if (rc) return rc;
+    if (kind < 0 || kind >= MI_PROF_KINDS) return fail(MI_ERR_INVALID, "bad kind %d", kind);
+    MI_HIP(hipSetDevice(s->p.device));
+    rc = prof_drain(s);
+    if (rc) return rc;
+    if (total_ms) *total_ms = s->prof_ms[kind];
+    if (launches) *launches = s->prof_n[kind];
+    if (algorithmic_bytes) *algorithmic_bytes = s->prof_bytes[kind];
+    return MI_OK;
+}
+
+int mi_combine_select(int device, void* stream, int n, const void* cand_e, const void* cand_lap,
+                      size_t npix, void* out_e, void* out_lap) {
+    if (n < 1 || !cand_e || !cand_lap || !out_e || !out_lap) return fail(MI_ERR_INVALID, "bad argument");
+    MI_HIP(hipSetDevice(device));
+    hipLaunchKernelGGL(combine_select, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, n, (const float*)cand_e, (const float*)cand_lap, npix,
+                       (float*)out_e, (float*)out_lap);
+    MI_HIP(hipGetLastError());
+    return MI_OK;
+}
+
+int mi_synth_frames_device(int device, void* dev_out, int dtype, int height, int width,
+                           int first_frame, int n_frames, int stack_size, uint32_t seed) {
+    if (!dev_out || height < 1 || width < 1 || n_frames < 0 || stack_size < 1)
+        return fail(MI_ERR_INVALID, "bad argument");
+    MI_HIP(hipSetDevice(device));
+    size_t per = (size_t)height * width * 3;
+    // one launch per frame keeps the grid within 32-bit block counts
+    for (int f = 0; f < n_frames; ++f) {
+        dim3 g((unsigned)((per + 255) / 256));
+        char* dst = (char*)dev_out + (size_t)f * per * dtype_size(dtype);
+        switch (dtype) {
+            case MI_U8:
+                hipLaunchKernelGGL((synth_frames<uint8_t>), g, dim3(256), 0, 0, (uint8_t*)dst,
+                                   height, width, first_frame + f, 1, stack_size, seed, 1);
+                break;
+            case MI_U16:
+                hipLaunchKernelGGL((synth_frames<uint16_t>), g, dim3(256), 0, 0, (uint16_t*)dst,
+                                   height, width, first_frame + f, 1, stack_size, seed, 257);
+                break;
+            case MI_F32:
+                hipLaunchKernelGGL((synth_frames<float>), g, dim3(256), 0, 0, (float*)dst, height,
+                                   width, first_frame + f, 1, stack_size, seed, 1);
+                break;
+            default: return fail(MI_ERR_INVALID, "bad dtype %d", dtype);
+        }
+    }
+    MI_HIP(hipGetLastError());
+    MI_HIP(hipDeviceSynchronize());
+    return MI_OK;
+}
+
+}  // extern "C"

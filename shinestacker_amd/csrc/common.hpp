@@ -1,0 +1,100 @@
+// common.hpp -- shared device/host helpers for libmi355stack (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/mi355stack.h"
+
+// Every multiply-add in this library is either an explicit fma or two
+// separately rounded operations -- never the compiler's choice -- because the
+// results are compared bit-for-bit with the CPU oracle.
+#pragma clang fp contract(off)
+
+namespace mi {
+
+struct K25 {
+    float k[25];
+};
+
+// ---- thread-local error text ------------------------------------------------
+inline std::string& last_error() {
+    static thread_local std::string e;
+    return e;
+}
+inline int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    last_error() = buf;
+    return code;
+}
+
+#define MI_HIP(call)                                                                      \
+    do {                                                                                  \
+        hipError_t _e = (call);                                                           \
+        if (_e != hipSuccess)                                                             \
+            return mi::fail(_e == hipErrorOutOfMemory ? MI_ERR_NOMEM : MI_ERR_HIP,        \
+                            "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e),        \
+                            __FILE__, __LINE__);                                          \
+    } while (0)
+
+// ---- device helpers -----------------------------------------------------------
+// BORDER_REFLECT101 for an overshoot smaller than n (all pyramid stencils: |o| <= 2 < 4 <= n)
+__device__ __forceinline__ int r101(int i, int n) {
+    i = i < 0 ? -i : i;
+    return i >= n ? 2 * n - 2 - i : i;
+}
+// any overshoot (base-level window with a large kernel_size on a tiny base)
+__device__ __forceinline__ int r101_loop(int i, int n) {
+    if (n == 1) return 0;
+    while (i < 0 || i >= n) {
+        if (i < 0) i = -i;
+        if (i >= n) i = 2 * n - 2 - i;
+    }
+    return i;
+}
+
+template <bool FMA>
+__device__ __forceinline__ float mac(float k, float x, float s) {
+    if constexpr (FMA) {
+        return __builtin_fmaf(k, x, s);
+    } else {
+        float p = k * x;  // contraction is off for this TU
+        return s + p;
+    }
+}
+
+// cv2.cvtColor(BGR2GRAY) on float32 [from memory: fma(R,cr, fma(G,cg, B*cb))]
+template <bool FMA>
+__device__ __forceinline__ float gray_of(float b, float g, float r) {
+    const float cb = 0.114f, cg = 0.587f, cr = 0.299f;
+    if constexpr (FMA) {
+        return __builtin_fmaf(r, cr, __builtin_fmaf(g, cg, b * cb));
+    } else {
+        float pb = b * cb, pg = g * cg, pr = r * cr;
+        float s = pb + pg;
+        return s + pr;
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ float to_f32(T v) {
+    return (float)v;
+}
+
+__device__ __forceinline__ uint32_t lowbias32(uint32_t x) {
+    x ^= x >> 16;
+    x *= 0x7feb352dU;
+    x ^= x >> 15;
+    x *= 0x846ca68bU;
+    x ^= x >> 16;
+    return x;
+}
+
+inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+}  // namespace mi

@@ -1,0 +1,297 @@
+// kernels_simple.hpp -- one-thread-per-output kernels with global-memory taps.
+// They are the on-GPU cross-check (MI_IMPL_SIMPLE) for the LDS-tiled production
+// kernels, and the implementation of everything that is O(1) in the frame
+// count (base level, collapse, finalise, cross-GPU combine).
+//
+// Arithmetic contract (identical in every implementation and in oracle/):
+//   * 5x5 stencils: taps in row-major order, s = 0, s = mac(k, x, s) per tap
+//     (reference algorithms/pyramid.py:24-25 -> cv2.filter2D, REFLECT101);
+//   * reduce  = that stencil at even coordinates (pyramid.py:27-32);
+//   * expand  = the stencil on the zero-stuffed 2h x 2w grid with the zero taps
+//     skipped (exact: they add +0), times 4 (pyramid.py:34-46);
+//   * laplacian = G_l - expand(G_{l+1})[:h,:w] (pyramid.py:133-138);
+//   * energy = stencil(gray(lap)^2), selection = first maximum over frames
+//     (pyramid.py:48-55), winner's lap with -0 -> +0.
+#pragma once
+#include "common.hpp"
+
+namespace mi {
+
+// ---------------------------------------------------------------- reduce
+template <typename TIn, bool FMA>
+__global__ void reduce_simple(const TIn* __restrict__ g, int h, int w, float* __restrict__ out,
+                              int ho, int wo, K25 K) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    int i = blockIdx.y * blockDim.y + threadIdx.y;
+    if (i >= ho || j >= wo) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int ty = 0; ty < 5; ++ty) {
+        const TIn* row = g + (size_t)r101(2 * i + ty - 2, h) * w * 3;
+#pragma unroll
+        for (int tx = 0; tx < 5; ++tx) {
+            const TIn* p = row + (size_t)r101(2 * j + tx - 2, w) * 3;
+            float k = K.k[ty * 5 + tx];
+            s0 = mac<FMA>(k, to_f32(p[0]), s0);
+            s1 = mac<FMA>(k, to_f32(p[1]), s1);
+            s2 = mac<FMA>(k, to_f32(p[2]), s2);
+        }
+    }
+    float* o = out + ((size_t)i * wo + j) * 3;
+    o[0] = s0;
+    o[1] = s1;
+    o[2] = s2;
+}
+
+// expand_layer(src)[y, x, :] for an hs x ws x 3 source
+template <bool FMA>
+__device__ __forceinline__ void expand_at(const float* __restrict__ src, int hs, int ws,
+                                          const K25& K, int y, int x, float& e0, float& e1,
+                                          float& e2) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    const int H2 = 2 * hs, W2 = 2 * ws;
+#pragma unroll
+    for (int ty = 0; ty < 5; ++ty) {
+        int yy = r101(y + ty - 2, H2);
+        if (yy & 1) continue;
+#pragma unroll
+        for (int tx = 0; tx < 5; ++tx) {
+            int xx = r101(x + tx - 2, W2);
+            if (xx & 1) continue;
+            const float* p = src + ((size_t)(yy >> 1) * ws + (xx >> 1)) * 3;
+            float k = K.k[ty * 5 + tx];
+            s0 = mac<FMA>(k, p[0], s0);
+            s1 = mac<FMA>(k, p[1], s1);
+            s2 = mac<FMA>(k, p[2], s2);
+        }
+    }
+    e0 = 4.0f * s0;
+    e1 = 4.0f * s1;
+    e2 = 4.0f * s2;
+}
+
+// ---------------------------------------------------------------- laplacian + gray^2
+template <typename TIn, bool FMA>
+__global__ void lapq_simple(const TIn* __restrict__ g, int h, int w, const float* __restrict__ gn,
+                            int hs, int ws, float* __restrict__ lap, float* __restrict__ q,
+                            K25 K) {
+    int x = blockIdx.x * blockDim.x + threadIdx.x;
+    int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (y >= h || x >= w) return;
+    float e0, e1, e2;
+    expand_at<FMA>(gn, hs, ws, K, y, x, e0, e1, e2);
+    size_t p = (size_t)y * w + x;
+    float l0 = to_f32(g[p * 3 + 0]) - e0;
+    float l1 = to_f32(g[p * 3 + 1]) - e1;
+    float l2 = to_f32(g[p * 3 + 2]) - e2;
+    lap[p * 3 + 0] = l0;
+    lap[p * 3 + 1] = l1;
+    lap[p * 3 + 2] = l2;
+    float gr = gray_of<FMA>(l0, l1, l2);
+    q[p] = gr * gr;
+}
+
+// ---------------------------------------------------------------- energy + running first-max
+template <bool FMA>
+__global__ void select_simple(const float* __restrict__ q, const float* __restrict__ lap, int h,
+                              int w, int frame_idx, int first, float* __restrict__ best_e,
+                              float* __restrict__ best_lap, int32_t* __restrict__ best_idx,
+                              K25 K) {
+    int x = blockIdx.x * blockDim.x + threadIdx.x;
+    int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (y >= h || x >= w) return;
+    float s = 0.f;
+#pragma unroll
+    for (int ty = 0; ty < 5; ++ty) {
+        const float* row = q + (size_t)r101(y + ty - 2, h) * w;
+#pragma unroll
+        for (int tx = 0; tx < 5; ++tx) s = mac<FMA>(K.k[ty * 5 + tx], row[r101(x + tx - 2, w)], s);
+    }
+    size_t p = (size_t)y * w + x;
+    if (first || s > best_e[p]) {
+        best_e[p] = s;
+        best_idx[p] = frame_idx;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float lv = lap[p * 3 + c];
+            best_lap[p * 3 + c] = (lv == 0.0f) ? 0.0f : lv;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- base level (pyramid.py:66-111)
+template <bool FMA>
+__global__ void base_gray_hist(const float* __restrict__ base, int npix, int nlevels,
+                               int32_t* __restrict__ lev, uint32_t* __restrict__ cnt) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix) return;
+    float gr = gray_of<FMA>(base[3 * i], base[3 * i + 1], base[3 * i + 2]);
+    int l = (int)gr;  // .astype(uint8/uint16): truncation
+    l = l < 0 ? 0 : (l >= nlevels ? nlevels - 1 : l);
+    lev[i] = l;
+    atomicAdd(&cnt[l], 1u);
+}
+
+// log table: p = float32(float64(float32(count)) / float64(npix)); logp = float32(log(float64(p)))
+__global__ void base_logp(const uint32_t* __restrict__ cnt, int nlevels, int npix,
+                          float* __restrict__ logp) {
+    int l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= nlevels) return;
+    uint32_t c = cnt[l];
+    float v = 0.f;
+    if (c) {
+        float p = (float)((double)(float)c / (double)npix);
+        v = (float)log((double)p);
+    }
+    logp[l] = v;
+}
+
+// NumPy's float32 add.reduce order (pairwise, 8 accumulators) for n <= 128
+template <typename F>
+__device__ __forceinline__ float np_sum(int n, F elem) {
+    if (n < 8) {
+        float res = -0.0f;
+        for (int i = 0; i < n; ++i) res += elem(i);
+        return res;
+    }
+    float r[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = elem(j);
+    int i;
+    for (i = 8; i < n - (n % 8); i += 8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] += elem(i + j);
+    }
+    float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res += elem(i);
+    return res;
+}
+
+// entropy / deviation features of one frame's base + running first-max selection.
+// The winner's base pixel is copied next to the running maxima so the final
+// (img[best_e] + img[best_d]) / 2 needs no per-frame storage.
+__global__ void base_feat_select(const int32_t* __restrict__ lev, const float* __restrict__ logp,
+                                 const float* __restrict__ base, int hb, int wb, int pad,
+                                 int frame_idx, int first, float* __restrict__ best_ent,
+                                 float* __restrict__ best_dev, int32_t* __restrict__ idx_e,
+                                 int32_t* __restrict__ idx_d, float* __restrict__ base_e,
+                                 float* __restrict__ base_d) {
+    int x = blockIdx.x * blockDim.x + threadIdx.x;
+    int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (y >= hb || x >= wb) return;
+    const int win = 2 * pad + 1, n = win * win;
+    auto level_at = [&](int t) {
+        int dy = t / win - pad, dx = t % win - pad;
+        return lev[(size_t)r101_loop(y + dy, hb) * wb + r101_loop(x + dx, wb)];
+    };
+    float ent = -1.0f * np_sum(n, [&](int t) {
+                    int l = level_at(t);
+                    return (float)l * logp[l];
+                });
+    double isum = 0.0;
+    for (int t = 0; t < n; ++t) isum += (double)level_at(t);
+    float mean = (float)(isum / (double)n);
+    float dev = np_sum(n, [&](int t) {
+                    float d = (float)level_at(t) - mean;
+                    return d * d;
+                }) / (float)n;
+    size_t p = (size_t)y * wb + x;
+    if (first || ent > best_ent[p]) {
+        best_ent[p] = ent;
+        idx_e[p] = frame_idx;
+        for (int c = 0; c < 3; ++c) base_e[p * 3 + c] = base[p * 3 + c];
+    }
+    if (first || dev > best_dev[p]) {
+        best_dev[p] = dev;
+        idx_d[p] = frame_idx;
+        for (int c = 0; c < 3; ++c) base_d[p * 3 + c] = base[p * 3 + c];
+    }
+}
+
+__global__ void base_fuse(const float* __restrict__ base_e, const float* __restrict__ base_d,
+                          size_t n, float* __restrict__ out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.0f + base_e[i];  // zeros + where(best_e == f, img, 0) ...
+    s = s + base_d[i];           // ... + where(best_d == f, img, 0); a+b is commutative
+    out[i] = s / 2.0f;
+}
+
+// ---------------------------------------------------------------- collapse (pyramid.py:57-64)
+template <bool FMA>
+__global__ void collapse_simple(const float* __restrict__ up, int hs, int ws,
+                                const float* __restrict__ lap, int h, int w,
+                                float* __restrict__ out, K25 K) {
+    int x = blockIdx.x * blockDim.x + threadIdx.x;
+    int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (y >= h || x >= w) return;
+    float e0, e1, e2;
+    expand_at<FMA>(up, hs, ws, K, y, x, e0, e1, e2);
+    size_t p = ((size_t)y * w + x) * 3;
+    out[p + 0] = e0 + lap[p + 0];
+    out[p + 1] = e1 + lap[p + 1];
+    out[p + 2] = e2 + lap[p + 2];
+}
+
+// clip(abs(img), 0, max) then .astype(dtype) (truncation), pyramid.py:64, :179
+template <typename TOut>
+__global__ void finalize_cast(const float* __restrict__ img, size_t n, float maxv,
+                              float* __restrict__ clipped, TOut* __restrict__ out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float v = fabsf(img[i]);
+    v = v > maxv ? maxv : v;
+    if (clipped) clipped[i] = v;
+    out[i] = (TOut)v;
+}
+
+// ---------------------------------------------------------------- cross-GPU combine
+// candidates in ascending global frame order: strict '>' keeps the first maximum.
+__global__ void combine_select(int n, const float* __restrict__ cand_e,
+                               const float* __restrict__ cand_lap, size_t npix,
+                               float* __restrict__ out_e, float* __restrict__ out_lap) {
+    size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npix) return;
+    float be = cand_e[p];
+    int bi = 0;
+    for (int r = 1; r < n; ++r) {
+        float e = cand_e[(size_t)r * npix + p];
+        if (e > be) {
+            be = e;
+            bi = r;
+        }
+    }
+    out_e[p] = be;
+    const float* l = cand_lap + ((size_t)bi * npix + p) * 3;
+    out_lap[p * 3 + 0] = l[0];
+    out_lap[p * 3 + 1] = l[1];
+    out_lap[p * 3 + 2] = l[2];
+}
+
+// ---------------------------------------------------------------- synthetic frames
+template <typename T>
+__global__ void synth_frames(T* __restrict__ out, int H, int W, int f0, int nf, int N,
+                             uint32_t seed, int scale) {
+    size_t per = (size_t)H * W * 3;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= per * nf) return;
+    int fi = (int)(i / per);
+    size_t r = i - (size_t)fi * per;
+    int c = (int)(r % 3);
+    size_t px = r / 3;
+    int x = (int)(px % W), y = (int)(px / W);
+    int f = f0 + fi;
+    uint32_t hsh = lowbias32(seed ^ ((uint32_t)f * 0x9E3779B1U) ^ ((uint32_t)y * 0x85EBCA77U) ^
+                             ((uint32_t)x * 0xC2B2AE3DU) ^ (uint32_t)c);
+    int noise = (int)(hsh >> 24) - 128;
+    int band = (int)(((int64_t)y * N) / H);
+    int d = band - f;
+    d = d < 0 ? -d : d;
+    int amp = 64 >> (d < 6 ? d : 6);
+    int base = ((3 * x + 5 * y + 17 * c) & 127) + 64;
+    int v = base + ((noise * amp) >> 7);
+    v = v < 0 ? 0 : (v > 255 ? 255 : v);
+    out[i] = (T)(v * scale);
+}
+
+}  // namespace mi

@@ -1,0 +1,174 @@
+"""PyramidStack on MI355X: the stacker plug-in behind FocusStack / FocusStackBunch.
+
+Drop-in for the reference's `PyramidStack` (algorithms/pyramid.py:114-179) and its
+`BaseStackAlgo` protocol (algorithms/base_stack_algo.py:9-42):
+
+* constructor  PyramidStack(min_size=32, kernel_size=5, gen_kernel=0.4, float_type='float-32')
+* set by the owning action: ``.process`` (stack.py:23), ``.do_step_callback`` (stack.py:103 / :76)
+* name() -> 'pyramid', steps_per_frame() -> 2, print_message(), focus_stack(filenames) -> H x W x 3
+  array of the input dtype, BGR, C-contiguous, host memory
+* callbacks: 'after_step' (indices 0..2N-1) and 'check_running' after every file of both
+  passes (pyramid.py:166-169, :174-177); RunStopException when 'check_running' returns False
+* errors: ImageLoadError / ShapeError / BitDepthError / InvalidOptionError / RuntimeError as the
+  reference raises them (base_stack_algo.py:19-22, :33-42; utils.py:12-13, :56-63)
+
+All arithmetic runs in libmi355stack.so (HIP, gfx950).  There is no CPU path: without the
+library or without a GPU, focus_stack raises DeviceError.
+
+Differences from the reference that do not change results: every frame is decoded once (the
+reference decodes twice, pyramid.py:158 and :172) and is pushed to the device during the
+validation pass, and no per-frame pyramid is kept -- selection is a running first-max on the
+device.
+"""
+import numpy as np
+
+from . import _lib
+from .defaults import constants
+from .errors import ImageLoadError, InvalidOptionError, RunStopException
+from .imageio import get_img_metadata, read_img, validate_image
+
+
+def _cyan(msg):
+    return f"\033[36m{msg}\033[0m"
+
+
+class BaseStackAlgo:
+    """Plug-in base shared by stackers (reference base_stack_algo.py:9-42)."""
+
+    def __init__(self, name, steps_per_frame, float_type=constants.DEFAULT_PY_FLOAT):
+        self._name = name
+        self._steps_per_frame = steps_per_frame
+        self.process = None
+        if float_type == constants.FLOAT_32:
+            self.float_type = np.float32
+        elif float_type == constants.FLOAT_64:
+            self.float_type = np.float64
+        else:
+            raise InvalidOptionError("float_type", float_type,
+                                     details=" valid values are FLOAT_32 and FLOAT_64")
+
+    def name(self):
+        return self._name
+
+    def steps_per_frame(self):
+        return self._steps_per_frame
+
+    def print_message(self, msg):
+        self.process.sub_message_r(_cyan(msg))
+
+    def read_image_and_update_metadata(self, img_path, metadata):
+        img = read_img(img_path)
+        if img is None:
+            raise ImageLoadError(img_path)
+        updated = metadata is None
+        if updated:
+            metadata = get_img_metadata(img)
+        else:
+            validate_image(img, *metadata)
+        return img, metadata, updated
+
+
+class PyramidStack(BaseStackAlgo):
+    def __init__(self, min_size=constants.DEFAULT_PY_MIN_SIZE,
+                 kernel_size=constants.DEFAULT_PY_KERNEL_SIZE,
+                 gen_kernel=constants.DEFAULT_PY_GEN_KERNEL,
+                 float_type=constants.DEFAULT_PY_FLOAT, *, device=0, use_fma=True,
+                 impl=_lib.IMPL_AUTO, batch_frames=0):
+        super().__init__("pyramid", 2, float_type)
+        if self.float_type is np.float64:
+            raise InvalidOptionError("float_type", float_type,
+                                     details=" float-64 is not implemented on the MI355X path")
+        self.min_size = min_size
+        self.kernel_size = kernel_size
+        self.pad_amount = (kernel_size - 1) // 2
+        self.gen_kernel_a = gen_kernel
+        self.do_step_callback = False
+        self.device = device
+        self.use_fma = use_fma
+        self.impl = impl
+        self.batch_frames = batch_frames
+        self.dtype = None
+        self.num_pixel_values = None
+        self.max_pixel_value = None
+        self._stack = None
+
+    # ------------------------------------------------------------------ device handle
+    def _handle(self, shape, dtype):
+        """One handle per (shape, dtype); FocusStackBunch reuses the stacker for every bunch."""
+        key = (tuple(shape[:2]), np.dtype(dtype))
+        if self._stack is not None and self._stack_key == key:
+            self._stack.reset()
+            return self._stack
+        if self._stack is not None:
+            self._stack.close()
+        self._stack = _lib.Stack(shape[0], shape[1], in_dtype=dtype, out_dtype=dtype,
+                                 min_size=self.min_size, kernel_size=self.kernel_size,
+                                 gen_kernel=self.gen_kernel_a, use_fma=self.use_fma,
+                                 device=self.device, impl=self.impl,
+                                 batch_frames=self.batch_frames)
+        self._stack_key = key
+        return self._stack
+
+    def close(self):
+        if self._stack is not None:
+            self._stack.close()
+            self._stack = None
+
+    # ------------------------------------------------------------------ callbacks
+    def _step(self, i):
+        if self.do_step_callback:
+            self.process.callback('after_step', self.process.id, self.process.name, i)
+        if self.process.callback('check_running', self.process.id, self.process.name) is False:
+            raise RunStopException(self.process.name)
+
+    def _set_dtype(self, dtype):
+        self.dtype = dtype
+        is8 = dtype == np.uint8
+        self.num_pixel_values = constants.NUM_UINT8 if is8 else constants.NUM_UINT16
+        self.max_pixel_value = constants.MAX_UINT8 if is8 else constants.MAX_UINT16
+
+    # ------------------------------------------------------------------ the hot path
+    def focus_stack(self, filenames):
+        """pyramid.py:150-179.  `filenames`: sorted list of image paths."""
+        _lib.require_device()
+        n = len(filenames)
+        metadata = None
+        stack = None
+        # pass 1: decode + validate every file (as pyramid.py:155-169) and hand each
+        # frame to the device right away, so decoding overlaps the GPU work.  A
+        # validation error still aborts the whole stack before any result exists.
+        for i, img_path in enumerate(filenames):
+            self.print_message(f": validating file {img_path.split('/')[-1]}")
+            img, metadata, updated = self.read_image_and_update_metadata(img_path, metadata)
+            if updated:
+                self._set_dtype(metadata[1])
+                stack = self._handle(metadata[0], metadata[1])
+            stack.push_frame(img)
+            self._step(i)
+        # pass 2: the reference decodes and builds pyramids here (pyramid.py:170-177);
+        # that work is already enqueued, only the progress protocol remains.
+        for i, img_path in enumerate(filenames):
+            self.print_message(f": processing file {img_path.split('/')[-1]}")
+            self._step(i + n)
+        self.print_message(': pyramids fusion completed')
+        return stack.finish()
+
+    def focus_stack_arrays(self, frames):
+        """In-memory variant (no file I/O): `frames` is a sequence of H x W x 3 uint8/uint16
+        BGR arrays.  Same callbacks as focus_stack, one step per frame per pass."""
+        _lib.require_device()
+        n = len(frames)
+        if n == 0:
+            raise ValueError("no frames")
+        meta = get_img_metadata(frames[0])
+        self._set_dtype(meta[1])
+        for i, fr in enumerate(frames):
+            validate_image(fr, *meta)
+            if self.process is not None:
+                self._step(i)
+        stack = self._handle(meta[0], meta[1])
+        for i, fr in enumerate(frames):
+            stack.push_frame(fr)
+            if self.process is not None:
+                self._step(i + n)
+        return stack.finish()

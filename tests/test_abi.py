@@ -1,0 +1,73 @@
+"""CPU: the C-ABI library loads and exports every symbol include/mi355stack.h declares;
+without a GPU the product path fails loudly (no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "mi355stack.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mi_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_expected_entry_points():
+    syms = header_symbols()
+    for must in ("mi_stack_create", "mi_stack_push_frame", "mi_stack_push_frames_device",
+                 "mi_stack_finish", "mi_stack_reset", "mi_stack_destroy", "mi_last_error",
+                 "mi_stack_get_level", "mi_combine_select"):
+        assert must in syms
+
+
+def test_library_exports_every_declared_symbol(hiplib):
+    lib = ctypes.CDLL(hiplib.LIB_PATH)
+    for name in header_symbols():
+        assert hasattr(lib, name), f"{name} declared in mi355stack.h but not exported"
+
+
+def test_python_binding_covers_header(hiplib):
+    assert sorted(hiplib.SIGNATURES) == header_symbols()
+    assert hiplib.load().mi_abi_version() == 1
+
+
+def test_params_struct_layout(hiplib):
+    # int32 x6, double, int32 x5, reserved[5]  -> 24 + 8 + 20 + 20 = 72 bytes
+    assert ctypes.sizeof(hiplib.StackParams) == 72
+    p = hiplib.StackParams()
+    hiplib.load().mi_stack_default_params(ctypes.byref(p))
+    assert (p.min_size, p.kernel_size, p.gen_kernel, p.use_fma) == (32, 5, 0.4, 1)
+
+
+def test_argument_validation_without_gpu(hiplib):
+    lib = hiplib.load()
+    assert lib.mi_stack_create(None, None) == hiplib.MI_ERR_INVALID
+    assert b"null" in lib.mi_last_error()
+    assert lib.mi_stack_levels(None, None) == hiplib.MI_ERR_INVALID
+
+
+@pytest.mark.skipif(os.environ.get("MI_EXPECT_GPU") == "1", reason="GPU box")
+def test_no_gpu_means_loud_failure(hiplib):
+    if hiplib.device_count() > 0:
+        pytest.skip("a GPU is visible here")
+    from shinestacker_amd import PyramidStack, DeviceError
+    with pytest.raises(DeviceError):
+        hiplib.Stack(64, 64)
+    algo = PyramidStack()
+    with pytest.raises(DeviceError):
+        algo.focus_stack_arrays([np.zeros((64, 64, 3), np.uint8)])
+
+
+def test_product_does_not_import_oracle():
+    """The oracle is test infrastructure: nothing under shinestacker_amd/ may reference it."""
+    pkg = os.path.join(ROOT, "shinestacker_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".hpp", ".h")):
+                txt = open(os.path.join(dirpath, fn)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), fn
+                assert "liboracle" not in txt, fn

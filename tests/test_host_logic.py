@@ -1,0 +1,200 @@
+"""CPU: the host-side mirror of the action API (no GPU compute).  The stacker used
+here is a test double built on the oracle -- it only exists to drive actions.py."""
+import json
+import os
+import shutil
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, load_golden
+from shinestacker_amd import (BaseStackAlgo, CombinedActions, FocusStack, FocusStackBunch,
+                              InvalidOptionError, PyramidStack, RunStopException, StackJob,
+                              SubAction, get_bunches)
+from shinestacker_amd.errors import BitDepthError, ImageLoadError, ShapeError
+from shinestacker_amd.imageio import read_img, validate_image, write_img
+
+
+class OracleStacker(BaseStackAlgo):
+    """Follows the same protocol as PyramidStack.focus_stack, arithmetic by oracle/."""
+
+    def __init__(self, oracle):
+        super().__init__("pyramid", 2)
+        self.oracle = oracle
+        self.do_step_callback = False
+
+    def _step(self, i):
+        if self.do_step_callback:
+            self.process.callback('after_step', self.process.id, self.process.name, i)
+        if self.process.callback('check_running', self.process.id, self.process.name) is False:
+            raise RunStopException(self.process.name)
+
+    def focus_stack(self, filenames):
+        frames, meta = [], None
+        for i, p in enumerate(filenames):
+            img, meta, _ = self.read_image_and_update_metadata(p, meta)
+            frames.append(img)
+            self._step(i)
+        for i in range(len(filenames)):
+            self._step(i + len(filenames))
+        so = self.oracle.StreamingOracle(frames[0].shape[0], frames[0].shape[1],
+                                         frames[0].dtype)
+        for f in frames:
+            so.push_frame(f)
+        return so.finish()
+
+
+@pytest.fixture()
+def workdir(tmp_path):
+    src = os.path.join(GOLDEN, "img_jpg_crop")
+    os.makedirs(tmp_path / "input")
+    for n in sorted(os.listdir(src)):
+        shutil.copy(os.path.join(src, n), tmp_path / "input" / n)
+    return str(tmp_path)
+
+
+def recorder():
+    trace = []
+
+    def cb(key):
+        def _f(*args):
+            trace.append([key] + [a if isinstance(a, (int, str)) else str(a) for a in args])
+        return _f
+    keys = ("before_action", "after_action", "step_counts", "begin_steps", "end_steps",
+            "after_step", "save_plot", "check_running")
+    return trace, {k: cb(k) for k in keys}
+
+
+def normalise(trace, work):
+    out = []
+    for t in trace:
+        out.append([x.replace(work, "<W>").replace("/tmp/_golden_work", "<W>")
+                    if isinstance(x, str) else x for x in t])
+    return out
+
+
+def test_get_bunches_golden():
+    with open(os.path.join(GOLDEN, "plumbing.json")) as fh:
+        gb = json.load(fh)["get_bunches"]
+    for key, want in gb.items():
+        n, fr, ov = map(int, key.split("_"))
+        assert get_bunches(list(range(n)), fr, ov) == want
+
+
+def test_focus_stack_job_trace_and_output(oracle, workdir):
+    with open(os.path.join(GOLDEN, "plumbing.json")) as fh:
+        gold = json.load(fh)
+    trace, cbs = recorder()
+    job = StackJob("job", workdir, input_path="input", callbacks=cbs)
+    job.add_action(FocusStack("stack-pyramid", OracleStacker(oracle), output_path="out-stack",
+                              prefix="pyr_"))
+    job.run()
+    assert sorted(os.listdir(os.path.join(workdir, "out-stack"))) == gold["stack_out_files"]
+    assert normalise(trace, workdir) == normalise(gold["trace_stack"], workdir)
+    out = read_img(os.path.join(workdir, "out-stack", gold["stack_out_files"][0]))
+    assert np.array_equal(out, load_golden("plumbing_outputs")["stack"])
+
+
+def test_focus_stack_bunch_trace_and_outputs(oracle, workdir):
+    with open(os.path.join(GOLDEN, "plumbing.json")) as fh:
+        gold = json.load(fh)
+    trace, cbs = recorder()
+    job = StackJob("job", workdir, input_path="input", callbacks=cbs)
+    job.add_action(FocusStackBunch("bunches", OracleStacker(oracle), output_path="out-bunch",
+                                   frames=3))
+    job.run()
+    files = sorted(os.listdir(os.path.join(workdir, "out-bunch")))
+    assert files == gold["bunch_out_files"]
+    assert normalise(trace, workdir) == normalise(gold["trace_bunch"], workdir)
+    outs = load_golden("plumbing_outputs")
+    for i, f in enumerate(files):
+        assert np.array_equal(read_img(os.path.join(workdir, "out-bunch", f)), outs[f"bunch_{i}"])
+
+
+def test_cancel_raises_runstop(oracle, workdir):
+    calls = {"n": 0}
+
+    def check(*_a):
+        calls["n"] += 1
+        return calls["n"] < 4
+    job = StackJob("job", workdir, input_path="input", callbacks={"check_running": check})
+    job.add_action(FocusStack("s", OracleStacker(oracle), output_path="o"))
+    with pytest.raises(RunStopException):
+        job.run()
+
+
+def test_output_dir_scratched_and_chained(oracle, workdir):
+    os.makedirs(os.path.join(workdir, "o"))
+    open(os.path.join(workdir, "o", "stale.png"), "w").close()
+    job = StackJob("job", workdir, input_path="input")
+    a = FocusStack("s", OracleStacker(oracle), output_path="o")
+    job.add_action(a)
+    assert os.listdir(os.path.join(workdir, "o")) == []
+    assert job.paths[-1] == "o" and a.input_path == "input"
+    b = FocusStack("s2", OracleStacker(oracle))
+    job.add_action(b)
+    assert b.input_path == "o" and b.output_path == "s2"
+
+
+def test_option_errors():
+    with pytest.raises(InvalidOptionError):
+        PyramidStack(float_type="float-16")
+    with pytest.raises(InvalidOptionError):
+        PyramidStack(float_type="float-64")  # documented gap of the HIP path
+    with pytest.raises(InvalidOptionError):
+        FocusStackBunch("b", PyramidStack(), frames=3, overlap=3)
+    algo = PyramidStack()
+    assert algo.name() == "pyramid" and algo.steps_per_frame() == 2
+
+
+def test_image_validation_errors(tmp_path):
+    a = np.zeros((8, 9, 3), np.uint8)
+    with pytest.raises(ShapeError):
+        validate_image(np.zeros((8, 10, 3), np.uint8), a.shape[:2], a.dtype)
+    with pytest.raises(BitDepthError):
+        validate_image(np.zeros((8, 9, 3), np.uint16), a.shape[:2], a.dtype)
+    with pytest.raises(RuntimeError):
+        read_img(str(tmp_path / "missing.png"))
+    bad = tmp_path / "bad.png"
+    bad.write_bytes(b"not a png")
+    algo = PyramidStack()
+    with pytest.raises(ImageLoadError):
+        algo.read_image_and_update_metadata(str(bad), None)
+
+
+def test_image_io_roundtrip(tmp_path):
+    rng = np.random.default_rng(0)
+    a8 = rng.integers(0, 256, (17, 23, 3), dtype=np.uint8)
+    a16 = rng.integers(0, 65536, (17, 23, 3), dtype=np.uint16)
+    write_img(str(tmp_path / "a.png"), a8)
+    write_img(str(tmp_path / "a.tif"), a8)
+    write_img(str(tmp_path / "b.tif"), a16)
+    assert np.array_equal(read_img(str(tmp_path / "a.png")), a8)
+    assert np.array_equal(read_img(str(tmp_path / "a.tif")), a8)
+    b = read_img(str(tmp_path / "b.tif"))
+    assert b.dtype == np.uint16 and np.array_equal(b, a16)
+
+
+class Recorder(SubAction):
+    def __init__(self):
+        super().__init__()
+        self.seen = []
+
+    def run_frame(self, idx, ref_idx, img):
+        self.seen.append((idx, ref_idx))
+        return img
+
+
+@pytest.mark.parametrize("step_process,want", [
+    (False, [(0, 3), (1, 3), (2, 3), (3, 3), (4, 3), (5, 3)]),
+    (True, [(3, 3), (4, 3), (5, 4), (2, 3), (1, 2), (0, 1)]),
+])
+def test_combined_actions_iteration_order(workdir, step_process, want):
+    """stack_framework.py:214-232: fixed reference vs. chained neighbours."""
+    rec = Recorder()
+    job = StackJob("job", workdir, input_path="input")
+    job.add_action(CombinedActions("combo", [rec], step_process=step_process,
+                                   output_path="aligned"))
+    job.run()
+    assert rec.seen == want
+    assert len(os.listdir(os.path.join(workdir, "aligned"))) == 6
