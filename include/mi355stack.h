@@ -143,7 +143,13 @@ MI_API int mi_stack_state(mi_stack_t* s, int level, void** dev_energy, void** de
 MI_API int mi_stack_stream(mi_stack_t* s, void** stream);
 
 /* ---- per-kernel timing (hipEvent pairs on the handle's stream) ---- */
-enum { MI_PROF_LEVEL = 0, MI_PROF_BASE = 1, MI_PROF_COLLAPSE = 2, MI_PROF_KINDS = 3 };
+enum {
+    MI_PROF_LEVEL = 0,    /* fused level launches of levels >= 1 (simple impl: whole frames) */
+    MI_PROF_BASE = 1,     /* base-level feature kernels                                      */
+    MI_PROF_COLLAPSE = 2, /* base fusion + collapse + finalise                               */
+    MI_PROF_LEVEL0 = 3,   /* fused level-0 launches: the dominant kernel                     */
+    MI_PROF_KINDS = 4
+};
 MI_API int mi_stack_profile(mi_stack_t* s, int enable);
 /* sums since the last reset; algorithmic_bytes follows SURVEY.md 8(d) */
 MI_API int mi_stack_profile_get(mi_stack_t* s, int kind, double* total_ms, int64_t* launches,

@@ -81,11 +81,12 @@ struct mi_stack {
     bool prof = false;
     std::vector<ProfRec> recs;
     std::vector<hipEvent_t> ev_pool;
-    double prof_ms[MI_PROF_KINDS] = {0, 0, 0};
-    int64_t prof_n[MI_PROF_KINDS] = {0, 0, 0};
-    double prof_bytes[MI_PROF_KINDS] = {0, 0, 0};
+    double prof_ms[MI_PROF_KINDS] = {};
+    int64_t prof_n[MI_PROF_KINDS] = {};
+    double prof_bytes[MI_PROF_KINDS] = {};
 
     std::vector<void*> allocs;
+    void* tiled = nullptr;  // TiledState (tiled_host.hpp)
 };
 
 namespace {
