@@ -136,7 +136,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt_s = float(t.item())
 
-    ms_level, n_level, bytes_level = st.profile_get(L.PROF_LEVEL)
+    prof = {k: st.profile_get(v) for k, v in (("level0", L.PROF_LEVEL0), ("levels", L.PROF_LEVEL),
+                                              ("base", L.PROF_BASE), ("collapse", L.PROF_COLLAPSE))}
+    tiled = prof["level0"][1] > 0
+    ms_level, n_level, bytes_level = prof["level0"] if tiled else prof["levels"]
+    # read level 0 once + 36 B per pixel of every coarser Gaussian level
+    job_bytes_per_frame = float(np.dtype(dt).itemsize * 3 * H * W +
+                                36 * sum(h * w for (h, w) in st.shapes[1:]))
     if rank == 0:
         ms_per_step = dt_s / args.steps * 1e3
         value = total_frames * H * W * args.steps / dt_s / 1e6
@@ -160,10 +166,13 @@ def main():
                        "parallelism": f"frames sharded over {world} GPU(s)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "level pass (pyramid build + select of one launch)",
+                         "kernel": ("level_fused<level 0> (stage+reduce+laplacian+energy+select, "
+                                    "one launch per frame batch)") if tiled else
+                                   "simple impl: all level kernels of one frame",
                          "algorithmic_bytes_per_launch": bytes_level / max(n_level, 1),
                          "avg_launch_ms": ms_level / max(n_level, 1), "launches": n_level},
-            "job_roofline_frac": (24.0 * H * W * total_frames * args.steps / dt_s)
+            "breakdown_ms_per_step": {k: v[0] / args.steps for k, v in prof.items()},
+            "job_roofline_frac": (job_bytes_per_frame * total_frames * args.steps / dt_s)
                                  / (HBM_PEAK_GBS * 1e9 * world),
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -14,7 +14,7 @@ SOURCES = ["capi.hip"]
 DEPS = ["capi.hip", "common.hpp", "kernels_simple.hpp", "kernels_tiled.hpp", "tiled_host.hpp",
         os.path.join(ROOT, "include", "mi355stack.h")]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
-               "-fno-fast-math", "-shared", "-fPIC", "-fvisibility=hidden",
+               "-fno-fast-math", "-fno-slp-vectorize", "-shared", "-fPIC", "-fvisibility=hidden",
                "-Wall", "-Wno-unused-function"]
 
 
@@ -39,7 +39,12 @@ def needs_build():
 def build_extension(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
-    cmd = [_hipcc(), *HIPCC_FLAGS, "-I", os.path.join(ROOT, "include"),
+    extra = []
+    cfg = os.environ.get("MI_TILE_CFG")  # "TH,TW,NT,PAD" -- tuning builds only
+    if cfg:
+        th, tw, nt, pad = cfg.split(",")
+        extra = [f"-DMI_TILE_H={th}", f"-DMI_TILE_W={tw}", f"-DMI_TILE_NT={nt}", f"-DMI_TILE_PAD={pad}"]
+    cmd = [_hipcc(), *HIPCC_FLAGS, *extra, "-I", os.path.join(ROOT, "include"),
            *[os.path.join(CSRC, s) for s in SOURCES], "-o", LIB]
     if verbose:
         print(" ".join(cmd))

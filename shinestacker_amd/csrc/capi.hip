@@ -3,6 +3,7 @@
 #include <stdarg.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -489,11 +490,6 @@ int mi_stack_reset(mi_stack_t* s) {
     MI_HIP(hipStreamSynchronize(s->stream));
     rc = prof_drain(s);
     if (rc) return rc;
-    for (int k = 0; k < MI_PROF_KINDS; ++k) {
-        s->prof_ms[k] = 0;
-        s->prof_n[k] = 0;
-        s->prof_bytes[k] = 0;
-    }
     s->n_pushed = 0;
     s->finished = false;
     return tiled_reset(s);
@@ -671,6 +667,16 @@ int mi_stack_stream(mi_stack_t* s, void** stream) {
 int mi_stack_profile(mi_stack_t* s, int enable) {
     int rc = check_handle(s);
     if (rc) return rc;
+    MI_HIP(hipSetDevice(s->p.device));
+    rc = prof_drain(s);
+    if (rc) return rc;
+    if (enable) {  // (re)enabling starts a fresh accumulation
+        for (int k = 0; k < MI_PROF_KINDS; ++k) {
+            s->prof_ms[k] = 0;
+            s->prof_n[k] = 0;
+            s->prof_bytes[k] = 0;
+        }
+    }
     s->prof = enable != 0;
     return MI_OK;
 }

@@ -19,6 +19,12 @@
 // staging is a linear copy and every thread works on all three channels of its
 // pixels (which the gray conversion needs anyway).
 //
+// Two instantiations per input type: INTERIOR tiles (no coordinate can leave the
+// image: no reflection logic at all, launched over 8x8-tile super-blocks so the
+// tiles an XCD runs concurrently share their halos in that XCD's L2) and BORDER
+// tiles (every coordinate goes through the REFLECT101 maps; a thin frame of
+// tiles plus all tiles of the small levels).
+//
 // Arithmetic is identical, operation by operation, to kernels_simple.hpp and to
 // oracle/: taps of one output are applied in row-major order; interleaving the
 // chains of different outputs does not change any of them.
@@ -26,6 +32,17 @@
 #include "common.hpp"
 
 namespace mi {
+
+// The 25 taps float32(k[i]*k[j]) of the symmetric generating kernel
+// [a0 a1 a2 a1 a0] take only 6 distinct values.
+struct K6 {
+    float c[6];  // (0,0) (0,1) (0,2) (1,1) (1,2) (2,2)
+    __host__ __device__ __forceinline__ float operator()(int ty, int tx) const {
+        int a = ty > 2 ? 4 - ty : ty, b = tx > 2 ? 4 - tx : tx;
+        int lo = a < b ? a : b, hi = a < b ? b : a;
+        return c[lo == 0 ? hi : (lo == 1 ? 2 + hi : 5)];
+    }
+};
 
 struct LevelArgs {
     const void* src;        // level-l images of the batch (TIn for l == 0, else f32)
@@ -35,29 +52,60 @@ struct LevelArgs {
     int nframes;
     int h, w, hn, wn;
     int tiles_x, tiles_y;
+    // interior launch: tiles [ty_lo, ty_hi) x [tx_lo, tx_hi) as super-blocks of SB x SB
+    int ty_lo, ty_hi, tx_lo, tx_hi, sb_x;  // sb_x = super-blocks per row
     float* best_e;          // running state of level l
     float* best_lap;
     int32_t* best_idx;
     int first;              // state holds nothing yet
     int frame_idx0;         // global index of the batch's first frame
-    K25 K;
+    int ablate;             // debug: bit mask of phases to skip (timing studies only)
+    K6 K;
 };
+
+constexpr int SB = 8;  // super-block edge in tiles (64 tiles = one XCD's concurrent set)
+
+// tile configuration (compile-time; tools/tune.sh builds variants with -D)
+#ifndef MI_TILE_H
+#define MI_TILE_H 32
+#endif
+#ifndef MI_TILE_W
+#define MI_TILE_W 32
+#endif
+#ifndef MI_TILE_NT
+#define MI_TILE_NT 256
+#endif
+#ifndef MI_TILE_PAD
+#define MI_TILE_PAD 1
+#endif
 
 template <int TH_, int TW_>
 struct TileGeom {
     static constexpr int TH = TH_, TW = TW_;
-    static constexpr int NT = 256;                    // threads per workgroup
+    static constexpr int NT = MI_TILE_NT;             // threads per workgroup
+    static constexpr bool PAD = MI_TILE_PAD != 0;     // bank-conflict padding of the LDS images
     static constexpr int GH = TH + 12, GW = TW + 12;  // G_l patch (pixels)
-    static constexpr int GS = GW * 3;                 // row stride (floats)
+    static constexpr int GD = GW * 3;                 // data floats per patch row
+    // sG row stride: multiple of 4 (ds_read_b128 alignment) and = 28 (mod 32), so that the
+    // reduce phase's 16-lane b128 groups -- lanes step 12 dwords along a row and wrap to the
+    // next output row (2 patch rows, 2*GS = 56 mod 64) after NW/2 items -- hit 16 distinct
+    // 4-bank slots
+    static constexpr int GS = PAD ? ((GD - 28 + 31) / 32) * 32 + 28 : GD;
     static constexpr int NH = TH / 2 + 4, NW = TW / 2 + 4;
-    static constexpr int NS = NW * 3;
+    // sN row stride = 16 (mod 32): the 3-dword lane stride of the laplacian phase then maps
+    // the two quad rows of a 32-lane group onto disjoint banks
+    static constexpr int NS = PAD ? ((NW * 3 - 16 + 31) / 32) * 32 + 16 : NW * 3;
     static constexpr int QH = TH + 4, QW = TW + 4;
-    static constexpr int QS = QW;
-    static constexpr int G_ELEMS = GH * GS;
-    static constexpr int NPRE = (G_ELEMS + NT - 1) / NT;  // staged elements per thread
+    // Q row stride: 2*QS = 32 (mod 64) so the two quad rows a 32-lane group reads
+    // with ds_read_b64 fall into disjoint bank halves
+    static constexpr int QS = PAD ? ((QW + 15) / 32) * 32 + 16 : QW;
+    static constexpr int PR = GD / 2;                     // element pairs per patch row
+    static constexpr int RPP = NT / PR;                   // patch rows staged per pass
+    static constexpr int NPRE = (GH + RPP - 1) / RPP;     // passes = staged pairs per thread
     static constexpr int NQ = (TH / 2) * (TW / 2) / NT;   // owned 2x2 quads per thread
     static constexpr int LDS_FLOATS = GH * GS + NH * NS + QH * QS;
     static_assert((TH / 2) * (TW / 2) % NT == 0, "tile must split into whole quads per thread");
+    static_assert(GS % 4 == 0 && GS >= GD && NS >= NW * 3 && QS >= QW && GD % 2 == 0 && RPP >= 1, "layout");
 };
 
 // clamp(reflect101(v)) -- cells whose overshoot exceeds 2 are never consumed by a
@@ -75,40 +123,105 @@ __device__ __forceinline__ int map_expand_src(int i, int n) {
 }
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
-template <typename TIn, bool FMA, int TH, int TW>
-__global__ __launch_bounds__(256) void level_fused(LevelArgs a) {
+// native vector types: one IR load/store each, so the access width is what we wrote
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+// full-rate 24-bit multiply for LDS/pixel index arithmetic (v_mul_lo_u32 is quarter rate)
+__device__ __forceinline__ int mul24(int a, int b) { return __mul24(a, b); }
+
+// two consecutive elements -> two floats; `p` is aligned to 2 elements
+__device__ __forceinline__ void load_pair(const float* p, float& a, float& b) {
+    v2f v = *reinterpret_cast<const v2f*>(p);
+    a = v.x;
+    b = v.y;
+}
+__device__ __forceinline__ void load_pair(const uint16_t* p, float& a, float& b) {
+    uint32_t v = *reinterpret_cast<const uint32_t*>(p);
+    a = (float)(v & 0xffffu);
+    b = (float)(v >> 16);
+}
+__device__ __forceinline__ void load_pair(const uint8_t* p, float& a, float& b) {
+    uint16_t v = *reinterpret_cast<const uint16_t*>(p);
+    a = (float)(v & 0xffu);
+    b = (float)(v >> 8);
+}
+
+// keeps the compiler from hoisting LDS loads across this point (bounds live ranges)
+#define MI_LDS_FENCE() asm volatile("" ::: "memory")
+
+// 16-byte LDS load that stays a ds_read_b128: the empty asm pins the four lanes of
+// the result, so the compiler cannot re-split the access into narrower reads (it
+// otherwise does, to pre-pair operands for v_pk_fma_f32, and the narrow reads at a
+// 12-dword lane stride are 4-way bank conflicted).
+__device__ __forceinline__ v4f lds_load4(const float* p) {
+    return *reinterpret_cast<const v4f*>(p);
+}
+// global access as uniform base + 32-bit lane byte offset (one VGPR of addressing)
+template <typename T>
+__device__ __forceinline__ void gstore32(T* base, uint32_t byte_off, T v) {
+    *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + byte_off) = v;
+}
+__device__ __forceinline__ v2f lds_load2(const float* p) {
+    return *reinterpret_cast<const v2f*>(p);
+}
+__device__ __forceinline__ void lds_store2(float* p, float a, float b) {
+    v2f v = {a, b};
+    *reinterpret_cast<v2f*>(p) = v;
+}
+
+template <typename TIn, bool FMA, bool INTERIOR, int TH, int TW>
+__global__ __launch_bounds__(MI_TILE_NT) void level_fused(LevelArgs a) {
     using G = TileGeom<TH, TW>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sG = smem;
     float* sN = sG + G::GH * G::GS;
     float* sQ = sN + G::NH * G::NS;
-
-    // XCD-aware tile order: block b runs on XCD b % 8; give every XCD one
-    // contiguous band of tiles so neighbouring tiles share an L2.
-    const int ntiles = a.tiles_x * a.tiles_y;
-    const int per_xcd = (ntiles + 7) >> 3;
-    const int tile = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    if (tile >= ntiles) return;
-    const int tyi = tile / a.tiles_x, txi = tile - tyi * a.tiles_x;
-    const int y0 = tyi * TH, x0 = txi * TW;
     const int tid = threadIdx.x;
     const int h = a.h, w = a.w, hn = a.hn, wn = a.wn;
-    const bool interior = (y0 >= 6) && (x0 >= 6) && (y0 + TH + 6 <= h) && (x0 + TW + 6 <= w);
 
-    // ---- per-thread constants of the staging copy: global element offsets
-    int goff[G::NPRE];
-#pragma unroll
-    for (int n = 0; n < G::NPRE; ++n) {
-        int e = tid + n * G::NT;
-        int r = e / G::GS, k = e - r * G::GS;
-        int col = k / 3, c = k - col * 3;
-        int gy = map_clamp(y0 - 6 + r, h), gx = map_clamp(x0 - 6 + col, w);
-        goff[n] = (e < G::G_ELEMS) ? (gy * w + gx) * 3 + c : -1;
+    // ---- which tile?
+    int tyi, txi;
+    if constexpr (INTERIOR) {
+        // Block b runs on XCD b % 8.  Super-block S = 8 * (slot / 64) + xcd: the 64 tiles an
+        // XCD works on at a time form one 8x8 square, whose inner halos hit that XCD's L2.
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int S = (slot >> 6) * 8 + xcd, within = slot & 63;
+        const int sby = S / a.sb_x, sbx = S - sby * a.sb_x;
+        tyi = a.ty_lo + sby * SB + (within >> 3);
+        txi = a.tx_lo + sbx * SB + (within & 7);
+        if (tyi >= a.ty_hi || txi >= a.tx_hi) return;
+    } else {
+        // border frame: rows above/below the interior rectangle, then the side columns
+        const int nyi = a.ty_hi - a.ty_lo, nxi = a.tx_hi - a.tx_lo;
+        int t = blockIdx.x;
+        const int top = a.ty_lo * a.tiles_x;
+        const int bot = (a.tiles_y - a.ty_hi) * a.tiles_x;
+        if (nyi <= 0 || nxi <= 0) {  // no interior at all: plain raster
+            tyi = t / a.tiles_x;
+            txi = t - tyi * a.tiles_x;
+        } else if (t < top) {
+            tyi = t / a.tiles_x;
+            txi = t - tyi * a.tiles_x;
+        } else if (t < top + bot) {
+            t -= top;
+            tyi = a.ty_hi + t / a.tiles_x;
+            txi = t - (t / a.tiles_x) * a.tiles_x;
+        } else {
+            t -= top + bot;
+            const int side = a.tiles_x - nxi;  // side tiles per interior row
+            tyi = a.ty_lo + t / side;
+            int k = t - (t / side) * side;
+            txi = k < a.tx_lo ? k : a.tx_hi + (k - a.tx_lo);
+        }
+        if (tyi >= a.tiles_y || txi >= a.tiles_x) return;
     }
+    const int y0 = tyi * TH, x0 = txi * TW;
 
-    // ---- running state of the thread's own quads
-    float bE[G::NQ][4], bL[G::NQ][4][3];
-    int bI[G::NQ][4];
+    // ---- running state of the thread's own quads.  Only the running maximum lives in
+    // registers; the winner's laplacian and index go straight to global memory when a pixel
+    // finds a new maximum (about ln(N) times per pixel over an N-frame stack).
+    float bE[G::NQ][4];
     int qoy[G::NQ], qox[G::NQ];
 #pragma unroll
     for (int q = 0; q < G::NQ; ++q) {
@@ -118,160 +231,185 @@ __global__ __launch_bounds__(256) void level_fused(LevelArgs a) {
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             int y = y0 + 2 * qoy[q] + (p >> 1), x = x0 + 2 * qox[q] + (p & 1);
-            bool valid = y < h && x < w;
-            if (!a.first && valid) {
-                size_t px = (size_t)y * w + x;
-                bE[q][p] = a.best_e[px];
-                bI[q][p] = a.best_idx[px];
-                bL[q][p][0] = a.best_lap[px * 3 + 0];
-                bL[q][p][1] = a.best_lap[px * 3 + 1];
-                bL[q][p][2] = a.best_lap[px * 3 + 2];
-            } else {
-                bE[q][p] = -1.0f;  // every energy is >= 0: the first frame always wins
-                bI[q][p] = -1;
-                bL[q][p][0] = bL[q][p][1] = bL[q][p][2] = 0.f;
-            }
+            bool valid = INTERIOR || (y < h && x < w);
+            // every energy is >= 0: with -1 the first frame always wins
+            bE[q][p] = (!a.first && valid) ? a.best_e[(size_t)y * w + x] : -1.0f;
         }
     }
 
-    float pre[G::NPRE];
+    // ---- staging: pass n copies patch rows [n*RPP, (n+1)*RPP); a thread always handles the
+    // same element pair of "its" row, so global and LDS offsets advance by constants.
+    float pre[G::NPRE][2];
+    const bool pair_ok = (w & 1) == 0;  // every patch row then starts on an even element
+    const int srow = tid / G::PR, sk2 = tid - srow * G::PR;
+    const bool sact = tid < G::RPP * G::PR;
+    // interior only: byte offsets inside a frame (uniform base + 32-bit lane offset)
+    const uint32_t goff0 = (uint32_t)(((y0 - 6 + srow) * w + (x0 - 6)) * 3 + 2 * sk2) * (uint32_t)sizeof(TIn);
+    const uint32_t gstep = (uint32_t)(G::RPP * w * 3) * (uint32_t)sizeof(TIn);
     auto prefetch = [&](int b) {
-        const TIn* fr = (const TIn*)((const char*)a.src + (size_t)b * a.src_stride);
+        const char* frb = (const char*)a.src + (size_t)b * a.src_stride;
+        const TIn* fr = (const TIn*)frb;
+        if (!sact) return;
+        if constexpr (INTERIOR) {
+            if (pair_ok) {
 #pragma unroll
-        for (int n = 0; n < G::NPRE; ++n) pre[n] = goff[n] >= 0 ? to_f32(fr[goff[n]]) : 0.f;
+                for (int n = 0; n < G::NPRE; ++n)
+                    if ((n + 1) * G::RPP <= G::GH || srow + n * G::RPP < G::GH)
+                        load_pair((const TIn*)(frb + (size_t)n * gstep + goff0), pre[n][0], pre[n][1]);
+            } else {
+#pragma unroll
+                for (int n = 0; n < G::NPRE; ++n)
+                    if ((n + 1) * G::RPP <= G::GH || srow + n * G::RPP < G::GH) {
+                        const TIn* p = (const TIn*)(frb + (size_t)n * gstep + goff0);
+                        pre[n][0] = to_f32(p[0]);
+                        pre[n][1] = to_f32(p[1]);
+                    }
+            }
+        } else {
+#pragma unroll
+            for (int n = 0; n < G::NPRE; ++n) {
+                const int r = srow + n * G::RPP;
+                if (r < G::GH) {
+                    const int gy = map_clamp(y0 - 6 + r, h);
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        int k = 2 * sk2 + s, col = k / 3, c = k - col * 3;
+                        int gx = map_clamp(x0 - 6 + col, w);
+                        pre[n][s] = to_f32(fr[((size_t)gy * w + gx) * 3 + c]);
+                    }
+                }
+            }
+        }
     };
     prefetch(0);
 
+    const K6 K = a.K;
     for (int b = 0; b < a.nframes; ++b) {
+        // Derive every per-thread coordinate of this iteration from a laundered copy of the
+        // thread id: the compiler then recomputes the (cheap) addresses per frame instead of
+        // keeping dozens of hoisted loop invariants alive, which would cost a wave of occupancy.
+        int ltid = tid;
+        asm volatile("" : "+v"(ltid));
         // ---------------- stage
+        if (sact) {
 #pragma unroll
-        for (int n = 0; n < G::NPRE; ++n) {
-            int e = tid + n * G::NT;
-            if (e < G::G_ELEMS) sG[e] = pre[n];
+            for (int n = 0; n < G::NPRE; ++n)
+                if ((n + 1) * G::RPP <= G::GH || srow + n * G::RPP < G::GH)
+                    lds_store2(sG + mul24(srow + n * G::RPP, G::GS) + 2 * sk2, pre[n][0], pre[n][1]);
         }
         __syncthreads();
-        if (b + 1 < a.nframes) prefetch(b + 1);
+        if (b + 1 < a.nframes && !(a.ablate & 16)) prefetch(b + 1);
 
-        // ---------------- reduce: 2x2 output blocks, all three channels
-        {
-            constexpr int BY = G::NH / 2, BX = G::NW / 2;
-            for (int it = tid; it < BY * BX; it += G::NT) {
-                int by = it / BX, bx = it - by * BX;
-                int ri = 2 * by, rj = 2 * bx;  // local sN coordinates of the block
-                float acc[2][2][3];
+        // ---------------- reduce: items of 1 output row x 2 output pixels x 3 channels
+        if (!(a.ablate & 1)) {
+            constexpr int BX = G::NW / 2;
+            for (int it = ltid; it < G::NH * BX; it += G::NT) {
+                const int ri = it / BX, bx = it - ri * BX, rj = 2 * bx;
+                float acc[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+                if constexpr (INTERIOR) {
+                    // input rows 2ri .. 2ri+4, pixels 2rj .. 2rj+6: 21 floats, 16-byte aligned
+                    const float* p0 = sG + mul24(2 * ri, G::GS) + 2 * rj * 3;
 #pragma unroll
-                for (int u = 0; u < 2; ++u)
+                    for (int ty = 0; ty < 5; ++ty) {
+                        float v[24];
 #pragma unroll
-                    for (int v = 0; v < 2; ++v) acc[u][v][0] = acc[u][v][1] = acc[u][v][2] = 0.f;
-                if (interior) {
-                    // input rows 2ri .. 2ri+6, pixels 2rj .. 2rj+6 (21 floats per row)
-#pragma unroll
-                    for (int rr = 0; rr < 7; ++rr) {
-                        const float* row = sG + (2 * ri + rr) * G::GS + 2 * rj * 3;
-                        float v[21];
-#pragma unroll
-                        for (int t = 0; t < 21; ++t) v[t] = row[t];
-#pragma unroll
-                        for (int u = 0; u < 2; ++u) {
-                            int ty = rr - 2 * u;  // tap row of output row u
-                            if (ty < 0 || ty > 4) continue;
-#pragma unroll
-                            for (int vv = 0; vv < 2; ++vv)
-#pragma unroll
-                                for (int tx = 0; tx < 5; ++tx) {
-                                    float k = a.K.k[ty * 5 + tx];
-#pragma unroll
-                                    for (int c = 0; c < 3; ++c)
-                                        acc[u][vv][c] = mac<FMA>(k, v[(2 * vv + tx) * 3 + c], acc[u][vv][c]);
-                                }
+                        for (int t = 0; t < 5; ++t) {
+                            v4f q4 = lds_load4(p0 + ty * G::GS + 4 * t);
+                            v[4 * t] = q4.x; v[4 * t + 1] = q4.y; v[4 * t + 2] = q4.z; v[4 * t + 3] = q4.w;
                         }
+                        v[20] = p0[ty * G::GS + 20];
+#pragma unroll
+                        for (int vv = 0; vv < 2; ++vv)
+#pragma unroll
+                            for (int tx = 0; tx < 5; ++tx) {
+                                const float k = K(ty, tx);
+#pragma unroll
+                                for (int c = 0; c < 3; ++c)
+                                    acc[vv][c] = mac<FMA>(k, v[(2 * vv + tx) * 3 + c], acc[vv][c]);
+                            }
+                        MI_LDS_FENCE();
                     }
                 } else {
+                    const int im = map_expand_src(y0 / 2 - 2 + ri, hn);
 #pragma unroll
-                    for (int u = 0; u < 2; ++u)
+                    for (int vv = 0; vv < 2; ++vv) {
+                        const int jm = map_expand_src(x0 / 2 - 2 + rj + vv, wn);
+                        for (int ty = 0; ty < 5; ++ty) {
+                            // rows/cols beyond the image already hold reflected data (staging)
+                            const int r = clampi(2 * im - 2 + ty - (y0 - 6), 0, G::GH - 1);
 #pragma unroll
-                        for (int vv = 0; vv < 2; ++vv) {
-                            int im = map_expand_src(y0 / 2 - 2 + ri + u, hn);
-                            int jm = map_expand_src(x0 / 2 - 2 + rj + vv, wn);
-                            for (int ty = 0; ty < 5; ++ty) {
-                                int r = clampi(2 * im - 2 + ty - (y0 - 6), 0, G::GH - 1);
-                                // rows beyond the image already hold reflected data (staging)
-                                for (int tx = 0; tx < 5; ++tx) {
-                                    int cc = clampi(2 * jm - 2 + tx - (x0 - 6), 0, G::GW - 1);
-                                    float k = a.K.k[ty * 5 + tx];
-                                    const float* p = sG + r * G::GS + cc * 3;
+                            for (int tx = 0; tx < 5; ++tx) {
+                                const int cc = clampi(2 * jm - 2 + tx - (x0 - 6), 0, G::GW - 1);
+                                const float k = K(ty, tx);
+                                const float* p = sG + r * G::GS + cc * 3;
 #pragma unroll
-                                    for (int c = 0; c < 3; ++c) acc[u][vv][c] = mac<FMA>(k, p[c], acc[u][vv][c]);
-                                }
+                                for (int c = 0; c < 3; ++c) acc[vv][c] = mac<FMA>(k, p[c], acc[vv][c]);
                             }
                         }
+                    }
                 }
-#pragma unroll
-                for (int u = 0; u < 2; ++u)
-#pragma unroll
-                    for (int vv = 0; vv < 2; ++vv)
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) sN[(ri + u) * G::NS + (rj + vv) * 3 + c] = acc[u][vv][c];
+                float* o = sN + mul24(ri, G::NS) + rj * 3;  // 6 floats, 8-byte aligned
+                lds_store2(o, acc[0][0], acc[0][1]);
+                lds_store2(o + 2, acc[0][2], acc[1][0]);
+                lds_store2(o + 4, acc[1][1], acc[1][2]);
             }
         }
         __syncthreads();
 
         // ---------------- store the tile centre of G_{l+1}
-        {
+        if (!(a.ablate & 2)) {
             float* gout = a.gnext + (size_t)b * a.gnext_stride;
             const int i0 = y0 / 2, j0 = x0 / 2;
             constexpr int CW = (TW / 2) * 3;
-            for (int e = tid; e < (TH / 2) * CW; e += G::NT) {
-                int r = e / CW, k = e - r * CW;
-                int i = i0 + r, j = j0 + k / 3;
-                if (i < hn && j < wn) gout[((size_t)i * wn + j0) * 3 + k] = sN[(r + 2) * G::NS + 6 + k];
+            for (int e = ltid; e < (TH / 2) * CW; e += G::NT) {
+                const int r = e / CW, k = e - r * CW;
+                const int i = i0 + r, j = j0 + k / 3;
+                if (INTERIOR || (i < hn && j < wn))
+                    gstore32(gout, (uint32_t)(mul24(mul24(i, wn) + j0, 3) + k) * 4u, sN[mul24(r + 2, G::NS) + 6 + k]);
             }
         }
 
         // ---------------- laplacian + Q on (TH+4) x (TW+4), as 2x2 quads
         float myLap[G::NQ][4][3];
-        {
+#pragma unroll
+        for (int q = 0; q < G::NQ; ++q)
+#pragma unroll
+            for (int p = 0; p < 4; ++p) myLap[q][p][0] = myLap[q][p][1] = myLap[q][p][2] = 0.f;
+        if (!(a.ablate & 4)) {
             constexpr int QY = TH / 2 + 2, QX = TW / 2 + 2;
             auto do_quad = [&](int qy, int qx, float (*keep)[3]) {
-                // rows: even cell then odd cell of the quad, mapped into the image
-                int ye, yo, xe, xo;
-                if (interior) {
-                    ye = y0 - 2 + 2 * qy; yo = ye + 1;
-                    xe = x0 - 2 + 2 * qx; xo = xe + 1;
+                // local sN rows/cols of the expand source, local sG rows/cols of the cells
+                int re, ro, ce, co, gre, gro, gce, gco;
+                if constexpr (INTERIOR) {
+                    re = ro = qy + 1;
+                    ce = co = qx + 1;
+                    gre = 2 * qy + 4; gro = gre + 1;
+                    gce = 2 * qx + 4; gco = gce + 1;
                 } else {
-                    ye = map_clamp(y0 - 2 + 2 * qy, h); yo = map_clamp(y0 - 1 + 2 * qy, h);
-                    xe = map_clamp(x0 - 2 + 2 * qx, w); xo = map_clamp(x0 - 1 + 2 * qx, w);
-                }
-                // expand-source rows/cols (local sN coordinates)
-                int re = (ye >> 1) - (y0 / 2 - 2), ro = ((yo - 1) >> 1) - (y0 / 2 - 2);
-                int ce = (xe >> 1) - (x0 / 2 - 2), co = ((xo - 1) >> 1) - (x0 / 2 - 2);
-                if (!interior) {
-                    re = clampi(re, 1, G::NH - 2); ro = clampi(ro, 0, G::NH - 2);
-                    ce = clampi(ce, 1, G::NW - 2); co = clampi(co, 0, G::NW - 2);
-                }
-                // G_l cells (local sG coordinates)
-                int gre = ye - (y0 - 6), gro = yo - (y0 - 6), gce = xe - (x0 - 6), gco = xo - (x0 - 6);
-                if (!interior) {
-                    gre = clampi(gre, 0, G::GH - 1); gro = clampi(gro, 0, G::GH - 1);
-                    gce = clampi(gce, 0, G::GW - 1); gco = clampi(gco, 0, G::GW - 1);
+                    const int ye = map_clamp(y0 - 2 + 2 * qy, h), yo = map_clamp(y0 - 1 + 2 * qy, h);
+                    const int xe = map_clamp(x0 - 2 + 2 * qx, w), xo = map_clamp(x0 - 1 + 2 * qx, w);
+                    re = clampi((ye >> 1) - (y0 / 2 - 2), 1, G::NH - 2);
+                    ro = clampi(((yo - 1) >> 1) - (y0 / 2 - 2), 0, G::NH - 2);
+                    ce = clampi((xe >> 1) - (x0 / 2 - 2), 1, G::NW - 2);
+                    co = clampi(((xo - 1) >> 1) - (x0 / 2 - 2), 0, G::NW - 2);
+                    gre = clampi(ye - (y0 - 6), 0, G::GH - 1); gro = clampi(yo - (y0 - 6), 0, G::GH - 1);
+                    gce = clampi(xe - (x0 - 6), 0, G::GW - 1); gco = clampi(xo - (x0 - 6), 0, G::GW - 1);
                 }
                 float see[3] = {0, 0, 0}, seo[3] = {0, 0, 0}, soe[3] = {0, 0, 0}, soo[3] = {0, 0, 0};
-                const K25& K = a.K;
-                // (even row, even col): taps ty in {0,2,4} x tx in {0,2,4}
-                // (even row, odd  col): ty in {0,2,4} x tx in {1,3}
+                // (even row, even col): taps ty in {0,2,4} x tx in {0,2,4};  (even, odd): tx in {1,3}
 #pragma unroll
                 for (int ar = 0; ar < 3; ++ar) {
-                    const float* nrow = sN + (re - 1 + ar) * G::NS;
+                    const float* nrow = sN + mul24(re - 1 + ar, G::NS);
 #pragma unroll
                     for (int ac = 0; ac < 3; ++ac) {
-                        float k = K.k[(2 * ar) * 5 + 2 * ac];
+                        const float k = K(2 * ar, 2 * ac);
                         const float* p = nrow + (ce - 1 + ac) * 3;
 #pragma unroll
                         for (int c = 0; c < 3; ++c) see[c] = mac<FMA>(k, p[c], see[c]);
                     }
 #pragma unroll
                     for (int ac = 0; ac < 2; ++ac) {
-                        float k = K.k[(2 * ar) * 5 + 2 * ac + 1];
+                        const float k = K(2 * ar, 2 * ac + 1);
                         const float* p = nrow + (co + ac) * 3;
 #pragma unroll
                         for (int c = 0; c < 3; ++c) seo[c] = mac<FMA>(k, p[c], seo[c]);
@@ -280,26 +418,26 @@ __global__ __launch_bounds__(256) void level_fused(LevelArgs a) {
                 // (odd row, *): ty in {1,3}
 #pragma unroll
                 for (int ar = 0; ar < 2; ++ar) {
-                    const float* nrow = sN + (ro + ar) * G::NS;
+                    const float* nrow = sN + mul24(ro + ar, G::NS);
 #pragma unroll
                     for (int ac = 0; ac < 3; ++ac) {
-                        float k = K.k[(2 * ar + 1) * 5 + 2 * ac];
+                        const float k = K(2 * ar + 1, 2 * ac);
                         const float* p = nrow + (ce - 1 + ac) * 3;
 #pragma unroll
                         for (int c = 0; c < 3; ++c) soe[c] = mac<FMA>(k, p[c], soe[c]);
                     }
 #pragma unroll
                     for (int ac = 0; ac < 2; ++ac) {
-                        float k = K.k[(2 * ar + 1) * 5 + 2 * ac + 1];
+                        const float k = K(2 * ar + 1, 2 * ac + 1);
                         const float* p = nrow + (co + ac) * 3;
 #pragma unroll
                         for (int c = 0; c < 3; ++c) soo[c] = mac<FMA>(k, p[c], soo[c]);
                     }
                 }
-                const float* gee = sG + gre * G::GS + gce * 3;
-                const float* geo = sG + gre * G::GS + gco * 3;
-                const float* goe = sG + gro * G::GS + gce * 3;
-                const float* goo = sG + gro * G::GS + gco * 3;
+                const float* gee = sG + mul24(gre, G::GS) + gce * 3;
+                const float* geo = sG + mul24(gre, G::GS) + gco * 3;
+                const float* goe = sG + mul24(gro, G::GS) + gce * 3;
+                const float* goo = sG + mul24(gro, G::GS) + gco * 3;
                 float l[4][3];
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
@@ -308,23 +446,30 @@ __global__ __launch_bounds__(256) void level_fused(LevelArgs a) {
                     l[2][c] = goe[c] - 4.0f * soe[c];
                     l[3][c] = goo[c] - 4.0f * soo[c];
                 }
+                float qv[4];
 #pragma unroll
                 for (int p = 0; p < 4; ++p) {
                     float gr = gray_of<FMA>(l[p][0], l[p][1], l[p][2]);
-                    sQ[(2 * qy + (p >> 1)) * G::QS + 2 * qx + (p & 1)] = gr * gr;
+                    qv[p] = gr * gr;
                     if (keep) {
                         keep[p][0] = l[p][0];
                         keep[p][1] = l[p][1];
                         keep[p][2] = l[p][2];
                     }
                 }
+                float* qo = sQ + mul24(2 * qy, G::QS) + 2 * qx;
+                lds_store2(qo, qv[0], qv[1]);
+                lds_store2(qo + G::QS, qv[2], qv[3]);
             };
             // own quads (tile interior) ...
 #pragma unroll
-            for (int q = 0; q < G::NQ; ++q) do_quad(qoy[q] + 1, qox[q] + 1, myLap[q]);
+            for (int q = 0; q < G::NQ; ++q) {
+                const int qi = ltid + q * G::NT;
+                do_quad(qi / (TW / 2) + 1, qi % (TW / 2) + 1, myLap[q]);
+            }
             // ... and the halo ring, spread over the first threads
             constexpr int RING = QY * QX - (TH / 2) * (TW / 2);
-            for (int it = tid; it < RING; it += G::NT) {
+            for (int it = ltid; it < RING; it += G::NT) {
                 int qy, qx;
                 if (it < QX) { qy = 0; qx = it; }
                 else if (it < 2 * QX) { qy = QY - 1; qx = it - QX; }
@@ -339,36 +484,39 @@ __global__ __launch_bounds__(256) void level_fused(LevelArgs a) {
         __syncthreads();
 
         // ---------------- energy of the own quads + running first-max
-        {
+        if (!(a.ablate & 8)) {
             const int fidx = a.frame_idx0 + b;
 #pragma unroll
             for (int q = 0; q < G::NQ; ++q) {
                 float e[4] = {0.f, 0.f, 0.f, 0.f};
-                const float* base = sQ + (2 * qoy[q]) * G::QS + 2 * qox[q];
+                const int qi = ltid + q * G::NT, oy = qi / (TW / 2), ox = qi % (TW / 2);
+                const float* base = sQ + mul24(2 * oy, G::QS) + 2 * ox;  // 8-byte aligned
 #pragma unroll
                 for (int rr = 0; rr < 6; ++rr) {
-                    float v[6];
-#pragma unroll
-                    for (int t = 0; t < 6; ++t) v[t] = base[rr * G::QS + t];
+                    const float* rp = base + rr * G::QS;
+                    v2f v0 = lds_load2(rp), v1 = lds_load2(rp + 2), v2 = lds_load2(rp + 4);
+                    const float v[6] = {v0.x, v0.y, v1.x, v1.y, v2.x, v2.y};
 #pragma unroll
                     for (int dy = 0; dy < 2; ++dy) {
-                        int ty = rr - dy;
+                        const int ty = rr - dy;
                         if (ty < 0 || ty > 4) continue;
 #pragma unroll
                         for (int dx = 0; dx < 2; ++dx)
 #pragma unroll
                             for (int tx = 0; tx < 5; ++tx)
-                                e[dy * 2 + dx] = mac<FMA>(a.K.k[ty * 5 + tx], v[dx + tx], e[dy * 2 + dx]);
+                                e[dy * 2 + dx] = mac<FMA>(K(ty, tx), v[dx + tx], e[dy * 2 + dx]);
                     }
                 }
 #pragma unroll
                 for (int p = 0; p < 4; ++p) {
-                    if (e[p] > bE[q][p]) {
+                    const int y = y0 + 2 * oy + (p >> 1), x = x0 + 2 * ox + (p & 1);
+                    if (e[p] > bE[q][p] && (INTERIOR || (y < h && x < w))) {
                         bE[q][p] = e[p];
-                        bI[q][p] = fidx;
-                        bL[q][p][0] = myLap[q][p][0] + 0.0f;  // -0 -> +0 (np.where sum)
-                        bL[q][p][1] = myLap[q][p][1] + 0.0f;
-                        bL[q][p][2] = myLap[q][p][2] + 0.0f;
+                        const uint32_t px = (uint32_t)(mul24(y, w) + x);
+                        gstore32(a.best_idx, px * 4u, fidx);
+                        gstore32(a.best_lap, px * 12u, myLap[q][p][0] + 0.0f);  // -0 -> +0 (np.where sum)
+                        gstore32(a.best_lap, px * 12u + 4u, myLap[q][p][1] + 0.0f);
+                        gstore32(a.best_lap, px * 12u + 8u, myLap[q][p][2] + 0.0f);
                     }
                 }
             }
@@ -378,20 +526,13 @@ __global__ __launch_bounds__(256) void level_fused(LevelArgs a) {
         // rewritten only after the next iteration's two barriers.
     }
 
-    // ---- write the running state back
+    // ---- write the running maxima back
 #pragma unroll
     for (int q = 0; q < G::NQ; ++q)
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             int y = y0 + 2 * qoy[q] + (p >> 1), x = x0 + 2 * qox[q] + (p & 1);
-            if (y < h && x < w) {
-                size_t px = (size_t)y * w + x;
-                a.best_e[px] = bE[q][p];
-                a.best_idx[px] = bI[q][p];
-                a.best_lap[px * 3 + 0] = bL[q][p][0];
-                a.best_lap[px * 3 + 1] = bL[q][p][1];
-                a.best_lap[px * 3 + 2] = bL[q][p][2];
-            }
+            if (INTERIOR || (y < h && x < w)) a.best_e[(size_t)y * w + x] = bE[q][p];
         }
 }
 

@@ -4,7 +4,7 @@
 
 namespace mi {
 
-constexpr int TILE_H = 32, TILE_W = 32;
+constexpr int TILE_H = MI_TILE_H, TILE_W = MI_TILE_W;
 
 struct TiledState {
     int bcap = 0;                // frames per fused launch
@@ -70,6 +70,12 @@ const float* tiled_last_gauss(mi_stack* s, int level) {
     return t->Gb[level] + (size_t)last * t->gstride[level];
 }
 
+template <typename Kern>
+int set_lds_once(Kern kern, size_t lds) {
+    MI_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    return MI_OK;
+}
+
 template <typename TIn, bool FMA>
 int launch_level(mi_stack* s, int l, const void* src, size_t src_stride, int nb) {
     using Gm = TileGeom<TILE_H, TILE_W>;
@@ -86,27 +92,52 @@ int launch_level(mi_stack* s, int l, const void* src, size_t src_stride, int nb)
     a.wn = s->lw[l + 1];
     a.tiles_x = cdiv(a.w, TILE_W);
     a.tiles_y = cdiv(a.h, TILE_H);
+    // interior tiles: the whole 6-pixel-haloed patch lies inside the image
+    a.ty_lo = cdiv(6, TILE_H);
+    a.tx_lo = cdiv(6, TILE_W);
+    a.ty_hi = (a.h - 6) / TILE_H;
+    a.tx_hi = (a.w - 6) / TILE_W;
+    int nyi = a.ty_hi - a.ty_lo, nxi = a.tx_hi - a.tx_lo;
+    if (nyi <= 0 || nxi <= 0) {
+        a.ty_lo = a.ty_hi = a.tx_lo = a.tx_hi = 0;
+        nyi = nxi = 0;
+    }
+    a.sb_x = nxi > 0 ? cdiv(nxi, SB) : 1;
     a.best_e = s->bestE[l];
     a.best_lap = s->bestLap[l];
     a.best_idx = s->bestIdx[l];
     a.first = s->n_pushed == 0;
     a.frame_idx0 = s->first_index + s->n_pushed;
-    a.K = s->K;
-    const int ntiles = a.tiles_x * a.tiles_y;
-    const int per_xcd = (ntiles + 7) / 8;
+    for (int i = 0; i < 3; ++i)
+        for (int j = i; j < 3; ++j) a.K.c[i == 0 ? j : (i == 1 ? 2 + j : 5)] = s->K.k[i * 5 + j];
+    {
+        const char* ab = getenv("MI_ABLATE");  // timing studies only; results are wrong when set
+        a.ablate = ab ? atoi(ab) : 0;
+    }
     const size_t lds = (size_t)Gm::LDS_FLOATS * sizeof(float);
-    auto kern = level_fused<TIn, FMA, TILE_H, TILE_W>;
+    auto kin = level_fused<TIn, FMA, true, TILE_H, TILE_W>;
+    auto kbd = level_fused<TIn, FMA, false, TILE_H, TILE_W>;
     static thread_local bool attr_set = false;
     if (!attr_set) {
-        MI_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        int rc;
+        if ((rc = set_lds_once(kin, lds)) || (rc = set_lds_once(kbd, lds))) return rc;
         attr_set = true;
     }
-    // algorithmic bytes of this launch, SURVEY.md 8(d) attribution: read G_l once,
+    // algorithmic bytes of this level pass, SURVEY.md 8(d) attribution: read G_l once,
     // write G_{l+1} once, read G_{l+1} once as the expand source.
-    double bytes = ((double)(l == 0 ? dtype_size(s->p.in_dtype) : 4) * 3.0 * a.h * a.w +
-                    24.0 * a.hn * a.wn) * nb;
-    ProfScope ps(s, l == 0 ? MI_PROF_LEVEL0 : MI_PROF_LEVEL, bytes);
-    hipLaunchKernelGGL(kern, dim3(per_xcd * 8), dim3(256), lds, s->stream, a);
+    const double bytes = ((double)(l == 0 ? dtype_size(s->p.in_dtype) : 4) * 3.0 * a.h * a.w +
+                          24.0 * a.hn * a.wn) * nb;
+    const double frac_in = (double)nyi * TILE_H * nxi * TILE_W / ((double)a.h * a.w);
+    if (nyi > 0) {
+        const int nsb = a.sb_x * cdiv(nyi, SB);
+        ProfScope ps(s, l == 0 ? MI_PROF_LEVEL0 : MI_PROF_LEVEL, bytes * frac_in);
+        hipLaunchKernelGGL(kin, dim3(cdiv(nsb, 8) * 8 * SB * SB), dim3(MI_TILE_NT), lds, s->stream, a);
+    }
+    {
+        const int nborder = a.tiles_x * a.tiles_y - nyi * nxi;
+        ProfScope ps(s, MI_PROF_LEVEL, bytes * (1.0 - frac_in));
+        if (nborder > 0) hipLaunchKernelGGL(kbd, dim3(nborder), dim3(MI_TILE_NT), lds, s->stream, a);
+    }
     return MI_OK;
 }
 
