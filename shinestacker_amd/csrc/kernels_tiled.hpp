@@ -218,22 +218,29 @@ __global__ __launch_bounds__(MI_TILE_NT) void level_fused(LevelArgs a) {
     }
     const int y0 = tyi * TH, x0 = txi * TW;
 
-    // ---- running state of the thread's own quads.  Only the running maximum lives in
-    // registers; the winner's laplacian and index go straight to global memory when a pixel
-    // finds a new maximum (about ln(N) times per pixel over an N-frame stack).
-    float bE[G::NQ][4];
-    int qoy[G::NQ], qox[G::NQ];
+    // ---- running state of the thread's own quads: (E, idx, lap) live in registers for the
+    // whole batch; strict '>' keeps the first maximum.
+    float bE[G::NQ][4], bL[G::NQ][4][3];
+    int bI[G::NQ][4];
 #pragma unroll
     for (int q = 0; q < G::NQ; ++q) {
-        int qi = tid + q * G::NT;
-        qoy[q] = qi / (TW / 2);
-        qox[q] = qi - qoy[q] * (TW / 2);
+        const int qi = tid + q * G::NT, oy = qi / (TW / 2), ox = qi % (TW / 2);
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
-            int y = y0 + 2 * qoy[q] + (p >> 1), x = x0 + 2 * qox[q] + (p & 1);
-            bool valid = INTERIOR || (y < h && x < w);
-            // every energy is >= 0: with -1 the first frame always wins
-            bE[q][p] = (!a.first && valid) ? a.best_e[(size_t)y * w + x] : -1.0f;
+            const int y = y0 + 2 * oy + (p >> 1), x = x0 + 2 * ox + (p & 1);
+            const bool valid = INTERIOR || (y < h && x < w);
+            if (!a.first && valid) {
+                const size_t px = (size_t)y * w + x;
+                bE[q][p] = a.best_e[px];
+                bI[q][p] = a.best_idx[px];
+                bL[q][p][0] = a.best_lap[px * 3 + 0];
+                bL[q][p][1] = a.best_lap[px * 3 + 1];
+                bL[q][p][2] = a.best_lap[px * 3 + 2];
+            } else {
+                bE[q][p] = -1.0f;  // every energy is >= 0: the first frame always wins
+                bI[q][p] = -1;
+                bL[q][p][0] = bL[q][p][1] = bL[q][p][2] = 0.f;
+            }
         }
     }
 
@@ -307,17 +314,29 @@ __global__ __launch_bounds__(MI_TILE_NT) void level_fused(LevelArgs a) {
                 const int ri = it / BX, bx = it - ri * BX, rj = 2 * bx;
                 float acc[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
                 if constexpr (INTERIOR) {
-                    // input rows 2ri .. 2ri+4, pixels 2rj .. 2rj+6: 21 floats, 16-byte aligned
+                    // input rows 2ri .. 2ri+4, pixels 2rj .. 2rj+6: 21 floats, 16-byte aligned.
+                    // Row ty+1 is loaded while row ty is consumed (two register sets).
                     const float* p0 = sG + mul24(2 * ri, G::GS) + 2 * rj * 3;
+                    v4f rq[2][5];
+                    float rl[2];
+                    auto load_row = [&](int ty, int s) {
+#pragma unroll
+                        for (int t = 0; t < 5; ++t) rq[s][t] = lds_load4(p0 + ty * G::GS + 4 * t);
+                        rl[s] = p0[ty * G::GS + 20];
+                    };
+                    load_row(0, 0);
 #pragma unroll
                     for (int ty = 0; ty < 5; ++ty) {
-                        float v[24];
+                        const int s = ty & 1;
+                        if (ty < 4) load_row(ty + 1, s ^ 1);
+                        MI_LDS_FENCE();
+                        float v[21];
 #pragma unroll
                         for (int t = 0; t < 5; ++t) {
-                            v4f q4 = lds_load4(p0 + ty * G::GS + 4 * t);
-                            v[4 * t] = q4.x; v[4 * t + 1] = q4.y; v[4 * t + 2] = q4.z; v[4 * t + 3] = q4.w;
+                            v[4 * t] = rq[s][t].x; v[4 * t + 1] = rq[s][t].y;
+                            v[4 * t + 2] = rq[s][t].z; v[4 * t + 3] = rq[s][t].w;
                         }
-                        v[20] = p0[ty * G::GS + 20];
+                        v[20] = rl[s];
 #pragma unroll
                         for (int vv = 0; vv < 2; ++vv)
 #pragma unroll
@@ -327,7 +346,6 @@ __global__ __launch_bounds__(MI_TILE_NT) void level_fused(LevelArgs a) {
                                 for (int c = 0; c < 3; ++c)
                                     acc[vv][c] = mac<FMA>(k, v[(2 * vv + tx) * 3 + c], acc[vv][c]);
                             }
-                        MI_LDS_FENCE();
                     }
                 } else {
                     const int im = map_expand_src(y0 / 2 - 2 + ri, hn);
@@ -356,16 +374,30 @@ __global__ __launch_bounds__(MI_TILE_NT) void level_fused(LevelArgs a) {
         }
         __syncthreads();
 
-        // ---------------- store the tile centre of G_{l+1}
+        // ---------------- store the tile centre of G_{l+1}: (TH/2) rows of (TW/2)*3 floats
         if (!(a.ablate & 2)) {
             float* gout = a.gnext + (size_t)b * a.gnext_stride;
             const int i0 = y0 / 2, j0 = x0 / 2;
             constexpr int CW = (TW / 2) * 3;
-            for (int e = ltid; e < (TH / 2) * CW; e += G::NT) {
-                const int r = e / CW, k = e - r * CW;
-                const int i = i0 + r, j = j0 + k / 3;
-                if (INTERIOR || (i < hn && j < wn))
-                    gstore32(gout, (uint32_t)(mul24(mul24(i, wn) + j0, 3) + k) * 4u, sN[mul24(r + 2, G::NS) + 6 + k]);
+            if (INTERIOR && (wn & 3) == 0 && (CW & 3) == 0) {
+                // rows start 16-byte aligned in global memory: one float4 per lane
+                constexpr int C4 = CW / 4;
+                for (int e = ltid; e < (TH / 2) * C4; e += G::NT) {
+                    const int r = e / C4, k = (e - r * C4) * 4;
+                    const float* sp = sN + mul24(r + 2, G::NS) + 6 + k;  // 8-byte aligned
+                    const v2f lo = lds_load2(sp), hi = lds_load2(sp + 2);
+                    v4f v = {lo.x, lo.y, hi.x, hi.y};
+                    *reinterpret_cast<v4f*>(reinterpret_cast<char*>(gout) +
+                                            (uint32_t)(mul24(mul24(i0 + r, wn) + j0, 3) + k) * 4u) = v;
+                }
+            } else {
+                for (int e = ltid; e < (TH / 2) * CW; e += G::NT) {
+                    const int r = e / CW, k = e - r * CW;
+                    const int i = i0 + r, j = j0 + k / 3;
+                    if (INTERIOR || (i < hn && j < wn))
+                        gstore32(gout, (uint32_t)(mul24(mul24(i, wn) + j0, 3) + k) * 4u,
+                                 sN[mul24(r + 2, G::NS) + 6 + k]);
+                }
             }
         }
 
@@ -441,10 +473,11 @@ __global__ __launch_bounds__(MI_TILE_NT) void level_fused(LevelArgs a) {
                 float l[4][3];
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
-                    l[0][c] = gee[c] - 4.0f * see[c];
-                    l[1][c] = geo[c] - 4.0f * seo[c];
-                    l[2][c] = goe[c] - 4.0f * soe[c];
-                    l[3][c] = goo[c] - 4.0f * soo[c];
+                    // g - 4*s: the product is exact, so one fused op rounds identically
+                    l[0][c] = __builtin_fmaf(-4.0f, see[c], gee[c]);
+                    l[1][c] = __builtin_fmaf(-4.0f, seo[c], geo[c]);
+                    l[2][c] = __builtin_fmaf(-4.0f, soe[c], goe[c]);
+                    l[3][c] = __builtin_fmaf(-4.0f, soo[c], goo[c]);
                 }
                 float qv[4];
 #pragma unroll
@@ -509,15 +542,12 @@ __global__ __launch_bounds__(MI_TILE_NT) void level_fused(LevelArgs a) {
                 }
 #pragma unroll
                 for (int p = 0; p < 4; ++p) {
-                    const int y = y0 + 2 * oy + (p >> 1), x = x0 + 2 * ox + (p & 1);
-                    if (e[p] > bE[q][p] && (INTERIOR || (y < h && x < w))) {
-                        bE[q][p] = e[p];
-                        const uint32_t px = (uint32_t)(mul24(y, w) + x);
-                        gstore32(a.best_idx, px * 4u, fidx);
-                        gstore32(a.best_lap, px * 12u, myLap[q][p][0] + 0.0f);  // -0 -> +0 (np.where sum)
-                        gstore32(a.best_lap, px * 12u + 4u, myLap[q][p][1] + 0.0f);
-                        gstore32(a.best_lap, px * 12u + 8u, myLap[q][p][2] + 0.0f);
-                    }
+                    const bool win = e[p] > bE[q][p];
+                    bE[q][p] = win ? e[p] : bE[q][p];
+                    bI[q][p] = win ? fidx : bI[q][p];
+                    bL[q][p][0] = win ? myLap[q][p][0] : bL[q][p][0];
+                    bL[q][p][1] = win ? myLap[q][p][1] : bL[q][p][1];
+                    bL[q][p][2] = win ? myLap[q][p][2] : bL[q][p][2];
                 }
             }
         }
@@ -526,14 +556,23 @@ __global__ __launch_bounds__(MI_TILE_NT) void level_fused(LevelArgs a) {
         // rewritten only after the next iteration's two barriers.
     }
 
-    // ---- write the running maxima back
+    // ---- write the running state back (winner's lap with -0 -> +0, as the np.where sum gives)
 #pragma unroll
-    for (int q = 0; q < G::NQ; ++q)
+    for (int q = 0; q < G::NQ; ++q) {
+        const int qi = tid + q * G::NT, oy = qi / (TW / 2), ox = qi % (TW / 2);
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
-            int y = y0 + 2 * qoy[q] + (p >> 1), x = x0 + 2 * qox[q] + (p & 1);
-            if (INTERIOR || (y < h && x < w)) a.best_e[(size_t)y * w + x] = bE[q][p];
+            const int y = y0 + 2 * oy + (p >> 1), x = x0 + 2 * ox + (p & 1);
+            if (INTERIOR || (y < h && x < w)) {
+                const size_t px = (size_t)y * w + x;
+                a.best_e[px] = bE[q][p];
+                a.best_idx[px] = bI[q][p];
+                a.best_lap[px * 3 + 0] = bL[q][p][0] + 0.0f;
+                a.best_lap[px * 3 + 1] = bL[q][p][1] + 0.0f;
+                a.best_lap[px * 3 + 2] = bL[q][p][2] + 0.0f;
+            }
         }
+    }
 }
 
 // ---------------------------------------------------------------- batched base level
