@@ -24,6 +24,7 @@ int tiled_pending(const mi_stack* s);
 int tiled_push(mi_stack* s, const void* dev_frames, int n, size_t stride);
 int tiled_push_host(mi_stack* s, const void* host_bgr, size_t row_stride_bytes);
 int tiled_flush(mi_stack* s);
+int tiled_sync_all(mi_stack* s);
 const float* tiled_last_gauss(mi_stack* s, int level);
 int dispatch_push(mi_stack* s, const void* dev_frames, int n, size_t stride);
 }  // namespace mi
@@ -117,24 +118,28 @@ struct ProfScope {
     mi_stack* s;
     ProfRec r{};
     bool on;
-    ProfScope(mi_stack* s_, int kind, double bytes) : s(s_), on(s_->prof) {
+    hipStream_t st;
+    ProfScope(mi_stack* s_, int kind, double bytes, hipStream_t stream = nullptr)
+        : s(s_), on(s_->prof), st(stream ? stream : s_->stream) {
         if (!on) return;
         r.kind = kind;
         r.bytes = bytes;
         r.a = get_event(s);
         r.b = get_event(s);
         if (!r.a || !r.b) { on = false; return; }
-        (void)hipEventRecord(r.a, s->stream);
+        (void)hipEventRecord(r.a, st);
     }
     ~ProfScope() {
         if (!on) return;
-        (void)hipEventRecord(r.b, s->stream);
+        (void)hipEventRecord(r.b, st);
         s->recs.push_back(r);
     }
 };
 
 int prof_drain(mi_stack* s) {
     if (s->recs.empty()) return MI_OK;
+    int rc0 = tiled_sync_all(s);
+    if (rc0) return rc0;
     MI_HIP(hipStreamSynchronize(s->stream));
     for (auto& r : s->recs) {
         float ms = 0.f;
@@ -471,6 +476,7 @@ int mi_stack_create(mi_stack_t** out, const mi_stack_params_t* params) {
 void mi_stack_destroy(mi_stack_t* s) {
     if (!s) return;
     (void)hipSetDevice(s->p.device);
+    (void)tiled_sync_all(s);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     tiled_destroy(s);
     for (auto& r : s->recs) {
@@ -487,6 +493,8 @@ int mi_stack_reset(mi_stack_t* s) {
     int rc = check_handle(s);
     if (rc) return rc;
     MI_HIP(hipSetDevice(s->p.device));
+    rc = tiled_sync_all(s);
+    if (rc) return rc;
     MI_HIP(hipStreamSynchronize(s->stream));
     rc = prof_drain(s);
     if (rc) return rc;
@@ -553,6 +561,8 @@ int mi_stack_sync(mi_stack_t* s) {
     int rc = check_handle(s);
     if (rc) return rc;
     MI_HIP(hipSetDevice(s->p.device));
+    rc = tiled_sync_all(s);
+    if (rc) return rc;
     MI_HIP(hipStreamSynchronize(s->stream));
     return MI_OK;
 }

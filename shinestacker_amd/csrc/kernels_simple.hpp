@@ -208,6 +208,60 @@ __global__ void base_feat_select(const int32_t* __restrict__ lev, const float* _
     }
 }
 
+// batch version: one launch for `nframes` consecutive frames (index order kept per pixel)
+__global__ void base_feat_select_batch(const int32_t* __restrict__ lev, const float* __restrict__ logp,
+                                       const float* __restrict__ bases, size_t base_stride,
+                                       int nlevels, int nframes, int hb, int wb, int pad,
+                                       int frame_idx0, int first, float* __restrict__ best_ent,
+                                       float* __restrict__ best_dev, int32_t* __restrict__ idx_e,
+                                       int32_t* __restrict__ idx_d, float* __restrict__ base_e,
+                                       float* __restrict__ base_d) {
+    int x = blockIdx.x * blockDim.x + threadIdx.x;
+    int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (y >= hb || x >= wb) return;
+    const size_t p = (size_t)y * wb + x;
+    const int npix = hb * wb;
+    float be = first ? -INFINITY : best_ent[p], bd = first ? -INFINITY : best_dev[p];
+    int ie = first ? -1 : idx_e[p], id = first ? -1 : idx_d[p];
+    int fe = -1, fd = -1;  // frame of this batch that currently holds the maximum
+    const int win = 2 * pad + 1, n = win * win;
+    for (int f = 0; f < nframes; ++f) {
+        const int32_t* lv = lev + (size_t)f * npix;
+        const float* lp = logp + (size_t)f * nlevels;
+        auto level_at = [&](int t) {
+            int dy = t / win - pad, dx = t % win - pad;
+            return lv[(size_t)r101_loop(y + dy, hb) * wb + r101_loop(x + dx, wb)];
+        };
+        float ent = -1.0f * np_sum(n, [&](int t) {
+                        int l = level_at(t);
+                        return (float)l * lp[l];
+                    });
+        double isum = 0.0;
+        for (int t = 0; t < n; ++t) isum += (double)level_at(t);
+        float mean = (float)(isum / (double)n);
+        float dev = np_sum(n, [&](int t) {
+                        float d = (float)level_at(t) - mean;
+                        return d * d;
+                    }) / (float)n;
+        // the very first frame of a stack wins unconditionally (as `first ||` does in the
+        // single-frame kernel): -inf start values give exactly that for finite features
+        if (ent > be || (first && f == 0)) { be = ent; ie = frame_idx0 + f; fe = f; }
+        if (dev > bd || (first && f == 0)) { bd = dev; id = frame_idx0 + f; fd = f; }
+    }
+    best_ent[p] = be;
+    best_dev[p] = bd;
+    idx_e[p] = ie;
+    idx_d[p] = id;
+    if (fe >= 0) {
+        const float* b = bases + (size_t)fe * base_stride + p * 3;
+        base_e[p * 3 + 0] = b[0]; base_e[p * 3 + 1] = b[1]; base_e[p * 3 + 2] = b[2];
+    }
+    if (fd >= 0) {
+        const float* b = bases + (size_t)fd * base_stride + p * 3;
+        base_d[p * 3 + 0] = b[0]; base_d[p * 3 + 1] = b[1]; base_d[p * 3 + 2] = b[2];
+    }
+}
+
 __global__ void base_fuse(const float* __restrict__ base_e, const float* __restrict__ base_d,
                           size_t n, float* __restrict__ out) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -51,9 +51,10 @@ struct LevelArgs {
     size_t gnext_stride;    // floats between consecutive frames
     int nframes;
     int h, w, hn, wn;
-    int tiles_x, tiles_y;
-    // interior launch: tiles [ty_lo, ty_hi) x [tx_lo, tx_hi) as super-blocks of SB x SB
-    int ty_lo, ty_hi, tx_lo, tx_hi, sb_x;  // sb_x = super-blocks per row
+    // Interior region in pixels, [iy0, iy1) x [ix0, ix1): a multiple of both the interior
+    // and the border kernel's tile size, at least 6 pixels away from every image edge.  The
+    // interior kernel tiles it (as SB x SB super-blocks); the border kernel tiles the rest.
+    int iy0, iy1, ix0, ix1;
     float* best_e;          // running state of level l
     float* best_lap;
     int32_t* best_idx;
@@ -65,7 +66,17 @@ struct LevelArgs {
 
 constexpr int SB = 8;  // super-block edge in tiles (64 tiles = one XCD's concurrent set)
 
-// tile configuration (compile-time; tools/tune.sh builds variants with -D)
+// tile configurations (compile-time; tools/tune.sh builds variants with -D):
+// level 0 -- 75% of all pixels -- and the coarser levels are tuned separately
+#ifndef MI_TILE0_H
+#define MI_TILE0_H 32
+#endif
+#ifndef MI_TILE0_W
+#define MI_TILE0_W 64
+#endif
+#ifndef MI_TILE0_NT
+#define MI_TILE0_NT 512
+#endif
 #ifndef MI_TILE_H
 #define MI_TILE_H 32
 #endif
@@ -79,11 +90,11 @@ constexpr int SB = 8;  // super-block edge in tiles (64 tiles = one XCD's concur
 #define MI_TILE_PAD 1
 #endif
 
-template <int TH_, int TW_>
+template <int TH_, int TW_, int NT_, bool PAD_>
 struct TileGeom {
     static constexpr int TH = TH_, TW = TW_;
-    static constexpr int NT = MI_TILE_NT;             // threads per workgroup
-    static constexpr bool PAD = MI_TILE_PAD != 0;     // bank-conflict padding of the LDS images
+    static constexpr int NT = NT_;                    // threads per workgroup
+    static constexpr bool PAD = PAD_;                 // bank-conflict padding of the LDS images
     static constexpr int GH = TH + 12, GW = TW + 12;  // G_l patch (pixels)
     static constexpr int GD = GW * 3;                 // data floats per patch row
     // sG row stride: multiple of 4 (ds_read_b128 alignment) and = 28 (mod 32), so that the
@@ -170,9 +181,9 @@ __device__ __forceinline__ void lds_store2(float* p, float a, float b) {
     *reinterpret_cast<v2f*>(p) = v;
 }
 
-template <typename TIn, bool FMA, bool INTERIOR, int TH, int TW>
-__global__ __launch_bounds__(MI_TILE_NT) void level_fused(LevelArgs a) {
-    using G = TileGeom<TH, TW>;
+template <typename TIn, bool FMA, bool INTERIOR, int TH, int TW, int NT, bool PAD>
+__global__ __launch_bounds__(NT) void level_fused(LevelArgs a) {
+    using G = TileGeom<TH, TW, NT, PAD>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sG = smem;
     float* sN = sG + G::GH * G::GS;
@@ -185,36 +196,41 @@ __global__ __launch_bounds__(MI_TILE_NT) void level_fused(LevelArgs a) {
     if constexpr (INTERIOR) {
         // Block b runs on XCD b % 8.  Super-block S = 8 * (slot / 64) + xcd: the 64 tiles an
         // XCD works on at a time form one 8x8 square, whose inner halos hit that XCD's L2.
+        const int ty_lo = a.iy0 / TH, ty_hi = a.iy1 / TH, tx_lo = a.ix0 / TW, tx_hi = a.ix1 / TW;
+        const int sb_x = (tx_hi - tx_lo + SB - 1) / SB;
         const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
         const int S = (slot >> 6) * 8 + xcd, within = slot & 63;
-        const int sby = S / a.sb_x, sbx = S - sby * a.sb_x;
-        tyi = a.ty_lo + sby * SB + (within >> 3);
-        txi = a.tx_lo + sbx * SB + (within & 7);
-        if (tyi >= a.ty_hi || txi >= a.tx_hi) return;
+        const int sby = S / sb_x, sbx = S - sby * sb_x;
+        tyi = ty_lo + sby * SB + (within >> 3);
+        txi = tx_lo + sbx * SB + (within & 7);
+        if (tyi >= ty_hi || txi >= tx_hi) return;
     } else {
-        // border frame: rows above/below the interior rectangle, then the side columns
-        const int nyi = a.ty_hi - a.ty_lo, nxi = a.tx_hi - a.tx_lo;
+        // everything outside the interior rectangle: the tile rows above and below it, then
+        // the side columns of the rows it spans
+        const int tiles_x = (w + TW - 1) / TW, tiles_y = (h + TH - 1) / TH;
+        const int ty_lo = a.iy0 / TH, ty_hi = a.iy1 / TH, tx_lo = a.ix0 / TW, tx_hi = a.ix1 / TW;
+        const int nyi = ty_hi - ty_lo, nxi = tx_hi - tx_lo;
         int t = blockIdx.x;
-        const int top = a.ty_lo * a.tiles_x;
-        const int bot = (a.tiles_y - a.ty_hi) * a.tiles_x;
+        const int top = ty_lo * tiles_x;
+        const int bot = (tiles_y - ty_hi) * tiles_x;
         if (nyi <= 0 || nxi <= 0) {  // no interior at all: plain raster
-            tyi = t / a.tiles_x;
-            txi = t - tyi * a.tiles_x;
+            tyi = t / tiles_x;
+            txi = t - tyi * tiles_x;
         } else if (t < top) {
-            tyi = t / a.tiles_x;
-            txi = t - tyi * a.tiles_x;
+            tyi = t / tiles_x;
+            txi = t - tyi * tiles_x;
         } else if (t < top + bot) {
             t -= top;
-            tyi = a.ty_hi + t / a.tiles_x;
-            txi = t - (t / a.tiles_x) * a.tiles_x;
+            tyi = ty_hi + t / tiles_x;
+            txi = t - (t / tiles_x) * tiles_x;
         } else {
             t -= top + bot;
-            const int side = a.tiles_x - nxi;  // side tiles per interior row
-            tyi = a.ty_lo + t / side;
+            const int side = tiles_x - nxi;  // side tiles per interior row
+            tyi = ty_lo + t / side;
             int k = t - (t / side) * side;
-            txi = k < a.tx_lo ? k : a.tx_hi + (k - a.tx_lo);
+            txi = k < tx_lo ? k : tx_hi + (k - tx_lo);
         }
-        if (tyi >= a.tiles_y || txi >= a.tiles_x) return;
+        if (tyi >= tiles_y || txi >= tiles_x) return;
     }
     const int y0 = tyi * TH, x0 = txi * TW;
 
@@ -604,5 +620,6 @@ __global__ void base_logp_batch(const uint32_t* __restrict__ cnt, int nlevels, i
     }
     logp[(size_t)f * nlevels + l] = v;
 }
+
 
 }  // namespace mi

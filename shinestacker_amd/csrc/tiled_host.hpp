@@ -1,27 +1,39 @@
 // tiled_host.hpp -- host side of the tiled production path and of host-frame staging.
 // Included by capi.hip after `struct mi_stack` is complete.
+//
+// Batch pipeline over three HIP streams (all work of one handle):
+//   st0 = s->stream : level-0 interior kernel of batch k      (the big one)
+//   st1             : level-0 border kernel of batch k
+//   st2             : levels 1..L-1 (interior + border) and the base features of batch k
+// Level 0 of batch k+1 runs while st2 still works on batch k, so the latency-bound small
+// levels hide behind the bandwidth-bound level-0 kernel.  The per-batch Gaussian images
+// Gb[set][l] are double-buffered (set = k & 1); events order producers and consumers.
+// Selection state is only ever touched by one stream per level (level 0: st0/st1 on
+// disjoint pixels; levels >= 1 and base: st2), so stream order alone keeps the
+// first-max semantics.
 #pragma once
 
 namespace mi {
 
-constexpr int TILE_H = MI_TILE_H, TILE_W = MI_TILE_W;
-
 struct TiledState {
-    int bcap = 0;                // frames per fused launch
-    std::vector<float*> Gb;      // Gb[l], l = 1..L : bcap images of level l
-    std::vector<size_t> gstride; // floats between frames in Gb[l]
-    void* ring = nullptr;        // staging ring for host-pushed frames (bcap frames, in_dtype)
+    int bcap = 0;                   // frames per fused launch
+    std::vector<float*> Gb[2];      // Gb[set][l], l = 1..L : bcap images of level l
+    std::vector<size_t> gstride;    // floats between frames in Gb[.][l]
+    void* ring = nullptr;           // staging ring for host-pushed frames (bcap frames, in_dtype)
     size_t frame_bytes = 0;
-    int pending = 0;             // frames staged in the ring, not yet processed
-    int last_nb = 0;             // size of the most recently processed batch
-    int32_t* lev = nullptr;      // base batch scratch
-    uint32_t* cnt = nullptr;
-    float* logp = nullptr;
+    int pending = 0;                // frames staged in the ring, not yet processed
+    int last_nb = 0;                // size of the most recently processed batch
+    int last_set = 0;
+    long batch_no = 0;
+    int32_t* lev[2] = {nullptr, nullptr};   // base batch scratch, per set
+    uint32_t* cnt[2] = {nullptr, nullptr};
+    float* logp[2] = {nullptr, nullptr};
+    hipStream_t st1 = nullptr, st2 = nullptr;
+    hipEvent_t evL0i[2] = {nullptr, nullptr}, evL0b[2] = {nullptr, nullptr}, evRest[2] = {nullptr, nullptr};
+    bool streams_dirty = false;     // work may be in flight on st1/st2
 };
 
-inline TiledState*& tstate(mi_stack* s) {
-    return *reinterpret_cast<TiledState**>(&s->tiled);
-}
+inline TiledState*& tstate(mi_stack* s) { return *reinterpret_cast<TiledState**>(&s->tiled); }
 inline TiledState* tstate(const mi_stack* s) { return reinterpret_cast<TiledState*>(s->tiled); }
 
 bool tiled_available() { return true; }
@@ -36,28 +48,60 @@ int tiled_create(mi_stack* s) {
         t->bcap = 1;  // simple impl: the ring holds one frame (s->frame_dev)
         return MI_OK;
     }
-    t->Gb.assign(L + 1, nullptr);
+    // the short, latency-bound kernels (level-0 border frame, coarser levels, base) get the
+    // highest priority so they are dispatched ahead of the bulk level-0 interior kernel
+    // they run beside; otherwise they starve and become the critical path.
+    int prio_lo = 0, prio_hi = 0;
+    MI_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+    MI_HIP(hipStreamCreateWithPriority(&t->st1, hipStreamNonBlocking, prio_hi));
+    MI_HIP(hipStreamCreateWithPriority(&t->st2, hipStreamNonBlocking, prio_hi));
     t->gstride.assign(L + 1, 0);
     int rc;
-    for (int l = 1; l <= L; ++l) {
-        t->gstride[l] = (size_t)s->lh[l] * s->lw[l] * 3;
-        if ((rc = dev_alloc_t(s, &t->Gb[l], t->gstride[l] * t->bcap))) return rc;
+    for (int set = 0; set < 2; ++set) {
+        MI_HIP(hipEventCreateWithFlags(&t->evL0i[set], hipEventDisableTiming));
+        MI_HIP(hipEventCreateWithFlags(&t->evL0b[set], hipEventDisableTiming));
+        MI_HIP(hipEventCreateWithFlags(&t->evRest[set], hipEventDisableTiming));
+        t->Gb[set].assign(L + 1, nullptr);
+        for (int l = 1; l <= L; ++l) {
+            t->gstride[l] = (size_t)s->lh[l] * s->lw[l] * 3;
+            if ((rc = dev_alloc_t(s, &t->Gb[set][l], t->gstride[l] * t->bcap))) return rc;
+        }
+        const size_t nb = (size_t)s->lh[L] * s->lw[L];
+        if ((rc = dev_alloc_t(s, &t->lev[set], nb * t->bcap))) return rc;
+        if ((rc = dev_alloc_t(s, &t->cnt[set], (size_t)s->nlevels_hist * t->bcap))) return rc;
+        if ((rc = dev_alloc_t(s, &t->logp[set], (size_t)s->nlevels_hist * t->bcap))) return rc;
     }
-    const size_t nb = (size_t)s->lh[L] * s->lw[L];
-    if ((rc = dev_alloc_t(s, &t->lev, nb * t->bcap))) return rc;
-    if ((rc = dev_alloc_t(s, &t->cnt, (size_t)s->nlevels_hist * t->bcap))) return rc;
-    if ((rc = dev_alloc_t(s, &t->logp, (size_t)s->nlevels_hist * t->bcap))) return rc;
+    return MI_OK;
+}
+
+int tiled_sync_all(mi_stack* s) {
+    TiledState* t = tstate(s);
+    if (!t) return MI_OK;
+    if (t->st1) MI_HIP(hipStreamSynchronize(t->st1));
+    if (t->st2) MI_HIP(hipStreamSynchronize(t->st2));
+    t->streams_dirty = false;
     return MI_OK;
 }
 
 void tiled_destroy(mi_stack* s) {
-    delete tstate(s);
+    TiledState* t = tstate(s);
+    if (!t) return;
+    for (int set = 0; set < 2; ++set) {
+        if (t->evL0i[set]) (void)hipEventDestroy(t->evL0i[set]);
+        if (t->evL0b[set]) (void)hipEventDestroy(t->evL0b[set]);
+        if (t->evRest[set]) (void)hipEventDestroy(t->evRest[set]);
+    }
+    if (t->st1) (void)hipStreamDestroy(t->st1);
+    if (t->st2) (void)hipStreamDestroy(t->st2);
+    delete t;
     tstate(s) = nullptr;
 }
 
 int tiled_reset(mi_stack* s) {
-    tstate(s)->pending = 0;
-    tstate(s)->last_nb = 0;
+    TiledState* t = tstate(s);
+    t->pending = 0;
+    t->last_nb = 0;
+    t->batch_no = 0;
     return MI_OK;
 }
 
@@ -67,7 +111,7 @@ const float* tiled_last_gauss(mi_stack* s, int level) {
     TiledState* t = tstate(s);
     if (s->p.impl != MI_IMPL_TILED) return s->G[level];
     int last = t->last_nb > 0 ? t->last_nb - 1 : 0;
-    return t->Gb[level] + (size_t)last * t->gstride[level];
+    return t->Gb[t->last_set][level] + (size_t)last * t->gstride[level];
 }
 
 template <typename Kern>
@@ -76,33 +120,40 @@ int set_lds_once(Kern kern, size_t lds) {
     return MI_OK;
 }
 
-template <typename TIn, bool FMA>
-int launch_level(mi_stack* s, int l, const void* src, size_t src_stride, int nb) {
-    using Gm = TileGeom<TILE_H, TILE_W>;
+constexpr int ilcm(int a, int b) {
+    int x = a, y = b;
+    while (y) { int t = x % y; x = y; y = t; }
+    return a / x * b;
+}
+
+// Launch the interior and border kernels of level l for `nb` frames.
+//   interior kernel: tile config A (TH, TW, NT, padded LDS), stream st_in
+//   border kernel  : tile config B (BH, BW, BNT, unpadded LDS: small enough to co-reside
+//                    with two level-0 interior workgroups on one CU), stream st_bd
+template <typename TIn, bool FMA, int TH, int TW, int NT, bool PADA, int BH, int BW, int BNT>
+int launch_level(mi_stack* s, int l, int set, const void* src, size_t src_stride, int nb,
+                 hipStream_t st_in, hipStream_t st_bd) {
+    using GA = TileGeom<TH, TW, NT, PADA>;
+    using GB = TileGeom<BH, BW, BNT, false>;
     TiledState* t = tstate(s);
     LevelArgs a{};
     a.src = src;
     a.src_stride = src_stride;
-    a.gnext = t->Gb[l + 1];
+    a.gnext = t->Gb[set][l + 1];
     a.gnext_stride = t->gstride[l + 1];
     a.nframes = nb;
     a.h = s->lh[l];
     a.w = s->lw[l];
     a.hn = s->lh[l + 1];
     a.wn = s->lw[l + 1];
-    a.tiles_x = cdiv(a.w, TILE_W);
-    a.tiles_y = cdiv(a.h, TILE_H);
-    // interior tiles: the whole 6-pixel-haloed patch lies inside the image
-    a.ty_lo = cdiv(6, TILE_H);
-    a.tx_lo = cdiv(6, TILE_W);
-    a.ty_hi = (a.h - 6) / TILE_H;
-    a.tx_hi = (a.w - 6) / TILE_W;
-    int nyi = a.ty_hi - a.ty_lo, nxi = a.tx_hi - a.tx_lo;
-    if (nyi <= 0 || nxi <= 0) {
-        a.ty_lo = a.ty_hi = a.tx_lo = a.tx_hi = 0;
-        nyi = nxi = 0;
-    }
-    a.sb_x = nxi > 0 ? cdiv(nxi, SB) : 1;
+    // interior rectangle: whole 6-pixel-haloed patches inside the image, aligned to both tilings
+    constexpr int AY = ilcm(TH, BH), AX = ilcm(TW, BW);
+    a.iy0 = cdiv(6, AY) * AY;
+    a.ix0 = cdiv(6, AX) * AX;
+    a.iy1 = (a.h - 6) / AY * AY;
+    a.ix1 = (a.w - 6) / AX * AX;
+    if (a.iy1 <= a.iy0 || a.ix1 <= a.ix0) a.iy0 = a.iy1 = a.ix0 = a.ix1 = 0;
+    const int nyi = (a.iy1 - a.iy0) / TH, nxi = (a.ix1 - a.ix0) / TW;
     a.best_e = s->bestE[l];
     a.best_lap = s->bestLap[l];
     a.best_idx = s->bestIdx[l];
@@ -114,29 +165,30 @@ int launch_level(mi_stack* s, int l, const void* src, size_t src_stride, int nb)
         const char* ab = getenv("MI_ABLATE");  // timing studies only; results are wrong when set
         a.ablate = ab ? atoi(ab) : 0;
     }
-    const size_t lds = (size_t)Gm::LDS_FLOATS * sizeof(float);
-    auto kin = level_fused<TIn, FMA, true, TILE_H, TILE_W>;
-    auto kbd = level_fused<TIn, FMA, false, TILE_H, TILE_W>;
+    const size_t ldsA = (size_t)GA::LDS_FLOATS * sizeof(float), ldsB = (size_t)GB::LDS_FLOATS * sizeof(float);
+    auto kin = level_fused<TIn, FMA, true, TH, TW, NT, PADA>;
+    auto kbd = level_fused<TIn, FMA, false, BH, BW, BNT, false>;
     static thread_local bool attr_set = false;
     if (!attr_set) {
         int rc;
-        if ((rc = set_lds_once(kin, lds)) || (rc = set_lds_once(kbd, lds))) return rc;
+        if ((rc = set_lds_once(kin, ldsA)) || (rc = set_lds_once(kbd, ldsB))) return rc;
         attr_set = true;
     }
     // algorithmic bytes of this level pass, SURVEY.md 8(d) attribution: read G_l once,
     // write G_{l+1} once, read G_{l+1} once as the expand source.
     const double bytes = ((double)(l == 0 ? dtype_size(s->p.in_dtype) : 4) * 3.0 * a.h * a.w +
                           24.0 * a.hn * a.wn) * nb;
-    const double frac_in = (double)nyi * TILE_H * nxi * TILE_W / ((double)a.h * a.w);
-    if (nyi > 0) {
-        const int nsb = a.sb_x * cdiv(nyi, SB);
-        ProfScope ps(s, l == 0 ? MI_PROF_LEVEL0 : MI_PROF_LEVEL, bytes * frac_in);
-        hipLaunchKernelGGL(kin, dim3(cdiv(nsb, 8) * 8 * SB * SB), dim3(MI_TILE_NT), lds, s->stream, a);
+    const double frac_in = (double)(a.iy1 - a.iy0) * (a.ix1 - a.ix0) / ((double)a.h * a.w);
+    {   // border first: its few, latency-bound workgroups should claim their slots early
+        const int tbx = cdiv(a.w, BW), tby = cdiv(a.h, BH);
+        const int nborder = tbx * tby - ((a.iy1 - a.iy0) / BH) * ((a.ix1 - a.ix0) / BW);
+        ProfScope ps(s, MI_PROF_LEVEL, bytes * (1.0 - frac_in), st_bd);
+        if (nborder > 0) hipLaunchKernelGGL(kbd, dim3(nborder), dim3(BNT), ldsB, st_bd, a);
     }
-    {
-        const int nborder = a.tiles_x * a.tiles_y - nyi * nxi;
-        ProfScope ps(s, MI_PROF_LEVEL, bytes * (1.0 - frac_in));
-        if (nborder > 0) hipLaunchKernelGGL(kbd, dim3(nborder), dim3(MI_TILE_NT), lds, s->stream, a);
+    if (nyi > 0) {
+        const int nsb = cdiv(nxi, SB) * cdiv(nyi, SB);
+        ProfScope ps(s, l == 0 ? MI_PROF_LEVEL0 : MI_PROF_LEVEL, bytes * frac_in, st_in);
+        hipLaunchKernelGGL(kin, dim3(cdiv(nsb, 8) * 8 * SB * SB), dim3(NT), ldsA, st_in, a);
     }
     return MI_OK;
 }
@@ -145,30 +197,56 @@ template <typename TIn, bool FMA>
 int run_batch(mi_stack* s, const void* frames, size_t stride, int nb) {
     TiledState* t = tstate(s);
     const int L = s->L;
+    const int set = (int)(t->batch_no & 1);
+    hipStream_t st0 = s->stream, st1 = t->st1, st2 = t->st2;
     int rc;
-    if ((rc = launch_level<TIn, FMA>(s, 0, frames, stride, nb))) return rc;
+    // Gb[set] is free once st2 finished batch k-2 (no-op for the first two batches)
+    MI_HIP(hipStreamWaitEvent(st0, t->evRest[set], 0));
+    MI_HIP(hipStreamWaitEvent(st1, t->evRest[set], 0));
+    if ((rc = launch_level<TIn, FMA, MI_TILE0_H, MI_TILE0_W, MI_TILE0_NT, MI_TILE_PAD != 0, MI_TILE_H, MI_TILE_W, MI_TILE_NT>(
+             s, 0, set, frames, stride, nb, st0, st1)))
+        return rc;
+    MI_HIP(hipEventRecord(t->evL0i[set], st0));
+    MI_HIP(hipEventRecord(t->evL0b[set], st1));
+    MI_HIP(hipStreamWaitEvent(st2, t->evL0i[set], 0));
+    MI_HIP(hipStreamWaitEvent(st2, t->evL0b[set], 0));
     for (int l = 1; l < L; ++l)
-        if ((rc = launch_level<float, FMA>(s, l, t->Gb[l], t->gstride[l] * sizeof(float), nb))) return rc;
+        if ((rc = launch_level<float, FMA, MI_TILE_H, MI_TILE_W, MI_TILE_NT, false, MI_TILE_H, MI_TILE_W, MI_TILE_NT>(
+                 s, l, set, t->Gb[set][l], t->gstride[l] * sizeof(float), nb, st2, st2)))
+            return rc;
     MI_HIP(hipGetLastError());
     {   // base level of the whole batch
-        ProfScope ps(s, MI_PROF_BASE, 0.0);
+        ProfScope ps(s, MI_PROF_BASE, 0.0, st2);
         const int hb = s->lh[L], wb = s->lw[L], npix = hb * wb;
-        MI_HIP(hipMemsetAsync(t->cnt, 0, sizeof(uint32_t) * s->nlevels_hist * nb, s->stream));
-        hipLaunchKernelGGL((base_gray_hist_batch<FMA>), dim3(cdiv(npix, 256), nb), dim3(256), 0,
-                           s->stream, t->Gb[L], t->gstride[L], npix, s->nlevels_hist, t->lev, t->cnt);
-        hipLaunchKernelGGL(base_logp_batch, dim3(cdiv(s->nlevels_hist, 256), nb), dim3(256), 0,
-                           s->stream, t->cnt, s->nlevels_hist, npix, t->logp);
-        const dim3 blk(32, 8);
-        for (int f = 0; f < nb; ++f)
-            hipLaunchKernelGGL(base_feat_select, grid2d(wb, hb, blk), blk, 0, s->stream,
-                               t->lev + (size_t)f * npix, t->logp + (size_t)f * s->nlevels_hist,
-                               t->Gb[L] + (size_t)f * t->gstride[L], hb, wb, s->pad,
-                               s->first_index + s->n_pushed + f, (s->n_pushed + f) == 0, s->bEnt,
-                               s->bDev, s->idxE, s->idxD, s->baseE, s->baseD);
+        MI_HIP(hipMemsetAsync(t->cnt[set], 0, sizeof(uint32_t) * s->nlevels_hist * nb, st2));
+        hipLaunchKernelGGL((base_gray_hist_batch<FMA>), dim3(cdiv(npix, 256), nb), dim3(256), 0, st2,
+                           t->Gb[set][L], t->gstride[L], npix, s->nlevels_hist, t->lev[set], t->cnt[set]);
+        hipLaunchKernelGGL(base_logp_batch, dim3(cdiv(s->nlevels_hist, 256), nb), dim3(256), 0, st2,
+                           t->cnt[set], s->nlevels_hist, npix, t->logp[set]);
+        const dim3 blk(16, 4);
+        hipLaunchKernelGGL(base_feat_select_batch, grid2d(wb, hb, blk), blk, 0, st2, t->lev[set],
+                           t->logp[set], t->Gb[set][L], t->gstride[L], s->nlevels_hist, nb, hb, wb,
+                           s->pad, s->first_index + s->n_pushed, s->n_pushed == 0, s->bEnt, s->bDev,
+                           s->idxE, s->idxD, s->baseE, s->baseD);
         MI_HIP(hipGetLastError());
     }
+    MI_HIP(hipEventRecord(t->evRest[set], st2));
+    t->streams_dirty = true;
     s->n_pushed += nb;
     t->last_nb = nb;
+    t->last_set = set;
+    t->batch_no++;
+    return MI_OK;
+}
+
+// make s->stream wait for everything enqueued on the side streams
+int tiled_join(mi_stack* s) {
+    TiledState* t = tstate(s);
+    if (!t || !t->streams_dirty) return MI_OK;
+    for (int set = 0; set < 2; ++set) {
+        MI_HIP(hipStreamWaitEvent(s->stream, t->evL0b[set], 0));
+        MI_HIP(hipStreamWaitEvent(s->stream, t->evRest[set], 0));
+    }
     return MI_OK;
 }
 
@@ -189,7 +267,8 @@ int tiled_push(mi_stack* s, const void* dev_frames, int n, size_t stride) {
         }
         if (rc) return rc;
     }
-    return MI_OK;
+    // later work on s->stream (host-frame copies, collapse, taps) is ordered behind all of it
+    return tiled_join(s);
 }
 
 int tiled_flush(mi_stack* s) {

@@ -3,7 +3,7 @@
 cd "$(dirname "$0")/.."
 export MI_EXPECT_GPU=1
 python -m pytest tests -q -m gpu -x -k "golden_fusion or seeded or large" 2>&1 | tail -3
-for f in 32; do
+for f in 32 128; do
 python bench.py --frames $f --steps 3 --warmup 1 --no-cpu-baseline "$@" | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
