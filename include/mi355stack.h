@@ -156,10 +156,11 @@ MI_API int mi_stack_profile_get(mi_stack_t* s, int kind, double* total_ms, int64
                          double* algorithmic_bytes);
 
 /* ---- cross-GPU combine kernels (local parts of the frame-sharded reduce) ---- */
-/* cand_e: [n][npix] f32, cand_lap: [n][npix*3] f32, candidates in ascending
- * global-frame order; writes the first-max winner's energy / lap to out_*. */
+/* cand_e: [n][npix] f32, cand_lap: [n][npix*3] f32, cand_idx: [n][npix] i32 (may be
+ * NULL), candidates in ascending global-frame order; writes the first-max winner's
+ * energy / lap / index to out_*.  `stream` is a hipStream_t (NULL = default stream). */
 MI_API int mi_combine_select(int device, void* stream, int n, const void* cand_e, const void* cand_lap,
-                      size_t npix, void* out_e, void* out_lap);
+                      const void* cand_idx, size_t npix, void* out_e, void* out_lap, void* out_idx);
 
 /* ---- synthetic stack generator, device side ---- */
 MI_API int mi_synth_frames_device(int device, void* dev_out, int dtype, int height, int width,

@@ -69,7 +69,7 @@ SIGNATURES = {
     "mi_stack_profile_get": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double),
                                        C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "mi_combine_select": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
-                                    C.c_size_t, C.c_void_p, C.c_void_p]),
+                                    C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mi_synth_frames_device": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.c_int, C.c_int, C.c_uint32]),
 }

@@ -705,12 +705,14 @@ int mi_stack_profile_get(mi_stack_t* s, int kind, double* total_ms, int64_t* lau
 }
 
 int mi_combine_select(int device, void* stream, int n, const void* cand_e, const void* cand_lap,
-                      size_t npix, void* out_e, void* out_lap) {
+                      const void* cand_idx, size_t npix, void* out_e, void* out_lap, void* out_idx) {
     if (n < 1 || !cand_e || !cand_lap || !out_e || !out_lap) return fail(MI_ERR_INVALID, "bad argument");
+    if (npix == 0) return MI_OK;
     MI_HIP(hipSetDevice(device));
     hipLaunchKernelGGL(combine_select, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0,
-                       (hipStream_t)stream, n, (const float*)cand_e, (const float*)cand_lap, npix,
-                       (float*)out_e, (float*)out_lap);
+                       (hipStream_t)stream, n, (const float*)cand_e, (const float*)cand_lap,
+                       (const int32_t*)cand_idx, npix, (float*)out_e, (float*)out_lap,
+                       (int32_t*)out_idx);
     MI_HIP(hipGetLastError());
     return MI_OK;
 }

@@ -302,8 +302,10 @@ __global__ void finalize_cast(const float* __restrict__ img, size_t n, float max
 // ---------------------------------------------------------------- cross-GPU combine
 // candidates in ascending global frame order: strict '>' keeps the first maximum.
 __global__ void combine_select(int n, const float* __restrict__ cand_e,
-                               const float* __restrict__ cand_lap, size_t npix,
-                               float* __restrict__ out_e, float* __restrict__ out_lap) {
+                               const float* __restrict__ cand_lap,
+                               const int32_t* __restrict__ cand_idx, size_t npix,
+                               float* __restrict__ out_e, float* __restrict__ out_lap,
+                               int32_t* __restrict__ out_idx) {
     size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= npix) return;
     float be = cand_e[p];
@@ -320,6 +322,7 @@ __global__ void combine_select(int n, const float* __restrict__ cand_e,
     out_lap[p * 3 + 0] = l[0];
     out_lap[p * 3 + 1] = l[1];
     out_lap[p * 3 + 2] = l[2];
+    if (cand_idx && out_idx) out_idx[p] = cand_idx[(size_t)bi * npix + p];
 }
 
 // ---------------------------------------------------------------- synthetic frames

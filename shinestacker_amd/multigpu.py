@@ -1,0 +1,121 @@
+"""Frame-sharded multi-GPU stacking: the cross-GPU combine of the per-level selection state.
+
+Frames of one stack are split into contiguous blocks, one block per rank (one process per
+GPU, `torch.distributed`, backend "nccl" = RCCL over xGMI).  Every rank runs the ordinary
+single-GPU path on its block (`Stack.set_first_index(first global frame)`); what remains is an
+arg-max-with-payload reduction of the running state `(E, idx, lap)` of every level and of the
+two base-level features -- the multi-GPU form of `np.argmax(energies, axis=0)` with first-max
+tie-breaking (reference algorithms/pyramid.py:48-55, :103-110).
+
+No stock collective has that operator, and a ring all-reduce of the ~640 MB of state would be
+per-link bound on xGMI.  The exchange is therefore a pixel-domain reduce-scatter over the full
+point-to-point mesh:
+
+  1. all_to_all_single  -- rank r receives, from every rank, the r-th pixel chunk of (E, idx, lap)
+                           (7 of 8 chunks travel, each over its own xGMI link, in parallel);
+  2. local first-max    -- candidates are ordered by rank = by global frame index, strict '>'
+                           keeps the first maximum (HIP kernel `mi_combine_select`);
+  3. send/recv          -- the winners' chunks go to rank 0, which owns the collapse.
+
+Everything here is host-side plumbing on torch tensors; the same function runs on CPU tensors
+under the "gloo" backend in tests/ (with a torch implementation of step 2 injected there).
+"""
+import ctypes as C
+
+import torch
+import torch.distributed as dist
+
+from . import _lib
+
+
+def chunk_bounds(n, world):
+    """Pixel range owned by every rank: contiguous, sizes differ by at most one chunk tail."""
+    per = -(-n // world)
+    return [(min(r * per, n), min((r + 1) * per, n)) for r in range(world)]
+
+
+def combine_state(energy, lap, index, group, select_fn, width=3):
+    """In-place combine of one level's state across `group`; rank 0 ends up with the result.
+
+    energy: (n,) f32, lap: (n*width,) f32, index: (n,) i32 -- this rank's running state.
+    select_fn(cand_e [W,m], cand_lap [W,m*width], cand_idx [W,m]) -> (e [m], lap [m*width], idx [m])
+    """
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    n = energy.numel()
+    bounds = chunk_bounds(n, world)
+    sizes = [b - a for a, b in bounds]
+    mine = sizes[rank]
+
+    def exchange(t, w):
+        out = torch.empty(world * mine * w, dtype=t.dtype, device=t.device)
+        dist.all_to_all_single(out, t, output_split_sizes=[mine * w] * world,
+                               input_split_sizes=[s * w for s in sizes], group=group)
+        return out.view(world, mine * w)
+
+    cand_e = exchange(energy, 1)
+    cand_l = exchange(lap, width)
+    cand_i = exchange(index, 1)
+    win_e, win_l, win_i = select_fn(cand_e, cand_l, cand_i)
+    # winners to rank 0
+    if rank == 0:
+        a, b = bounds[0]
+        energy[a:b] = win_e
+        lap[a * width:b * width] = win_l
+        index[a:b] = win_i
+        for r in range(1, world):
+            a, b = bounds[r]
+            if b > a:
+                dist.recv(energy[a:b], src=dist.get_global_rank(group, r), group=group)
+                dist.recv(lap[a * width:b * width], src=dist.get_global_rank(group, r), group=group)
+                dist.recv(index[a:b], src=dist.get_global_rank(group, r), group=group)
+    elif mine > 0:
+        root = dist.get_global_rank(group, 0)
+        dist.send(win_e.contiguous(), dst=root, group=group)
+        dist.send(win_l.contiguous(), dst=root, group=group)
+        dist.send(win_i.contiguous(), dst=root, group=group)
+
+
+class _DevArray:
+    """`__cuda_array_interface__` view of library-owned device memory (no copy)."""
+
+    def __init__(self, ptr, n, typestr):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False),
+                                         "version": 2}
+
+
+def wrap_device(ptr, n, dtype, device):
+    typestr = {torch.float32: "<f4", torch.int32: "<i4"}[dtype]
+    return torch.as_tensor(_DevArray(ptr, n, typestr), device=torch.device("cuda", device))
+
+
+class Combiner:
+    """Cross-GPU combine for a `_lib.Stack` on every rank of `group`."""
+
+    def __init__(self, stack, group=None):
+        self.stack = stack
+        self.group = group if group is not None else dist.group.WORLD
+        self.device = stack.device
+
+    def _select_hip(self, cand_e, cand_l, cand_i):
+        world, m = cand_e.shape
+        out_e = torch.empty(m, dtype=torch.float32, device=cand_e.device)
+        out_l = torch.empty(cand_l.shape[1], dtype=torch.float32, device=cand_e.device)
+        out_i = torch.empty(m, dtype=torch.int32, device=cand_e.device)
+        stream = torch.cuda.current_stream(cand_e.device).cuda_stream
+        _lib.check(_lib.load().mi_combine_select(
+            self.device, C.c_void_p(stream), world, cand_e.data_ptr(), cand_l.data_ptr(),
+            cand_i.data_ptr(), m, out_e.data_ptr(), out_l.data_ptr(), out_i.data_ptr()))
+        return out_e, out_l, out_i
+
+    def combine(self):
+        """Call on every rank after its frames were pushed; rank 0 may then finish()."""
+        st = self.stack
+        st.sync()  # the library's streams are not torch's
+        for level in range(st.levels + 2):  # levels, then base entropy twin, base deviation twin
+            e_ptr, l_ptr, i_ptr, n = st.state_ptrs(level)
+            e = wrap_device(e_ptr, n, torch.float32, self.device)
+            lp = wrap_device(l_ptr, n * 3, torch.float32, self.device)
+            ix = wrap_device(i_ptr, n, torch.int32, self.device)
+            combine_state(e, lp, ix, self.group, self._select_hip)
+        torch.cuda.current_stream(torch.device("cuda", self.device)).synchronize()

@@ -239,3 +239,45 @@ def L_energy_crop(L, buf, H, W, N):
     e = st.tap(L.TAP_ENERGY, 0)
     st.close()
     return e[:256, :256]
+
+
+def test_sharded_state_combine_on_one_gpu(L):
+    """Two handles play two ranks (frame blocks [0,3) and [3,6)); their state, combined with
+    mi_combine_select in rank order, equals one handle that saw all six frames -- including a
+    duplicate frame that sits in the second block (the first copy must win)."""
+    import ctypes as C
+    rng = np.random.default_rng(21)
+    frames = [rng.integers(0, 256, (160, 224, 3), dtype=np.uint8) for _ in range(5)]
+    frames.insert(4, frames[1].copy())
+    whole = run_stack(L, frames, L.IMPL_TILED)
+    parts = []
+    for r, blk in enumerate((frames[:3], frames[3:])):
+        st = L.Stack(160, 224, impl=L.IMPL_TILED)
+        st.set_first_index(3 * r)
+        for f in blk:
+            st.push_frame(f)
+        parts.append(st)
+    lib = L.load()
+    for level in range(whole.levels + 2):
+        ptrs = [p.state_ptrs(level) for p in parts]
+        n = ptrs[0][3]
+        cand_e, cand_l, cand_i = L.DeviceBuffer(2 * n * 4), L.DeviceBuffer(2 * n * 12), L.DeviceBuffer(2 * n * 4)
+        host = []
+        for r, (e, l, i, _n) in enumerate(ptrs):
+            for src, dst, sz in ((e, cand_e, n * 4), (l, cand_l, n * 12), (i, cand_i, n * 4)):
+                tmp = np.empty(sz, np.uint8)
+                L.check(lib.mi_memcpy_d2h(0, tmp.ctypes.data, src, sz))
+                dst.upload(tmp, r * sz)
+        out_e, out_l, out_i = L.DeviceBuffer(n * 4), L.DeviceBuffer(n * 12), L.DeviceBuffer(n * 4)
+        L.check(lib.mi_combine_select(0, None, 2, cand_e.ptr, cand_l.ptr, cand_i.ptr, n,
+                                      out_e.ptr, out_l.ptr, out_i.ptr))
+        L.check(lib.mi_device_synchronize(0))
+        we, wl, wi, _ = whole.state_ptrs(level)
+        for got, want_ptr, sz, dt in ((out_e, we, n, np.float32), (out_l, wl, 3 * n, np.float32),
+                                      (out_i, wi, n, np.int32)):
+            want = np.empty(sz, dt)
+            L.check(lib.mi_memcpy_d2h(0, want.ctypes.data, want_ptr, want.nbytes))
+            assert np.array_equal(got.download((sz,), dt), want), f"level {level}"
+    for p in parts:
+        p.close()
+    whole.close()

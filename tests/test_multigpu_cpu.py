@@ -1,0 +1,121 @@
+"""CPU, world_size 2, gloo: the frame-sharded combine (shinestacker_amd/multigpu.py).
+
+Each rank builds the running state of ITS frame block with the oracle (standing in for the
+per-GPU HIP path), the ranks exchange and combine with the product's combine_state(), and rank
+0 must hold exactly the state of the whole stack processed in one go -- including first-max
+tie-breaking across ranks (the stack contains duplicate frames on different ranks)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _frames():
+    rng = np.random.default_rng(77)
+    fr = [rng.integers(0, 256, (72, 104, 3), dtype=np.uint8) for _ in range(5)]
+    fr.insert(3, fr[1].copy())   # duplicates: index 3 == index 1 (other rank), 6 == 0
+    fr.append(fr[0].copy())
+    return fr  # 7 frames: rank 0 gets [0,4), rank 1 gets [4,7)
+
+
+def _torch_select(cand_e, cand_l, cand_i):
+    """Reference first-max for CPU tensors (test double of mi_combine_select)."""
+    world, m = cand_e.shape
+    best = torch.zeros(m, dtype=torch.long)
+    be = cand_e[0].clone()
+    for r in range(1, world):
+        win = cand_e[r] > be
+        be = torch.where(win, cand_e[r], be)
+        best = torch.where(win, torch.full_like(best, r), best)
+    ar = torch.arange(m)
+    lap = cand_l.view(world, m, -1)[best, ar].reshape(-1)
+    return be, lap, cand_i[best, ar]
+
+
+def _worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import oracle as orc
+        from shinestacker_amd import multigpu
+        frames = _frames()
+        cut = [0, 4, 7]
+        so = orc.StreamingOracle(72, 104, np.uint8, min_size=8)
+        so.n = 0
+        first = cut[rank]
+        for k, f in enumerate(frames[cut[rank]:cut[rank + 1]]):
+            so.push_frame(f)
+        # global frame indices (the HIP path gets them from set_first_index)
+        for lv in range(so.levels):
+            so.best_idx[lv] += first
+        so.idx_e += first
+        so.idx_d += first
+        levels = [(so.best_e[lv], so.best_lap[lv], so.best_idx[lv]) for lv in range(so.levels)]
+        # base twins: (entropy, winner's base pixel), (deviation, winner's base pixel)
+        bases = np.stack(so.bases)
+        hb, wb = so.shapes[so.levels]
+        yy, xx = np.mgrid[0:hb, 0:wb]
+        base_e = bases[so.idx_e - first, yy, xx]
+        base_d = bases[so.idx_d - first, yy, xx]
+        levels.append((so.b_ent, base_e, so.idx_e))
+        levels.append((so.b_dev, base_d, so.idx_d))
+        out = []
+        for e, l, i in levels:
+            te = torch.from_numpy(np.ascontiguousarray(e).ravel().copy())
+            tl = torch.from_numpy(np.ascontiguousarray(l).ravel().copy())
+            ti = torch.from_numpy(np.ascontiguousarray(i).ravel().copy())
+            multigpu.combine_state(te, tl, ti, dist.group.WORLD, _torch_select)
+            out.append((te.numpy(), tl.numpy(), ti.numpy()))
+        if rank == 0:
+            ret["state"] = out
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_combine_equals_single_stack(oracle):
+    port = _free_port()
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
+        state = ret["state"]
+    frames = _frames()
+    so = oracle.StreamingOracle(72, 104, np.uint8, min_size=8)
+    for f in frames:
+        so.push_frame(f)
+    for lv in range(so.levels):
+        e, l, i = state[lv]
+        assert np.array_equal(e, so.best_e[lv].ravel())
+        assert np.array_equal(i, so.best_idx[lv].ravel())
+        assert np.array_equal(l, so.best_lap[lv].ravel())
+        # duplicates live on the other rank: the earlier copy must have won
+        assert not np.isin(i, [3, 6]).any()
+    e, l, i = state[so.levels]
+    assert np.array_equal(e, so.b_ent.ravel()) and np.array_equal(i, so.idx_e.ravel())
+    e, l, i = state[so.levels + 1]
+    assert np.array_equal(e, so.b_dev.ravel()) and np.array_equal(i, so.idx_d.ravel())
+    # fused base from the combined twins == oracle
+    be = state[so.levels][1].reshape(-1)
+    bd = state[so.levels + 1][1].reshape(-1)
+    fused = ((0.0 + be) + bd) / 2.0
+    assert np.array_equal(fused.astype(np.float32), so.fused_base().ravel())
+
+
+def test_chunk_bounds_cover_everything():
+    from shinestacker_amd.multigpu import chunk_bounds
+    for n in (0, 1, 7, 8, 9, 1000003):
+        for w in (1, 2, 3, 8):
+            b = chunk_bounds(n, w)
+            assert b[0][0] == 0 and b[-1][1] == n
+            assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
