@@ -40,10 +40,10 @@ def build_extension(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
     extra = []
-    cfg = os.environ.get("MI_TILE_CFG")  # "TH0,TW0,NT0,TH,TW,NT,PAD" -- tuning builds only
+    cfg = os.environ.get("MI_TILE_CFG")  # "TH0,TW0,NT0,TH,TW,NT,PAD[,RU]" -- tuning builds only
     if cfg:
         names = ["MI_TILE0_H", "MI_TILE0_W", "MI_TILE0_NT", "MI_TILE_H", "MI_TILE_W", "MI_TILE_NT",
-                 "MI_TILE_PAD"]
+                 "MI_TILE_PAD", "MI_REDUCE_RU"]
         extra = [f"-D{n}={v}" for n, v in zip(names, cfg.split(","))]
     cmd = [_hipcc(), *HIPCC_FLAGS, *extra, "-I", os.path.join(ROOT, "include"),
            *[os.path.join(CSRC, s) for s in SOURCES], "-o", LIB]

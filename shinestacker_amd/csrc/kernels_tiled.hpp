@@ -89,6 +89,9 @@ constexpr int SB = 8;  // super-block edge in tiles (64 tiles = one XCD's concur
 #ifndef MI_TILE_PAD
 #define MI_TILE_PAD 1
 #endif
+#ifndef MI_REDUCE_RU
+#define MI_REDUCE_RU 2
+#endif
 
 template <int TH_, int TW_, int NT_, bool PAD_>
 struct TileGeom {
@@ -323,28 +326,36 @@ __global__ __launch_bounds__(NT) void level_fused(LevelArgs a) {
         __syncthreads();
         if (b + 1 < a.nframes && !(a.ablate & 16)) prefetch(b + 1);
 
-        // ---------------- reduce: items of 1 output row x 2 output pixels x 3 channels
+        // ---------------- reduce: items of RU output rows x 2 output pixels x 3 channels
         if (!(a.ablate & 1)) {
             constexpr int BX = G::NW / 2;
-            for (int it = ltid; it < G::NH * BX; it += G::NT) {
-                const int ri = it / BX, bx = it - ri * BX, rj = 2 * bx;
-                float acc[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+            constexpr int RU = INTERIOR ? MI_REDUCE_RU : 1;  // output rows per item
+            static_assert(G::NH % RU == 0, "reduce rows per item must divide the patch height");
+            for (int it = ltid; it < (G::NH / RU) * BX; it += G::NT) {
+                const int rb = it / BX, bx = it - rb * BX, ri = rb * RU, rj = 2 * bx;
+                float acc[RU][2][3];
+#pragma unroll
+                for (int u = 0; u < RU; ++u)
+#pragma unroll
+                    for (int vv = 0; vv < 2; ++vv) acc[u][vv][0] = acc[u][vv][1] = acc[u][vv][2] = 0.f;
                 if constexpr (INTERIOR) {
-                    // input rows 2ri .. 2ri+4, pixels 2rj .. 2rj+6: 21 floats, 16-byte aligned.
-                    // Row ty+1 is loaded while row ty is consumed (two register sets).
+                    // input rows 2ri .. 2ri+2RU+2, pixels 2rj .. 2rj+6: 21 floats, 16-byte aligned.
+                    // Row rr+1 is loaded while row rr is consumed (two register sets); input row
+                    // rr is tap row rr-2u of output row u.
+                    constexpr int NR = 2 * RU + 3;
                     const float* p0 = sG + mul24(2 * ri, G::GS) + 2 * rj * 3;
                     v4f rq[2][5];
                     float rl[2];
-                    auto load_row = [&](int ty, int s) {
+                    auto load_row = [&](int rr, int s) {
 #pragma unroll
-                        for (int t = 0; t < 5; ++t) rq[s][t] = lds_load4(p0 + ty * G::GS + 4 * t);
-                        rl[s] = p0[ty * G::GS + 20];
+                        for (int t = 0; t < 5; ++t) rq[s][t] = lds_load4(p0 + rr * G::GS + 4 * t);
+                        rl[s] = p0[rr * G::GS + 20];
                     };
                     load_row(0, 0);
 #pragma unroll
-                    for (int ty = 0; ty < 5; ++ty) {
-                        const int s = ty & 1;
-                        if (ty < 4) load_row(ty + 1, s ^ 1);
+                    for (int rr = 0; rr < NR; ++rr) {
+                        const int s = rr & 1;
+                        if (rr + 1 < NR) load_row(rr + 1, s ^ 1);
                         MI_LDS_FENCE();
                         float v[21];
 #pragma unroll
@@ -354,14 +365,19 @@ __global__ __launch_bounds__(NT) void level_fused(LevelArgs a) {
                         }
                         v[20] = rl[s];
 #pragma unroll
-                        for (int vv = 0; vv < 2; ++vv)
+                        for (int u = 0; u < RU; ++u) {
+                            const int ty = rr - 2 * u;
+                            if (ty < 0 || ty > 4) continue;
 #pragma unroll
-                            for (int tx = 0; tx < 5; ++tx) {
-                                const float k = K(ty, tx);
+                            for (int vv = 0; vv < 2; ++vv)
 #pragma unroll
-                                for (int c = 0; c < 3; ++c)
-                                    acc[vv][c] = mac<FMA>(k, v[(2 * vv + tx) * 3 + c], acc[vv][c]);
-                            }
+                                for (int tx = 0; tx < 5; ++tx) {
+                                    const float k = K(ty, tx);
+#pragma unroll
+                                    for (int c = 0; c < 3; ++c)
+                                        acc[u][vv][c] = mac<FMA>(k, v[(2 * vv + tx) * 3 + c], acc[u][vv][c]);
+                                }
+                        }
                     }
                 } else {
                     const int im = map_expand_src(y0 / 2 - 2 + ri, hn);
@@ -377,15 +393,18 @@ __global__ __launch_bounds__(NT) void level_fused(LevelArgs a) {
                                 const float k = K(ty, tx);
                                 const float* p = sG + r * G::GS + cc * 3;
 #pragma unroll
-                                for (int c = 0; c < 3; ++c) acc[vv][c] = mac<FMA>(k, p[c], acc[vv][c]);
+                                for (int c = 0; c < 3; ++c) acc[0][vv][c] = mac<FMA>(k, p[c], acc[0][vv][c]);
                             }
                         }
                     }
                 }
-                float* o = sN + mul24(ri, G::NS) + rj * 3;  // 6 floats, 8-byte aligned
-                lds_store2(o, acc[0][0], acc[0][1]);
-                lds_store2(o + 2, acc[0][2], acc[1][0]);
-                lds_store2(o + 4, acc[1][1], acc[1][2]);
+#pragma unroll
+                for (int u = 0; u < RU; ++u) {
+                    float* o = sN + mul24(ri + u, G::NS) + rj * 3;  // 6 floats, 8-byte aligned
+                    lds_store2(o, acc[u][0][0], acc[u][0][1]);
+                    lds_store2(o + 2, acc[u][0][2], acc[u][1][0]);
+                    lds_store2(o + 4, acc[u][1][1], acc[u][1][2]);
+                }
             }
         }
         __syncthreads();
