@@ -36,6 +36,7 @@ def parse():
     ap.add_argument("--width", type=int, default=6000)
     ap.add_argument("--dtype", default="f32", choices=["u8", "u16", "f32"])
     ap.add_argument("--impl", default="auto", choices=["auto", "simple", "tiled"])
+    ap.add_argument("--batch", type=int, default=0, help="frames per fused launch (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=4)
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic.json"),
@@ -96,7 +97,7 @@ def main():
     L.synth_frames_device(buf.ptr, dt, H, W, rank * F, F, total_frames, device=device)
     impl = {"auto": L.IMPL_AUTO, "simple": L.IMPL_SIMPLE, "tiled": L.IMPL_TILED}[args.impl]
     st = L.Stack(H, W, in_dtype=dt, out_dtype=np.uint16 if args.dtype == "u16" else np.uint8,
-                 device=device, impl=impl)
+                 device=device, impl=impl, batch_frames=args.batch)
     st.set_first_index(rank * F)
     combiner = None
     if world > 1:

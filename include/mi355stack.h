@@ -19,7 +19,7 @@
  *                                         pyramid.py:103-111, :57-64, :178-179
  *   mi_stack_get_level                    debug/parity taps (no reference counterpart)
  *   mi_stack_state / _set_first_index     hooks for the frame-sharded multi-GPU combine
- *   mi_warp_affine                        cv2.warpAffine + mask + border blur composite,
+ *   mi_warp_affine[_device]               cv2.warpAffine + warped mask + border blur composite,
  *                                         algorithms/align.py:238-251
  *
  * Ownership: the caller owns every host buffer it passes and every device
@@ -161,6 +161,21 @@ MI_API int mi_stack_profile_get(mi_stack_t* s, int kind, double* total_ms, int64
  * energy / lap / index to out_*.  `stream` is a hipStream_t (NULL = default stream). */
 MI_API int mi_combine_select(int device, void* stream, int n, const void* cand_e, const void* cand_lap,
                       const void* cand_idx, size_t npix, void* out_e, void* out_lap, void* out_idx);
+
+/* ---- alignment apply step: cv2.warpAffine(img, M, (w,h), borderMode, borderValue) for the
+ * ALIGN_RIGID transform of align_images (reference algorithms/align.py:238-251), H x W x 3
+ * uint8 / uint16.  M is the 2x3 src->dst matrix as OpenCV takes it (row-major, 6 doubles).
+ * border_mode: 0 = BORDER_CONSTANT(border_value), 1 = BORDER_REPLICATE,
+ *              2 = BORDER_REPLICATE_BLUR: replicate, then pixels whose warped all-ones mask is 0
+ *                  are replaced by GaussianBlur(warp, (blur_ksize, blur_ksize), blur_sigma).
+ * mask (optional, H x W bytes): the warped all-ones uint8 mask (align.py:245-247).
+ * The _device form works on device buffers (dev_tmp: one image of scratch, needed for mode 2). */
+MI_API int mi_warp_affine(int device, const void* host_src, void* host_dst, void* host_mask, int height,
+                   int width, int dtype, const double* M, int border_mode, const double* border_value,
+                   int blur_ksize, double blur_sigma);
+MI_API int mi_warp_affine_device(int device, void* stream, const void* dev_src, void* dev_dst, void* dev_tmp,
+                          void* dev_mask, int height, int width, int dtype, const double* M,
+                          int border_mode, const double* border_value, int blur_ksize, double blur_sigma);
 
 /* ---- synthetic stack generator, device side ---- */
 MI_API int mi_synth_frames_device(int device, void* dev_out, int dtype, int height, int width,

@@ -1,0 +1,198 @@
+/*
+ * oracle/align_oracle.c -- CPU restatement of the alignment APPLY step of shinestacker's
+ * align_images (reference src/shinestacker/algorithms/align.py:238-251, ALIGN_RIGID):
+ *   img_warp = cv2.warpAffine(img_0, M, (w, h), borderMode, borderValue)        :242-244
+ *   mask     = cv2.warpAffine(ones_u8, M, (w, h), BORDER_CONSTANT, 0)            :245-247
+ *   blurred  = cv2.GaussianBlur(img_warp, (21, 21), sigmaX=border_blur)          :249
+ *   img_warp[mask == 0] = blurred[mask == 0]                                     :251
+ * TEST INFRASTRUCTURE ONLY (see pyramid_oracle.c).
+ *
+ * PARITY STATUS: "parity unpinned" -- OpenCV is absent here and the reference's tests hold no
+ * pixel values for this step.  Restated from OpenCV's imgwarp.cpp [from memory]:
+ *  - M (src->dst) is inverted in double (no WARP_INVERSE_MAP);
+ *  - fixed-point source coordinates: AB_BITS = 10, INTER_BITS = 5:
+ *      X0 = cvRound((iM01*y + iM02)*1024) + 16, adelta[x] = cvRound(iM00*x*1024),
+ *      X = (X0 + adelta[x]) >> 5;  sx = X >> 5, fx = X & 31   (same for Y);
+ *  - bilinear weights from the 32x32 table of products (1-f/32 | f/32):
+ *      8-bit : 15-bit integer weights w*32768 (exact multiples of 32; the w = 1.0 entry saturates
+ *              to 32767 and its missing unit goes to the diagonal tap), result (sum + 16384) >> 15;
+ *      16-bit: float weights, sum in tap order, rounded half-to-even, saturated;
+ *  - border: a tap outside the image takes the replicated edge pixel (REPLICATE) or the constant;
+ *    a pixel whose four taps are all outside takes the constant directly;
+ *  - the all-ones uint8 mask warped with constant 0 is therefore 1 iff the in-image 15-bit
+ *    weights sum to >= 16384.
+ *  - GaussianBlur: OpenCV uses a fixed-point separable path for 8/16-bit; it is NOT restated.
+ *    Here: float32 kernel = float32(getGaussianKernel(21, sigma)) (double exp, normalised),
+ *    horizontal pass then vertical pass in float32, taps in index order, REFLECT101, final
+ *    round-half-even + saturate.  Only pixels with mask == 0 (out-of-frame filler) use it.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#define ORC_API __attribute__((visibility("default")))
+
+static inline int cv_round(double v) {
+    if (v >= 2147483647.0) return 2147483647;
+    if (v <= -2147483648.0) return (-2147483647 - 1);
+    return (int)lrint(v);
+}
+static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+static inline int r101(int i, int n) {
+    if (n == 1) return 0;
+    while (i < 0 || i >= n) {
+        if (i < 0) i = -i;
+        if (i >= n) i = 2 * n - 2 - i;
+    }
+    return i;
+}
+
+ORC_API void orc_invert_affine(const double* M, double* iM) {
+    double D = M[0] * M[4] - M[1] * M[3];
+    D = D != 0.0 ? 1.0 / D : 0.0;
+    double A11 = M[4] * D, A22 = M[0] * D;
+    iM[0] = A11;
+    iM[1] = M[1] * (-D);
+    iM[3] = M[3] * (-D);
+    iM[4] = A22;
+    iM[2] = -iM[0] * M[2] - iM[1] * M[5];
+    iM[5] = -iM[3] * M[2] - iM[4] * M[5];
+}
+
+/* 15-bit bilinear weights of table entry (fy, fx) */
+static inline void wtab_i(int fx, int fy, int* iw) {
+    iw[0] = (32 - fy) * (32 - fx) * 32;
+    iw[1] = (32 - fy) * fx * 32;
+    iw[2] = fy * (32 - fx) * 32;
+    iw[3] = fy * fx * 32;
+    if (fx == 0 && fy == 0) { iw[0] = 32767; iw[3] = 1; } /* short saturation + OpenCV's fix-up */
+}
+
+/* dtype: 0 = u8, 1 = u16.  mode: 0 = constant(border[c]), 1 = replicate.
+ * valid (may be NULL): h*w bytes, the warped all-ones mask. */
+ORC_API void orc_warp_affine(const void* src_, void* dst_, uint8_t* valid, int h, int w, int dtype,
+                             const double* M, int mode, const double* border) {
+    double iM[6];
+    orc_invert_affine(M, iM);
+    const uint8_t* s8 = (const uint8_t*)src_;
+    const uint16_t* s16 = (const uint16_t*)src_;
+    uint8_t* d8 = (uint8_t*)dst_;
+    uint16_t* d16 = (uint16_t*)dst_;
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < h; ++y) {
+        int X0 = cv_round((iM[1] * y + iM[2]) * 1024.0) + 16;
+        int Y0 = cv_round((iM[4] * y + iM[5]) * 1024.0) + 16;
+        for (int x = 0; x < w; ++x) {
+            int X = (X0 + cv_round(iM[0] * x * 1024.0)) >> 5;
+            int Y = (Y0 + cv_round(iM[3] * x * 1024.0)) >> 5;
+            int sx = X >> 5, sy = Y >> 5, fx = X & 31, fy = Y & 31;
+            int in00 = sx >= 0 && sx < w && sy >= 0 && sy < h;
+            int in01 = sx + 1 >= 0 && sx + 1 < w && sy >= 0 && sy < h;
+            int in10 = sx >= 0 && sx < w && sy + 1 >= 0 && sy + 1 < h;
+            int in11 = sx + 1 >= 0 && sx + 1 < w && sy + 1 >= 0 && sy + 1 < h;
+            int iw[4];
+            wtab_i(fx, fy, iw);
+            if (valid) {
+                int s = (in00 ? iw[0] : 0) + (in01 ? iw[1] : 0) + (in10 ? iw[2] : 0) + (in11 ? iw[3] : 0);
+                valid[(size_t)y * w + x] = (uint8_t)(((s + 16384) >> 15) != 0);
+            }
+            int all_out = !(in00 || in01 || in10 || in11);
+            int x0 = clampi(sx, 0, w - 1), x1 = clampi(sx + 1, 0, w - 1);
+            int y0 = clampi(sy, 0, h - 1), y1 = clampi(sy + 1, 0, h - 1);
+            for (int c = 0; c < 3; ++c) {
+                size_t o = ((size_t)y * w + x) * 3 + c;
+                double bv = border[c];
+                if (dtype == 0) {
+                    int cb = clampi(cv_round(bv), 0, 255);
+                    int v00, v01, v10, v11;
+                    if (mode == 1) {
+                        v00 = s8[((size_t)y0 * w + x0) * 3 + c]; v01 = s8[((size_t)y0 * w + x1) * 3 + c];
+                        v10 = s8[((size_t)y1 * w + x0) * 3 + c]; v11 = s8[((size_t)y1 * w + x1) * 3 + c];
+                    } else {
+                        v00 = in00 ? s8[((size_t)sy * w + sx) * 3 + c] : cb;
+                        v01 = in01 ? s8[((size_t)sy * w + sx + 1) * 3 + c] : cb;
+                        v10 = in10 ? s8[((size_t)(sy + 1) * w + sx) * 3 + c] : cb;
+                        v11 = in11 ? s8[((size_t)(sy + 1) * w + sx + 1) * 3 + c] : cb;
+                    }
+                    int r = (mode == 0 && all_out) ? cb
+                            : clampi((v00 * iw[0] + v01 * iw[1] + v10 * iw[2] + v11 * iw[3] + 16384) >> 15, 0, 255);
+                    d8[o] = (uint8_t)r;
+                } else {
+                    int cb = clampi(cv_round(bv), 0, 65535);
+                    float v00, v01, v10, v11;
+                    if (mode == 1) {
+                        v00 = s16[((size_t)y0 * w + x0) * 3 + c]; v01 = s16[((size_t)y0 * w + x1) * 3 + c];
+                        v10 = s16[((size_t)y1 * w + x0) * 3 + c]; v11 = s16[((size_t)y1 * w + x1) * 3 + c];
+                    } else {
+                        v00 = in00 ? s16[((size_t)sy * w + sx) * 3 + c] : (float)cb;
+                        v01 = in01 ? s16[((size_t)sy * w + sx + 1) * 3 + c] : (float)cb;
+                        v10 = in10 ? s16[((size_t)(sy + 1) * w + sx) * 3 + c] : (float)cb;
+                        v11 = in11 ? s16[((size_t)(sy + 1) * w + sx + 1) * 3 + c] : (float)cb;
+                    }
+                    float wx1 = fx * (1.0f / 32), wx0 = 1.0f - wx1, wy1 = fy * (1.0f / 32), wy0 = 1.0f - wy1;
+                    volatile float p0 = v00 * (wy0 * wx0), p1 = v01 * (wy0 * wx1);
+                    volatile float p2 = v10 * (wy1 * wx0), p3 = v11 * (wy1 * wx1);
+                    volatile float s = p0 + p1;
+                    s = s + p2;
+                    s = s + p3;
+                    int r = (mode == 0 && all_out) ? cb : clampi((int)lrintf(s), 0, 65535);
+                    d16[o] = (uint16_t)r;
+                }
+            }
+        }
+    }
+}
+
+ORC_API void orc_gauss_kernel_f32(int ksize, double sigma, float* k) {
+    /* cv::getGaussianKernel(ksize, sigma, CV_32F) for sigma > 0 [from memory] */
+    double sum = 0.0, *t = (double*)malloc(sizeof(double) * ksize);
+    double scale2x = -0.5 / (sigma * sigma);
+    for (int i = 0; i < ksize; ++i) {
+        double x = i - (ksize - 1) * 0.5;
+        t[i] = exp(scale2x * x * x);
+        sum += t[i];
+    }
+    sum = 1.0 / sum;
+    for (int i = 0; i < ksize; ++i) k[i] = (float)(t[i] * sum);
+    free(t);
+}
+
+/* out = valid ? warp : gaussian_blur(warp)   (blur: see header) */
+ORC_API void orc_border_blur_composite(const void* warp_, const uint8_t* valid, void* out_, int h, int w,
+                                       int dtype, int ksize, double sigma) {
+    float* k = (float*)malloc(sizeof(float) * ksize);
+    orc_gauss_kernel_f32(ksize, sigma, k);
+    const int r = ksize / 2;
+    const uint8_t* s8 = (const uint8_t*)warp_;
+    const uint16_t* s16 = (const uint16_t*)warp_;
+    uint8_t* d8 = (uint8_t*)out_;
+    uint16_t* d16 = (uint16_t*)out_;
+    const int maxv = dtype == 0 ? 255 : 65535;
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x)
+            for (int c = 0; c < 3; ++c) {
+                size_t o = ((size_t)y * w + x) * 3 + c;
+                if (valid[(size_t)y * w + x]) {
+                    if (dtype == 0) d8[o] = s8[o]; else d16[o] = s16[o];
+                    continue;
+                }
+                float acc = 0.0f;
+                for (int dy = 0; dy < ksize; ++dy) {
+                    int yy = r101(y + dy - r, h);
+                    float row = 0.0f;
+                    for (int dx = 0; dx < ksize; ++dx) {
+                        int xx = r101(x + dx - r, w);
+                        float v = dtype == 0 ? (float)s8[((size_t)yy * w + xx) * 3 + c]
+                                             : (float)s16[((size_t)yy * w + xx) * 3 + c];
+                        volatile float p = k[dx] * v;
+                        row = row + p;
+                    }
+                    volatile float q = k[dy] * row;
+                    acc = acc + q;
+                }
+                int rr = clampi((int)lrintf(acc), 0, maxv);
+                if (dtype == 0) d8[o] = (uint8_t)rr; else d16[o] = (uint16_t)rr;
+            }
+    free(k);
+}

@@ -33,8 +33,8 @@ _SO = os.path.join(_HERE, "_build", "liboracle.so")
 
 def build(force=False):
     """Compile liboracle.so with gcc (oracle/Makefile)."""
-    src = os.path.join(_HERE, "pyramid_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("pyramid_oracle.c", "align_oracle.c")]
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(map(os.path.getmtime, srcs)):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _SO
 
@@ -75,6 +75,12 @@ def lib():
                                           _f32p, _i32p, _i32p]
         L.orc_base_fuse_f32.argtypes = [_f32p, C.c_size_t, _i32p, _i32p, _f32p]
         L.orc_synth_frame_u8.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32]
+        L.orc_warp_affine.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                      _f64p, C.c_int, _f64p]
+        L.orc_border_blur_composite.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                                C.c_int, C.c_int, C.c_double]
+        L.orc_gauss_kernel_f32.argtypes = [C.c_int, C.c_double, _f32p]
+        L.orc_invert_affine.argtypes = [_f64p, _f64p]
         _lib = L
     return _lib
 
@@ -396,3 +402,29 @@ def synth_frame_numpy(h, w, f, n, seed=20250824, dtype=np.uint8):
     if np.dtype(dtype) == np.uint16:
         return (v * 257).astype(np.uint16)
     return v.astype(np.uint8)
+
+
+# --------------------------------------------------------------------------
+# alignment apply step (align.py:238-251), see align_oracle.c
+# --------------------------------------------------------------------------
+BORDER_CONSTANT, BORDER_REPLICATE, BORDER_REPLICATE_BLUR = 0, 1, 2
+
+
+def warp_affine(img, M, border_mode=BORDER_REPLICATE_BLUR, border_value=(0, 0, 0, 0),
+                blur_ksize=21, blur_sigma=50.0, want_mask=False):
+    """warpAffine (+ mask + border blur for BORDER_REPLICATE_BLUR) of an HxWx3 uint8/uint16 image."""
+    img = np.ascontiguousarray(img)
+    h, w = img.shape[:2]
+    dt = 0 if img.dtype == np.uint8 else 1
+    M = np.ascontiguousarray(np.asarray(M, dtype=np.float64).reshape(6))
+    bv = np.ascontiguousarray(np.asarray(list(border_value) + [0, 0, 0, 0], dtype=np.float64)[:4])
+    warp = np.empty_like(img)
+    valid = np.empty((h, w), np.uint8)
+    mode = 0 if border_mode == BORDER_CONSTANT else 1
+    lib().orc_warp_affine(img.ctypes.data, warp.ctypes.data, valid.ctypes.data, h, w, dt, M, mode, bv)
+    out = warp
+    if border_mode == BORDER_REPLICATE_BLUR:
+        out = np.empty_like(img)
+        lib().orc_border_blur_composite(warp.ctypes.data, valid.ctypes.data, out.ctypes.data, h, w, dt,
+                                        blur_ksize, float(blur_sigma))
+    return (out, valid) if want_mask else out

@@ -7,5 +7,7 @@ from .pyramid import BaseStackAlgo, PyramidStack  # noqa: F401
 from .actions import (StackJob, FocusStack, FocusStackBunch, CombinedActions, SubAction,  # noqa: F401
                       get_bunches)
 
-__all__ = ["PyramidStack", "BaseStackAlgo", "StackJob", "FocusStack", "FocusStackBunch",
+from .align import AlignFrames, align_images  # noqa: F401,E402
+
+__all__ = ["AlignFrames", "align_images", "PyramidStack", "BaseStackAlgo", "StackJob", "FocusStack", "FocusStackBunch",
            "CombinedActions", "SubAction", "get_bunches", "constants"]

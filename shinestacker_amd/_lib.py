@@ -70,6 +70,12 @@ SIGNATURES = {
                                        C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "mi_combine_select": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mi_warp_affine": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                 C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double), C.c_int,
+                                 C.c_double]),
+    "mi_warp_affine_device": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double),
+                                        C.c_int, C.POINTER(C.c_double), C.c_int, C.c_double]),
     "mi_synth_frames_device": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.c_int, C.c_int, C.c_uint32]),
 }
@@ -310,3 +316,24 @@ def synth_frames_device(dev_ptr, dtype, height, width, first_frame, n_frames, st
                         seed=20250824, device=0):
     check(load().mi_synth_frames_device(device, dev_ptr, DTYPE_CODE[np.dtype(dtype)], height,
                                         width, first_frame, n_frames, stack_size, seed))
+
+
+BORDER_CONSTANT, BORDER_REPLICATE, BORDER_REPLICATE_BLUR = 0, 1, 2
+
+
+def warp_affine(img, M, border_mode=BORDER_REPLICATE_BLUR, border_value=(0, 0, 0, 0), blur_ksize=21,
+                blur_sigma=50.0, want_mask=False, device=0):
+    """cv2.warpAffine + warped mask + blurred-border composite on the GPU (mi_warp_affine)."""
+    require_device()
+    a = np.ascontiguousarray(img)
+    if a.ndim != 3 or a.shape[2] != 3 or a.dtype not in (np.uint8, np.uint16):
+        raise ValueError("warp_affine expects an H x W x 3 uint8/uint16 image")
+    h, w = a.shape[:2]
+    m = (C.c_double * 6)(*np.asarray(M, dtype=np.float64).reshape(6))
+    bv = (C.c_double * 4)(*(list(border_value) + [0, 0, 0, 0])[:4])
+    out = np.empty_like(a)
+    mask = np.empty((h, w), np.uint8) if want_mask else None
+    check(load().mi_warp_affine(device, a.ctypes.data, out.ctypes.data,
+                                mask.ctypes.data if want_mask else None, h, w, DTYPE_CODE[a.dtype], m,
+                                int(border_mode), bv, int(blur_ksize), float(blur_sigma)))
+    return (out, mask) if want_mask else out

@@ -10,6 +10,7 @@
 #include "common.hpp"
 #include "kernels_simple.hpp"
 #include "kernels_tiled.hpp"
+#include "kernels_align.hpp"
 
 using namespace mi;
 
@@ -295,6 +296,39 @@ int check_handle(const mi_stack* s) {
 
 // tiled implementation hooks (kernels_tiled.hpp) need the handle layout
 #include "tiled_host.hpp"
+
+namespace {
+
+void invert_affine_host(const double* M, double* iM) {
+    double D = M[0] * M[4] - M[1] * M[3];
+    D = D != 0.0 ? 1.0 / D : 0.0;
+    const double A11 = M[4] * D, A22 = M[0] * D;
+    iM[0] = A11;
+    iM[1] = M[1] * (-D);
+    iM[3] = M[3] * (-D);
+    iM[4] = A22;
+    iM[2] = -iM[0] * M[2] - iM[1] * M[5];
+    iM[5] = -iM[3] * M[2] - iM[4] * M[5];
+}
+
+int round_sat(double v, int hi) {
+    double r = std::nearbyint(v);
+    return r < 0 ? 0 : (r > hi ? hi : (int)r);
+}
+
+template <typename T>
+int warp_launch(hipStream_t st, const void* src, void* warp, void* out, uint8_t* valid, int h, int w,
+                const AffineArgs& a, bool blur, const GaussArgs& g) {
+    const dim3 blk(64, 4), grid(cdiv(w, 64), cdiv(h, 4));
+    hipLaunchKernelGGL((warp_affine_kernel<T>), grid, blk, 0, st, (const T*)src, (T*)warp, valid, a);
+    if (blur)
+        hipLaunchKernelGGL((border_blur_composite_kernel<T>), grid, blk, 0, st, (const T*)warp, valid,
+                           (T*)out, h, w, g);
+    MI_HIP(hipGetLastError());
+    return MI_OK;
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -714,6 +748,77 @@ int mi_combine_select(int device, void* stream, int n, const void* cand_e, const
                        (const int32_t*)cand_idx, npix, (float*)out_e, (float*)out_lap,
                        (int32_t*)out_idx);
     MI_HIP(hipGetLastError());
+    return MI_OK;
+}
+
+int mi_warp_affine_device(int device, void* stream, const void* dev_src, void* dev_dst, void* dev_tmp,
+                          void* dev_mask, int height, int width, int dtype, const double* M,
+                          int border_mode, const double* border_value, int blur_ksize, double blur_sigma) {
+    if (!dev_src || !dev_dst || !M || height < 1 || width < 1) return fail(MI_ERR_INVALID, "bad argument");
+    if (dtype != MI_U8 && dtype != MI_U16) return fail(MI_ERR_INVALID, "dtype must be MI_U8 or MI_U16");
+    if (border_mode < 0 || border_mode > 2) return fail(MI_ERR_INVALID, "bad border_mode %d", border_mode);
+    const bool blur = border_mode == 2;
+    if (blur && (!dev_tmp || !dev_mask)) return fail(MI_ERR_INVALID, "border blur needs dev_tmp and dev_mask");
+    if (blur && (blur_ksize < 1 || blur_ksize > 31 || !(blur_ksize & 1) || !(blur_sigma > 0)))
+        return fail(MI_ERR_INVALID, "blur kernel size must be odd and <= 31, sigma > 0");
+    MI_HIP(hipSetDevice(device));
+    AffineArgs a{};
+    invert_affine_host(M, a.iM);
+    a.h = height;
+    a.w = width;
+    a.mode = border_mode == 0 ? 0 : 1;
+    const int hi = dtype == MI_U8 ? 255 : 65535;
+    for (int c = 0; c < 3; ++c) a.border[c] = border_value ? round_sat(border_value[c], hi) : 0;
+    GaussArgs g{};
+    if (blur) {
+        // cv::getGaussianKernel(ksize, sigma) in double, stored as float32 [from memory]
+        g.ksize = blur_ksize;
+        double t[32], sum = 0.0;
+        const double scale2x = -0.5 / (blur_sigma * blur_sigma);
+        for (int i = 0; i < blur_ksize; ++i) {
+            const double x = i - (blur_ksize - 1) * 0.5;
+            t[i] = std::exp(scale2x * x * x);
+            sum += t[i];
+        }
+        sum = 1.0 / sum;
+        for (int i = 0; i < blur_ksize; ++i) g.k[i] = (float)(t[i] * sum);
+    }
+    void* warp = blur ? dev_tmp : dev_dst;
+    if (dtype == MI_U8)
+        return warp_launch<uint8_t>((hipStream_t)stream, dev_src, warp, dev_dst, (uint8_t*)dev_mask, height, width, a, blur, g);
+    return warp_launch<uint16_t>((hipStream_t)stream, dev_src, warp, dev_dst, (uint8_t*)dev_mask, height, width, a, blur, g);
+}
+
+int mi_warp_affine(int device, const void* host_src, void* host_dst, void* host_mask, int height, int width,
+                   int dtype, const double* M, int border_mode, const double* border_value,
+                   int blur_ksize, double blur_sigma) {
+    if (!host_src || !host_dst) return fail(MI_ERR_INVALID, "null image");
+    if (dtype != MI_U8 && dtype != MI_U16) return fail(MI_ERR_INVALID, "dtype must be MI_U8 or MI_U16");
+    if (height < 1 || width < 1) return fail(MI_ERR_INVALID, "bad image size");
+    int ndev = 0;
+    int rc = mi_device_count(&ndev);
+    if (rc) return rc;
+    if (ndev == 0) return fail(MI_ERR_NO_DEVICE, "no HIP device visible");
+    MI_HIP(hipSetDevice(device));
+    const size_t nb = (size_t)height * width * 3 * dtype_size(dtype), np = (size_t)height * width;
+    void *src = nullptr, *dst = nullptr, *tmp = nullptr, *mask = nullptr;
+    auto cleanup = [&]() {
+        (void)hipFree(src); (void)hipFree(dst); (void)hipFree(tmp); (void)hipFree(mask);
+    };
+#define TRYH(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { cleanup(); return fail(e_ == hipErrorOutOfMemory ? MI_ERR_NOMEM : MI_ERR_HIP, "%s: %s", #x, hipGetErrorString(e_)); } } while (0)
+    TRYH(hipMalloc(&src, nb));
+    TRYH(hipMalloc(&dst, nb));
+    TRYH(hipMalloc(&tmp, nb));
+    TRYH(hipMalloc(&mask, np));
+    TRYH(hipMemcpy(src, host_src, nb, hipMemcpyHostToDevice));
+    rc = mi_warp_affine_device(device, nullptr, src, dst, tmp, mask, height, width, dtype, M, border_mode,
+                               border_value, blur_ksize, blur_sigma);
+    if (rc) { cleanup(); return rc; }
+    TRYH(hipDeviceSynchronize());
+    TRYH(hipMemcpy(host_dst, dst, nb, hipMemcpyDeviceToHost));
+    if (host_mask) TRYH(hipMemcpy(host_mask, mask, np, hipMemcpyDeviceToHost));
+#undef TRYH
+    cleanup();
     return MI_OK;
 }
 

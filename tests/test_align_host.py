@@ -1,0 +1,122 @@
+"""CPU: host logic of align_images / AlignFrames (no GPU: the apply step is injected)."""
+import os
+import shutil
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from shinestacker_amd import AlignFrames, CombinedActions, StackJob, align_images
+from shinestacker_amd.align import img_subsample
+from shinestacker_amd.errors import AlignmentError, InvalidOptionError, ShapeError
+
+
+def fake_estimator(n, m):
+    calls = []
+
+    def est(i0, i1, fc, mc, ac):
+        calls.append((i0.shape, i1.shape))
+        return n, (None if m is None else np.array(m, dtype=np.float64))
+    est.calls = calls
+    return est
+
+
+def record_apply():
+    seen = {}
+
+    def apply(img, m, cfg):
+        seen["m"], seen["cfg"] = np.array(m), cfg
+        return img.copy()
+    apply.seen = seen
+    return apply
+
+
+def test_subsample_rescales_translation_and_casts_to_float32():
+    img = np.zeros((64, 80, 3), np.uint8)
+    est = fake_estimator(500, [[0.99, 0.01, 1.5], [-0.01, 0.99, -2.25]])
+    ap = record_apply()
+    n, m, warp = align_images(img, img, estimator=est, apply_fn=ap,
+                              alignment_config={'fast_subsampling': True})
+    assert n == 500 and warp.shape == img.shape
+    assert est.calls == [((32, 40, 3), (32, 40, 3))]           # default subsample = 2
+    assert m.dtype == np.float32                                 # align.py:220-223
+    assert np.allclose(m, [[0.99, 0.01, 3.0], [-0.01, 0.99, -4.5]])
+    assert ap.seen["cfg"]["border_mode"] == "BORDER_REPLICATE_BLUR" and ap.seen["cfg"]["border_blur"] == 50
+
+
+def test_retry_without_subsampling_when_few_matches():
+    img = np.zeros((64, 80, 3), np.uint8)
+    results = iter([(10, [[1, 0, 1], [0, 1, 1]]), (150, [[1, 0, 2], [0, 1, 2]])])
+    shapes, warnings = [], []
+
+    def est(i0, i1, fc, mc, ac):
+        shapes.append(i0.shape)
+        n, m = next(results)
+        return n, np.array(m, float)
+    n, m, _ = align_images(img, img, estimator=est, apply_fn=record_apply(),
+                           alignment_config={'fast_subsampling': True},
+                           callbacks={'warning': warnings.append})
+    assert shapes == [(32, 40, 3), (64, 80, 3)] and n == 150
+    assert m.dtype == np.float64 and m[0, 2] == 2                # no rescale at subsample 1
+    assert "retrying without subsampling" in warnings[0]
+
+
+def test_too_few_matches_returns_none():
+    img = np.zeros((16, 16, 3), np.uint8)
+    n, m, warp = align_images(img, img, estimator=fake_estimator(2, None), apply_fn=record_apply(),
+                              alignment_config={'subsample': 1})
+    assert (n, m, warp) == (2, None, None)
+
+
+def test_option_and_shape_errors():
+    img = np.zeros((16, 16, 3), np.uint8)
+    with pytest.raises(InvalidOptionError):
+        align_images(img, img, alignment_config={'border_mode': 'BORDER_WRAP'}, estimator=fake_estimator(5, None))
+    with pytest.raises(InvalidOptionError):
+        align_images(img, img, alignment_config={'transform': 'ALIGN_HOMOGRAPHY'}, estimator=fake_estimator(5, None))
+    with pytest.raises(ShapeError):
+        align_images(img, np.zeros((16, 17, 3), np.uint8), estimator=fake_estimator(5, None))
+
+
+def test_default_estimator_needs_opencv():
+    try:
+        import cv2  # noqa: F401
+        pytest.skip("OpenCV is installed here")
+    except ImportError:
+        pass
+    img = np.zeros((16, 16, 3), np.uint8)
+    with pytest.raises(RuntimeError, match="OpenCV"):
+        align_images(img, img, alignment_config={'subsample': 1})
+
+
+def test_area_subsample_rounds_half_up():
+    a = np.array([[[1], [2], [3], [4]], [[2], [2], [3], [3]]], np.uint8)  # 2x4x1
+    out = img_subsample(a, 2, fast=False)
+    assert out.shape == (1, 2, 1) and out[0, 0, 0] == 2 and out[0, 1, 0] == 3   # 7/4 -> 2, 13/4 -> 3
+    assert np.array_equal(img_subsample(a, 2, fast=True), a[::2, ::2])
+
+
+def test_align_frames_subaction_protocol(tmp_path, monkeypatch):
+    """AlignFrames inside CombinedActions: reference frame untouched, AlignmentError on few matches."""
+    import shinestacker_amd.align as al
+    monkeypatch.setattr(al, "apply_transform", lambda img, m, cfg, device=0: img[::-1].copy())
+    work = str(tmp_path)
+    os.makedirs(os.path.join(work, "input"))
+    for n in sorted(os.listdir(os.path.join(GOLDEN, "img_jpg_crop")))[:3]:
+        shutil.copy(os.path.join(GOLDEN, "img_jpg_crop", n), os.path.join(work, "input", n))
+    af = AlignFrames(estimator=fake_estimator(200, [[1, 0, 0], [0, 1, 0]]), subsample=1)
+    job = StackJob("job", work, input_path="input")
+    job.add_action(CombinedActions("align", [af], output_path="aligned"))
+    job.run()
+    from shinestacker_amd.imageio import read_img
+    names = sorted(os.listdir(os.path.join(work, "input")))
+    ref = read_img(os.path.join(work, "input", names[1]))
+    assert np.array_equal(read_img(os.path.join(work, "aligned", names[1])), ref)       # ref_idx = 1
+    mov = read_img(os.path.join(work, "input", names[0]))
+    assert np.array_equal(read_img(os.path.join(work, "aligned", names[0])), mov[::-1])
+    assert list(af.n_matches) == [200, 0, 200]
+    bad = AlignFrames(estimator=fake_estimator(1, None), subsample=1)
+    job = StackJob("job", work, input_path="input")
+    job.add_action(CombinedActions("align2", [bad], output_path="aligned2"))
+    with pytest.raises(AlignmentError):
+        job.run()

@@ -1,0 +1,101 @@
+"""GPU: the alignment apply step (mi_warp_affine) against oracle/align_oracle.c -- bit-exact --
+plus analytic known answers."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def L(hiplib):
+    hiplib.require_device()
+    return hiplib
+
+
+def rot(theta_deg, s, tx, ty, cx=0.0, cy=0.0):
+    t = np.deg2rad(theta_deg)
+    a, b = s * np.cos(t), s * np.sin(t)
+    return [[a, b, (1 - a) * cx - b * cy + tx], [-b, a, b * cx + (1 - a) * cy + ty]]
+
+
+TRANSFORMS = [
+    [[1, 0, 0], [0, 1, 0]],
+    [[1, 0, 7], [0, 1, -3]],
+    [[1, 0, 0.5], [0, 1, 0.25]],
+    rot(0.37, 1.0003, 3.37, -2.21, 150, 100),
+    rot(15.0, 0.9, 30, 20, 128, 96),
+    rot(-4.0, 1.2, -45.5, 61.3),
+    [[1, 0, 500], [0, 1, 0]],          # entirely out of frame
+]
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16])
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("ti", range(len(TRANSFORMS)))
+def test_warp_matches_oracle(L, oracle, dtype, mode, ti):
+    rng = np.random.default_rng(100 + ti)
+    hi = 256 if dtype == np.uint8 else 65536
+    img = rng.integers(0, hi, (197, 263, 3)).astype(dtype)
+    M = np.array(TRANSFORMS[ti], dtype=np.float64)
+    bv = (10, 200, 3000 if dtype == np.uint16 else 77, 0)
+    want, wmask = oracle.warp_affine(img, M, border_mode=mode, border_value=bv, want_mask=True)
+    got, gmask = L.warp_affine(img, M, border_mode=mode, border_value=bv, want_mask=True)
+    assert np.array_equal(gmask, wmask)
+    assert got.dtype == img.dtype and np.array_equal(got, want)
+
+
+def test_float32_matrix_as_the_reference_passes_it(L, oracle):
+    """After sub-sampling the reference hands cv2 a float32 matrix (align.py:220-223)."""
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, (120, 90, 3), dtype=np.uint8)
+    m32 = np.array(rot(1.3, 0.998, 4.4, -3.3), dtype=np.float32)
+    assert np.array_equal(L.warp_affine(img, m32), oracle.warp_affine(img, m32.astype(np.float64)))
+
+
+def test_identity_and_integer_shift_are_exact(L):
+    rng = np.random.default_rng(6)
+    img = rng.integers(0, 65536, (64, 80, 3), dtype=np.uint16)
+    out, mask = L.warp_affine(img, [[1, 0, 0], [0, 1, 0]], want_mask=True)
+    assert np.array_equal(out, img) and mask.all()
+    out, mask = L.warp_affine(img, [[1, 0, 5], [0, 1, 2]], border_mode=L.BORDER_REPLICATE, want_mask=True)
+    assert np.array_equal(out[2:, 5:], img[:-2, :-5])
+    assert np.array_equal(out[:2, 5:], np.broadcast_to(img[0, :-5], (2, 75, 3)))   # replicated edge
+    assert not mask[:2].any() and not mask[:, :5].any() and mask[2:, 5:].all()
+    out = L.warp_affine(img, [[1, 0, 5], [0, 1, 2]], border_mode=L.BORDER_CONSTANT, border_value=(1, 2, 3, 0))
+    assert np.array_equal(out[0, 0], [1, 2, 3])
+
+
+def test_half_pixel_shift_of_a_ramp(L):
+    """bilinear interpolation of a linear ramp is exact up to the final rounding."""
+    ramp = np.tile((np.arange(100) * 2)[None, :, None], (40, 1, 3)).astype(np.uint8)
+    out = L.warp_affine(ramp, [[1, 0, 0.5], [0, 1, 0.25]], border_mode=L.BORDER_REPLICATE)
+    assert np.array_equal(out[5, 1:50, 0], np.arange(1, 50) * 2 - 1)
+
+
+def test_border_blur_only_touches_out_of_frame_pixels(L):
+    rng = np.random.default_rng(7)
+    img = rng.integers(0, 256, (150, 200, 3), dtype=np.uint8)
+    M = [[1, 0, 12.5], [0, 1, 0]]
+    plain = L.warp_affine(img, M, border_mode=L.BORDER_REPLICATE)
+    blur, mask = L.warp_affine(img, M, border_mode=L.BORDER_REPLICATE_BLUR, want_mask=True)
+    assert np.array_equal(blur[mask == 1], plain[mask == 1])
+    assert not np.array_equal(blur[mask == 0], plain[mask == 0])
+    assert (mask == 0).sum() == 150 * 12      # columns 0..11: less than half of the footprint in frame
+
+
+def test_align_images_end_to_end_with_a_known_transform(L, oracle):
+    """align_images with an injected estimator == oracle applied with the rescaled float32 matrix."""
+    from shinestacker_amd import align_images
+    rng = np.random.default_rng(8)
+    ref = rng.integers(0, 256, (128, 160, 3), dtype=np.uint8)
+    mov = rng.integers(0, 256, (128, 160, 3), dtype=np.uint8)
+    m_sub = np.array(rot(0.8, 1.001, 1.75, -0.6))
+
+    def est(i0, i1, fc, mc, ac):
+        return 321, m_sub
+    n, m, warp = align_images(ref, mov, estimator=est, alignment_config={'fast_subsampling': True})
+    m_full = np.empty((2, 3), np.float32)
+    m_full[:, :2] = m_sub[:, :2]
+    m_full[:, 2] = m_sub[:, 2] * 2
+    assert n == 321 and np.array_equal(m, m_full)
+    assert np.array_equal(warp, oracle.warp_affine(mov, m_full.astype(np.float64)))
