@@ -54,7 +54,7 @@ def cpu_baseline(args):
     frames = [orc.synth_frame_u8(H, W, f, args.frames) for f in range(n)]
     if args.dtype == "u16":
         frames = [(f.astype(np.uint16) * 257) for f in frames]
-    so = orc.StreamingOracle(H, W, frames[0].dtype)
+    so = orc.StreamingOracle(H, W, frames[0].dtype, keep_gauss=False)
     t0 = time.perf_counter()
     for f in frames:
         so.push_frame(f)

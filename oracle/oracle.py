@@ -75,6 +75,8 @@ def lib():
                                           _f32p, _i32p, _i32p]
         L.orc_base_fuse_f32.argtypes = [_f32p, C.c_size_t, _i32p, _i32p, _f32p]
         L.orc_synth_frame_u8.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32]
+        L.orc_to_f32_u8.argtypes = [_u8p, C.c_size_t, _f32p]
+        L.orc_to_f32_u16.argtypes = [_u16p, C.c_size_t, _f32p]
         L.orc_warp_affine.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                       _f64p, C.c_int, _f64p]
         L.orc_border_blur_composite.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
@@ -295,7 +297,8 @@ class StreamingOracle:
     apart from the per-frame base images (tiny)."""
 
     def __init__(self, h, w, dtype=np.uint8, min_size=32, kernel_size=5, gen_kernel=0.4,
-                 use_fma=True, levels=None):
+                 use_fma=True, levels=None, keep_gauss=True):
+        self.keep_gauss = keep_gauss
         self.h, self.w, self.dtype = h, w, np.dtype(dtype)
         self.levels = num_levels(h, w, min_size) if levels is None else levels
         self.shapes = level_shapes(h, w, self.levels)
@@ -313,15 +316,25 @@ class StreamingOracle:
         self.idx_e = np.zeros((hb, wb), np.int32)
         self.idx_d = np.zeros((hb, wb), np.int32)
         self.bases = []
-        self._scratch = np.empty(h * w * 4, np.float32)
+        # every per-frame buffer is allocated and touched once, so a timed push measures
+        # arithmetic, not first-touch page faults
+        self._scratch = np.zeros(h * w * 4, np.float32)
+        self._g = [np.zeros(s + (3,), np.float32) for s in self.shapes]
+        for a in self.best_e + self.best_lap + self.best_idx:
+            a.fill(0)
 
     def gaussians(self, frame):
-        g = [np.ascontiguousarray(frame.astype(np.float32))]
+        g = self._g
+        src = np.ascontiguousarray(frame)
+        if src.dtype == np.uint8:
+            lib().orc_to_f32_u8(src, src.size, g[0])
+        elif src.dtype == np.uint16:
+            lib().orc_to_f32_u16(src, src.size, g[0])
+        else:
+            g[0][...] = src
         for lv in range(self.levels):
             h, w = self.shapes[lv]
-            out = np.empty(self.shapes[lv + 1] + (3,), np.float32)
-            lib().orc_reduce_f32(g[-1], h, w, 3, self.k, out, self.fma)
-            g.append(out)
+            lib().orc_reduce_f32(g[lv], h, w, 3, self.k, g[lv + 1], self.fma)
         return g
 
     def push_frame(self, frame):
@@ -341,9 +354,9 @@ class StreamingOracle:
         lib().orc_base_features_f32(g[-1], hb, wb, nlev, self.pad, ent, dev, self.fma)
         lib().orc_base_select_f32(ent, dev, hb * wb, self.n, first, self.b_ent, self.b_dev,
                                   self.idx_e, self.idx_d)
-        self.bases.append(g[-1])
+        self.bases.append(g[-1].copy())
         self.n += 1
-        return g
+        return [a.copy() for a in g] if self.keep_gauss else None
 
     def fused_base(self):
         hb, wb = self.shapes[self.levels]

@@ -144,13 +144,18 @@ ORC_API void orc_reduce_f32(const float* g, int h, int w, int C, const float* k2
         for (int t = 0; t < 5; ++t) ry[t] = r101(2 * i + t - 2, h);
         for (int j = 0; j < wo; ++j) {
             int rx[5];
-            for (int t = 0; t < 5; ++t) rx[t] = r101(2 * j + t - 2, w);
+            if (2 * j - 2 >= 0 && 2 * j + 2 < w) {
+                for (int t = 0; t < 5; ++t) rx[t] = 2 * j + t - 2;
+            } else {
+                for (int t = 0; t < 5; ++t) rx[t] = r101(2 * j + t - 2, w);
+            }
             for (int c = 0; c < C; ++c) {
                 float s = 0.0f;
-                for (int ty = 0; ty < 5; ++ty)
+                for (int ty = 0; ty < 5; ++ty) {
+                    const float* row = g + (size_t)ry[ty] * w * C + c;
                     for (int tx = 0; tx < 5; ++tx)
-                        s = mac32(k25[ty * 5 + tx],
-                                  g[((size_t)ry[ty] * w + rx[tx]) * C + c], s, use_fma);
+                        s = mac32(k25[ty * 5 + tx], row[(size_t)rx[tx] * C], s, use_fma);
+                }
                 out[((size_t)i * wo + j) * C + c] = s;
             }
         }
@@ -163,6 +168,16 @@ static inline float expand_at(const float* src, int hs, int ws, int C, const flo
                               int y, int x, int c, int use_fma) {
     float s = 0.0f;
     int H2 = 2 * hs, W2 = 2 * ws;
+    if (y >= 2 && y + 2 < H2 && x >= 2 && x + 2 < W2) {
+        /* interior: no reflection; the non-stuffed taps are those with (y+ty) and (x+tx) even */
+        const int ty0 = y & 1, tx0 = x & 1; /* first tap index with even target coordinate */
+        for (int ty = ty0; ty < 5; ty += 2) {
+            const float* row = src + ((size_t)((y + ty - 2) >> 1) * ws) * C + c;
+            for (int tx = tx0; tx < 5; tx += 2)
+                s = mac32(k25[ty * 5 + tx], row[(size_t)((x + tx - 2) >> 1) * C], s, use_fma);
+        }
+        return 4.0f * s;
+    }
     for (int ty = 0; ty < 5; ++ty) {
         int yy = r101(y + ty - 2, H2);
         if (yy & 1) continue; /* stuffed zero row */
@@ -215,10 +230,17 @@ ORC_API void orc_level_select_f32(const float* g, int h, int w, const float* gn,
         for (int t = 0; t < 5; ++t) ry[t] = r101(y + t - 2, h);
         for (int x = 0; x < w; ++x) {
             float s = 0.0f;
-            for (int ty = 0; ty < 5; ++ty)
-                for (int tx = 0; tx < 5; ++tx)
-                    s = mac32(k25[ty * 5 + tx], q[(size_t)ry[ty] * w + r101(x + tx - 2, w)], s,
-                              use_fma);
+            if (x >= 2 && x + 2 < w) {
+                for (int ty = 0; ty < 5; ++ty) {
+                    const float* row = q + (size_t)ry[ty] * w + x - 2;
+                    for (int tx = 0; tx < 5; ++tx) s = mac32(k25[ty * 5 + tx], row[tx], s, use_fma);
+                }
+            } else {
+                for (int ty = 0; ty < 5; ++ty)
+                    for (int tx = 0; tx < 5; ++tx)
+                        s = mac32(k25[ty * 5 + tx], q[(size_t)ry[ty] * w + r101(x + tx - 2, w)], s,
+                                  use_fma);
+            }
             size_t p = (size_t)y * w + x;
             if (first || s > best_e[p]) {
                 best_e[p] = s;
@@ -372,6 +394,16 @@ ORC_API void orc_base_fuse_f32(const float* bases /* N x npix x 3 */, size_t npi
             s = s + hi;
             out[i * 3 + c] = s / 2.0f;
         }
+}
+
+/* img.astype(float32), pyramid.py:126 (parallel, into a caller-owned buffer) */
+ORC_API void orc_to_f32_u8(const uint8_t* src, size_t n, float* dst) {
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; ++i) dst[i] = (float)src[i];
+}
+ORC_API void orc_to_f32_u16(const uint16_t* src, size_t n, float* dst) {
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; ++i) dst[i] = (float)src[i];
 }
 
 /* ---- synthetic stack generator, SURVEY.md 8(d) config 2 -------------------- */
