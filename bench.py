@@ -37,6 +37,9 @@ def parse():
     ap.add_argument("--dtype", default="f32", choices=["u8", "u16", "f32"])
     ap.add_argument("--impl", default="auto", choices=["auto", "simple", "tiled"])
     ap.add_argument("--batch", type=int, default=0, help="frames per fused launch (0 = library default)")
+    ap.add_argument("--source", default="device", choices=["device", "host"],
+                    help="host: frames are pushed from host memory one by one (PCIe-inclusive rate; "
+                         "never the headline value)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=4)
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic.json"),
@@ -111,10 +114,19 @@ def main():
             torch.cuda.synchronize()
         st.sync()
 
+    host_frames = None
+    if args.source == "host":
+        nh = min(F, 8)  # a few distinct host frames, cycled
+        host_frames = [buf.download((H, W, 3), dt, offset=i * per) for i in range(nh)]
+
     def step():
         st.reset()
         st.set_first_index(rank * F)
-        st.push_frames_device(buf.ptr, F)
+        if host_frames is not None:
+            for i in range(F):
+                st.push_frame(host_frames[i % len(host_frames)])
+        else:
+            st.push_frames_device(buf.ptr, F)
         if combiner is not None:
             combiner.combine()          # arg-max-with-payload exchange over xGMI
             if rank == 0:
@@ -162,7 +174,7 @@ def main():
             "config": {"workload": f"{total_frames}x{W}x{H}x3 {args.dtype} frames resident in "
                                    f"HBM, {st.levels}-level Laplacian pyramid fusion "
                                    f"(BASELINE.json configs[1])",
-                       "frames_per_gpu": F, "impl": ["auto", "simple", "tiled"][st.params.impl],
+                       "frames_per_gpu": F, "source": args.source, "impl": ["auto", "simple", "tiled"][st.params.impl],
                        "device": L.device_name(device),
                        "parallelism": f"frames sharded over {world} GPU(s)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,

@@ -31,6 +31,15 @@ struct TiledState {
     hipStream_t st1 = nullptr, st2 = nullptr;
     hipEvent_t evL0i[2] = {nullptr, nullptr}, evL0b[2] = {nullptr, nullptr}, evRest[2] = {nullptr, nullptr};
     bool streams_dirty = false;     // work may be in flight on st1/st2
+    // host-frame upload: pinned bounce buffers + a copy stream, so push_frame returns after a
+    // host memcpy and the PCIe transfer overlaps decoding of the next frame and the kernels
+    static constexpr int NPIN = 3;
+    void* pin[NPIN] = {nullptr, nullptr, nullptr};
+    hipEvent_t evPin[NPIN] = {nullptr, nullptr, nullptr};   // H2D out of pin[i] finished
+    hipStream_t stc = nullptr;                              // copy stream
+    hipEvent_t evCopied = nullptr;                          // all H2D of the staged batch done
+    hipEvent_t evRingFree = nullptr;                        // level-0 kernels finished reading the ring
+    long pin_no = 0;
 };
 
 inline TiledState*& tstate(mi_stack* s) { return *reinterpret_cast<TiledState**>(&s->tiled); }
@@ -77,6 +86,7 @@ int tiled_create(mi_stack* s) {
 int tiled_sync_all(mi_stack* s) {
     TiledState* t = tstate(s);
     if (!t) return MI_OK;
+    if (t->stc) MI_HIP(hipStreamSynchronize(t->stc));
     if (t->st1) MI_HIP(hipStreamSynchronize(t->st1));
     if (t->st2) MI_HIP(hipStreamSynchronize(t->st2));
     t->streams_dirty = false;
@@ -91,6 +101,13 @@ void tiled_destroy(mi_stack* s) {
         if (t->evL0b[set]) (void)hipEventDestroy(t->evL0b[set]);
         if (t->evRest[set]) (void)hipEventDestroy(t->evRest[set]);
     }
+    for (int i = 0; i < TiledState::NPIN; ++i) {
+        if (t->pin[i]) (void)hipHostFree(t->pin[i]);
+        if (t->evPin[i]) (void)hipEventDestroy(t->evPin[i]);
+    }
+    if (t->evCopied) (void)hipEventDestroy(t->evCopied);
+    if (t->evRingFree) (void)hipEventDestroy(t->evRingFree);
+    if (t->stc) (void)hipStreamDestroy(t->stc);
     if (t->st1) (void)hipStreamDestroy(t->st1);
     if (t->st2) (void)hipStreamDestroy(t->st2);
     delete t;
@@ -276,10 +293,25 @@ int tiled_flush(mi_stack* s) {
     if (!t || t->pending == 0) return MI_OK;
     int n = t->pending;
     t->pending = 0;
-    return dispatch_push(s, t->ring, n, t->frame_bytes);
+    if (t->stc) {
+        // the kernels must see every staged frame: order the compute streams behind the copies
+        MI_HIP(hipEventRecord(t->evCopied, t->stc));
+        MI_HIP(hipStreamWaitEvent(s->stream, t->evCopied, 0));
+        if (t->st1) MI_HIP(hipStreamWaitEvent(t->st1, t->evCopied, 0));
+    }
+    int rc = dispatch_push(s, t->ring, n, t->frame_bytes);
+    if (rc) return rc;
+    if (t->stc) {
+        // ... and the next batch's copies must not overwrite the ring before level 0 has read it
+        // (tiled_push joined st1 into s->stream, so one event on s->stream covers both kernels)
+        MI_HIP(hipEventRecord(t->evRingFree, s->stream));
+        MI_HIP(hipStreamWaitEvent(t->stc, t->evRingFree, 0));
+    }
+    return MI_OK;
 }
 
-// One host frame: stage it in the device ring; a full ring triggers a fused batch.
+// One host frame: copy it into a pinned bounce buffer, start the asynchronous upload into the
+// device ring and return (the caller's buffer is free again); a full ring triggers a fused batch.
 int tiled_push_host(mi_stack* s, const void* host_bgr, size_t row_stride_bytes) {
     TiledState* t = tstate(s);
     const size_t rb = (size_t)s->p.width * 3 * dtype_size(s->p.in_dtype);
@@ -293,10 +325,32 @@ int tiled_push_host(mi_stack* s, const void* host_bgr, size_t row_stride_bytes) 
         }
     }
     char* dst = (char*)t->ring + (size_t)t->pending * t->frame_bytes;
-    MI_HIP(hipMemcpy2DAsync(dst, rb, host_bgr, row_stride_bytes, rb, s->p.height,
-                            hipMemcpyHostToDevice, s->stream));
-    // pageable source: the host buffer must be reusable when we return
-    MI_HIP(hipStreamSynchronize(s->stream));
+    if (s->p.impl != MI_IMPL_TILED) {
+        // simple implementation: synchronous staging of the single frame
+        MI_HIP(hipMemcpy2DAsync(dst, rb, host_bgr, row_stride_bytes, rb, s->p.height,
+                                hipMemcpyHostToDevice, s->stream));
+        MI_HIP(hipStreamSynchronize(s->stream));
+    } else {
+        if (!t->stc) {
+            MI_HIP(hipStreamCreateWithFlags(&t->stc, hipStreamNonBlocking));
+            MI_HIP(hipEventCreateWithFlags(&t->evCopied, hipEventDisableTiming));
+            MI_HIP(hipEventCreateWithFlags(&t->evRingFree, hipEventDisableTiming));
+            for (int i = 0; i < TiledState::NPIN; ++i) {
+                MI_HIP(hipHostMalloc(&t->pin[i], t->frame_bytes, hipHostMallocDefault));
+                MI_HIP(hipEventCreateWithFlags(&t->evPin[i], hipEventDisableTiming));
+            }
+        }
+        const int slot = (int)(t->pin_no % TiledState::NPIN);
+        MI_HIP(hipEventSynchronize(t->evPin[slot]));  // bounce buffer free again? (no-op when unused)
+        char* pb = (char*)t->pin[slot];
+        if (row_stride_bytes == rb) memcpy(pb, host_bgr, rb * s->p.height);
+        else
+            for (int y = 0; y < s->p.height; ++y)
+                memcpy(pb + (size_t)y * rb, (const char*)host_bgr + (size_t)y * row_stride_bytes, rb);
+        MI_HIP(hipMemcpyAsync(dst, pb, t->frame_bytes, hipMemcpyHostToDevice, t->stc));
+        MI_HIP(hipEventRecord(t->evPin[slot], t->stc));
+        t->pin_no++;
+    }
     t->pending++;
     if (t->pending == t->bcap) return tiled_flush(s);
     return MI_OK;
