@@ -310,12 +310,62 @@ __global__ __launch_bounds__(NT) void level_fused(LevelArgs a) {
     prefetch(0);
 
     const K6 K = a.K;
+    // ---- per-thread work coordinates, packed (hi << 16 | lo); -1 = no item.  They are
+    // laundered at the top of every iteration: the compiler then rebuilds the few addresses it
+    // needs per frame (a multiply-add each) instead of either re-deriving them from the thread
+    // id (integer divisions) or hoisting dozens of loop-invariant addresses into registers
+    // (which cost a wave of occupancy).
+    constexpr int RED_BX = G::NW / 2;
+    constexpr int RED_RU = INTERIOR ? MI_REDUCE_RU : 1;
+    constexpr int RED_N = (G::NH / RED_RU) * RED_BX;
+    constexpr int RED_ITEMS = (RED_N + G::NT - 1) / G::NT;
+    constexpr int QY = TH / 2 + 2, QX = TW / 2 + 2;
+    constexpr int RING = QY * QX - (TH / 2) * (TW / 2);
+    constexpr int RING_ITEMS = (RING + G::NT - 1) / G::NT;
+    constexpr int GN_CW = (TW / 2) * 3;
+    constexpr int GN_C4 = GN_CW / 4;
+    constexpr int GN_N4 = (TH / 2) * GN_C4;
+    constexpr int GN_ITEMS4 = (GN_N4 + G::NT - 1) / G::NT;
+    int c_red[RED_ITEMS], c_ring[RING_ITEMS], c_own[G::NQ], c_gn[GN_ITEMS4];
+#pragma unroll
+    for (int k = 0; k < RED_ITEMS; ++k) {
+        const int it = tid + k * G::NT, rb = it / RED_BX;
+        c_red[k] = it < RED_N ? (rb << 16) | (it - rb * RED_BX) : -1;
+    }
+#pragma unroll
+    for (int k = 0; k < RING_ITEMS; ++k) {
+        const int it = tid + k * G::NT;
+        int qy, qx;
+        if (it < QX) { qy = 0; qx = it; }
+        else if (it < 2 * QX) { qy = QY - 1; qx = it - QX; }
+        else {
+            const int sidx = it - 2 * QX;  // left/right columns, rows 1..QY-2
+            qy = 1 + (sidx >> 1);
+            qx = (sidx & 1) ? QX - 1 : 0;
+        }
+        c_ring[k] = it < RING ? (qy << 16) | qx : -1;
+    }
+#pragma unroll
+    for (int q = 0; q < G::NQ; ++q) {
+        const int qi = tid + q * G::NT, oy = qi / (TW / 2);
+        c_own[q] = (oy << 16) | (qi - oy * (TW / 2));
+    }
+#pragma unroll
+    for (int k = 0; k < GN_ITEMS4; ++k) {
+        const int e = tid + k * G::NT, r = e / GN_C4;
+        c_gn[k] = e < GN_N4 ? (r << 16) | ((e - r * GN_C4) * 4) : -1;
+    }
     for (int b = 0; b < a.nframes; ++b) {
-        // Derive every per-thread coordinate of this iteration from a laundered copy of the
-        // thread id: the compiler then recomputes the (cheap) addresses per frame instead of
-        // keeping dozens of hoisted loop invariants alive, which would cost a wave of occupancy.
         int ltid = tid;
-        asm volatile("" : "+v"(ltid));
+        asm volatile("" : "+v"(ltid));  // used by the border variants only
+#pragma unroll
+        for (int k = 0; k < RED_ITEMS; ++k) asm volatile("" : "+v"(c_red[k]));
+#pragma unroll
+        for (int k = 0; k < RING_ITEMS; ++k) asm volatile("" : "+v"(c_ring[k]));
+#pragma unroll
+        for (int q = 0; q < G::NQ; ++q) asm volatile("" : "+v"(c_own[q]));
+#pragma unroll
+        for (int k = 0; k < GN_ITEMS4; ++k) asm volatile("" : "+v"(c_gn[k]));
         // ---------------- stage
         if (sact) {
 #pragma unroll
@@ -328,11 +378,12 @@ __global__ __launch_bounds__(NT) void level_fused(LevelArgs a) {
 
         // ---------------- reduce: items of RU output rows x 2 output pixels x 3 channels
         if (!(a.ablate & 1)) {
-            constexpr int BX = G::NW / 2;
-            constexpr int RU = INTERIOR ? MI_REDUCE_RU : 1;  // output rows per item
+            constexpr int RU = RED_RU;  // output rows per item
             static_assert(G::NH % RU == 0, "reduce rows per item must divide the patch height");
-            for (int it = ltid; it < (G::NH / RU) * BX; it += G::NT) {
-                const int rb = it / BX, bx = it - rb * BX, ri = rb * RU, rj = 2 * bx;
+#pragma unroll
+            for (int kk = 0; kk < RED_ITEMS; ++kk) {
+                if (c_red[kk] < 0) continue;
+                const int rb = c_red[kk] >> 16, bx = c_red[kk] & 0xffff, ri = rb * RU, rj = 2 * bx;
                 float acc[RU][2][3];
 #pragma unroll
                 for (int u = 0; u < RU; ++u)
@@ -416,9 +467,10 @@ __global__ __launch_bounds__(NT) void level_fused(LevelArgs a) {
             constexpr int CW = (TW / 2) * 3;
             if (INTERIOR && (wn & 3) == 0 && (CW & 3) == 0) {
                 // rows start 16-byte aligned in global memory: one float4 per lane
-                constexpr int C4 = CW / 4;
-                for (int e = ltid; e < (TH / 2) * C4; e += G::NT) {
-                    const int r = e / C4, k = (e - r * C4) * 4;
+#pragma unroll
+                for (int kk = 0; kk < GN_ITEMS4; ++kk) {
+                    if (c_gn[kk] < 0) continue;
+                    const int r = c_gn[kk] >> 16, k = c_gn[kk] & 0xffff;
                     const float* sp = sN + mul24(r + 2, G::NS) + 6 + k;  // 8-byte aligned
                     const v2f lo = lds_load2(sp), hi = lds_load2(sp + 2);
                     v4f v = {lo.x, lo.y, hi.x, hi.y};
@@ -443,7 +495,6 @@ __global__ __launch_bounds__(NT) void level_fused(LevelArgs a) {
 #pragma unroll
             for (int p = 0; p < 4; ++p) myLap[q][p][0] = myLap[q][p][1] = myLap[q][p][2] = 0.f;
         if (!(a.ablate & 4)) {
-            constexpr int QY = TH / 2 + 2, QX = TW / 2 + 2;
             auto do_quad = [&](int qy, int qx, float (*keep)[3]) {
                 // local sN rows/cols of the expand source, local sG rows/cols of the cells
                 int re, ro, ce, co, gre, gro, gce, gco;
@@ -531,23 +582,12 @@ __global__ __launch_bounds__(NT) void level_fused(LevelArgs a) {
             };
             // own quads (tile interior) ...
 #pragma unroll
-            for (int q = 0; q < G::NQ; ++q) {
-                const int qi = ltid + q * G::NT;
-                do_quad(qi / (TW / 2) + 1, qi % (TW / 2) + 1, myLap[q]);
-            }
+            for (int q = 0; q < G::NQ; ++q)
+                do_quad((c_own[q] >> 16) + 1, (c_own[q] & 0xffff) + 1, myLap[q]);
             // ... and the halo ring, spread over the first threads
-            constexpr int RING = QY * QX - (TH / 2) * (TW / 2);
-            for (int it = ltid; it < RING; it += G::NT) {
-                int qy, qx;
-                if (it < QX) { qy = 0; qx = it; }
-                else if (it < 2 * QX) { qy = QY - 1; qx = it - QX; }
-                else {
-                    int s = it - 2 * QX;  // left/right columns, rows 1..QY-2
-                    qy = 1 + (s >> 1);
-                    qx = (s & 1) ? QX - 1 : 0;
-                }
-                do_quad(qy, qx, nullptr);
-            }
+#pragma unroll
+            for (int kk = 0; kk < RING_ITEMS; ++kk)
+                if (c_ring[kk] >= 0) do_quad(c_ring[kk] >> 16, c_ring[kk] & 0xffff, nullptr);
         }
         __syncthreads();
 
@@ -557,7 +597,7 @@ __global__ __launch_bounds__(NT) void level_fused(LevelArgs a) {
 #pragma unroll
             for (int q = 0; q < G::NQ; ++q) {
                 float e[4] = {0.f, 0.f, 0.f, 0.f};
-                const int qi = ltid + q * G::NT, oy = qi / (TW / 2), ox = qi % (TW / 2);
+                const int oy = c_own[q] >> 16, ox = c_own[q] & 0xffff;
                 const float* base = sQ + mul24(2 * oy, G::QS) + 2 * ox;  // 8-byte aligned
 #pragma unroll
                 for (int rr = 0; rr < 6; ++rr) {
