@@ -79,17 +79,26 @@ def main():
             raise SystemExit("--gpus N>1 must be launched with torch.distributed.run")
         args.gpus = world
 
+    dist = None
+    force_dist = os.environ.get("MI_BENCH_FORCE_COMBINE") == "1"  # exercise the combine at world 1
+    if world > 1 or force_dist:
+        # torch ships its own HIP runtime: it must be loaded BEFORE libmi355stack.so pulls in
+        # /opt/rocm's, otherwise the process holds two runtimes and torch sees no GPU
+        import torch
+        import torch.distributed as dist
+        torch.cuda.init()
+
     from shinestacker_amd import _lib as L
     from shinestacker_amd import build
     build.build_extension()
     L.require_device()
 
-    dist = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist
+    if world > 1 or force_dist:
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
     device = local_rank
 
     dt = {"u8": np.uint8, "u16": np.uint16, "f32": np.float32}[args.dtype]
@@ -103,12 +112,12 @@ def main():
                  device=device, impl=impl, batch_frames=args.batch)
     st.set_first_index(rank * F)
     combiner = None
-    if world > 1:
+    if world > 1 or force_dist:
         from shinestacker_amd import multigpu
         combiner = multigpu.Combiner(st, dist.group.WORLD)
 
     def barrier():
-        if world > 1:
+        if world > 1 or force_dist:
             import torch
             dist.barrier()
             torch.cuda.synchronize()
@@ -143,7 +152,7 @@ def main():
         step()
     barrier()
     dt_s = time.perf_counter() - t0
-    if world > 1:
+    if world > 1 or force_dist:
         import torch
         t = torch.tensor([dt_s], device=f"cuda:{local_rank}", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -191,7 +200,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 

@@ -87,6 +87,11 @@ def load():
     """dlopen the library and declare every prototype. Raises DeviceError if absent."""
     global _lib
     if _lib is None:
+        # In a torch.distributed job torch's bundled HIP runtime must be loaded before this
+        # library pulls in /opt/rocm's: two runtimes in one process leave torch without a GPU.
+        import sys
+        if int(os.environ.get("WORLD_SIZE", "1")) > 1 and "torch" not in sys.modules:
+            import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise DeviceError(
                 f"{LIB_PATH} not found: build it with `python -m shinestacker_amd.build` "

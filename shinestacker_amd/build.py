@@ -45,6 +45,7 @@ def build_extension(force=False, verbose=False):
         names = ["MI_TILE0_H", "MI_TILE0_W", "MI_TILE0_NT", "MI_TILE_H", "MI_TILE_W", "MI_TILE_NT",
                  "MI_TILE_PAD", "MI_REDUCE_RU"]
         extra = [f"-D{n}={v}" for n, v in zip(names, cfg.split(","))]
+    extra += os.environ.get("MI_EXTRA_FLAGS", "").split()
     cmd = [_hipcc(), *HIPCC_FLAGS, *extra, "-I", os.path.join(ROOT, "include"),
            *[os.path.join(CSRC, s) for s in SOURCES], "-o", LIB]
     if verbose:
