@@ -113,13 +113,10 @@ struct TileGeom {
     // Q row stride: 2*QS = 32 (mod 64) so the two quad rows a 32-lane group reads
     // with ds_read_b64 fall into disjoint bank halves
     static constexpr int QS = PAD ? ((QW + 15) / 32) * 32 + 16 : QW;
-    static constexpr int PR = GD / 2;                     // element pairs per patch row
-    static constexpr int RPP = NT / PR;                   // patch rows staged per pass
-    static constexpr int NPRE = (GH + RPP - 1) / RPP;     // passes = staged pairs per thread
     static constexpr int NQ = (TH / 2) * (TW / 2) / NT;   // owned 2x2 quads per thread
     static constexpr int LDS_FLOATS = GH * GS + NH * NS + QH * QS;
     static_assert((TH / 2) * (TW / 2) % NT == 0, "tile must split into whole quads per thread");
-    static_assert(GS % 4 == 0 && GS >= GD && NS >= NW * 3 && QS >= QW && GD % 2 == 0 && RPP >= 1, "layout");
+    static_assert(GS % 4 == 0 && GS >= GD && NS >= NW * 3 && QS >= QW && GD % 4 == 0, "layout");
 };
 
 // clamp(reflect101(v)) -- cells whose overshoot exceeds 2 are never consumed by a
@@ -161,6 +158,33 @@ __device__ __forceinline__ void load_pair(const uint8_t* p, float& a, float& b) 
     b = (float)(v >> 8);
 }
 
+// EPL consecutive elements -> floats.  u8 / u16: one (possibly unaligned) 4- / 8-byte load --
+// global memory accesses need no alignment on gfx950/amdhsa; f32: see load_pair.
+template <int EPL, typename TIn>
+__device__ __forceinline__ void load_elems(const TIn* p, float* out, bool aligned) {
+    if constexpr (sizeof(TIn) == 1) {
+        static_assert(EPL == 4, "u8 staging moves 4 elements per lane");
+        uint32_t v;
+        __builtin_memcpy(&v, p, 4);
+        out[0] = (float)(v & 0xffu);
+        out[1] = (float)((v >> 8) & 0xffu);
+        out[2] = (float)((v >> 16) & 0xffu);
+        out[3] = (float)(v >> 24);
+    } else if constexpr (sizeof(TIn) == 2) {
+        static_assert(EPL == 4, "u16 staging moves 4 elements per lane");
+        uint64_t v;
+        __builtin_memcpy(&v, p, 8);
+        out[0] = (float)(uint32_t)(v & 0xffffu);
+        out[1] = (float)(uint32_t)((v >> 16) & 0xffffu);
+        out[2] = (float)(uint32_t)((v >> 32) & 0xffffu);
+        out[3] = (float)(uint32_t)(v >> 48);
+    } else {
+        static_assert(EPL == 2, "f32 staging moves 2 elements per lane");
+        if (aligned) load_pair(p, out[0], out[1]);
+        else { out[0] = to_f32(p[0]); out[1] = to_f32(p[1]); }
+    }
+}
+
 // keeps the compiler from hoisting LDS loads across this point (bounds live ranges)
 #define MI_LDS_FENCE() asm volatile("" ::: "memory")
 
@@ -182,6 +206,10 @@ __device__ __forceinline__ v2f lds_load2(const float* p) {
 __device__ __forceinline__ void lds_store2(float* p, float a, float b) {
     v2f v = {a, b};
     *reinterpret_cast<v2f*>(p) = v;
+}
+__device__ __forceinline__ void lds_store4(float* p, float a, float b, float c, float d) {
+    v4f v = {a, b, c, d};
+    *reinterpret_cast<v4f*>(p) = v;
 }
 
 template <typename TIn, bool FMA, bool INTERIOR, int TH, int TW, int NT, bool PAD>
@@ -264,44 +292,40 @@ __global__ __launch_bounds__(NT) void level_fused(LevelArgs a) {
     }
 
     // ---- staging: pass n copies patch rows [n*RPP, (n+1)*RPP); a thread always handles the
-    // same element pair of "its" row, so global and LDS offsets advance by constants.
-    float pre[G::NPRE][2];
-    const bool pair_ok = (w & 1) == 0;  // every patch row then starts on an even element
-    const int srow = tid / G::PR, sk2 = tid - srow * G::PR;
-    const bool sact = tid < G::RPP * G::PR;
+    // same EPL consecutive elements of "its" row, so global and LDS offsets advance by constants.
+    constexpr int EPL = sizeof(TIn) <= 2 ? 4 : 2;           // elements per lane and load
+    static_assert(G::GD % EPL == 0, "patch row must split into whole loads");
+    constexpr int PR = G::GD / EPL;                           // loads per patch row
+    constexpr int RPP = G::NT / PR;                           // patch rows staged per pass
+    constexpr int NPRE = (G::GH + RPP - 1) / RPP;             // passes = loads per thread
+    static_assert(RPP >= 1, "workgroup too small for one patch row per pass");
+    float pre[NPRE][EPL];
+    const bool pair_ok = (w & 1) == 0;  // f32: every patch row then starts on an even element
+    const int srow = tid / PR, sk = tid - srow * PR;
+    const bool sact = tid < RPP * PR;
     // interior only: byte offsets inside a frame (uniform base + 32-bit lane offset)
-    const uint32_t goff0 = (uint32_t)(((y0 - 6 + srow) * w + (x0 - 6)) * 3 + 2 * sk2) * (uint32_t)sizeof(TIn);
-    const uint32_t gstep = (uint32_t)(G::RPP * w * 3) * (uint32_t)sizeof(TIn);
+    const uint32_t goff0 = (uint32_t)(((y0 - 6 + srow) * w + (x0 - 6)) * 3 + EPL * sk) * (uint32_t)sizeof(TIn);
+    const uint32_t gstep = (uint32_t)(RPP * w * 3) * (uint32_t)sizeof(TIn);
     auto prefetch = [&](int b) {
         const char* frb = (const char*)a.src + (size_t)b * a.src_stride;
         const TIn* fr = (const TIn*)frb;
         if (!sact) return;
         if constexpr (INTERIOR) {
-            if (pair_ok) {
 #pragma unroll
-                for (int n = 0; n < G::NPRE; ++n)
-                    if ((n + 1) * G::RPP <= G::GH || srow + n * G::RPP < G::GH)
-                        load_pair((const TIn*)(frb + (size_t)n * gstep + goff0), pre[n][0], pre[n][1]);
-            } else {
-#pragma unroll
-                for (int n = 0; n < G::NPRE; ++n)
-                    if ((n + 1) * G::RPP <= G::GH || srow + n * G::RPP < G::GH) {
-                        const TIn* p = (const TIn*)(frb + (size_t)n * gstep + goff0);
-                        pre[n][0] = to_f32(p[0]);
-                        pre[n][1] = to_f32(p[1]);
-                    }
-            }
+            for (int n = 0; n < NPRE; ++n)
+                if ((n + 1) * RPP <= G::GH || srow + n * RPP < G::GH)
+                    load_elems<EPL>((const TIn*)(frb + (size_t)n * gstep + goff0), pre[n], pair_ok);
         } else {
 #pragma unroll
-            for (int n = 0; n < G::NPRE; ++n) {
-                const int r = srow + n * G::RPP;
+            for (int n = 0; n < NPRE; ++n) {
+                const int r = srow + n * RPP;
                 if (r < G::GH) {
                     const int gy = map_clamp(y0 - 6 + r, h);
 #pragma unroll
-                    for (int s = 0; s < 2; ++s) {
-                        int k = 2 * sk2 + s, col = k / 3, c = k - col * 3;
+                    for (int e = 0; e < EPL; ++e) {
+                        int k = EPL * sk + e, col = k / 3, c = k - col * 3;
                         int gx = map_clamp(x0 - 6 + col, w);
-                        pre[n][s] = to_f32(fr[((size_t)gy * w + gx) * 3 + c]);
+                        pre[n][e] = to_f32(fr[((size_t)gy * w + gx) * 3 + c]);
                     }
                 }
             }
@@ -369,9 +393,12 @@ __global__ __launch_bounds__(NT) void level_fused(LevelArgs a) {
         // ---------------- stage
         if (sact) {
 #pragma unroll
-            for (int n = 0; n < G::NPRE; ++n)
-                if ((n + 1) * G::RPP <= G::GH || srow + n * G::RPP < G::GH)
-                    lds_store2(sG + mul24(srow + n * G::RPP, G::GS) + 2 * sk2, pre[n][0], pre[n][1]);
+            for (int n = 0; n < NPRE; ++n)
+                if ((n + 1) * RPP <= G::GH || srow + n * RPP < G::GH) {
+                    float* d = sG + mul24(srow + n * RPP, G::GS) + EPL * sk;
+                    if constexpr (EPL == 4) lds_store4(d, pre[n][0], pre[n][1], pre[n][2], pre[n][3]);
+                    else lds_store2(d, pre[n][0], pre[n][1]);
+                }
         }
         __syncthreads();
         if (b + 1 < a.nframes && !(a.ablate & 16)) prefetch(b + 1);
