@@ -1,0 +1,107 @@
+"""In-memory align -> stack pipeline (BASELINE config 4).
+
+The reference round-trips every frame through image files between `AlignFrames` and
+`FocusStack` (stack_framework.py:269-297, pyramid.py:158,172).  Here a frame is uploaded once,
+warped on the device (`mi_warp_affine_device`) straight into the stacker's input batch and fused
+(`mi_stack_push_frames_device`); only the transform estimate runs on the host.
+
+Result: identical to `align_images` on every frame (reference frame passed through untouched)
+followed by `PyramidStack` on the aligned frames -- without the intermediate quantised files the
+two-action reference job writes, which for lossless formats changes nothing.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .align import (_BORDER_CODE, _DEFAULT_ALIGNMENT_CONFIG, _DEFAULT_FEATURE_CONFIG,
+                    _DEFAULT_MATCHING_CONFIG, img_subsample, opencv_estimator)
+from .defaults import constants
+from .errors import AlignmentError, InvalidOptionError
+from .imageio import validate_image
+
+
+def align_and_stack(frames, ref_idx=-1, estimator=None, alignment_config=None, feature_config=None,
+                    matching_config=None, device=0, batch_frames=16, check_running=None,
+                    **stack_kwargs):
+    """Align every frame to frames[ref_idx] (fixed reference, `step_process=False` order,
+    stack_framework.py:191-232) and fuse them.  `frames`: sequence of H x W x 3 uint8/uint16 BGR
+    arrays.  Returns (fused image, list of n_good_matches)."""
+    _lib.require_device()
+    n = len(frames)
+    if n == 0:
+        raise ValueError("no frames")
+    feature_config = {**_DEFAULT_FEATURE_CONFIG, **(feature_config or {})}
+    matching_config = {**_DEFAULT_MATCHING_CONFIG, **(matching_config or {})}
+    cfg = {**_DEFAULT_ALIGNMENT_CONFIG, **(alignment_config or {})}
+    if cfg['border_mode'] not in _BORDER_CODE:
+        raise InvalidOptionError("border_mode", cfg['border_mode'])
+    if cfg['transform'] != constants.ALIGN_RIGID:
+        raise InvalidOptionError("transform", cfg['transform'],
+                                 "the MI355X apply path implements ALIGN_RIGID only")
+    estimator = estimator or opencv_estimator
+    if ref_idx == -1:
+        ref_idx = n // 2
+    ref = np.ascontiguousarray(frames[ref_idx])
+    h, w = ref.shape[:2]
+    dt = ref.dtype
+    fb = h * w * 3 * dt.itemsize
+    lib = _lib.load()
+    stack = _lib.Stack(h, w, in_dtype=dt, out_dtype=dt, device=device, batch_frames=batch_frames,
+                       **stack_kwargs)
+    src = _lib.DeviceBuffer(fb, device)            # uploaded moving frame
+    tmp = _lib.DeviceBuffer(fb, device)            # warp scratch (border blur)
+    mask = _lib.DeviceBuffer(h * w, device)
+    batch = _lib.DeviceBuffer(fb * batch_frames, device)
+    mode = _BORDER_CODE[cfg['border_mode']]
+    bv = (C.c_double * 4)(*(list(cfg['border_value']) + [0, 0, 0, 0])[:4])
+    matches, filled = [], 0
+
+    def flush():
+        nonlocal filled
+        if filled:
+            lib.mi_device_synchronize(device)  # warps ran on the default stream
+            stack.push_frames_device(batch.ptr, filled, fb)
+            stack.sync()                       # the batch buffer is reused next
+            filled = 0
+
+    for i, fr in enumerate(frames):
+        fr = np.ascontiguousarray(fr)
+        validate_image(fr, (h, w), dt)
+        dst = batch.ptr + filled * fb
+        if i == ref_idx:
+            batch.upload(fr, filled * fb)      # reference frame: untouched (align.py:279-280)
+            matches.append(0)
+        else:
+            sub = cfg['subsample']
+            while True:
+                a, b = (img_subsample(fr, sub, cfg['fast_subsampling']),
+                        img_subsample(ref, sub, cfg['fast_subsampling'])) if sub > 1 else (fr, ref)
+                ng, m = estimator(a, b, feature_config, matching_config, cfg)
+                if ng > cfg['min_good_matches'] or sub == 1:
+                    break
+                sub = 1
+            matches.append(ng)
+            if ng < 3 or m is None:
+                raise AlignmentError(i, f"too few matches found: {ng} < 3")
+            m = np.asarray(m)
+            if sub > 1:
+                full = np.empty((2, 3), dtype=np.float32)
+                full[:2, :2] = m[:2, :2]
+                full[:, 2] = m[:, 2] * sub
+                m = full
+            mm = (C.c_double * 6)(*np.asarray(m, dtype=np.float64).reshape(6))
+            src.upload(fr)
+            _lib.check(lib.mi_warp_affine_device(device, None, src.ptr, dst, tmp.ptr, mask.ptr, h, w,
+                                                 _lib.DTYPE_CODE[dt], mm, mode, bv, 21,
+                                                 float(cfg['border_blur'])))
+        filled += 1
+        if filled == batch_frames:
+            flush()
+        if check_running is not None and check_running() is False:
+            from .errors import RunStopException
+            raise RunStopException("align_and_stack")
+    flush()
+    out = stack.finish()
+    stack.close()
+    return out, matches

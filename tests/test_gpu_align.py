@@ -99,3 +99,33 @@ def test_align_images_end_to_end_with_a_known_transform(L, oracle):
     m_full[:, 2] = m_sub[:, 2] * 2
     assert n == 321 and np.array_equal(m, m_full)
     assert np.array_equal(warp, oracle.warp_affine(mov, m_full.astype(np.float64)))
+
+
+def test_align_and_stack_pipeline_equals_two_step_path(L, oracle):
+    """In-memory align -> stack == align_images per frame, then the stacker on the aligned frames."""
+    from shinestacker_amd import align_images
+    from shinestacker_amd.pipeline import align_and_stack
+    rng = np.random.default_rng(9)
+    base = rng.integers(0, 256, (160, 208, 3), dtype=np.uint8)
+    frames = [np.roll(base, (k - 2, 2 * (k - 2)), axis=(0, 1)) for k in range(5)]
+    transforms = {k: np.array(rot(0.1 * (k - 2), 1 + 1e-3 * (k - 2), -2.0 * (k - 2) + 0.3, -(k - 2) + 0.2))
+                  for k in range(5)}
+    key = {f.tobytes()[:64]: k for k, f in enumerate(frames)}
+
+    def est(i0, i1, fc, mc, ac):
+        return 500, transforms[key[np.ascontiguousarray(i0).tobytes()[:64]]]
+    cfg = {'subsample': 1}
+    fused, matches = align_and_stack(frames, ref_idx=2, estimator=est, alignment_config=cfg,
+                                     batch_frames=2)
+    aligned = []
+    for k, f in enumerate(frames):
+        if k == 2:
+            aligned.append(f)
+        else:
+            _n, _m, wimg = align_images(frames[2], f, estimator=est, alignment_config=cfg)
+            aligned.append(wimg)
+    so = oracle.StreamingOracle(160, 208, np.uint8)
+    for f in aligned:
+        so.push_frame(f)
+    assert matches == [500, 500, 0, 500, 500]
+    assert np.array_equal(fused, so.finish())
