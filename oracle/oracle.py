@@ -39,6 +39,29 @@ def build(force=False):
     return _SO
 
 
+def usable_cpus():
+    """CPUs this process may really use: affinity mask capped by the cgroup CPU quota
+    (OpenMP's default of one thread per visible core oversubscribes a quota-limited container)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:  # cgroup v2
+            quota, period = fh.read().split()
+            if quota != "max":
+                n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fq, \
+                    open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fp:
+                q, per = int(fq.read()), int(fp.read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    if os.environ.get("OMP_NUM_THREADS", "").isdigit():
+        n = int(os.environ["OMP_NUM_THREADS"])
+    return n
+
+
 _lib = None
 _f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
 _f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
@@ -54,6 +77,8 @@ def lib():
             build()
         L = C.CDLL(_SO)
         L.orc_num_threads.restype = C.c_int
+        L.orc_set_threads.argtypes = [C.c_int]
+        L.orc_set_threads(usable_cpus())
         L.orc_filter2d_f32.argtypes = [_f32p, C.c_int, C.c_int, _f32p, _f32p, C.c_int]
         L.orc_filter2d_f64.argtypes = [_f64p, C.c_int, C.c_int, _f64p, _f64p, C.c_int]
         L.orc_bgr2gray_f32.argtypes = [_f32p, C.c_size_t, _f32p, C.c_int]

@@ -61,6 +61,14 @@ static inline double mac64(double k, double x, double s, int use_fma) {
     return s + p;
 }
 
+ORC_API void orc_set_threads(int n) {
+#if defined(_OPENMP)
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 ORC_API int orc_num_threads(void) {
 #if defined(_OPENMP)
     return omp_get_max_threads();

@@ -106,13 +106,21 @@ struct TileGeom {
     // 4-bank slots
     static constexpr int GS = PAD ? ((GD - 28 + 31) / 32) * 32 + 28 : GD;
     static constexpr int NH = TH / 2 + 4, NW = TW / 2 + 4;
-    // sN row stride = 16 (mod 32): the 3-dword lane stride of the laplacian phase then maps
-    // the two quad rows of a 32-lane group onto disjoint banks
-    static constexpr int NS = PAD ? ((NW * 3 - 16 + 31) / 32) * 32 + 16 : NW * 3;
+    // sN row stride.  Narrow tiles (16 quads per row): = 16 (mod 32), so the two quad rows of a
+    // 32-lane group fall on disjoint banks.  Wide tiles (>= 32 quads per row: a 32-lane group
+    // is one row, conflict-free at any stride): = 6 (mod 32), which spreads the halo ring's
+    // side columns -- lanes stepping DOWN the patch -- over the banks (tools/lds_banks.py:
+    // 324 -> 135 cycles per tile for the ring's reads at 32x64).
+    static constexpr int NS = !PAD ? NW * 3 + 2  // +2: ring columns / quad-row pairs (lds_banks.py)
+                              : (TW / 2 >= 32 ? ((NW * 3 - 6 + 31) / 32) * 32 + 6
+                                              : ((NW * 3 - 16 + 31) / 32) * 32 + 16);
     static constexpr int QH = TH + 4, QW = TW + 4;
-    // Q row stride: 2*QS = 32 (mod 64) so the two quad rows a 32-lane group reads
-    // with ds_read_b64 fall into disjoint bank halves
-    static constexpr int QS = PAD ? ((QW + 15) / 32) * 32 + 16 : QW;
+    // Q row stride.  Narrow tiles: 2*QS = 32 (mod 64) so the two quad rows a 32-lane group
+    // reads with ds_read_b64 fall into disjoint bank halves.  Wide tiles: = 18 (mod 32) for the
+    // ring's column-wise ds_write_b64 (44 -> 16 cycles per tile).
+    static constexpr int QS = !PAD ? QW
+                              : (TW / 2 >= 32 ? ((QW - 18 + 31) / 32) * 32 + 18
+                                              : ((QW + 15) / 32) * 32 + 16);
     static constexpr int NQ = (TH / 2) * (TW / 2) / NT;   // owned 2x2 quads per thread
     static constexpr int LDS_FLOATS = GH * GS + NH * NS + QH * QS;
     static_assert((TH / 2) * (TW / 2) % NT == 0, "tile must split into whole quads per thread");
