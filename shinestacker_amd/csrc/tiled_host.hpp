@@ -3,8 +3,9 @@
 //
 // Batch pipeline over three HIP streams (all work of one handle):
 //   st0 = s->stream : level-0 interior kernel of batch k      (the big one)
-//   st1             : level-0 border kernel of batch k
-//   st2             : levels 1..L-1 (interior + border) and the base features of batch k
+//   st1             : level-0 border kernel of batch k, then the border kernels of levels 1..L-1
+//   st2             : interior kernels of levels 1..L-1 (joined with st1 after every level) and
+//                     the base features of batch k
 // Level 0 of batch k+1 runs while st2 still works on batch k, so the latency-bound small
 // levels hide behind the bandwidth-bound level-0 kernel.  The per-batch Gaussian images
 // Gb[set][l] are double-buffered (set = k & 1); events order producers and consumers.
@@ -30,6 +31,7 @@ struct TiledState {
     float* logp[2] = {nullptr, nullptr};
     hipStream_t st1 = nullptr, st2 = nullptr;
     hipEvent_t evL0i[2] = {nullptr, nullptr}, evL0b[2] = {nullptr, nullptr}, evRest[2] = {nullptr, nullptr};
+    std::vector<hipEvent_t> evLvl;  // [set][level][interior|border]: per-level joins of st2 and st1
     bool streams_dirty = false;     // work may be in flight on st1/st2
     // host-frame upload: pinned bounce buffers + a copy stream, so push_frame returns after a
     // host memcpy and the PCIe transfer overlaps decoding of the next frame and the kernels
@@ -70,6 +72,11 @@ int tiled_create(mi_stack* s) {
         MI_HIP(hipEventCreateWithFlags(&t->evL0i[set], hipEventDisableTiming));
         MI_HIP(hipEventCreateWithFlags(&t->evL0b[set], hipEventDisableTiming));
         MI_HIP(hipEventCreateWithFlags(&t->evRest[set], hipEventDisableTiming));
+        for (int i = 0; i < 2 * (L + 1); ++i) {
+            hipEvent_t e;
+            MI_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            t->evLvl.push_back(e);
+        }
         t->Gb[set].assign(L + 1, nullptr);
         for (int l = 1; l <= L; ++l) {
             t->gstride[l] = (size_t)s->lh[l] * s->lw[l] * 3;
@@ -101,6 +108,7 @@ void tiled_destroy(mi_stack* s) {
         if (t->evL0b[set]) (void)hipEventDestroy(t->evL0b[set]);
         if (t->evRest[set]) (void)hipEventDestroy(t->evRest[set]);
     }
+    for (auto e : t->evLvl) (void)hipEventDestroy(e);
     for (int i = 0; i < TiledState::NPIN; ++i) {
         if (t->pin[i]) (void)hipHostFree(t->pin[i]);
         if (t->evPin[i]) (void)hipEventDestroy(t->evPin[i]);
@@ -227,10 +235,19 @@ int run_batch(mi_stack* s, const void* frames, size_t stride, int nb) {
     MI_HIP(hipEventRecord(t->evL0b[set], st1));
     MI_HIP(hipStreamWaitEvent(st2, t->evL0i[set], 0));
     MI_HIP(hipStreamWaitEvent(st2, t->evL0b[set], 0));
-    for (int l = 1; l < L; ++l)
+    MI_HIP(hipStreamWaitEvent(st1, t->evL0i[set], 0));
+    // coarser levels: interior tiles on st2, border tiles on st1 (disjoint tiles of one level run
+    // side by side); both streams join after every level because level l+1 reads all of G_{l+1}
+    for (int l = 1; l < L; ++l) {
         if ((rc = launch_level<float, FMA, MI_TILE_H, MI_TILE_W, MI_TILE_NT, false, MI_TILE_H, MI_TILE_W, MI_TILE_NT>(
-                 s, l, set, t->Gb[set][l], t->gstride[l] * sizeof(float), nb, st2, st2)))
+                 s, l, set, t->Gb[set][l], t->gstride[l] * sizeof(float), nb, st2, st1)))
             return rc;
+        hipEvent_t ei = t->evLvl[(set * (L + 1) + l) * 2], eb = t->evLvl[(set * (L + 1) + l) * 2 + 1];
+        MI_HIP(hipEventRecord(ei, st2));
+        MI_HIP(hipEventRecord(eb, st1));
+        MI_HIP(hipStreamWaitEvent(st2, eb, 0));
+        MI_HIP(hipStreamWaitEvent(st1, ei, 0));
+    }
     MI_HIP(hipGetLastError());
     {   // base level of the whole batch
         ProfScope ps(s, MI_PROF_BASE, 0.0, st2);
