@@ -681,6 +681,11 @@ int mi_stack_state(mi_stack_t* s, int level, void** dev_energy, void** dev_lap, 
     MI_HIP(hipSetDevice(s->p.device));
     rc = tiled_flush(s);
     if (rc) return rc;
+    // hand-off point to foreign streams (RCCL, hipMemcpy on the null stream ...): everything this
+    // handle enqueued on its own non-blocking streams must have finished
+    rc = tiled_sync_all(s);
+    if (rc) return rc;
+    MI_HIP(hipStreamSynchronize(s->stream));
     const int L = s->L;
     void *e = nullptr, *l = nullptr, *i = nullptr;
     size_t n = 0;
