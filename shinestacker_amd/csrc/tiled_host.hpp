@@ -290,8 +290,13 @@ int tiled_push(mi_stack* s, const void* dev_frames, int n, size_t stride) {
     int rc = tiled_flush(s);  // keep global frame order: staged host frames come first
     if (rc) return rc;
     const bool fma = s->p.use_fma != 0;
-    for (int f0 = 0; f0 < n; f0 += t->bcap) {
-        int nb = n - f0 < t->bcap ? n - f0 : t->bcap;
+    for (int f0 = 0; f0 < n;) {
+        // Full batches while more than one batch is left; the last `bcap` frames are tapered
+        // (1/2, 1/4, 1/4): what cannot overlap anything is the final batch's chain of coarser
+        // levels, which is latency-bound and scales with the batch length.
+        const int left = n - f0;
+        int nb = left > t->bcap ? t->bcap : left;
+        if (left <= t->bcap && left >= 16 && n > t->bcap) nb = (left / 2 + 3) & ~3;
         const void* fr = (const char*)dev_frames + (size_t)f0 * stride;
         switch (s->p.in_dtype) {
             case MI_U8: rc = fma ? run_batch<uint8_t, true>(s, fr, stride, nb) : run_batch<uint8_t, false>(s, fr, stride, nb); break;
@@ -300,6 +305,7 @@ int tiled_push(mi_stack* s, const void* dev_frames, int n, size_t stride) {
             default: rc = fail(MI_ERR_INVALID, "bad in_dtype");
         }
         if (rc) return rc;
+        f0 += nb;
     }
     // later work on s->stream (host-frame copies, collapse, taps) is ordered behind all of it
     return tiled_join(s);
