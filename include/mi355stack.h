@@ -179,6 +179,17 @@ MI_API int mi_warp_affine_device(int device, void* stream, const void* dev_src, 
                           void* dev_mask, int height, int width, int dtype, const double* M,
                           int border_mode, const double* border_value, int blur_ksize, double blur_sigma);
 
+/* ---- GPU transform estimator (new capability; north_star's "ECC warp-affine alignment loop"):
+ * Enhanced-Correlation-Coefficient maximisation of a 4-DoF similarity -- the motion model of the
+ * reference's default ALIGN_RIGID estimate (cv2.estimateAffinePartial2D, algorithms/align.py:141-148)
+ * -- coarse-to-fine on a Gaussian pyramid of the two H x W x 3 uint8/uint16 images.
+ * M_out: 2x3 row-major matrix mapping the MOVING image onto the REFERENCE, i.e. what
+ * cv2.warpAffine / mi_warp_affine take.  cc_out: final correlation coefficient, iters_out: total
+ * Gauss-Newton iterations.  max_levels <= 0: automatic pyramid depth. */
+MI_API int mi_ecc_similarity(int device, const void* host_ref, const void* host_mov, int height, int width,
+                      int dtype, int max_levels, int max_iters, double eps, double* M_out, double* cc_out,
+                      int* iters_out);
+
 /* ---- synthetic stack generator, device side ---- */
 MI_API int mi_synth_frames_device(int device, void* dev_out, int dtype, int height, int width,
                            int first_frame, int n_frames, int stack_size, uint32_t seed);

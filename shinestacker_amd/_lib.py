@@ -76,6 +76,9 @@ SIGNATURES = {
     "mi_warp_affine_device": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double),
                                         C.c_int, C.POINTER(C.c_double), C.c_int, C.c_double]),
+    "mi_ecc_similarity": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                    C.c_int, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                    C.POINTER(C.c_int)]),
     "mi_synth_frames_device": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.c_int, C.c_int, C.c_uint32]),
 }
@@ -342,3 +345,18 @@ def warp_affine(img, M, border_mode=BORDER_REPLICATE_BLUR, border_value=(0, 0, 0
                                 mask.ctypes.data if want_mask else None, h, w, DTYPE_CODE[a.dtype], m,
                                 int(border_mode), bv, int(blur_ksize), float(blur_sigma)))
     return (out, mask) if want_mask else out
+
+
+def ecc_similarity(ref, mov, max_levels=0, max_iters=60, eps=1e-9, device=0):
+    """GPU ECC estimate of the similarity that maps `mov` onto `ref` (mi_ecc_similarity).
+    Returns (M 2x3 float64, correlation coefficient, iterations)."""
+    require_device()
+    a, b = np.ascontiguousarray(ref), np.ascontiguousarray(mov)
+    if a.shape != b.shape or a.dtype != b.dtype or a.ndim != 3 or a.shape[2] != 3:
+        raise ValueError("ecc_similarity expects two H x W x 3 images of the same shape and dtype")
+    m = (C.c_double * 6)()
+    cc, it = C.c_double(), C.c_int()
+    check(load().mi_ecc_similarity(device, a.ctypes.data, b.ctypes.data, a.shape[0], a.shape[1],
+                                   DTYPE_CODE[a.dtype], int(max_levels), int(max_iters), float(eps), m,
+                                   C.byref(cc), C.byref(it)))
+    return np.array(list(m), dtype=np.float64).reshape(2, 3), cc.value, it.value

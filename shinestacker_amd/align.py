@@ -85,6 +85,17 @@ def opencv_estimator(img_0_sub, img_1_sub, feature_config, matching_config, alig
     return len(good), m  # pragma: no cover
 
 
+def ecc_estimator(min_correlation=0.5, max_iters=60, device=0):
+    """Estimator for `align_images` that runs on the GPU (mi_ecc_similarity): ECC maximisation of
+    a 4-DoF similarity, coarse to fine.  It needs no feature matches; to satisfy the protocol it
+    reports 1000 "good matches" when the final correlation coefficient reaches `min_correlation`
+    and 0 otherwise (which makes align_images / AlignFrames raise AlignmentError as usual)."""
+    def estimate(img_0_sub, img_1_sub, _feature_config, _matching_config, _alignment_config):
+        m, cc, _iters = _lib.ecc_similarity(img_1_sub, img_0_sub, max_iters=max_iters, device=device)
+        return (1000, m) if cc >= min_correlation else (0, None)
+    return estimate
+
+
 def apply_transform(img, m, alignment_config, device=0):
     """align.py:238-251 on the GPU: warp + mask + blurred-border composite."""
     mode = _BORDER_CODE[alignment_config['border_mode']]

@@ -11,6 +11,7 @@
 #include "kernels_simple.hpp"
 #include "kernels_tiled.hpp"
 #include "kernels_align.hpp"
+#include "kernels_ecc.hpp"
 
 using namespace mi;
 
@@ -327,6 +328,52 @@ int warp_launch(hipStream_t st, const void* src, void* warp, void* out, uint8_t*
     MI_HIP(hipGetLastError());
     return MI_OK;
 }
+
+}  // namespace
+
+namespace {
+
+// solve the symmetric 4x4 system H d = r (column-scaled Gaussian elimination, partial pivoting)
+bool solve4(const double Hs[10], const double r[4], double d[4]) {
+    double A[4][5];
+    int k = 0;
+    double Hm[4][4];
+    for (int i = 0; i < 4; ++i)
+        for (int j = i; j < 4; ++j) Hm[i][j] = Hm[j][i] = Hs[k++];
+    double sc[4];
+    for (int i = 0; i < 4; ++i) {
+        if (!(Hm[i][i] > 0)) return false;
+        sc[i] = 1.0 / std::sqrt(Hm[i][i]);
+    }
+    for (int i = 0; i < 4; ++i) {
+        for (int j = 0; j < 4; ++j) A[i][j] = Hm[i][j] * sc[i] * sc[j];
+        A[i][4] = r[i] * sc[i];
+    }
+    for (int c = 0; c < 4; ++c) {
+        int piv = c;
+        for (int i = c + 1; i < 4; ++i)
+            if (std::fabs(A[i][c]) > std::fabs(A[piv][c])) piv = i;
+        if (std::fabs(A[piv][c]) < 1e-12) return false;
+        if (piv != c)
+            for (int j = 0; j < 5; ++j) std::swap(A[c][j], A[piv][j]);
+        for (int i = c + 1; i < 4; ++i) {
+            const double f = A[i][c] / A[c][c];
+            for (int j = c; j < 5; ++j) A[i][j] -= f * A[c][j];
+        }
+    }
+    for (int i = 3; i >= 0; --i) {
+        double v = A[i][4];
+        for (int j = i + 1; j < 4; ++j) v -= A[i][j] * d[j];
+        d[i] = v / A[i][i];
+    }
+    for (int i = 0; i < 4; ++i) d[i] *= sc[i];
+    return true;
+}
+
+struct EccLevel {
+    int h, w;
+    float *tmpl, *img, *gx, *gy;
+};
 
 }  // namespace
 
@@ -824,6 +871,131 @@ int mi_warp_affine(int device, const void* host_src, void* host_dst, void* host_
     if (host_mask) TRYH(hipMemcpy(host_mask, mask, np, hipMemcpyDeviceToHost));
 #undef TRYH
     cleanup();
+    return MI_OK;
+}
+
+int mi_ecc_similarity(int device, const void* host_ref, const void* host_mov, int height, int width,
+                      int dtype, int max_levels, int max_iters, double eps, double* M_out, double* cc_out,
+                      int* iters_out) {
+    if (!host_ref || !host_mov || !M_out) return fail(MI_ERR_INVALID, "null argument");
+    if (dtype != MI_U8 && dtype != MI_U16) return fail(MI_ERR_INVALID, "dtype must be MI_U8 or MI_U16");
+    if (height < 16 || width < 16) return fail(MI_ERR_INVALID, "image too small for ECC");
+    if (max_iters < 1) max_iters = 50;
+    if (!(eps > 0)) eps = 1e-8;
+    int ndev = 0;
+    int rc = mi_device_count(&ndev);
+    if (rc) return rc;
+    if (ndev == 0) return fail(MI_ERR_NO_DEVICE, "no HIP device visible");
+    MI_HIP(hipSetDevice(device));
+    std::vector<void*> bufs;
+    auto cleanup = [&]() { for (void* b : bufs) (void)hipFree(b); };
+    auto dalloc = [&](size_t bytes) -> void* {
+        void* p = nullptr;
+        if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+        bufs.push_back(p);
+        return p;
+    };
+#define ECC_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { cleanup(); return fail(MI_ERR_HIP, "%s: %s", #x, hipGetErrorString(e_)); } } while (0)
+    const size_t npx = (size_t)height * width, nb = npx * 3 * dtype_size(dtype);
+    void* raw = dalloc(nb);
+    float* gray = (float*)dalloc(npx * 4);
+    double* dsums = (double*)dalloc(ECC_NSUM * sizeof(double));
+    if (!raw || !gray || !dsums) { cleanup(); return fail(MI_ERR_NOMEM, "out of device memory"); }
+    // pyramid geometry: halve while the short side stays >= 48 pixels
+    std::vector<EccLevel> lv;
+    {
+        int h = height, w = width;
+        for (int l = 0; l < (max_levels > 0 ? max_levels : 8); ++l) {
+            lv.push_back({h, w, nullptr, nullptr, nullptr, nullptr});
+            if ((h < w ? h : w) / 2 < 48) break;
+            h = (h + 1) / 2;
+            w = (w + 1) / 2;
+        }
+    }
+    for (auto& L : lv) {
+        const size_t n = (size_t)L.h * L.w * 4;
+        L.tmpl = (float*)dalloc(n); L.img = (float*)dalloc(n); L.gx = (float*)dalloc(n); L.gy = (float*)dalloc(n);
+        if (!L.tmpl || !L.img || !L.gx || !L.gy) { cleanup(); return fail(MI_ERR_NOMEM, "out of device memory"); }
+    }
+    const dim3 blk(64, 4);
+    auto build = [&](const void* host, bool is_tmpl) -> int {
+        ECC_HIP(hipMemcpy(raw, host, nb, hipMemcpyHostToDevice));
+        if (dtype == MI_U8) hipLaunchKernelGGL((ecc_gray<uint8_t>), dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, 0, (const uint8_t*)raw, (int)npx, gray);
+        else hipLaunchKernelGGL((ecc_gray<uint16_t>), dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, 0, (const uint16_t*)raw, (int)npx, gray);
+        for (size_t l = 0; l < lv.size(); ++l) {
+            float* dst = is_tmpl ? lv[l].tmpl : lv[l].img;
+            const float* src = l == 0 ? gray : (is_tmpl ? lv[l - 1].tmpl : lv[l - 1].img);
+            const int sh = l == 0 ? height : lv[l - 1].h, sw = l == 0 ? width : lv[l - 1].w;
+            hipLaunchKernelGGL(ecc_blur_down, dim3(cdiv(lv[l].w, 64), cdiv(lv[l].h, 4)), blk, 0, 0, src, sh, sw,
+                               dst, lv[l].h, lv[l].w, l == 0 ? 0 : 1);
+            if (!is_tmpl)
+                hipLaunchKernelGGL(ecc_gradient, dim3(cdiv(lv[l].w, 64), cdiv(lv[l].h, 4)), blk, 0, 0, dst,
+                                   lv[l].h, lv[l].w, lv[l].gx, lv[l].gy);
+        }
+        ECC_HIP(hipGetLastError());
+        ECC_HIP(hipDeviceSynchronize());
+        return MI_OK;
+    };
+    if ((rc = build(host_ref, true)) || (rc = build(host_mov, false))) return rc;
+
+    // W in origin coordinates of the current level: u = A x + T, A = [a -b; b a]
+    double a = 1.0, b = 0.0, T0 = 0.0, T1 = 0.0, rho = -1.0;
+    int total_iters = 0;
+    for (int l = (int)lv.size() - 1; l >= 0; --l) {
+        const EccLevel& L = lv[l];
+        const double cx = 0.5 * (L.w - 1), cy = 0.5 * (L.h - 1);
+        // centred parameters: t = T - c + A c
+        double tx = T0 - cx + (a * cx - b * cy), ty = T1 - cy + (b * cx + a * cy);
+        const size_t np = (size_t)L.h * L.w;
+        const int step = np > (size_t)6000000 ? 2 : 1;
+        double last_rho = -2.0;
+        for (int it = 0; it < max_iters; ++it) {
+            ECC_HIP(hipMemsetAsync(dsums, 0, ECC_NSUM * sizeof(double), 0));
+            EccParams p{a, b, tx, ty};
+            hipLaunchKernelGGL(ecc_accumulate, dim3(2048), dim3(256), 0, 0, L.tmpl, L.img, L.gx, L.gy, L.h, L.w, p,
+                               step, dsums);
+            double S[ECC_NSUM];
+            ECC_HIP(hipMemcpy(S, dsums, sizeof S, hipMemcpyDeviceToHost));
+            ++total_iters;
+            const double n = S[0];
+            if (n < 64) { cleanup(); return fail(MI_ERR_STATE, "ECC: the images do not overlap"); }
+            const double mw = S[1] / n, mr = S[2] / n;
+            const double wn2 = S[3] - n * mw * mw, rn2 = S[4] - n * mr * mr, corr = S[5] - n * mw * mr;
+            if (!(wn2 > 0) || !(rn2 > 0)) { cleanup(); return fail(MI_ERR_STATE, "ECC: constant image"); }
+            rho = corr / std::sqrt(wn2 * rn2);
+            double ip[4], tp[4], Hi_ip[4];
+            for (int k = 0; k < 4; ++k) {
+                ip[k] = S[10 + k] - mw * S[6 + k];
+                tp[k] = S[14 + k] - mr * S[6 + k];
+            }
+            if (!solve4(&S[18], ip, Hi_ip)) break;
+            double ipH = 0, tpH = 0;
+            for (int k = 0; k < 4; ++k) { ipH += ip[k] * Hi_ip[k]; tpH += tp[k] * Hi_ip[k]; }
+            const double lam_n = wn2 - ipH, lam_d = corr - tpH;
+            if (!(lam_d > 0)) break;  // the algorithm stopped before its convergence
+            const double lam = lam_n / lam_d;
+            double ep[4], dp[4];
+            for (int k = 0; k < 4; ++k) ep[k] = lam * tp[k] - ip[k];
+            if (!solve4(&S[18], ep, dp)) break;
+            a += dp[0]; b += dp[1]; tx += dp[2]; ty += dp[3];
+            if (std::fabs(rho - last_rho) < eps) break;
+            last_rho = rho;
+        }
+        // back to origin coordinates, then up to the next finer level (u_f = 2 u_c, x_f = 2 x_c)
+        T0 = tx + cx - (a * cx - b * cy);
+        T1 = ty + cy - (b * cx + a * cy);
+        if (l > 0) { T0 *= 2.0; T1 *= 2.0; }
+    }
+    cleanup();
+#undef ECC_HIP
+    // M (moving -> reference) = W^-1
+    const double det = a * a + b * b;
+    if (!(det > 1e-12)) return fail(MI_ERR_STATE, "ECC: degenerate transform");
+    const double ia = a / det, ib = -b / det;  // A^-1 = [ia -ib; ib ia]
+    M_out[0] = ia;  M_out[1] = -ib; M_out[2] = -(ia * T0 - ib * T1);
+    M_out[3] = ib;  M_out[4] = ia;  M_out[5] = -(ib * T0 + ia * T1);
+    if (cc_out) *cc_out = rho;
+    if (iters_out) *iters_out = total_iters;
     return MI_OK;
 }
 

@@ -1,0 +1,123 @@
+// kernels_ecc.hpp -- GPU transform estimator for frame alignment: Enhanced Correlation
+// Coefficient (ECC) maximisation [Evangelidis & Psarakis, PAMI 2008] of a 4-DoF similarity
+// (the motion model of the reference's default ALIGN_RIGID = cv2.estimateAffinePartial2D,
+// algorithms/align.py:141-148), coarse-to-fine on a Gaussian pyramid.
+//
+// This is a NEW capability (north_star names it; the reference removed its ECC refinement in
+// v0.1.4, CHANGELOG.md:206): there is no reference output to match, it is validated against
+// ground-truth transforms with the reference author's tolerances
+// (tests/test_0031_align_precision.py:62-65: angle < 0.005 deg, shift < 0.2 px, scale < 1e-4).
+//
+// Warp model, in coordinates centred on the image centre c:   W(x) = c + [a -b; b a](x - c) + t
+// maps a pixel of the reference frame to the matching position in the moving frame, so the
+// matrix cv2.warpAffine wants (moving -> reference) is the inverse of W.
+#pragma once
+#include "common.hpp"
+
+namespace mi {
+
+// gray (float) of a BGR image; any fixed positive combination works for registration
+template <typename T>
+__global__ void ecc_gray(const T* __restrict__ img, int n, float* __restrict__ out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = 0.114f * (float)img[3 * i] + 0.587f * (float)img[3 * i + 1] + 0.299f * (float)img[3 * i + 2];
+}
+
+// 5x5 binomial blur ([1 4 6 4 1]/16 separable, replicate border) then 2x decimation
+__global__ void ecc_blur_down(const float* __restrict__ src, int h, int w, float* __restrict__ dst, int ho,
+                              int wo, int decimate) {
+    int x = blockIdx.x * blockDim.x + threadIdx.x;
+    int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= wo || y >= ho) return;
+    const float k[5] = {1.f / 16, 4.f / 16, 6.f / 16, 4.f / 16, 1.f / 16};
+    const int sx = decimate ? 2 * x : x, sy = decimate ? 2 * y : y;
+    float acc = 0.f;
+    for (int dy = -2; dy <= 2; ++dy) {
+        const int yy = min(max(sy + dy, 0), h - 1);
+        float row = 0.f;
+        for (int dx = -2; dx <= 2; ++dx) row += k[dx + 2] * src[(size_t)yy * w + min(max(sx + dx, 0), w - 1)];
+        acc += k[dy + 2] * row;
+    }
+    dst[(size_t)y * wo + x] = acc;
+}
+
+// central-difference gradients
+__global__ void ecc_gradient(const float* __restrict__ src, int h, int w, float* __restrict__ gx,
+                             float* __restrict__ gy) {
+    int x = blockIdx.x * blockDim.x + threadIdx.x;
+    int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= w || y >= h) return;
+    const int xm = max(x - 1, 0), xp = min(x + 1, w - 1), ym = max(y - 1, 0), yp = min(y + 1, h - 1);
+    gx[(size_t)y * w + x] = 0.5f * (src[(size_t)y * w + xp] - src[(size_t)y * w + xm]);
+    gy[(size_t)y * w + x] = 0.5f * (src[(size_t)yp * w + x] - src[(size_t)ym * w + x]);
+}
+
+__device__ __forceinline__ float bilerp(const float* __restrict__ im, int w, int x0, int y0, float fx, float fy) {
+    const float* p = im + (size_t)y0 * w + x0;
+    const float a = p[0] + fx * (p[1] - p[0]);
+    const float b = p[w] + fx * (p[w + 1] - p[w]);
+    return a + fy * (b - a);
+}
+
+constexpr int ECC_NSUM = 28;  // n, Siw, Sir, Siw2, Sir2, Siwir, SJ[4], SJiw[4], SJir[4], H[10]
+
+struct EccParams {
+    double a, b, tx, ty;  // similarity about the image centre
+};
+
+// One Gauss-Newton accumulation pass: every reference pixel samples the moving image (and its
+// gradients) at W(x) and adds its terms to 28 sums (double).  `step`: pixel stride (sub-sampling
+// of the sum at the finest levels).
+__global__ void ecc_accumulate(const float* __restrict__ tmpl, const float* __restrict__ img,
+                               const float* __restrict__ gx, const float* __restrict__ gy, int h, int w,
+                               EccParams p, int step, double* __restrict__ sums) {
+    double acc[ECC_NSUM];
+#pragma unroll
+    for (int i = 0; i < ECC_NSUM; ++i) acc[i] = 0.0;
+    const float cx = 0.5f * (w - 1), cy = 0.5f * (h - 1);
+    const float a = (float)p.a, b = (float)p.b, tx = (float)p.tx, ty = (float)p.ty;
+    const int nx = (w + step - 1) / step, ny = (h + step - 1) / step;
+    const size_t total = (size_t)nx * ny;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int y = (int)(i / nx) * step, x = (int)(i % nx) * step;
+        const float xc = x - cx, yc = y - cy;
+        const float u = cx + a * xc - b * yc + tx, v = cy + b * xc + a * yc + ty;
+        const int x0 = (int)floorf(u), y0 = (int)floorf(v);
+        if (x0 < 1 || y0 < 1 || x0 >= w - 2 || y0 >= h - 2) continue;
+        const float fx = u - x0, fy = v - y0;
+        const float iw = bilerp(img, w, x0, y0, fx, fy);
+        const float dgx = bilerp(gx, w, x0, y0, fx, fy), dgy = bilerp(gy, w, x0, y0, fx, fy);
+        const float ir = tmpl[(size_t)y * w + x];
+        const float J[4] = {dgx * xc + dgy * yc, -dgx * yc + dgy * xc, dgx, dgy};
+        acc[0] += 1.0;
+        acc[1] += iw;
+        acc[2] += ir;
+        acc[3] += (double)iw * iw;
+        acc[4] += (double)ir * ir;
+        acc[5] += (double)iw * ir;
+        int hk = 18;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            acc[6 + k] += J[k];
+            acc[10 + k] += (double)J[k] * iw;
+            acc[14 + k] += (double)J[k] * ir;
+#pragma unroll
+            for (int m = k; m < 4; ++m) acc[hk++] += (double)J[k] * J[m];
+        }
+    }
+    // block reduction through LDS, one atomic per sum per block
+    __shared__ double red[256];
+    for (int s = 0; s < ECC_NSUM; ++s) {
+        red[threadIdx.x] = acc[s];
+        __syncthreads();
+        for (int off = 128; off > 0; off >>= 1) {
+            if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) atomicAdd(&sums[s], red[0]);
+        __syncthreads();
+    }
+}
+
+}  // namespace mi

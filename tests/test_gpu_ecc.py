@@ -1,0 +1,114 @@
+"""GPU: the ECC similarity estimator (mi_ecc_similarity).  No reference output exists for it (the
+reference's estimator is OpenCV's SIFT+RANSAC); it is validated against ground-truth transforms
+with the acceptance tolerances of the reference's own precision test
+(tests/test_0031_align_precision.py:62-65): angle < 0.005 deg, shift < 0.2 px, scale < 1e-4."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def L(hiplib):
+    hiplib.require_device()
+    return hiplib
+
+
+def texture(h, w, seed):
+    from scipy import ndimage
+    rng = np.random.default_rng(seed)
+    img = np.zeros((h, w), np.float64)
+    for sigma, amp in ((1.5, 60), (4, 50), (12, 40)):
+        img += amp * ndimage.gaussian_filter(rng.standard_normal((h, w)), sigma) * sigma
+    img = 128 + img * (60 / img.std())
+    # a few hard-edged shapes, as in the reference's synthetic test image
+    yy, xx = np.mgrid[0:h, 0:w]
+    img[(yy - h * 0.3) ** 2 + (xx - w * 0.6) ** 2 < (0.08 * h) ** 2] += 70
+    img[int(h * 0.55):int(h * 0.8), int(w * 0.15):int(w * 0.4)] -= 60
+    return np.clip(img, 0, 255)
+
+
+def similarity(theta_deg, s, tx, ty, cx, cy):
+    t = np.deg2rad(theta_deg)
+    a, b = s * np.cos(t), s * np.sin(t)
+    return np.array([[a, -b, cx - a * cx + b * cy + tx], [b, a, cy - b * cx - a * cy + ty]])
+
+
+def invert(M):
+    A = M[:, :2]
+    Ai = np.linalg.inv(A)
+    return np.hstack([Ai, -Ai @ M[:, 2:3]])
+
+
+def decompose(M):
+    s = np.hypot(M[0, 0], M[1, 0])
+    return np.rad2deg(np.arctan2(M[1, 0], M[0, 0])), s, M[0, 2], M[1, 2]
+
+
+def make_pair(oracle, T, h=512, w=512, noise=5.0, seed=0, dtype=np.uint8):
+    rng = np.random.default_rng(seed + 100)
+    base = texture(h, w, seed)
+    scale = 1 if dtype == np.uint8 else 257
+    ref3 = np.repeat(base[:, :, None], 3, 2)
+    mov3 = oracle.warp_affine(np.clip(ref3, 0, 255).astype(np.uint8), T, border_mode=oracle.BORDER_REPLICATE)
+    ref = np.clip(ref3 + rng.normal(0, noise, ref3.shape), 0, 255)
+    mov = np.clip(mov3.astype(np.float64) + rng.normal(0, noise, ref3.shape), 0, 255)
+    return (ref * scale).astype(dtype), (mov * scale).astype(dtype)
+
+
+@pytest.mark.parametrize("theta,s,tx,ty,dtype", [
+    (0.5, 1.003, 7.3, -4.6, np.uint8),
+    (-0.8, 0.994, -12.4, 9.7, np.uint8),
+    (0.02, 1.0001, 0.37, -0.21, np.uint16),      # one step of the config-4 sequence
+    (1.28, 1.0064, 23.7, -13.4, np.uint8),       # the far end of the config-4 sequence
+])
+def test_recovers_known_similarity(L, oracle, theta, s, tx, ty, dtype):
+    T = similarity(theta, s, tx, ty, 255.5, 255.5)       # moving = warp(ref, T)
+    ref, mov = make_pair(oracle, T, dtype=dtype)
+    M, cc, iters = L.ecc_similarity(ref, mov)
+    want = invert(T)                                      # moving -> reference
+    a, sc, mx, my = decompose(M)
+    a0, s0, x0, y0 = decompose(want)
+    assert cc > 0.9
+    assert abs(a - a0) < 0.005, (a, a0)
+    assert abs(sc - s0) < 1e-4, (sc, s0)
+    # compare the mapping of the image centre (a translation-like quantity independent of the
+    # rotation pivot convention)
+    c = np.array([255.5, 255.5, 1.0])
+    assert np.abs(M @ c - want @ c).max() < 0.2
+
+
+def test_large_motion_of_the_reference_precision_test(L, oracle):
+    """15 deg rotation + (30, 20) px shift (tests/test_0031_align_precision.py:44-47)."""
+    T = similarity(15.0, 1.0, 30.0, 20.0, 255.5, 255.5)
+    ref, mov = make_pair(oracle, T, noise=10.0)
+    M, cc, iters = L.ecc_similarity(ref, mov, max_iters=150)
+    want = invert(T)
+    a, sc, _, _ = decompose(M)
+    a0, s0, _, _ = decompose(want)
+    c = np.array([255.5, 255.5, 1.0])
+    assert cc > 0.8
+    assert abs(a - a0) < 0.005 and abs(sc - s0) < 1e-4
+    assert np.abs(M @ c - want @ c).max() < 0.2
+
+
+def test_align_images_with_the_gpu_estimator(L, oracle):
+    """End to end: align_images(estimator=ecc_estimator()) brings the moving frame back onto the
+    reference (config 4's building block: estimate + warp + border blur, all on the GPU)."""
+    from shinestacker_amd import align_images
+    from shinestacker_amd.align import ecc_estimator
+    T = similarity(0.6, 1.002, 9.1, -6.3, 255.5, 255.5)
+    ref, mov = make_pair(oracle, T, noise=0.0)
+    n, M, warp = align_images(ref, mov, estimator=ecc_estimator(), alignment_config={'fast_subsampling': True})
+    assert n == 1000 and warp.shape == ref.shape
+    inner = (slice(40, -40), slice(40, -40))
+    err = np.abs(warp[inner].astype(np.int32) - ref[inner].astype(np.int32))
+    before = np.abs(mov[inner].astype(np.int32) - ref[inner].astype(np.int32)).mean()
+    # what remains is the double bilinear interpolation of a sharp texture, not misalignment
+    assert err.mean() < 4.0 and before > 5 * err.mean(), (err.mean(), before)
+
+
+def test_non_overlapping_or_flat_images_fail_cleanly(L):
+    flat = np.full((128, 128, 3), 7, np.uint8)
+    with pytest.raises(L.DeviceError):
+        L.ecc_similarity(flat, flat)
