@@ -105,6 +105,7 @@ MI_API int mi_device_malloc(int device, size_t bytes, void** dev_ptr);
 MI_API int mi_device_free(int device, void* dev_ptr);
 MI_API int mi_memcpy_h2d(int device, void* dev_dst, const void* host_src, size_t bytes);
 MI_API int mi_memcpy_d2h(int device, void* host_dst, const void* dev_src, size_t bytes);
+MI_API int mi_memcpy_d2d(int device, void* dev_dst, const void* dev_src, size_t bytes);
 MI_API int mi_device_synchronize(int device);
 
 /* ---- stacker handle ---- */
@@ -189,6 +190,21 @@ MI_API int mi_warp_affine_device(int device, void* stream, const void* dev_src, 
 MI_API int mi_ecc_similarity(int device, const void* host_ref, const void* host_mov, int height, int width,
                       int dtype, int max_levels, int max_iters, double eps, double* M_out, double* cc_out,
                       int* iters_out);
+
+/* Device-resident form of the same estimator for the AlignFrames loop (align.py:255-330): the
+ * pyramids are allocated once, the reference frame's pyramid is built once per reference, every
+ * moving frame costs one pyramid build plus the Gauss-Newton iterations.  `subsample` folds the
+ * reference's fast sub-sampling img[::s, ::s] (utils.py img_subsample) into the first kernel; the
+ * returned M is in full-resolution pixels (translation scaled back as align.py:224-231 does).
+ * dev_ref / dev_mov: H x W x 3 device images of the handle's dtype.  The kernels run on `stream`;
+ * mi_aligner_estimate returns after the last iteration (it reads 28 sums back per iteration). */
+typedef struct mi_aligner* mi_aligner_t;
+MI_API int mi_aligner_create(mi_aligner_t* out, int device, int height, int width, int dtype, int subsample,
+                      int max_levels);
+MI_API int mi_aligner_destroy(mi_aligner_t al);
+MI_API int mi_aligner_set_reference(mi_aligner_t al, void* stream, const void* dev_ref);
+MI_API int mi_aligner_estimate(mi_aligner_t al, void* stream, const void* dev_mov, int max_iters, double eps,
+                        double* M_out, double* cc_out, int* iters_out);
 
 /* ---- synthetic stack generator, device side ---- */
 MI_API int mi_synth_frames_device(int device, void* dev_out, int dtype, int height, int width,

@@ -46,6 +46,7 @@ SIGNATURES = {
     "mi_device_free": (C.c_int, [C.c_int, C.c_void_p]),
     "mi_memcpy_h2d": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]),
     "mi_memcpy_d2h": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "mi_memcpy_d2d": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]),
     "mi_device_synchronize": (C.c_int, [C.c_int]),
     "mi_stack_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(StackParams)]),
     "mi_stack_destroy": (None, [C.c_void_p]),
@@ -79,6 +80,12 @@ SIGNATURES = {
     "mi_ecc_similarity": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                     C.c_int, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                     C.POINTER(C.c_int)]),
+    "mi_aligner_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                    C.c_int]),
+    "mi_aligner_destroy": (C.c_int, [C.c_void_p]),
+    "mi_aligner_set_reference": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mi_aligner_estimate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double,
+                                      C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "mi_synth_frames_device": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.c_int, C.c_int, C.c_uint32]),
 }
@@ -360,3 +367,37 @@ def ecc_similarity(ref, mov, max_levels=0, max_iters=60, eps=1e-9, device=0):
                                    DTYPE_CODE[a.dtype], int(max_levels), int(max_iters), float(eps), m,
                                    C.byref(cc), C.byref(it)))
     return np.array(list(m), dtype=np.float64).reshape(2, 3), cc.value, it.value
+
+
+class Aligner:
+    """Device-resident ECC estimator (mi_aligner_t): frames stay in HBM, the pyramids are allocated
+    once, `subsample` is the reference's fast sub-sampling factor (align.py default 2)."""
+
+    def __init__(self, height, width, dtype=np.uint8, subsample=1, max_levels=0, device=0):
+        require_device()
+        self._h = C.c_void_p()
+        self.device = device
+        check(load().mi_aligner_create(C.byref(self._h), device, height, width,
+                                       DTYPE_CODE[np.dtype(dtype)], int(subsample), int(max_levels)))
+
+    def set_reference(self, dev_ptr, stream=None):
+        check(load().mi_aligner_set_reference(self._h, stream, dev_ptr))
+
+    def estimate(self, dev_ptr, max_iters=60, eps=1e-9, stream=None):
+        """-> (M 2x3 float64 in full-resolution pixels, correlation coefficient, iterations)"""
+        m = (C.c_double * 6)()
+        cc, it = C.c_double(), C.c_int()
+        check(load().mi_aligner_estimate(self._h, stream, dev_ptr, int(max_iters), float(eps), m,
+                                         C.byref(cc), C.byref(it)))
+        return np.array(list(m), dtype=np.float64).reshape(2, 3), cc.value, it.value
+
+    def close(self):
+        if self._h:
+            load().mi_aligner_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass

@@ -377,6 +377,130 @@ struct EccLevel {
 
 }  // namespace
 
+// Device-resident aligner: the pyramids of the reference (template) and of the moving frame, the
+// scratch for the sums, all allocated once per (shape, dtype, subsample).
+struct mi_aligner {
+    int device = 0, height = 0, width = 0, dtype = 0, subsample = 1;
+    int h = 0, w = 0;  // size of the sub-sampled images the estimate works on
+    std::vector<EccLevel> lv;
+    float* gray = nullptr;
+    double* partial = nullptr;       // [ECC_MAX_BLOCKS][ECC_NSUM]
+    unsigned int* ticket = nullptr;
+    double* hsums = nullptr;         // pinned, device-visible: the last block writes the 28 sums here
+    std::vector<void*> bufs;
+    bool have_ref = false;
+};
+
+namespace {
+
+void aligner_free(mi_aligner* al) {
+    for (void* b : al->bufs) (void)hipFree(b);
+    al->bufs.clear();
+    if (al->hsums) (void)hipHostFree(al->hsums);
+    al->hsums = nullptr;
+}
+
+int aligner_build(mi_aligner* al, hipStream_t st, const void* dev_img, bool is_tmpl) {
+    const size_t npx = (size_t)al->h * al->w;
+    const dim3 blk(64, 4), g0(cdiv(al->w, 64), cdiv(al->h, 4));
+    if (al->dtype == MI_U8)
+        hipLaunchKernelGGL((ecc_gray<uint8_t>), g0, blk, 0, st, (const uint8_t*)dev_img, al->width, al->h, al->w,
+                           al->subsample, al->gray);
+    else
+        hipLaunchKernelGGL((ecc_gray<uint16_t>), g0, blk, 0, st, (const uint16_t*)dev_img, al->width, al->h, al->w,
+                           al->subsample, al->gray);
+    (void)npx;
+    auto& lv = al->lv;
+    for (size_t l = 0; l < lv.size(); ++l) {
+        float* dst = is_tmpl ? lv[l].tmpl : lv[l].img;
+        const float* src = l == 0 ? al->gray : (is_tmpl ? lv[l - 1].tmpl : lv[l - 1].img);
+        const int sh = l == 0 ? al->h : lv[l - 1].h, sw = l == 0 ? al->w : lv[l - 1].w;
+        hipLaunchKernelGGL(ecc_blur_down, dim3(cdiv(lv[l].w, 64), cdiv(lv[l].h, 4)), blk, 0, st, src, sh, sw, dst,
+                           lv[l].h, lv[l].w, l == 0 ? 0 : 1);
+        if (!is_tmpl)
+            hipLaunchKernelGGL(ecc_gradient, dim3(cdiv(lv[l].w, 64), cdiv(lv[l].h, 4)), blk, 0, st, dst, lv[l].h,
+                               lv[l].w, lv[l].gx, lv[l].gy);
+    }
+    MI_HIP(hipGetLastError());
+    return MI_OK;
+}
+
+// coarse-to-fine forward-additive ECC on the pyramids held by `al`; M_out in FULL-resolution
+// pixel coordinates (translation scaled by the sub-sampling factor, as align.py:224-231 does)
+int aligner_solve(mi_aligner* al, hipStream_t st, int max_iters, double eps, double* M_out, double* cc_out,
+                  int* iters_out) {
+    if (max_iters < 1) max_iters = 50;
+    if (!(eps > 0)) eps = 1e-8;
+    auto& lv = al->lv;
+    // W in origin coordinates of the current level: u = A x + T, A = [a -b; b a]
+    double a = 1.0, b = 0.0, T0 = 0.0, T1 = 0.0, rho = -1.0;
+    int total_iters = 0;
+    for (int l = (int)lv.size() - 1; l >= 0; --l) {
+        const EccLevel& L = lv[l];
+        const double cx = 0.5 * (L.w - 1), cy = 0.5 * (L.h - 1);
+        // centred parameters: t = T - c + A c
+        double tx = T0 - cx + (a * cx - b * cy), ty = T1 - cy + (b * cx + a * cy);
+        const size_t np = (size_t)L.h * L.w;
+        const int step = np > (size_t)6000000 ? 2 : 1;
+        double last_rho = -2.0;
+        for (int it = 0; it < max_iters; ++it) {
+            EccParams p{a, b, tx, ty};
+            // ~8 pixels per thread, at most ECC_MAX_BLOCKS blocks (4 per CU)
+            const size_t work = (np / ((size_t)step * step) + 2047) / 2048;
+            const unsigned nblk = (unsigned)(work < 1 ? 1 : (work > (size_t)ECC_MAX_BLOCKS ? ECC_MAX_BLOCKS : work));
+            hipLaunchKernelGGL(ecc_accumulate, dim3(nblk), dim3(256), 0, st, L.tmpl, L.img, L.gx, L.gy, L.h, L.w, p,
+                               step, al->partial, al->ticket, al->hsums);
+            MI_HIP(hipStreamSynchronize(st));
+            double S[ECC_NSUM];
+            for (int k = 0; k < ECC_NSUM; ++k) S[k] = ((volatile double*)al->hsums)[k];
+            ++total_iters;
+            const double n = S[0];
+            if (n < 64) return fail(MI_ERR_STATE, "ECC: the images do not overlap");
+            const double mw = S[1] / n, mr = S[2] / n;
+            const double wn2 = S[3] - n * mw * mw, rn2 = S[4] - n * mr * mr, corr = S[5] - n * mw * mr;
+            if (!(wn2 > 0) || !(rn2 > 0)) return fail(MI_ERR_STATE, "ECC: constant image");
+            rho = corr / std::sqrt(wn2 * rn2);
+            double ip[4], tp[4], Hi_ip[4];
+            for (int k = 0; k < 4; ++k) {
+                ip[k] = S[10 + k] - mw * S[6 + k];
+                tp[k] = S[14 + k] - mr * S[6 + k];
+            }
+            if (!solve4(&S[18], ip, Hi_ip)) break;
+            double ipH = 0, tpH = 0;
+            for (int k = 0; k < 4; ++k) { ipH += ip[k] * Hi_ip[k]; tpH += tp[k] * Hi_ip[k]; }
+            const double lam_n = wn2 - ipH, lam_d = corr - tpH;
+            if (!(lam_d > 0)) break;  // the algorithm stopped before its convergence
+            const double lam = lam_n / lam_d;
+            double ep[4], dp[4];
+            for (int k = 0; k < 4; ++k) ep[k] = lam * tp[k] - ip[k];
+            if (!solve4(&S[18], ep, dp)) break;
+            a += dp[0]; b += dp[1]; tx += dp[2]; ty += dp[3];
+            // converged when the update moves no pixel of this level by more than 0.002 px
+            // (the image corners move the most), or when rho stalls
+            const double move = (std::fabs(dp[0]) + std::fabs(dp[1])) * std::hypot(cx, cy) +
+                                std::fabs(dp[2]) + std::fabs(dp[3]);
+            if (move < 2e-3 || std::fabs(rho - last_rho) < eps) break;
+            last_rho = rho;
+        }
+        // back to origin coordinates, then up to the next finer level (u_f = 2 u_c, x_f = 2 x_c)
+        T0 = tx + cx - (a * cx - b * cy);
+        T1 = ty + cy - (b * cx + a * cy);
+        if (l > 0) { T0 *= 2.0; T1 *= 2.0; }
+    }
+    // M (moving -> reference) = W^-1, translation back to full-resolution pixels
+    const double det = a * a + b * b;
+    if (!(det > 1e-12)) return fail(MI_ERR_STATE, "ECC: degenerate transform");
+    const double ia = a / det, ib = -b / det;  // A^-1 = [ia -ib; ib ia]
+    const double s = (double)al->subsample;
+    M_out[0] = ia;  M_out[1] = -ib; M_out[2] = -(ia * T0 - ib * T1) * s;
+    M_out[3] = ib;  M_out[4] = ia;  M_out[5] = -(ib * T0 + ia * T1) * s;
+    if (cc_out) *cc_out = rho;
+    if (iters_out) *iters_out = total_iters;
+    return MI_OK;
+}
+
+}  // namespace
+
 extern "C" {
 
 int mi_abi_version(void) { return MI_ABI_VERSION; }
@@ -437,6 +561,13 @@ int mi_memcpy_h2d(int device, void* dev_dst, const void* host_src, size_t bytes)
 int mi_memcpy_d2h(int device, void* host_dst, const void* dev_src, size_t bytes) {
     MI_HIP(hipSetDevice(device));
     MI_HIP(hipMemcpy(host_dst, dev_src, bytes, hipMemcpyDeviceToHost));
+    return MI_OK;
+}
+
+int mi_memcpy_d2d(int device, void* dev_dst, const void* dev_src, size_t bytes) {
+    if (!dev_dst || !dev_src) return fail(MI_ERR_INVALID, "null pointer");
+    MI_HIP(hipSetDevice(device));
+    MI_HIP(hipMemcpy(dev_dst, dev_src, bytes, hipMemcpyDeviceToDevice));
     return MI_OK;
 }
 int mi_device_synchronize(int device) {
@@ -874,129 +1005,113 @@ int mi_warp_affine(int device, const void* host_src, void* host_dst, void* host_
     return MI_OK;
 }
 
-int mi_ecc_similarity(int device, const void* host_ref, const void* host_mov, int height, int width,
-                      int dtype, int max_levels, int max_iters, double eps, double* M_out, double* cc_out,
-                      int* iters_out) {
-    if (!host_ref || !host_mov || !M_out) return fail(MI_ERR_INVALID, "null argument");
+int mi_aligner_create(mi_aligner_t* out, int device, int height, int width, int dtype, int subsample,
+                      int max_levels) {
+    if (!out) return fail(MI_ERR_INVALID, "null argument");
+    *out = nullptr;
     if (dtype != MI_U8 && dtype != MI_U16) return fail(MI_ERR_INVALID, "dtype must be MI_U8 or MI_U16");
-    if (height < 16 || width < 16) return fail(MI_ERR_INVALID, "image too small for ECC");
-    if (max_iters < 1) max_iters = 50;
-    if (!(eps > 0)) eps = 1e-8;
+    if (subsample < 1) return fail(MI_ERR_INVALID, "subsample must be >= 1");
+    const int h = (height + subsample - 1) / subsample, w = (width + subsample - 1) / subsample;
+    if (h < 16 || w < 16) return fail(MI_ERR_INVALID, "image too small for ECC");
     int ndev = 0;
     int rc = mi_device_count(&ndev);
     if (rc) return rc;
     if (ndev == 0) return fail(MI_ERR_NO_DEVICE, "no HIP device visible");
     MI_HIP(hipSetDevice(device));
-    std::vector<void*> bufs;
-    auto cleanup = [&]() { for (void* b : bufs) (void)hipFree(b); };
+    mi_aligner* al = new (std::nothrow) mi_aligner();
+    if (!al) return fail(MI_ERR_NOMEM, "out of host memory");
+    al->device = device; al->height = height; al->width = width; al->dtype = dtype; al->subsample = subsample;
+    al->h = h; al->w = w;
     auto dalloc = [&](size_t bytes) -> void* {
         void* p = nullptr;
         if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
-        bufs.push_back(p);
+        al->bufs.push_back(p);
         return p;
     };
-#define ECC_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { cleanup(); return fail(MI_ERR_HIP, "%s: %s", #x, hipGetErrorString(e_)); } } while (0)
-    const size_t npx = (size_t)height * width, nb = npx * 3 * dtype_size(dtype);
-    void* raw = dalloc(nb);
-    float* gray = (float*)dalloc(npx * 4);
-    double* dsums = (double*)dalloc(ECC_NSUM * sizeof(double));
-    if (!raw || !gray || !dsums) { cleanup(); return fail(MI_ERR_NOMEM, "out of device memory"); }
+    bool ok = true;
+    al->gray = (float*)dalloc((size_t)h * w * 4);
+    al->partial = (double*)dalloc((size_t)ECC_MAX_BLOCKS * ECC_NSUM * sizeof(double));
+    al->ticket = (unsigned int*)dalloc(sizeof(unsigned int));
+    ok = al->gray && al->partial && al->ticket;
+    if (ok) ok = hipMemset(al->ticket, 0, sizeof(unsigned int)) == hipSuccess;
+    if (ok) ok = hipHostMalloc((void**)&al->hsums, ECC_NSUM * sizeof(double), hipHostMallocDefault) == hipSuccess;
     // pyramid geometry: halve while the short side stays >= 48 pixels
-    std::vector<EccLevel> lv;
     {
-        int h = height, w = width;
+        int lh = h, lw = w;
         for (int l = 0; l < (max_levels > 0 ? max_levels : 8); ++l) {
-            lv.push_back({h, w, nullptr, nullptr, nullptr, nullptr});
-            if ((h < w ? h : w) / 2 < 48) break;
-            h = (h + 1) / 2;
-            w = (w + 1) / 2;
+            al->lv.push_back({lh, lw, nullptr, nullptr, nullptr, nullptr});
+            if ((lh < lw ? lh : lw) / 2 < 48) break;
+            lh = (lh + 1) / 2;
+            lw = (lw + 1) / 2;
         }
     }
-    for (auto& L : lv) {
+    for (auto& L : al->lv) {
         const size_t n = (size_t)L.h * L.w * 4;
         L.tmpl = (float*)dalloc(n); L.img = (float*)dalloc(n); L.gx = (float*)dalloc(n); L.gy = (float*)dalloc(n);
-        if (!L.tmpl || !L.img || !L.gx || !L.gy) { cleanup(); return fail(MI_ERR_NOMEM, "out of device memory"); }
+        ok = ok && L.tmpl && L.img && L.gx && L.gy;
     }
-    const dim3 blk(64, 4);
-    auto build = [&](const void* host, bool is_tmpl) -> int {
-        ECC_HIP(hipMemcpy(raw, host, nb, hipMemcpyHostToDevice));
-        if (dtype == MI_U8) hipLaunchKernelGGL((ecc_gray<uint8_t>), dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, 0, (const uint8_t*)raw, (int)npx, gray);
-        else hipLaunchKernelGGL((ecc_gray<uint16_t>), dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, 0, (const uint16_t*)raw, (int)npx, gray);
-        for (size_t l = 0; l < lv.size(); ++l) {
-            float* dst = is_tmpl ? lv[l].tmpl : lv[l].img;
-            const float* src = l == 0 ? gray : (is_tmpl ? lv[l - 1].tmpl : lv[l - 1].img);
-            const int sh = l == 0 ? height : lv[l - 1].h, sw = l == 0 ? width : lv[l - 1].w;
-            hipLaunchKernelGGL(ecc_blur_down, dim3(cdiv(lv[l].w, 64), cdiv(lv[l].h, 4)), blk, 0, 0, src, sh, sw,
-                               dst, lv[l].h, lv[l].w, l == 0 ? 0 : 1);
-            if (!is_tmpl)
-                hipLaunchKernelGGL(ecc_gradient, dim3(cdiv(lv[l].w, 64), cdiv(lv[l].h, 4)), blk, 0, 0, dst,
-                                   lv[l].h, lv[l].w, lv[l].gx, lv[l].gy);
-        }
-        ECC_HIP(hipGetLastError());
-        ECC_HIP(hipDeviceSynchronize());
-        return MI_OK;
-    };
-    if ((rc = build(host_ref, true)) || (rc = build(host_mov, false))) return rc;
-
-    // W in origin coordinates of the current level: u = A x + T, A = [a -b; b a]
-    double a = 1.0, b = 0.0, T0 = 0.0, T1 = 0.0, rho = -1.0;
-    int total_iters = 0;
-    for (int l = (int)lv.size() - 1; l >= 0; --l) {
-        const EccLevel& L = lv[l];
-        const double cx = 0.5 * (L.w - 1), cy = 0.5 * (L.h - 1);
-        // centred parameters: t = T - c + A c
-        double tx = T0 - cx + (a * cx - b * cy), ty = T1 - cy + (b * cx + a * cy);
-        const size_t np = (size_t)L.h * L.w;
-        const int step = np > (size_t)6000000 ? 2 : 1;
-        double last_rho = -2.0;
-        for (int it = 0; it < max_iters; ++it) {
-            ECC_HIP(hipMemsetAsync(dsums, 0, ECC_NSUM * sizeof(double), 0));
-            EccParams p{a, b, tx, ty};
-            hipLaunchKernelGGL(ecc_accumulate, dim3(2048), dim3(256), 0, 0, L.tmpl, L.img, L.gx, L.gy, L.h, L.w, p,
-                               step, dsums);
-            double S[ECC_NSUM];
-            ECC_HIP(hipMemcpy(S, dsums, sizeof S, hipMemcpyDeviceToHost));
-            ++total_iters;
-            const double n = S[0];
-            if (n < 64) { cleanup(); return fail(MI_ERR_STATE, "ECC: the images do not overlap"); }
-            const double mw = S[1] / n, mr = S[2] / n;
-            const double wn2 = S[3] - n * mw * mw, rn2 = S[4] - n * mr * mr, corr = S[5] - n * mw * mr;
-            if (!(wn2 > 0) || !(rn2 > 0)) { cleanup(); return fail(MI_ERR_STATE, "ECC: constant image"); }
-            rho = corr / std::sqrt(wn2 * rn2);
-            double ip[4], tp[4], Hi_ip[4];
-            for (int k = 0; k < 4; ++k) {
-                ip[k] = S[10 + k] - mw * S[6 + k];
-                tp[k] = S[14 + k] - mr * S[6 + k];
-            }
-            if (!solve4(&S[18], ip, Hi_ip)) break;
-            double ipH = 0, tpH = 0;
-            for (int k = 0; k < 4; ++k) { ipH += ip[k] * Hi_ip[k]; tpH += tp[k] * Hi_ip[k]; }
-            const double lam_n = wn2 - ipH, lam_d = corr - tpH;
-            if (!(lam_d > 0)) break;  // the algorithm stopped before its convergence
-            const double lam = lam_n / lam_d;
-            double ep[4], dp[4];
-            for (int k = 0; k < 4; ++k) ep[k] = lam * tp[k] - ip[k];
-            if (!solve4(&S[18], ep, dp)) break;
-            a += dp[0]; b += dp[1]; tx += dp[2]; ty += dp[3];
-            if (std::fabs(rho - last_rho) < eps) break;
-            last_rho = rho;
-        }
-        // back to origin coordinates, then up to the next finer level (u_f = 2 u_c, x_f = 2 x_c)
-        T0 = tx + cx - (a * cx - b * cy);
-        T1 = ty + cy - (b * cx + a * cy);
-        if (l > 0) { T0 *= 2.0; T1 *= 2.0; }
+    if (!ok) {
+        aligner_free(al);
+        delete al;
+        return fail(MI_ERR_NOMEM, "out of device memory");
     }
-    cleanup();
-#undef ECC_HIP
-    // M (moving -> reference) = W^-1
-    const double det = a * a + b * b;
-    if (!(det > 1e-12)) return fail(MI_ERR_STATE, "ECC: degenerate transform");
-    const double ia = a / det, ib = -b / det;  // A^-1 = [ia -ib; ib ia]
-    M_out[0] = ia;  M_out[1] = -ib; M_out[2] = -(ia * T0 - ib * T1);
-    M_out[3] = ib;  M_out[4] = ia;  M_out[5] = -(ib * T0 + ia * T1);
-    if (cc_out) *cc_out = rho;
-    if (iters_out) *iters_out = total_iters;
+    *out = al;
     return MI_OK;
+}
+
+int mi_aligner_destroy(mi_aligner_t al) {
+    if (!al) return MI_OK;
+    (void)hipSetDevice(al->device);
+    (void)hipDeviceSynchronize();
+    aligner_free(al);
+    delete al;
+    return MI_OK;
+}
+
+int mi_aligner_set_reference(mi_aligner_t al, void* stream, const void* dev_ref) {
+    if (!al || !dev_ref) return fail(MI_ERR_INVALID, "null argument");
+    MI_HIP(hipSetDevice(al->device));
+    int rc = aligner_build(al, (hipStream_t)stream, dev_ref, true);
+    if (rc) return rc;
+    al->have_ref = true;
+    return MI_OK;
+}
+
+int mi_aligner_estimate(mi_aligner_t al, void* stream, const void* dev_mov, int max_iters, double eps,
+                        double* M_out, double* cc_out, int* iters_out) {
+    if (!al || !dev_mov || !M_out) return fail(MI_ERR_INVALID, "null argument");
+    if (!al->have_ref) return fail(MI_ERR_STATE, "mi_aligner_set_reference has not been called");
+    MI_HIP(hipSetDevice(al->device));
+    int rc = aligner_build(al, (hipStream_t)stream, dev_mov, false);
+    if (rc) return rc;
+    return aligner_solve(al, (hipStream_t)stream, max_iters, eps, M_out, cc_out, iters_out);
+}
+
+int mi_ecc_similarity(int device, const void* host_ref, const void* host_mov, int height, int width,
+                      int dtype, int max_levels, int max_iters, double eps, double* M_out, double* cc_out,
+                      int* iters_out) {
+    if (!host_ref || !host_mov || !M_out) return fail(MI_ERR_INVALID, "null argument");
+    mi_aligner_t al = nullptr;
+    int rc = mi_aligner_create(&al, device, height, width, dtype, 1, max_levels);
+    if (rc) return rc;
+    const size_t nb = (size_t)height * width * 3 * dtype_size(dtype);
+    void* raw = nullptr;
+    if (hipMalloc(&raw, nb) != hipSuccess) {
+        mi_aligner_destroy(al);
+        return fail(MI_ERR_NOMEM, "out of device memory");
+    }
+    auto run = [&]() -> int {
+        MI_HIP(hipMemcpy(raw, host_ref, nb, hipMemcpyHostToDevice));
+        int r = mi_aligner_set_reference(al, nullptr, raw);
+        if (r) return r;
+        MI_HIP(hipDeviceSynchronize());
+        MI_HIP(hipMemcpy(raw, host_mov, nb, hipMemcpyHostToDevice));
+        return mi_aligner_estimate(al, nullptr, raw, max_iters, eps, M_out, cc_out, iters_out);
+    };
+    rc = run();
+    (void)hipFree(raw);
+    mi_aligner_destroy(al);
+    return rc;
 }
 
 int mi_synth_frames_device(int device, void* dev_out, int dtype, int height, int width,

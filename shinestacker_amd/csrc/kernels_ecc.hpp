@@ -16,12 +16,16 @@
 
 namespace mi {
 
-// gray (float) of a BGR image; any fixed positive combination works for registration
+// gray (float) of a BGR image, with the reference's fast sub-sampling img[::s, ::s]
+// (utils.py img_subsample, fast branch) folded in; any fixed positive combination of the channels
+// works for registration.  out is h x w, the source row pitch is src_w pixels.
 template <typename T>
-__global__ void ecc_gray(const T* __restrict__ img, int n, float* __restrict__ out) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    out[i] = 0.114f * (float)img[3 * i] + 0.587f * (float)img[3 * i + 1] + 0.299f * (float)img[3 * i + 2];
+__global__ void ecc_gray(const T* __restrict__ img, int src_w, int h, int w, int s, float* __restrict__ out) {
+    int x = blockIdx.x * blockDim.x + threadIdx.x;
+    int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= w || y >= h) return;
+    const T* p = img + ((size_t)y * s * src_w + (size_t)x * s) * 3;
+    out[(size_t)y * w + x] = 0.114f * (float)p[0] + 0.587f * (float)p[1] + 0.299f * (float)p[2];
 }
 
 // 5x5 binomial blur ([1 4 6 4 1]/16 separable, replicate border) then 2x decimation
@@ -66,20 +70,31 @@ struct EccParams {
     double a, b, tx, ty;  // similarity about the image centre
 };
 
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+constexpr int ECC_MAX_BLOCKS = 1024;
+
 // One Gauss-Newton accumulation pass: every reference pixel samples the moving image (and its
 // gradients) at W(x) and adds its terms to 28 sums (double).  `step`: pixel stride (sub-sampling
-// of the sum at the finest levels).
-__global__ void ecc_accumulate(const float* __restrict__ tmpl, const float* __restrict__ img,
+// of the sum at the finest levels).  Deterministic two-stage reduction in one launch: each block
+// writes its 28 partial sums to partial[block][28]; the block that draws the last ticket adds
+// the partials in block order and writes `sums` (host-visible memory), then re-arms the ticket.
+__global__ __launch_bounds__(256) void ecc_accumulate(const float* __restrict__ tmpl, const float* __restrict__ img,
                                const float* __restrict__ gx, const float* __restrict__ gy, int h, int w,
-                               EccParams p, int step, double* __restrict__ sums) {
+                               EccParams p, int step, double* __restrict__ partial,
+                               unsigned int* __restrict__ ticket, double* __restrict__ sums) {
     double acc[ECC_NSUM];
 #pragma unroll
     for (int i = 0; i < ECC_NSUM; ++i) acc[i] = 0.0;
     const float cx = 0.5f * (w - 1), cy = 0.5f * (h - 1);
     const float a = (float)p.a, b = (float)p.b, tx = (float)p.tx, ty = (float)p.ty;
     const int nx = (w + step - 1) / step, ny = (h + step - 1) / step;
-    const size_t total = (size_t)nx * ny;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const unsigned total = (unsigned)nx * ny;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         const int y = (int)(i / nx) * step, x = (int)(i % nx) * step;
         const float xc = x - cx, yc = y - cy;
         const float u = cx + a * xc - b * yc + tx, v = cy + b * xc + a * yc + ty;
@@ -106,18 +121,32 @@ __global__ void ecc_accumulate(const float* __restrict__ tmpl, const float* __re
             for (int m = k; m < 4; ++m) acc[hk++] += (double)J[k] * J[m];
         }
     }
-    // block reduction through LDS, one atomic per sum per block
-    __shared__ double red[256];
+    // wave reduction in registers, 4 waves through LDS
+    __shared__ double red[4][ECC_NSUM];
+    __shared__ bool last;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
     for (int s = 0; s < ECC_NSUM; ++s) {
-        red[threadIdx.x] = acc[s];
-        __syncthreads();
-        for (int off = 128; off > 0; off >>= 1) {
-            if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) atomicAdd(&sums[s], red[0]);
-        __syncthreads();
+        const double v = wave_sum(acc[s]);
+        if (lane == 0) red[wave][s] = v;
     }
+    __syncthreads();
+    if (threadIdx.x < ECC_NSUM)
+        partial[(size_t)blockIdx.x * ECC_NSUM + threadIdx.x] =
+            ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    if (threadIdx.x < ECC_NSUM) {
+        double t = 0.0;
+        for (unsigned bk = 0; bk < gridDim.x; ++bk)
+            t += __builtin_nontemporal_load(&partial[(size_t)bk * ECC_NSUM + threadIdx.x]);
+        sums[threadIdx.x] = t;
+    }
+    if (threadIdx.x == 0) *ticket = 0;
 }
 
 }  // namespace mi

@@ -105,3 +105,83 @@ def align_and_stack(frames, ref_idx=-1, estimator=None, alignment_config=None, f
     out = stack.finish()
     stack.close()
     return out, matches
+
+
+def align_and_stack_device(dev_frames, n_frames, height, width, dtype, ref_idx=-1, alignment_config=None,
+                           min_correlation=0.5, max_iters=60, device=0, batch_frames=16, out_dev=None,
+                           **stack_kwargs):
+    """BASELINE config 4 with every frame resident in HBM: `dev_frames` is the device address of
+    `n_frames` contiguous H x W x 3 frames.  Each frame is registered against frames[ref_idx] by
+    the device ECC estimator (mi_aligner_*), warped with the blurred replicate border of
+    align.py:238-251 straight into the stacker's input batch, and fused.  No frame crosses PCIe;
+    per frame the host sees 28 doubles per Gauss-Newton iteration.
+
+    Returns (fused image as ndarray, or None when `out_dev` -- a device address for the result --
+    is given; list of 2x3 transforms, None at ref_idx; list of correlation coefficients)."""
+    _lib.require_device()
+    if n_frames < 1:
+        raise ValueError("no frames")
+    cfg = {**_DEFAULT_ALIGNMENT_CONFIG, **(alignment_config or {})}
+    if cfg['border_mode'] not in _BORDER_CODE:
+        raise InvalidOptionError("border_mode", cfg['border_mode'])
+    if cfg['transform'] != constants.ALIGN_RIGID:
+        raise InvalidOptionError("transform", cfg['transform'],
+                                 "the MI355X apply path implements ALIGN_RIGID only")
+    if ref_idx == -1:
+        ref_idx = n_frames // 2
+    dt = np.dtype(dtype)
+    fb = height * width * 3 * dt.itemsize
+    lib = _lib.load()
+    stack = _lib.Stack(height, width, in_dtype=dt, out_dtype=dt, device=device, batch_frames=batch_frames,
+                       **stack_kwargs)
+    aligner = _lib.Aligner(height, width, dt, subsample=max(1, int(cfg['subsample'])), device=device)
+    tmp = _lib.DeviceBuffer(fb, device)
+    mask = _lib.DeviceBuffer(height * width, device)
+    # two batches of warped frames: one is being fused while the next is being filled
+    batches = [_lib.DeviceBuffer(fb * batch_frames, device) for _ in range(2)]
+    mode = _BORDER_CODE[cfg['border_mode']]
+    bv = (C.c_double * 4)(*(list(cfg['border_value']) + [0, 0, 0, 0])[:4])
+    transforms, ccs = [], []
+    cur, filled = 0, 0
+    aligner.set_reference(dev_frames + ref_idx * fb)
+
+    def flush():
+        nonlocal cur, filled
+        if filled:
+            lib.mi_device_synchronize(device)   # warps ran on the default stream; previous fuse done
+            stack.push_frames_device(batches[cur].ptr, filled, fb)
+            cur ^= 1
+            filled = 0
+
+    try:
+        for i in range(n_frames):
+            src = dev_frames + i * fb
+            dst = batches[cur].ptr + filled * fb
+            if i == ref_idx:
+                _lib.check(lib.mi_memcpy_d2d(device, dst, src, fb))   # align.py:279-280
+                transforms.append(None)
+                ccs.append(1.0)
+            else:
+                m, cc, _ = aligner.estimate(src, max_iters=max_iters)
+                if not cc >= min_correlation:
+                    raise AlignmentError(i, f"correlation {cc:.3f} < {min_correlation}")
+                mm = (C.c_double * 6)(*m.reshape(6))
+                _lib.check(lib.mi_warp_affine_device(device, None, src, dst, tmp.ptr, mask.ptr, height, width,
+                                                     _lib.DTYPE_CODE[dt], mm, mode, bv, 21,
+                                                     float(cfg['border_blur'])))
+                transforms.append(m)
+                ccs.append(cc)
+            filled += 1
+            if filled == batch_frames:
+                flush()
+        flush()
+        if out_dev is not None:
+            stack.finish_device(out_dev)
+            stack.sync()
+            out = None
+        else:
+            out = stack.finish()
+    finally:
+        aligner.close()
+        stack.close()
+    return out, transforms, ccs

@@ -112,3 +112,56 @@ def test_non_overlapping_or_flat_images_fail_cleanly(L):
     flat = np.full((128, 128, 3), 7, np.uint8)
     with pytest.raises(L.DeviceError):
         L.ecc_similarity(flat, flat)
+
+
+def test_device_resident_aligner_matches_host_entry(L, oracle):
+    """mi_aligner_* (frames in HBM, sub-sampling folded into the first kernel) returns what
+    mi_ecc_similarity returns on img[::2, ::2] with the translation scaled back (align.py:224-231)."""
+    T = similarity(0.3, 1.002, 9.0, -6.0, 383.5, 255.5)
+    ref, mov = make_pair(oracle, T, h=512, w=768, seed=3)
+    m_host, cc_host, it_host = L.ecc_similarity(ref[::2, ::2], mov[::2, ::2])
+    m_host[:, 2] *= 2
+    buf = L.DeviceBuffer(2 * ref.nbytes)
+    buf.upload(ref)
+    buf.upload(mov, ref.nbytes)
+    al = L.Aligner(512, 768, np.uint8, subsample=2)
+    al.set_reference(buf.ptr)
+    m_dev, cc_dev, it_dev = al.estimate(buf.ptr + ref.nbytes)
+    # a second estimate on the same handle must reproduce it (no state carried over)
+    m_dev2, _, _ = al.estimate(buf.ptr + ref.nbytes)
+    al.close()
+    assert it_dev == it_host
+    np.testing.assert_allclose(m_dev, m_host, rtol=0, atol=1e-7)
+    np.testing.assert_allclose(m_dev2, m_dev, rtol=0, atol=1e-7)
+    assert abs(cc_dev - cc_host) < 1e-9
+
+
+def test_align_and_stack_device_equals_host_pipeline(L, oracle):
+    """Frames resident in HBM -> same fused picture as the host-array pipeline with the GPU estimator."""
+    from shinestacker_amd.align import ecc_estimator
+    from shinestacker_amd.pipeline import align_and_stack, align_and_stack_device
+    h, w, n = 384, 512, 5
+    frames = []
+    for f in range(n):
+        d = f - n // 2
+        T = similarity(0.1 * d, 1 + 5e-4 * d, 1.7 * d, -1.1 * d, (w - 1) / 2, (h - 1) / 2)
+        ref, mov = make_pair(oracle, T, h=h, w=w, seed=11, noise=3.0)
+        frames.append(ref if d == 0 else mov)
+    cfg = {'fast_subsampling': True, 'subsample': 2}
+    fused_host, _ = align_and_stack(frames, estimator=ecc_estimator(), alignment_config=cfg, batch_frames=2)
+    buf = L.DeviceBuffer(n * frames[0].nbytes)
+    for f, fr in enumerate(frames):
+        buf.upload(fr, f * fr.nbytes)
+    fused_dev, transforms, ccs = align_and_stack_device(buf.ptr, n, h, w, np.uint8, alignment_config=cfg,
+                                                        batch_frames=2)
+    assert transforms[n // 2] is None and all(c > 0.9 for c in ccs)
+    # the host pipeline rounds M to float32 as the reference does (align.py:224-231); the device one keeps
+    # doubles: sub-1e-6 differences in M can flip single fixed-point roundings of the warp
+    diff = np.abs(fused_host.astype(np.int32) - fused_dev.astype(np.int32))
+    assert (diff > 0).mean() < 0.02 and diff.max() <= 8, ((diff > 0).mean(), diff.max())
+    # a device-side result buffer gives the same bytes as the host copy
+    out = L.DeviceBuffer(frames[0].nbytes)
+    none, _, _ = align_and_stack_device(buf.ptr, n, h, w, np.uint8, alignment_config=cfg, batch_frames=2,
+                                        out_dev=out.ptr)
+    assert none is None
+    np.testing.assert_array_equal(out.download((h, w, 3), np.uint8), fused_dev)
