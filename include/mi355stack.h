@@ -73,7 +73,9 @@ enum {
 enum {
     MI_IMPL_AUTO = 0,
     MI_IMPL_SIMPLE = 1, /* one thread per output, global-memory taps: the on-GPU cross-check */
-    MI_IMPL_TILED = 2   /* LDS-tiled fused level kernels: the production path                */
+    MI_IMPL_TILED = 2,  /* LDS-tiled fused level kernels                                     */
+    MI_IMPL_STREAM = 3  /* register-streaming kernel for level interiors (wave-private, DPP
+                           neighbours, packed fp32), LDS-tiled kernel for the border frame    */
 };
 
 typedef struct mi_stack mi_stack_t;

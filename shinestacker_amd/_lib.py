@@ -19,7 +19,7 @@ MI_OK, MI_ERR_INVALID, MI_ERR_NO_DEVICE, MI_ERR_HIP, MI_ERR_STATE, MI_ERR_NOMEM,
 MI_U8, MI_U16, MI_F32, MI_F64 = range(4)
 (TAP_GAUSS, TAP_FUSED_LAP, TAP_ENERGY, TAP_INDEX, TAP_FUSED_BASE, TAP_BASE_IDX_E,
  TAP_BASE_IDX_D, TAP_COLLAPSED, TAP_BASE_ENT, TAP_BASE_DEV) = range(10)
-IMPL_AUTO, IMPL_SIMPLE, IMPL_TILED = range(3)
+IMPL_AUTO, IMPL_SIMPLE, IMPL_TILED, IMPL_STREAM = range(4)
 PROF_LEVEL, PROF_BASE, PROF_COLLAPSE, PROF_LEVEL0 = range(4)
 
 DTYPE_CODE = {np.dtype(np.uint8): MI_U8, np.dtype(np.uint16): MI_U16,

@@ -10,6 +10,7 @@
 #include "common.hpp"
 #include "kernels_simple.hpp"
 #include "kernels_tiled.hpp"
+#include "kernels_stream.hpp"
 #include "kernels_align.hpp"
 #include "kernels_ecc.hpp"
 
@@ -78,6 +79,9 @@ struct mi_stack {
     float *colA = nullptr, *colB = nullptr, *clipped = nullptr;
     void* out_dev = nullptr;
 
+    int stream_levels = 0;    // levels 0..stream_levels-1 run their interior on the streaming kernel
+    int stream_seg = 64;      // rows per wave segment of the streaming kernel
+    int stream_min_waves = 1024;  // levels with fewer strip x segment waves stay on the tiled kernel
     int n_pushed = 0;
     int first_index = 0;
     bool finished = false;
@@ -591,7 +595,7 @@ int mi_stack_create(mi_stack_t** out, const mi_stack_params_t* params) {
     if (p.min_size < 1) return fail(MI_ERR_INVALID, "min_size must be >= 1");
     if (p.kernel_size < 1 || p.kernel_size > 12)
         return fail(MI_ERR_INVALID, "kernel_size must be in [1, 12] (base window <= 11x11)");
-    if (p.impl < MI_IMPL_AUTO || p.impl > MI_IMPL_TILED) return fail(MI_ERR_INVALID, "bad impl %d", p.impl);
+    if (p.impl < MI_IMPL_AUTO || p.impl > MI_IMPL_STREAM) return fail(MI_ERR_INVALID, "bad impl %d", p.impl);
     int ndev = 0;
     int rc = mi_device_count(&ndev);
     if (rc) return rc;
@@ -602,6 +606,13 @@ int mi_stack_create(mi_stack_t** out, const mi_stack_params_t* params) {
     mi_stack* s = new mi_stack();
     s->p = p;
     if (s->p.impl == MI_IMPL_AUTO) s->p.impl = tiled_available() ? MI_IMPL_TILED : MI_IMPL_SIMPLE;
+    if (s->p.impl == MI_IMPL_STREAM) {
+        s->p.impl = MI_IMPL_TILED;   // same batch pipeline, border frame and state layout
+        s->stream_levels = 1 << 20;
+    }
+    if (const char* e = getenv("MI_STREAM_LEVELS")) s->stream_levels = atoi(e);
+    if (const char* e = getenv("MI_STREAM_MIN_WAVES")) s->stream_min_waves = atoi(e);
+    if (const char* e = getenv("MI_STREAM_SEG")) s->stream_seg = atoi(e) > 1 ? atoi(e) & ~1 : 64;
     // levels = int(log2(min(h,w)/min_size)), pyramid.py:165; stop when a side < 4, :129-130
     {
         double r = (double)(p.height < p.width ? p.height : p.width) / (double)p.min_size;

@@ -172,11 +172,24 @@ int launch_level(mi_stack* s, int l, int set, const void* src, size_t src_stride
     a.hn = s->lh[l + 1];
     a.wn = s->lw[l + 1];
     // interior rectangle: whole 6-pixel-haloed patches inside the image, aligned to both tilings
+    // (streaming interior: 8 pixels away from every edge, aligned to the border tiling only)
+    bool stream = l < s->stream_levels;
+    if (stream) {   // enough waves to fill the chip?  (each wave walks the batch's frames in turn)
+        const int iw = (a.w - 8) / BW * BW - cdiv(8, BW) * BW, ih = (a.h - 8) / BH * BH - cdiv(8, BH) * BH;
+        stream = iw > 0 && ih > 0 && cdiv(iw, ST_UW) * cdiv(ih, s->stream_seg) >= s->stream_min_waves;
+    }
     constexpr int AY = ilcm(TH, BH), AX = ilcm(TW, BW);
-    a.iy0 = cdiv(6, AY) * AY;
-    a.ix0 = cdiv(6, AX) * AX;
-    a.iy1 = (a.h - 6) / AY * AY;
-    a.ix1 = (a.w - 6) / AX * AX;
+    if (stream) {
+        a.iy0 = cdiv(8, BH) * BH;
+        a.ix0 = cdiv(8, BW) * BW;
+        a.iy1 = (a.h - 8) / BH * BH;
+        a.ix1 = (a.w - 8) / BW * BW;
+    } else {
+        a.iy0 = cdiv(6, AY) * AY;
+        a.ix0 = cdiv(6, AX) * AX;
+        a.iy1 = (a.h - 6) / AY * AY;
+        a.ix1 = (a.w - 6) / AX * AX;
+    }
     if (a.iy1 <= a.iy0 || a.ix1 <= a.ix0) a.iy0 = a.iy1 = a.ix0 = a.ix1 = 0;
     const int nyi = (a.iy1 - a.iy0) / TH, nxi = (a.ix1 - a.ix0) / TW;
     a.best_e = s->bestE[l];
@@ -208,9 +221,24 @@ int launch_level(mi_stack* s, int l, int set, const void* src, size_t src_stride
         const int tbx = cdiv(a.w, BW), tby = cdiv(a.h, BH);
         const int nborder = tbx * tby - ((a.iy1 - a.iy0) / BH) * ((a.ix1 - a.ix0) / BW);
         ProfScope ps(s, MI_PROF_LEVEL, bytes * (1.0 - frac_in), st_bd);
-        if (nborder > 0) hipLaunchKernelGGL(kbd, dim3(nborder), dim3(BNT), ldsB, st_bd, a);
+        if (nborder > 0 && !(a.ablate & 256)) hipLaunchKernelGGL(kbd, dim3(nborder), dim3(BNT), ldsB, st_bd, a);
     }
-    if (nyi > 0) {
+    if (a.ablate & 512) {
+    } else if (stream && a.iy1 > a.iy0) {
+        StreamGeom sg;
+        sg.seg = s->stream_seg;
+        sg.nstrips = cdiv(a.ix1 - a.ix0, ST_UW);
+        sg.nsegs = cdiv(a.iy1 - a.iy0, sg.seg);
+        // vector loads/stores need rows that start 16 bytes (f32) / 4 bytes (u8, u16) aligned
+        const size_t esz = l == 0 ? dtype_size(s->p.in_dtype) : 4;
+        const bool vec = (a.w % 4) == 0 && ((uintptr_t)src % 16) == 0 && (src_stride % 16) == 0 &&
+                         ((a.w * 3 * esz) % (esz == 4 ? 16 : 4)) == 0;
+        // prefetch depth in steps: 2 where the raw rows are small (8/16-bit), 1 for f32 (register budget)
+        constexpr int PF = sizeof(TIn) <= 2 ? 2 : 1;
+        ProfScope ps(s, l == 0 ? MI_PROF_LEVEL0 : MI_PROF_LEVEL, bytes * frac_in, st_in);
+        if (vec) hipLaunchKernelGGL((level_stream<TIn, FMA, true, PF>), dim3(sg.nstrips * sg.nsegs), dim3(64), 0, st_in, a, sg);
+        else hipLaunchKernelGGL((level_stream<TIn, FMA, false, PF>), dim3(sg.nstrips * sg.nsegs), dim3(64), 0, st_in, a, sg);
+    } else if (nyi > 0) {
         const int nsb = cdiv(nxi, SB) * cdiv(nyi, SB);
         ProfScope ps(s, l == 0 ? MI_PROF_LEVEL0 : MI_PROF_LEVEL, bytes * frac_in, st_in);
         hipLaunchKernelGGL(kin, dim3(cdiv(nsb, 8) * 8 * SB * SB), dim3(NT), ldsA, st_in, a);

@@ -25,7 +25,7 @@ def make_frames(rng, shape, dtype, n):
     return out
 
 
-def check(L, oracle, frames, in_dtype=None, batch=0, device_frames=False, **kw):
+def check(L, oracle, frames, in_dtype=None, batch=0, device_frames=False, impl=None, **kw):
     h, w = frames[0].shape[:2]
     dt = frames[0].dtype
     so = oracle.StreamingOracle(h, w, dt, keep_gauss=False, **kw)
@@ -33,7 +33,7 @@ def check(L, oracle, frames, in_dtype=None, batch=0, device_frames=False, **kw):
         so.push_frame(f)
     want = so.finish()
     src_dt = in_dtype or dt
-    st = L.Stack(h, w, in_dtype=src_dt, out_dtype=dt, impl=L.IMPL_TILED, batch_frames=batch, **kw)
+    st = L.Stack(h, w, in_dtype=src_dt, out_dtype=dt, impl=L.IMPL_TILED if impl is None else impl, batch_frames=batch, **kw)
     assert st.levels == so.levels
     if device_frames:
         per = h * w * 3 * np.dtype(src_dt).itemsize
