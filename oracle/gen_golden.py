@@ -262,10 +262,22 @@ def plumbing_case():
     shutil.rmtree(work, ignore_errors=True)
 
 
+def nolevels_case():
+    """Frames smaller than 2*min_size: levels = int(log2(40/32)) = 0 (pyramid.py:165), the pyramid is the
+    base alone -- entropy/deviation fusion of the frames themselves, then clip/abs/cast."""
+    rng = np.random.default_rng(8)
+    frames = [rng.integers(0, 256, (40, 52, 3), dtype=np.uint8) for _ in range(3)]
+    frames[2][10:30, 5:40] = frames[0][10:30, 5:40] // 2
+    fusion_case("g8_nolevels", frames)
+
+
 def main():
     assert ri.available(), "needs /root/reference"
     os.makedirs(OUT, exist_ok=True)
     orc.build()
+    if "--only-nolevels" in sys.argv:
+        nolevels_case()
+        return
     rng = np.random.default_rng(20250824)
     print("G1 u8 odd sizes")
     fusion_case("g1_u8", [rng.integers(0, 256, (67, 101, 3), dtype=np.uint8) for _ in range(4)],
@@ -289,6 +301,8 @@ def main():
         img = 128 + 100 * np.sin(xx / blur / 2.0) * np.cos(yy / blur / 3.0)
         smooth.append(np.repeat(img[:, :, None], 3, 2).clip(0, 255).astype(np.uint8))
     fusion_case("g1c_smooth", smooth)
+    print("G8 no Laplacian levels")
+    nolevels_case()
     print("G5 primitives")
     primitive_cases()
     print("G7 base")

@@ -233,7 +233,15 @@ int push_device_frames(mi_stack* s, const void* dev_frames, int n, size_t stride
         const TIn* fr = (const TIn*)((const char*)dev_frames + (size_t)f * stride);
         int rc;
         if (s->L == 0) {
-            return fail(MI_ERR_UNSUPPORTED, "frames smaller than 2*min_size have no pyramid levels");
+            // frames smaller than 2*min_size: no Laplacian levels, the frame itself is the base
+            // (colA is free until the collapse)
+            const size_t n = (size_t)s->lh[0] * s->lw[0] * 3;
+            hipLaunchKernelGGL((frame_to_f32<TIn>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream,
+                               fr, n, s->colA);
+            rc = process_base<FMA>(s, s->colA);
+            if (rc) return rc;
+            s->n_pushed++;
+            continue;
         }
         rc = process_frame_simple<TIn, FMA>(s, fr);
         if (rc) return rc;
@@ -632,6 +640,7 @@ int mi_stack_create(mi_stack_t** out, const mi_stack_params_t* params) {
         }
         s->L = (int)s->lh.size() - 1;
     }
+    if (s->L == 0) s->p.impl = MI_IMPL_SIMPLE;  // base-only stacks (tiny frames): one frame at a time
     {
         double a = p.gen_kernel;
         double k[5] = {0.25 - a / 2.0, 0.25, a, 0.25, 0.25 - a / 2.0};

@@ -325,6 +325,14 @@ __global__ void combine_select(int n, const float* __restrict__ cand_e,
     if (cand_idx && out_idx) out_idx[p] = cand_idx[(size_t)bi * npix + p];
 }
 
+// ---------------------------------------------------------------- frame -> float32 (stacks without
+// Laplacian levels: the frame itself is the base, pyramid.py:126 img.astype(float_type))
+template <typename TIn>
+__global__ void frame_to_f32(const TIn* __restrict__ src, size_t n, float* __restrict__ dst) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = to_f32(src[i]);
+}
+
 // ---------------------------------------------------------------- synthetic frames
 template <typename T>
 __global__ void synth_frames(T* __restrict__ out, int H, int W, int f0, int nf, int N,

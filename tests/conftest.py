@@ -39,7 +39,7 @@ def hiplib():
 
 
 def fusion_cases():
-    return ["g1_u8", "g2_u16", "g3_ties", "g1b_nofma", "g1c_smooth"]
+    return ["g1_u8", "g2_u16", "g3_ties", "g1b_nofma", "g1c_smooth", "g8_nolevels"]
 
 
 def stack_kwargs(params):

@@ -70,6 +70,8 @@ CASES = [
     (513, 771, np.uint8, 3, {"min_size": 16, "gen_kernel": 0.35, "kernel_size": 3}, 0, False, None),
     (96, 128, np.uint16, 5, {"min_size": 4}, 2, False, None),        # deepest pyramid: 4 levels, tiny base
     (1000, 70, np.uint8, 2, {"min_size": 16}, 0, True, None),
+    (40, 52, np.uint8, 4, {}, 0, False, None),                       # smaller than 2*min_size: base only, no levels
+    (33, 47, np.uint16, 3, {}, 2, True, None),                       # same, 16-bit, device frames
 ]
 
 
