@@ -208,6 +208,28 @@ MI_API int mi_aligner_set_reference(mi_aligner_t al, void* stream, const void* d
 MI_API int mi_aligner_estimate(mi_aligner_t al, void* stream, const void* dev_mov, int max_iters, double eps,
                         double* M_out, double* cc_out, int* iters_out);
 
+/* ---- BalanceFrames device steps (reference algorithms/balance.py).
+ * mi_histogram: histogram of an H x W x 3 uint8/uint16 BGR image as balance.py:158-180
+ * (calc_hist_1ch) takes it -- after sub-sampling by `subsample` (fast: img[::s, ::s]; otherwise the
+ * integer-factor area mean of cv2.resize(INTER_AREA), utils.py:79-86) and, when mask_size > 0,
+ * inside the centred circle of radius min(w, h) * mask_size / 2 of the sub-sampled image.
+ * mode 0: one histogram per channel B, G, R (RGBCorrection, balance.py:264-266) -> counts[3][nbins];
+ * mode 1: histogram of cv2.cvtColor(BGR2GRAY) (LumiCorrection, balance.py:235-236) -> counts[1][nbins];
+ * nbins = 256 (uint8) or 65536 (uint16).  counts: int64, as np.histogram returns.
+ * The _device form takes a device image and a device scratch of 3 * nbins uint32. */
+MI_API int mi_histogram(int device, const void* host_img, int height, int width, int dtype, int mode,
+                 int subsample, int fast, double mask_size, int64_t* counts);
+MI_API int mi_histogram_device(int device, void* stream, const void* dev_img, void* dev_scratch, int height,
+                        int width, int dtype, int mode, int subsample, int fast, double mask_size,
+                        int64_t* counts);
+/* mi_apply_lut: dst[p][c] = lut[nlut == 1 ? 0 : c][src[p][c]] -- cv2.LUT (uint8) / np.take (uint16)
+ * as balance.py:30-50 applies them: one table for all channels (LUMI) or one per channel (RGB).
+ * lut: nlut tables of nbins entries of the image dtype. */
+MI_API int mi_apply_lut(int device, const void* host_src, void* host_dst, int height, int width, int dtype,
+                 const void* host_lut, int nlut);
+MI_API int mi_apply_lut_device(int device, void* stream, const void* dev_src, void* dev_dst, size_t npixels,
+                        int dtype, const void* dev_lut, int nlut);
+
 /* ---- synthetic stack generator, device side ---- */
 MI_API int mi_synth_frames_device(int device, void* dev_out, int dtype, int height, int width,
                            int first_frame, int n_frames, int stack_size, uint32_t seed);

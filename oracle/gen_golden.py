@@ -262,6 +262,58 @@ def plumbing_case():
     shutil.rmtree(work, ignore_errors=True)
 
 
+def balance_case():
+    """The reference's own correction classes (balance.py) on small frames: histograms, corrections,
+    look-up tables and corrected frames for LUMI / RGB x LINEAR / GAMMA / MATCH_HIST, uint8 and uint16,
+    with and without sub-sampling / mask.  cv2.LUT / split / merge are exact in the shim; BGR2GRAY and
+    the INTER_AREA resize are the restatements of oracle.py (parity unpinned for those two)."""
+    bal = ri.load_balance_module()
+    rng = np.random.default_rng(11)
+    arrays, meta = {}, []
+    k = 0
+    for dtype, hi in ((np.uint8, 256), (np.uint16, 65536)):
+        yy, xx = np.mgrid[0:48, 0:64]
+        base = (0.25 + 0.5 * (np.sin(xx / 9.0) * np.cos(yy / 7.0) * 0.5 + 0.5))[..., None] * \
+            np.array([0.9, 1.0, 0.8])
+        ref = np.clip(base * hi + rng.normal(0, hi / 40, base.shape), 0, hi - 1).astype(dtype)
+        mov = np.clip((base ** 1.15) * hi * 0.85 + rng.normal(0, hi / 40, base.shape), 0, hi - 1).astype(dtype)
+        for channel, cls in (("LUMI", bal.LumiCorrection), ("RGB", bal.RGBCorrection)):
+            for cmap in ("LINEAR", "GAMMA", "MATCH_HIST"):
+                for opts in ({"subsample": 1}, {"subsample": 2, "fast_subsampling": True},
+                             {"subsample": 4, "fast_subsampling": False, "mask_size": 0.8},
+                             {"subsample": 1, "intensity_interval": {"min": 10, "max": hi // 2}}):
+                    if cmap == "MATCH_HIST" and "intensity_interval" in opts:
+                        continue
+                    if dtype == np.uint16 and (opts != {"subsample": 1} or (channel == "RGB" and cmap != "MATCH_HIST")):
+                        continue   # 16-bit tables are 128 KiB each: a few cases keep the fixture small
+                    corr = cls(corr_map=cmap, **opts)
+                    corr.begin(ref, 2, 0)
+                    hist_ref = np.stack(corr.get_hist(corr.preprocess(ref), 0))
+                    hist_mov = np.stack(corr.get_hist(corr.preprocess(mov), 1))
+                    out = corr.apply_correction(1, mov.copy())
+                    c = corr.corr_map.correction(list(hist_mov))
+                    luts = np.stack([corr.corr_map.lut(c[i], corr.corr_map.reference[i])
+                                     for i in range(corr.channels)])
+                    tag = f"c{k}"
+                    arrays[f"{tag}_hist_ref"] = hist_ref.astype(np.int32)
+                    arrays[f"{tag}_hist_mov"] = hist_mov.astype(np.int32)
+                    arrays[f"{tag}_luts"] = luts
+                    arrays[f"{tag}_out"] = out
+                    arrays[f"{tag}_size"] = np.asarray(corr.corrections[1], dtype=np.float64)
+                    meta.append({"tag": tag, "dtype": np.dtype(dtype).name, "channel": channel,
+                                 "corr_map": cmap, "opts": opts})
+                    # the NumPy restatement of the device steps agrees with the reference run
+                    o = {"subsample": opts.get("subsample", 1), "fast": opts.get("fast_subsampling", False),
+                         "mask_size": opts.get("mask_size", 0)}
+                    assert np.array_equal(orc.balance_hist(mov, channel == "LUMI", **o), hist_mov)
+                    assert np.array_equal(orc.apply_lut(mov, luts), out)
+                    k += 1
+        arrays[f"ref_{np.dtype(dtype).name}"] = ref
+        arrays[f"mov_{np.dtype(dtype).name}"] = mov
+    arrays["meta"] = np.array(json.dumps(meta))
+    _save("balance", **arrays)
+
+
 def nolevels_case():
     """Frames smaller than 2*min_size: levels = int(log2(40/32)) = 0 (pyramid.py:165), the pyramid is the
     base alone -- entropy/deviation fusion of the frames themselves, then clip/abs/cast."""
@@ -277,6 +329,9 @@ def main():
     orc.build()
     if "--only-nolevels" in sys.argv:
         nolevels_case()
+        return
+    if "--only-balance" in sys.argv:
+        balance_case()
         return
     rng = np.random.default_rng(20250824)
     print("G1 u8 odd sizes")
@@ -303,6 +358,8 @@ def main():
     fusion_case("g1c_smooth", smooth)
     print("G8 no Laplacian levels")
     nolevels_case()
+    print("balance")
+    balance_case()
     print("G5 primitives")
     primitive_cases()
     print("G7 base")

@@ -466,3 +466,53 @@ def warp_affine(img, M, border_mode=BORDER_REPLICATE_BLUR, border_value=(0, 0, 0
         lib().orc_border_blur_composite(warp.ctypes.data, valid.ctypes.data, out.ctypes.data, h, w, dt,
                                         blur_ksize, float(blur_sigma))
     return (out, valid) if want_mask else out
+
+
+# --------------------------------------------------------------------------
+# BalanceFrames device steps (balance.py:158-180 histogram, :30-50 table apply) -- NumPy restatement
+# --------------------------------------------------------------------------
+def bgr2gray_int(img):
+    """cv2.cvtColor(BGR2GRAY) on uint8/uint16 [from memory: 14-bit fixed point, parity unpinned]."""
+    a = img.astype(np.uint64)
+    g = (a[..., 0] * 1868 + a[..., 1] * 9617 + a[..., 2] * 4899 + (1 << 13)) >> 14
+    return g.astype(img.dtype)
+
+
+def resize_area_int(img, s):
+    """cv2.resize(img, (0,0), fx=1/s, fy=1/s, INTER_AREA) for an integer factor [from memory: mean of
+    the s x s block; (sum+2)>>2 for s == 2, else round-half-even of sum * float32(1/s^2); parity
+    unpinned].  Whole blocks only."""
+    h, w = img.shape[0] // s * s, img.shape[1] // s * s
+    blk = img[:h, :w].reshape(h // s, s, w // s, s, -1).astype(np.uint32).sum(axis=(1, 3))
+    if s == 2:
+        out = (blk + 2) >> 2
+    else:
+        out = np.rint(blk.astype(np.float32) * np.float32(1.0 / (s * s))).astype(np.uint32)
+    return out.astype(img.dtype).reshape(h // s, w // s, *img.shape[2:])
+
+
+def balance_hist(img, lumi=False, subsample=1, fast=True, mask_size=0.0):
+    """What Correction.calc_hist_1ch returns for the luminance (lumi) or for each of B, G, R
+    (balance.py:158-180, :235-236, :264-266): int64 [nch][nbins]."""
+    nb = 256 if img.dtype == np.uint8 else 65536
+    chans = [bgr2gray_int(img)] if lumi else [img[..., c] for c in range(3)]
+    out = []
+    for ch in chans:
+        if subsample > 1:
+            ch = ch[::subsample, ::subsample] if fast else resize_area_int(ch[..., None], subsample)[..., 0]
+        if mask_size > 0:
+            hh, ww = ch.shape
+            xv, yv = np.meshgrid(np.linspace(0, ww - 1, ww), np.linspace(0, hh - 1, hh))
+            r = min(ww, hh) * mask_size / 2
+            ch = ch[(xv - ww / 2) ** 2 + (yv - hh / 2) ** 2 <= r ** 2]
+        out.append(np.bincount(ch.ravel(), minlength=nb).astype(np.int64))
+    return np.stack(out)
+
+
+def apply_lut(img, luts):
+    """cv2.LUT / np.take per channel (one table: all channels)."""
+    luts = np.asarray(luts).reshape(-1, 256 if img.dtype == np.uint8 else 65536)
+    out = np.empty_like(img)
+    for c in range(3):
+        out[..., c] = luts[0 if luts.shape[0] == 1 else c][img[..., c]]
+    return out

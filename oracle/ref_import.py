@@ -50,7 +50,25 @@ def make_cv2_shim(use_fma=True):
 
     def cvtColor(img, code):
         assert code == cv2.COLOR_BGR2GRAY
+        if img.dtype in (np.uint8, np.uint16):
+            return orc.bgr2gray_int(img)
         return orc.bgr2gray_f32(np.ascontiguousarray(img), use_fma)
+
+    def LUT(img, lut):
+        return np.asarray(lut)[img]
+
+    def split(img):
+        return [np.ascontiguousarray(img[..., c]) for c in range(img.shape[2])]
+
+    def merge(chans):
+        return np.stack(chans, axis=-1)
+
+    def resize(img, dsize, fx=None, fy=None, interpolation=None):
+        s = int(round(1.0 / fx))
+        assert dsize == (0, 0) and fx == fy and abs(1.0 / fx - s) < 1e-9 and interpolation == cv2.INTER_AREA
+        a = img if img.ndim == 3 else img[..., None]
+        out = orc.resize_area_int(a, s)
+        return out if img.ndim == 3 else out[..., 0]
 
     def copyMakeBorder(img, t, b, l, r, borderType):
         assert borderType == cv2.BORDER_REFLECT101 and t == b == l == r
@@ -62,7 +80,8 @@ def make_cv2_shim(use_fma=True):
     cv2.filter2D = filter2D
     cv2.cvtColor = cvtColor
     cv2.copyMakeBorder = copyMakeBorder
-    for name in ("imread", "imwrite", "resize", "warpAffine", "warpPerspective", "GaussianBlur",
+    cv2.LUT, cv2.split, cv2.merge, cv2.resize = LUT, split, merge, resize
+    for name in ("imread", "imwrite", "warpAffine", "warpPerspective", "GaussianBlur",
                  "SIFT_create", "ORB_create", "AKAZE_create", "BRISK_create",
                  "FastFeatureDetector_create", "FlannBasedMatcher", "BFMatcher",
                  "findHomography", "estimateAffinePartial2D", "getPerspectiveTransform",
@@ -134,3 +153,28 @@ def reference_stack(frames, use_fma=True, exact_log=False, **algo_kwargs):
     collapsed = algo.collapse(fused)
     out = collapsed.astype(algo.dtype)
     return out, {"pyramids": pyrs, "fused": fused, "collapsed": collapsed, "algo": algo}
+
+
+def load_balance_module():
+    """The reference's shinestacker.algorithms.balance (its correction maps and Correction classes).
+    matplotlib is stubbed when absent; no plot is ever requested."""
+    load_pyramid_module()
+    try:
+        import matplotlib.pyplot  # noqa: F401
+    except Exception:  # noqa: BLE001
+        mpl = types.ModuleType("matplotlib")
+        plt = types.ModuleType("matplotlib.pyplot")
+        mpl.pyplot = plt
+        sys.modules["matplotlib"], sys.modules["matplotlib.pyplot"] = mpl, plt
+    for stub in ("shinestacker.algorithms.exif", "shinestacker.algorithms.denoise"):
+        if stub not in sys.modules:
+            m = types.ModuleType(stub)
+            m.copy_exif_from_file_to_file = lambda *a, **k: None
+            m.denoise = lambda img, *a, **k: img
+            sys.modules[stub] = m
+    cfg = importlib.import_module("shinestacker.config.config").config
+    try:
+        cfg.init(DISABLE_TQDM=True)
+    except Exception:  # noqa: BLE001
+        pass
+    return importlib.import_module("shinestacker.algorithms.balance")

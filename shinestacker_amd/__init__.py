@@ -8,6 +8,7 @@ from .actions import (StackJob, FocusStack, FocusStackBunch, CombinedActions, Su
                       get_bunches)
 
 from .align import AlignFrames, align_images  # noqa: F401,E402
+from .balance import BalanceFrames  # noqa: F401,E402
 
-__all__ = ["AlignFrames", "align_images", "PyramidStack", "BaseStackAlgo", "StackJob", "FocusStack", "FocusStackBunch",
+__all__ = ["AlignFrames", "BalanceFrames", "align_images", "PyramidStack", "BaseStackAlgo", "StackJob", "FocusStack", "FocusStackBunch",
            "CombinedActions", "SubAction", "get_bunches", "constants"]

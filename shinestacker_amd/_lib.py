@@ -86,6 +86,14 @@ SIGNATURES = {
     "mi_aligner_set_reference": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "mi_aligner_estimate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double,
                                       C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    "mi_histogram": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                               C.c_double, C.c_void_p]),
+    "mi_histogram_device": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                      C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p]),
+    "mi_apply_lut": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                               C.c_int]),
+    "mi_apply_lut_device": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int,
+                                      C.c_void_p, C.c_int]),
     "mi_synth_frames_device": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.c_int, C.c_int, C.c_uint32]),
 }
@@ -401,3 +409,36 @@ class Aligner:
             self.close()
         except Exception:  # noqa: BLE001
             pass
+
+
+HIST_BGR, HIST_LUMI = 0, 1
+
+
+def histogram(img, mode=HIST_BGR, subsample=1, fast=True, mask_size=0.0, device=0):
+    """Histogram(s) of an H x W x 3 uint8/uint16 BGR image as balance.py:158-180 takes them
+    (mi_histogram): int64 array [3][nbins] (B, G, R) or [1][nbins] (luminance)."""
+    require_device()
+    a = np.ascontiguousarray(img)
+    if a.ndim != 3 or a.shape[2] != 3 or a.dtype not in (np.uint8, np.uint16):
+        raise ValueError("histogram expects an H x W x 3 uint8/uint16 image")
+    nbins = 256 if a.dtype == np.uint8 else 65536
+    out = np.zeros((3 if mode == HIST_BGR else 1, nbins), np.int64)
+    check(load().mi_histogram(device, a.ctypes.data, a.shape[0], a.shape[1], DTYPE_CODE[a.dtype], int(mode),
+                              int(subsample), int(bool(fast)), float(mask_size), out.ctypes.data))
+    return out
+
+
+def apply_lut(img, luts, device=0):
+    """dst[..., c] = luts[0 if one table else c][img[..., c]] on the GPU (mi_apply_lut)."""
+    require_device()
+    a = np.ascontiguousarray(img)
+    if a.ndim != 3 or a.shape[2] != 3 or a.dtype not in (np.uint8, np.uint16):
+        raise ValueError("apply_lut expects an H x W x 3 uint8/uint16 image")
+    nbins = 256 if a.dtype == np.uint8 else 65536
+    t = np.ascontiguousarray(np.asarray(luts, dtype=a.dtype).reshape(-1, nbins))
+    if t.shape[0] not in (1, 3):
+        raise ValueError("one look-up table, or one per channel")
+    out = np.empty_like(a)
+    check(load().mi_apply_lut(device, a.ctypes.data, out.ctypes.data, a.shape[0], a.shape[1],
+                              DTYPE_CODE[a.dtype], t.ctypes.data, t.shape[0]))
+    return out

@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <vector>
 
 #include "common.hpp"
@@ -13,6 +14,7 @@
 #include "kernels_stream.hpp"
 #include "kernels_align.hpp"
 #include "kernels_ecc.hpp"
+#include "kernels_balance.hpp"
 
 using namespace mi;
 
@@ -1131,6 +1133,111 @@ int mi_ecc_similarity(int device, const void* host_ref, const void* host_mov, in
     rc = run();
     (void)hipFree(raw);
     mi_aligner_destroy(al);
+    return rc;
+}
+
+int mi_histogram_device(int device, void* stream, const void* dev_img, void* dev_scratch, int height,
+                        int width, int dtype, int mode, int subsample, int fast, double mask_size,
+                        int64_t* counts) {
+    if (!dev_img || !dev_scratch || !counts) return fail(MI_ERR_INVALID, "null argument");
+    if (dtype != MI_U8 && dtype != MI_U16) return fail(MI_ERR_INVALID, "dtype must be MI_U8 or MI_U16");
+    if (height < 1 || width < 1 || subsample < 1 || (mode != 0 && mode != 1)) return fail(MI_ERR_INVALID, "bad argument");
+    MI_HIP(hipSetDevice(device));
+    hipStream_t st = (hipStream_t)stream;
+    const int nbins = dtype == MI_U8 ? 256 : 65536, nch = mode == 0 ? 3 : 1;
+    HistArgs a{};
+    a.img = dev_img; a.h = height; a.w = width; a.s = subsample; a.fast = fast ? 1 : 0; a.gray = mode;
+    if (subsample == 1) { a.hs = height; a.ws = width; }
+    else if (fast) { a.hs = cdiv(height, subsample); a.ws = cdiv(width, subsample); }
+    else { a.hs = height / subsample; a.ws = width / subsample; }   // whole blocks only
+    if (a.hs < 1 || a.ws < 1) return fail(MI_ERR_INVALID, "image smaller than the sub-sampling factor");
+    a.masked = mask_size > 0.0;
+    if (a.masked) {   // balance.py:165-175 on the sub-sampled grid
+        const double r = (double)(a.ws < a.hs ? a.ws : a.hs) * mask_size / 2.0;
+        a.cx = (double)a.ws / 2.0; a.cy = (double)a.hs / 2.0; a.r2 = r * r;
+    }
+    a.counts = (uint32_t*)dev_scratch;
+    MI_HIP(hipMemsetAsync(dev_scratch, 0, sizeof(uint32_t) * nch * nbins, st));
+    const size_t total = (size_t)a.hs * a.ws;
+    const unsigned nblk = (unsigned)std::min<size_t>((total + 255) / 256, 256 * 8);
+    if (dtype == MI_U8) hipLaunchKernelGGL(hist_u8, dim3(nblk), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(hist_u16, dim3(nblk), dim3(256), 0, st, a);
+    MI_HIP(hipGetLastError());
+    std::vector<uint32_t> tmp((size_t)nch * nbins);
+    MI_HIP(hipMemcpyAsync(tmp.data(), dev_scratch, tmp.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    MI_HIP(hipStreamSynchronize(st));
+    for (size_t i = 0; i < tmp.size(); ++i) counts[i] = (int64_t)tmp[i];
+    return MI_OK;
+}
+
+int mi_histogram(int device, const void* host_img, int height, int width, int dtype, int mode,
+                 int subsample, int fast, double mask_size, int64_t* counts) {
+    if (!host_img || !counts) return fail(MI_ERR_INVALID, "null argument");
+    if (dtype != MI_U8 && dtype != MI_U16) return fail(MI_ERR_INVALID, "dtype must be MI_U8 or MI_U16");
+    if (height < 1 || width < 1) return fail(MI_ERR_INVALID, "bad image size");
+    int ndev = 0;
+    int rc = mi_device_count(&ndev);
+    if (rc) return rc;
+    if (ndev == 0) return fail(MI_ERR_NO_DEVICE, "no HIP device visible");
+    MI_HIP(hipSetDevice(device));
+    const size_t nb = (size_t)height * width * 3 * dtype_size(dtype);
+    void *img = nullptr, *scr = nullptr;
+    auto cleanup = [&]() { (void)hipFree(img); (void)hipFree(scr); };
+    if (hipMalloc(&img, nb) != hipSuccess || hipMalloc(&scr, sizeof(uint32_t) * 3 * 65536) != hipSuccess) {
+        cleanup();
+        return fail(MI_ERR_NOMEM, "out of device memory");
+    }
+    if (hipMemcpy(img, host_img, nb, hipMemcpyHostToDevice) != hipSuccess) { cleanup(); return fail(MI_ERR_HIP, "upload failed"); }
+    rc = mi_histogram_device(device, nullptr, img, scr, height, width, dtype, mode, subsample, fast, mask_size, counts);
+    cleanup();
+    return rc;
+}
+
+int mi_apply_lut_device(int device, void* stream, const void* dev_src, void* dev_dst, size_t npixels,
+                        int dtype, const void* dev_lut, int nlut) {
+    if (!dev_src || !dev_dst || !dev_lut) return fail(MI_ERR_INVALID, "null argument");
+    if (dtype != MI_U8 && dtype != MI_U16) return fail(MI_ERR_INVALID, "dtype must be MI_U8 or MI_U16");
+    if (nlut != 1 && nlut != 3) return fail(MI_ERR_INVALID, "nlut must be 1 or 3");
+    MI_HIP(hipSetDevice(device));
+    const size_t n = npixels * 3;
+    if (n == 0) return MI_OK;
+    const unsigned nblk = (unsigned)std::min<size_t>((n / 12 + 255) / 256 + 1, 256 * 16);
+    if (dtype == MI_U8) {
+        if (((uintptr_t)dev_src | (uintptr_t)dev_dst) & 3) return fail(MI_ERR_INVALID, "images must be 4-byte aligned");
+        hipLaunchKernelGGL(lut_apply_u8, dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)dev_src,
+                           (uint8_t*)dev_dst, n, (const uint8_t*)dev_lut, nlut);
+    } else {
+        hipLaunchKernelGGL(lut_apply_u16, dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)dev_src,
+                           (uint16_t*)dev_dst, n, (const uint16_t*)dev_lut, nlut);
+    }
+    MI_HIP(hipGetLastError());
+    return MI_OK;
+}
+
+int mi_apply_lut(int device, const void* host_src, void* host_dst, int height, int width, int dtype,
+                 const void* host_lut, int nlut) {
+    if (!host_src || !host_dst || !host_lut) return fail(MI_ERR_INVALID, "null argument");
+    if (dtype != MI_U8 && dtype != MI_U16) return fail(MI_ERR_INVALID, "dtype must be MI_U8 or MI_U16");
+    if (height < 1 || width < 1 || (nlut != 1 && nlut != 3)) return fail(MI_ERR_INVALID, "bad argument");
+    int ndev = 0;
+    int rc = mi_device_count(&ndev);
+    if (rc) return rc;
+    if (ndev == 0) return fail(MI_ERR_NO_DEVICE, "no HIP device visible");
+    MI_HIP(hipSetDevice(device));
+    const size_t np = (size_t)height * width, nb = np * 3 * dtype_size(dtype);
+    const size_t lb = (size_t)nlut * (dtype == MI_U8 ? 256 : 65536) * dtype_size(dtype);
+    void *src = nullptr, *dst = nullptr, *lut = nullptr;
+    auto cleanup = [&]() { (void)hipFree(src); (void)hipFree(dst); (void)hipFree(lut); };
+    if (hipMalloc(&src, nb) != hipSuccess || hipMalloc(&dst, nb) != hipSuccess || hipMalloc(&lut, lb) != hipSuccess) {
+        cleanup();
+        return fail(MI_ERR_NOMEM, "out of device memory");
+    }
+    if (hipMemcpy(src, host_src, nb, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(lut, host_lut, lb, hipMemcpyHostToDevice) != hipSuccess) { cleanup(); return fail(MI_ERR_HIP, "upload failed"); }
+    rc = mi_apply_lut_device(device, nullptr, src, dst, np, dtype, lut, nlut);
+    if (!rc && hipDeviceSynchronize() != hipSuccess) rc = fail(MI_ERR_HIP, "LUT kernel failed");
+    if (!rc && hipMemcpy(host_dst, dst, nb, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(MI_ERR_HIP, "download failed");
+    cleanup();
     return rc;
 }
 

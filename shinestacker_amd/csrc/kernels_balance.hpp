@@ -1,0 +1,135 @@
+// kernels_balance.hpp -- the two data-parallel steps of BalanceFrames (reference
+// algorithms/balance.py): the histogram of a (sub-sampled, optionally
+// circular-masked) frame -- balance.py:158-180 calc_hist_1ch, per BGR channel (RGBCorrection
+// :264-266) or of the luminance (LumiCorrection :235-236) -- and the look-up-table apply
+// (cv2.LUT / np.take, balance.py:30-32, per channel :34-50).  The LUT itself (LINEAR / GAMMA /
+// MATCH_HIST: bisect, interp1d on 256 or 65536 entries) stays on the host in NumPy/SciPy, exactly
+// the reference's calls (shinestacker_amd/balance.py).
+//
+// Integer work: bit-exact by construction.  Two OpenCV primitives are restated from memory (OpenCV
+// is not in this image -- parity unpinned for them, stated in DESIGN.md):
+//   * cv2.cvtColor(BGR2GRAY) on 8/16-bit: (B*1868 + G*9617 + R*4899 + 2^13) >> 14;
+//   * cv2.resize(INTER_AREA) by an integer factor s: mean of the s x s block, (sum+2)>>2 for s = 2,
+//     otherwise round-half-even of sum * (1.f / s^2).
+#pragma once
+#include "common.hpp"
+
+namespace mi {
+
+struct HistArgs {
+    const void* img;   // H x W x 3, uint8 / uint16
+    int h, w;          // full-resolution size
+    int hs, ws;        // size of the sub-sampled image the histogram is taken of
+    int s;             // sub-sampling factor (1 = none)
+    int fast;          // img[::s, ::s] instead of the area mean
+    int gray;          // luminance histogram (1 channel) instead of B, G, R (3 channels)
+    int masked;        // keep (x - ws/2)^2 + (y - hs/2)^2 <= r2 only (balance.py:165-175)
+    double cx, cy, r2;
+    uint32_t* counts;  // [nch][nbins], zeroed by the caller
+};
+
+__device__ __forceinline__ uint32_t bgr2gray_int(uint32_t b, uint32_t g, uint32_t r) {
+    return (b * 1868u + g * 9617u + r * 4899u + (1u << 13)) >> 14;
+}
+
+// value of channel c (or of the luminance) of sub-sampled pixel (sy, sx)
+template <typename T>
+__device__ __forceinline__ void sub_pixel(const HistArgs& a, int sy, int sx, uint32_t out[3]) {
+    const T* img = (const T*)a.img;
+    const int nch = a.gray ? 1 : 3;
+    if (a.s == 1 || a.fast) {
+        const T* p = img + ((size_t)sy * a.s * a.w + (size_t)sx * a.s) * 3;
+        if (a.gray) out[0] = bgr2gray_int(p[0], p[1], p[2]);
+        else { out[0] = p[0]; out[1] = p[1]; out[2] = p[2]; }
+        return;
+    }
+    uint32_t sum[3] = {0, 0, 0};
+    for (int dy = 0; dy < a.s; ++dy) {
+        const T* row = img + ((size_t)(sy * a.s + dy) * a.w + (size_t)sx * a.s) * 3;
+        for (int dx = 0; dx < a.s; ++dx) {
+            const T* p = row + dx * 3;
+            if (a.gray) sum[0] += bgr2gray_int(p[0], p[1], p[2]);
+            else { sum[0] += p[0]; sum[1] += p[1]; sum[2] += p[2]; }
+        }
+    }
+    const float scale = 1.0f / (float)(a.s * a.s);
+    for (int c = 0; c < nch; ++c)
+        out[c] = a.s == 2 ? (sum[c] + 2u) >> 2 : (uint32_t)__float2int_rn((float)sum[c] * scale);
+}
+
+// 8-bit: per-workgroup histogram in LDS, one flush per bin and workgroup
+__global__ __launch_bounds__(256) void hist_u8(HistArgs a) {
+    __shared__ uint32_t sh[3 * 256];
+    for (int i = threadIdx.x; i < 3 * 256; i += blockDim.x) sh[i] = 0;
+    __syncthreads();
+    const size_t total = (size_t)a.hs * a.ws;
+    const int nch = a.gray ? 1 : 3;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int sy = (int)(i / a.ws), sx = (int)(i - (size_t)sy * a.ws);
+        if (a.masked) {
+            const double dx = (double)sx - a.cx, dy = (double)sy - a.cy;
+            if (!(dx * dx + dy * dy <= a.r2)) continue;
+        }
+        uint32_t v[3];
+        sub_pixel<uint8_t>(a, sy, sx, v);
+        for (int c = 0; c < nch; ++c) atomicAdd(&sh[c * 256 + (v[c] & 255u)], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nch * 256; i += blockDim.x)
+        if (sh[i]) atomicAdd(&a.counts[i], sh[i]);
+}
+
+// 16-bit: 65536 bins per channel do not fit LDS; atomics on the L2-resident table
+__global__ __launch_bounds__(256) void hist_u16(HistArgs a) {
+    const size_t total = (size_t)a.hs * a.ws;
+    const int nch = a.gray ? 1 : 3;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int sy = (int)(i / a.ws), sx = (int)(i - (size_t)sy * a.ws);
+        if (a.masked) {
+            const double dx = (double)sx - a.cx, dy = (double)sy - a.cy;
+            if (!(dx * dx + dy * dy <= a.r2)) continue;
+        }
+        uint32_t v[3];
+        sub_pixel<uint16_t>(a, sy, sx, v);
+        for (int c = 0; c < nch; ++c) atomicAdd(&a.counts[(size_t)c * 65536 + (v[c] & 65535u)], 1u);
+    }
+}
+
+// dst[p][c] = lut[nlut == 1 ? 0 : c][src[p][c]];  n = number of pixel*channel elements
+__global__ __launch_bounds__(256) void lut_apply_u8(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, size_t n,
+                                                    const uint8_t* __restrict__ lut, int nlut) {
+    __shared__ uint8_t sl[3 * 256];
+    for (int i = threadIdx.x; i < 3 * 256; i += blockDim.x) sl[i] = lut[nlut == 1 ? (i & 255) : i];
+    __syncthreads();
+    // 12 bytes (4 pixels) per thread and step: three dword loads, channel of byte k is k % 3
+    const size_t nq = n / 12;
+    const uint32_t* s4 = (const uint32_t*)src;
+    uint32_t* d4 = (uint32_t*)dst;
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (size_t)gridDim.x * blockDim.x) {
+        uint32_t in[3] = {s4[3 * q], s4[3 * q + 1], s4[3 * q + 2]}, out[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            uint32_t o = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int c = (4 * d + b) % 3;
+                o |= (uint32_t)sl[c * 256 + ((in[d] >> (8 * b)) & 255u)] << (8 * b);
+            }
+            out[d] = o;
+        }
+        d4[3 * q] = out[0]; d4[3 * q + 1] = out[1]; d4[3 * q + 2] = out[2];
+    }
+    // tail (n is a multiple of 3; fewer than 12 elements left)
+    if (blockIdx.x == 0)
+        for (size_t i = nq * 12 + threadIdx.x; i < n; i += blockDim.x) dst[i] = sl[(i % 3) * 256 + src[i]];
+}
+
+__global__ __launch_bounds__(256) void lut_apply_u16(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst, size_t n,
+                                                     const uint16_t* __restrict__ lut, int nlut) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = nlut == 1 ? 0 : (int)(i % 3);
+        dst[i] = lut[(size_t)c * 65536 + src[i]];
+    }
+}
+
+}  // namespace mi

@@ -109,12 +109,17 @@ def align_and_stack(frames, ref_idx=-1, estimator=None, alignment_config=None, f
 
 def align_and_stack_device(dev_frames, n_frames, height, width, dtype, ref_idx=-1, alignment_config=None,
                            min_correlation=0.5, max_iters=60, device=0, batch_frames=16, out_dev=None,
-                           **stack_kwargs):
+                           balance=None, **stack_kwargs):
     """BASELINE config 4 with every frame resident in HBM: `dev_frames` is the device address of
     `n_frames` contiguous H x W x 3 frames.  Each frame is registered against frames[ref_idx] by
     the device ECC estimator (mi_aligner_*), warped with the blurred replicate border of
     align.py:238-251 straight into the stacker's input batch, and fused.  No frame crosses PCIe;
     per frame the host sees 28 doubles per Gauss-Newton iteration.
+
+    `balance`: optional dict of BalanceFrames options (channel, corr_map, subsample, fast_subsampling,
+    mask_size, intensity_interval): every aligned frame is then balanced against the reference frame
+    (balance.py; the order of the reference's example projects: align, balance, stack) in place on the
+    device -- histogram on the GPU, the 256/65536-entry table on the host, table apply on the GPU.
 
     Returns (fused image as ndarray, or None when `out_dev` -- a device address for the result --
     is given; list of 2x3 transforms, None at ref_idx; list of correlation coefficients)."""
@@ -144,6 +149,18 @@ def align_and_stack_device(dev_frames, n_frames, height, width, dtype, ref_idx=-
     transforms, ccs = [], []
     cur, filled = 0, 0
     aligner.set_reference(dev_frames + ref_idx * fb)
+    corr = None
+    if balance is not None:
+        from .balance import LumiCorrection, RGBCorrection
+        opts = dict(balance)
+        channel = opts.pop('channel', constants.DEFAULT_CHANNEL)
+        if channel not in (constants.BALANCE_LUMI, constants.BALANCE_RGB):
+            raise InvalidOptionError("channel", channel, "the MI355X path implements LUMI and RGB balancing only")
+        if opts.get('subsample', -1) == -1:
+            opts['subsample'] = 1 if opts.get('corr_map') == constants.BALANCE_MATCH_HIST \
+                else constants.DEFAULT_BALANCE_SUBSAMPLE
+        corr = (LumiCorrection if channel == constants.BALANCE_LUMI else RGBCorrection)(device=device, **opts)
+        corr.begin_device(dev_frames + ref_idx * fb, height, width, dt, n_frames)
 
     def flush():
         nonlocal cur, filled
@@ -169,6 +186,8 @@ def align_and_stack_device(dev_frames, n_frames, height, width, dtype, ref_idx=-
                 _lib.check(lib.mi_warp_affine_device(device, None, src, dst, tmp.ptr, mask.ptr, height, width,
                                                      _lib.DTYPE_CODE[dt], mm, mode, bv, 21,
                                                      float(cfg['border_blur'])))
+                if corr is not None:
+                    corr.apply_correction_device(i, dst)
                 transforms.append(m)
                 ccs.append(cc)
             filled += 1

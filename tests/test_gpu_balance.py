@@ -1,0 +1,127 @@
+"""GPU: BalanceFrames device steps (mi_histogram, mi_apply_lut) bit-exact against the oracle's NumPy
+restatement and against the reference recording (tests/golden/balance.npz), and the sub-action end to end."""
+import json
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def L(hiplib):
+    hiplib.require_device()
+    return hiplib
+
+
+def test_golden_histograms_tables_and_frames(L):
+    g = load_golden("balance")
+    from shinestacker_amd import balance as b
+    cls = {"LUMI": b.LumiCorrection, "RGB": b.RGBCorrection}
+    for m in json.loads(str(g["meta"])):
+        t = m["tag"]
+        ref, mov = g["ref_" + m["dtype"]], g["mov_" + m["dtype"]]
+        corr = cls[m["channel"]](corr_map=m["corr_map"], **m["opts"])
+        corr.begin(ref, 2, 0)
+        assert np.array_equal(np.stack(corr.get_hist(mov)), g[f"{t}_hist_mov"]), m
+        out = corr.apply_correction(1, mov)
+        assert out.dtype == mov.dtype and np.array_equal(out, g[f"{t}_out"]), m
+        assert np.array_equal(np.asarray(corr.corrections[1], np.float64).ravel(), np.asarray(g[f"{t}_size"]).ravel())
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16])
+@pytest.mark.parametrize("shape", [(301, 453), (64, 64), (1000, 1504)])
+def test_histogram_vs_oracle(L, oracle, dtype, shape):
+    rng = np.random.default_rng(shape[0])
+    hi = 256 if dtype == np.uint8 else 65536
+    img = rng.integers(0, hi, shape + (3,)).astype(dtype)
+    img[: shape[0] // 3] //= 3   # make the histogram uneven
+    for lumi in (False, True):
+        for sub, fast, mask in ((1, True, 0.0), (2, True, 0.0), (2, False, 0.0), (8, False, 0.0), (3, True, 0.7),
+                                (4, False, 0.95), (1, True, 0.5)):
+            want = oracle.balance_hist(img, lumi, sub, fast, mask)
+            got = L.histogram(img, L.HIST_LUMI if lumi else L.HIST_BGR, sub, fast, mask)
+            assert got.dtype == np.int64 and np.array_equal(got, want), (lumi, sub, fast, mask)
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16])
+def test_apply_lut_vs_oracle(L, oracle, dtype):
+    rng = np.random.default_rng(5)
+    hi = 256 if dtype == np.uint8 else 65536
+    for shape in ((37, 53), (480, 641), (2, 2)):
+        img = rng.integers(0, hi, shape + (3,)).astype(dtype)
+        for nl in (1, 3):
+            luts = rng.integers(0, hi, (nl, hi)).astype(dtype)
+            assert np.array_equal(L.apply_lut(img, luts), oracle.apply_lut(img, luts))
+
+
+def test_balance_frames_sub_action(L, oracle, tmp_path):
+    """The sub-action protocol on files: reference frame untouched, the others brought to its histogram mean."""
+    from shinestacker_amd.balance import BalanceFrames
+    from shinestacker_amd.imageio import write_img
+    rng = np.random.default_rng(2)
+    base = rng.integers(40, 200, (96, 128, 3)).astype(np.uint8)
+    frames = [np.clip(base * f, 0, 255).astype(np.uint8) for f in (0.7, 1.0, 1.2)]
+    names = []
+    for i, fr in enumerate(frames):
+        names.append(f"f{i}.png")
+        write_img(str(tmp_path / names[-1]), fr)
+
+    class Proc:
+        input_full_path = str(tmp_path)
+        filenames = names
+        ref_idx = 1
+        counts = 3
+
+        def sub_message_r(self, *_a, **_k):
+            pass
+
+        def print_message(self, *_a, **_k):
+            pass
+
+    bal = BalanceFrames(subsample=1)   # LUMI, LINEAR
+    bal.begin(Proc())
+    outs = [bal.run_frame(i, 1, fr) for i, fr in enumerate(frames)]
+    bal.end()
+    assert outs[1] is frames[1]
+    ref_mean = oracle.bgr2gray_int(frames[1]).mean()
+    for i in (0, 2):
+        assert abs(oracle.bgr2gray_int(outs[i]).mean() - ref_mean) < 1.5
+        assert abs(oracle.bgr2gray_int(frames[i]).mean() - ref_mean) > 10
+    assert bal.correction.corrections[0, 0] > 1.2 and bal.correction.corrections[2, 0] < 0.95
+
+
+def test_resident_pipeline_with_balance(L, oracle):
+    """align -> balance -> stack with every frame in HBM: the device balance equals the host-array
+    sub-action applied to the same aligned frames."""
+    from shinestacker_amd.balance import LumiCorrection
+    from shinestacker_amd.pipeline import align_and_stack_device
+    from test_gpu_ecc import make_pair, similarity
+    h, w, n = 256, 384, 3
+    frames = []
+    for f in range(n):
+        d = f - 1
+        T = similarity(0.1 * d, 1.0, 1.5 * d, -1.0 * d, (w - 1) / 2, (h - 1) / 2)
+        ref, mov = make_pair(oracle, T, h=h, w=w, seed=21, noise=2.0)
+        fr = ref if d == 0 else mov
+        frames.append(np.clip(fr.astype(np.float64) * (1.0 + 0.15 * d), 0, 255).astype(np.uint8))
+    buf = L.DeviceBuffer(n * frames[0].nbytes)
+    for f, fr in enumerate(frames):
+        buf.upload(fr, f * fr.nbytes)
+    opts = {"channel": "LUMI", "corr_map": "LINEAR", "subsample": 2, "fast_subsampling": True}
+    cfg = {"subsample": 1}
+    fused_bal, tr, _ = align_and_stack_device(buf.ptr, n, h, w, np.uint8, alignment_config=cfg, batch_frames=2,
+                                              balance=opts)
+    fused_raw, _, _ = align_and_stack_device(buf.ptr, n, h, w, np.uint8, alignment_config=cfg, batch_frames=2)
+    assert (fused_bal != fused_raw).mean() > 0.2   # balancing changed the stack
+    # replay on host arrays: warp each frame with the recovered transform, balance with the sub-action's class,
+    # stack in memory -> identical bytes
+    from shinestacker_amd.pyramid import PyramidStack
+    aligned = [frames[1] if t is None else L.warp_affine(fr, t) for fr, t in zip(frames, tr)]
+    c = LumiCorrection(corr_map="LINEAR", subsample=2, fast_subsampling=True)
+    c.begin(frames[1], n, 1)
+    balanced = [a if i == 1 else c.apply_correction(i, a) for i, a in enumerate(aligned)]
+    want = PyramidStack().focus_stack_arrays(balanced)
+    assert np.array_equal(fused_bal, want)

@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--frames", type=int, default=16)
     ap.add_argument("--height", type=int, default=4000)
     ap.add_argument("--width", type=int, default=6000)
+    ap.add_argument("--balance", action="store_true", help="also balance every frame (LUMI / LINEAR, sub-sample 8)")
     ap.add_argument("--resident", action="store_true", help="frames resident in HBM (mi_aligner_* + device warp)")
     args = ap.parse_args()
     from shinestacker_amd import _lib as L
@@ -87,14 +88,15 @@ def main():
         for f, fr in enumerate(frames):
             buf.upload(fr, f * fb)
         out = L.DeviceBuffer(fb)
-        align_and_stack_device(buf.ptr, min(N, 4), H, W, np.uint8, out_dev=out.ptr)   # warm-up
+        bal = {'channel': 'LUMI', 'corr_map': 'LINEAR', 'subsample': 8} if args.balance else None
+        align_and_stack_device(buf.ptr, min(N, 4), H, W, np.uint8, out_dev=out.ptr, balance=bal)   # warm-up
         t0 = time.perf_counter()
-        _, tr, ccs = align_and_stack_device(buf.ptr, N, H, W, np.uint8, ref_idx=ref, out_dev=out.ptr)
+        _, tr, ccs = align_and_stack_device(buf.ptr, N, H, W, np.uint8, ref_idx=ref, out_dev=out.ptr, balance=bal)
         dt = time.perf_counter() - t0
         recovered = {k: m.copy() for k, m in enumerate(t for t in tr if t is not None)}
         for m in recovered.values():
             m[:, 2] /= 2    # compare at the sub-sampled scale like the host path below
-        report(N, H, W, dt, recovered, truth, ref, cx, cy, "resident", list(out.download((H, W, 3), np.uint8).shape))
+        report(N, H, W, dt, recovered, truth, ref, cx, cy, "resident + balance" if args.balance else "resident", list(out.download((H, W, 3), np.uint8).shape))
         return
     est = ecc_estimator()
     recovered = {}
