@@ -37,6 +37,14 @@ def _save(name, **arrays):
 
 def _check_restatements(frames, out_ref, det, use_fma=True, **kw):
     """RefShaped and StreamingOracle must equal the reference run."""
+    if kw.get("float_type") == "float-64":
+        kw = {k: v for k, v in kw.items() if k != "float_type"}
+        rs = orc.RefShaped(use_fma=use_fma, float_type=np.float64, **kw)
+        out_rs, d = rs.stack(frames, want_detail=True)
+        assert np.array_equal(out_rs, out_ref), "RefShaped(float64) final != reference"
+        for a, b in zip(d["fused"], det["fused"]):
+            assert a.dtype == np.float64 and np.array_equal(a, b), "RefShaped(float64) fused pyramid != reference"
+        return d, None, None
     rs = orc.RefShaped(use_fma=use_fma, **kw)
     out_rs, d = rs.stack(frames, want_detail=True)
     assert np.array_equal(out_rs, out_ref), "RefShaped final != reference"
@@ -314,6 +322,16 @@ def balance_case():
     _save("balance", **arrays)
 
 
+def f64_case():
+    """float_type='float-64' (base_stack_algo.py:14-17): float64 pyramids and base features."""
+    rng = np.random.default_rng(64)
+    frames = [rng.integers(0, 256, (70, 93, 3), dtype=np.uint8) for _ in range(3)]
+    frames[1][20:50, 30:70] = frames[0][20:50, 30:70] // 2 + 60
+    fusion_case("g9_f64", frames, min_size=16, float_type="float-64")
+    frames16 = [rng.integers(0, 65536, (41, 67, 3), dtype=np.uint16) for _ in range(3)]
+    fusion_case("g9_f64_u16", frames16, min_size=8, float_type="float-64", use_fma=False)
+
+
 def nolevels_case():
     """Frames smaller than 2*min_size: levels = int(log2(40/32)) = 0 (pyramid.py:165), the pyramid is the
     base alone -- entropy/deviation fusion of the frames themselves, then clip/abs/cast."""
@@ -329,6 +347,9 @@ def main():
     orc.build()
     if "--only-nolevels" in sys.argv:
         nolevels_case()
+        return
+    if "--only-f64" in sys.argv:
+        f64_case()
         return
     if "--only-balance" in sys.argv:
         balance_case()
@@ -358,6 +379,8 @@ def main():
     fusion_case("g1c_smooth", smooth)
     print("G8 no Laplacian levels")
     nolevels_case()
+    print("G9 float-64")
+    f64_case()
     print("balance")
     balance_case()
     print("G5 primitives")

@@ -252,22 +252,25 @@ class RefShaped:
         levels, counts = np.unique(gray, return_counts=True)
         p = np.zeros(nlev, self.ft)
         p[levels] = counts.astype(self.ft) / counts.sum()
-        # correctly rounded float32 log (see pyramid_oracle.c: orc_base_features_f32)
-        logp = np.zeros(nlev, np.float32)
+        f64 = self.ft == np.float64
+        # float-32: correctly rounded float32 log (see pyramid_oracle.c: orc_base_features_f32);
+        # float-64: logl rounded to double (NumPy's own log is CPU-dispatch dependent in both widths)
+        logp = np.zeros(nlev, self.ft)
         nz = p > 0
-        logp[nz] = np.log(p[nz].astype(np.float64)).astype(np.float32)
+        logp[nz] = np.log(p[nz].astype(np.longdouble)).astype(np.float64) if f64 \
+            else np.log(p[nz].astype(np.float64)).astype(np.float32)
         pad = self.pad
         padded = pad_reflect101(gray, pad)
         hb, wb = gray.shape
-        ent = np.empty((hb, wb), np.float32)
-        dev = np.empty((hb, wb), np.float32)
+        ent = np.empty((hb, wb), self.ft)
+        dev = np.empty((hb, wb), self.ft)
         n = (2 * pad + 1) ** 2
         for y in range(hb):
             for x in range(wb):
                 area = padded[y:y + 2 * pad + 1, x:x + 2 * pad + 1]
                 lv = area.flatten()
-                ent[y, x] = np.float32(-1.0 * (lv * logp[lv]).sum())
-                mean = np.average(area).astype(np.float32)
+                ent[y, x] = self.ft(-1.0 * (lv * logp[lv]).sum())
+                mean = np.average(area).astype(self.ft)
                 dev[y, x] = np.square(area - mean).sum() / n
         return ent, dev
 

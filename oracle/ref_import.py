@@ -93,7 +93,8 @@ def make_cv2_shim(use_fma=True):
 class _NumpyWithExactLog:
     """Proxy for the `np` name inside the reference module: identical to numpy
     except float32 log is the correctly rounded one the oracle uses (NumPy's
-    SIMD float32 log is CPU-dispatch dependent, so it cannot be a parity target)."""
+    SIMD float32 log is CPU-dispatch dependent, so it cannot be a parity target);
+    float64 log likewise goes through the x87 long-double logl and is rounded once."""
 
     def __getattr__(self, name):
         return getattr(np, name)
@@ -103,6 +104,8 @@ class _NumpyWithExactLog:
         x = np.asarray(x)
         if x.dtype == np.float32:
             return np.log(x.astype(np.float64)).astype(np.float32)
+        if x.dtype == np.float64:
+            return np.log(x.astype(np.longdouble)).astype(np.float64)
         return np.log(x)
 
 

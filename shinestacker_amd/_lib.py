@@ -216,6 +216,7 @@ class Stack:
         p.impl, p.batch_frames = int(impl), int(batch_frames)
         self.params = p
         self.in_dtype, self.out_dtype = in_dtype, out_dtype
+        self.float_type = int(float_type)
         self.height, self.width, self.device = p.height, p.width, p.device
         h = C.c_void_p()
         check(lib.mi_stack_create(C.byref(h), C.byref(p)))
@@ -293,20 +294,21 @@ class Stack:
     # -- taps
     def tap(self, what, level=0):
         L = self.levels
+        ft = np.float64 if self.float_type == MI_F64 else np.float32   # pyramid.py:126 float_type
         if what in (TAP_GAUSS, TAP_FUSED_LAP):
-            shape, dt = self.shapes[level] + (3,), np.float32
+            shape, dt = self.shapes[level] + (3,), ft
         elif what == TAP_ENERGY:
             shape, dt = self.shapes[level], np.float32
         elif what == TAP_INDEX:
             shape, dt = self.shapes[level], np.int32
         elif what == TAP_FUSED_BASE:
-            shape, dt, level = self.shapes[L] + (3,), np.float32, L
+            shape, dt, level = self.shapes[L] + (3,), ft, L
         elif what in (TAP_BASE_IDX_E, TAP_BASE_IDX_D):
             shape, dt, level = self.shapes[L], np.int32, L
         elif what in (TAP_BASE_ENT, TAP_BASE_DEV):
-            shape, dt, level = self.shapes[L], np.float32, L
+            shape, dt, level = self.shapes[L], ft, L
         elif what == TAP_COLLAPSED:
-            shape, dt, level = (self.height, self.width, 3), np.float32, 0
+            shape, dt, level = (self.height, self.width, 3), ft, 0
         else:
             raise ValueError(f"unknown tap {what}")
         out = np.empty(shape, dt)

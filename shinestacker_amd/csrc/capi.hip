@@ -15,6 +15,7 @@
 #include "kernels_align.hpp"
 #include "kernels_ecc.hpp"
 #include "kernels_balance.hpp"
+#include "kernels_f64.hpp"
 
 using namespace mi;
 
@@ -59,6 +60,8 @@ struct mi_stack {
     int L = 0;                // number of Laplacian levels; base is level L
     std::vector<int> lh, lw;  // level shapes, 0..L
     K25 K{};
+    K25d Kd{};                // float-64 mode: the float64 generating kernel (np.outer, pyramid.py:21)
+    bool f64 = false;         // float_type == MI_F64: float buffers below hold doubles (allocated twice as large)
     int pad = 2;
     int nlevels_hist = 256;
     float maxv = 255.f;
@@ -229,6 +232,120 @@ int process_base(mi_stack* s, const float* base) {
     return MI_OK;
 }
 
+// ------------------------------------------------------------------ float_type = float-64
+template <typename TIn, bool FMA>
+int process_frame_f64(mi_stack* s, const TIn* frame) {
+    const dim3 blk(64, 4);
+    const int idx = s->first_index + s->n_pushed;
+    const int first = s->n_pushed == 0;
+    auto G = [&](int l) { return reinterpret_cast<double*>(s->G[l]); };
+    double* lap = reinterpret_cast<double*>(s->lap_tmp);
+    {
+        ProfScope ps(s, MI_PROF_LEVEL, algorithmic_bytes_per_frame(s));
+        hipLaunchKernelGGL((reduce_f64<TIn, FMA>), grid2d(s->lw[1], s->lh[1], blk), blk, 0, s->stream, frame,
+                           s->lh[0], s->lw[0], G(1), s->lh[1], s->lw[1], s->Kd);
+        for (int l = 1; l < s->L; ++l)
+            hipLaunchKernelGGL((reduce_f64<double, FMA>), grid2d(s->lw[l + 1], s->lh[l + 1], blk), blk, 0, s->stream,
+                               (const double*)G(l), s->lh[l], s->lw[l], G(l + 1), s->lh[l + 1], s->lw[l + 1], s->Kd);
+        for (int l = 0; l < s->L; ++l) {
+            dim3 g = grid2d(s->lw[l], s->lh[l], blk);
+            if (l == 0)
+                hipLaunchKernelGGL((lapq_f64<TIn, FMA>), g, blk, 0, s->stream, frame, s->lh[0], s->lw[0],
+                                   (const double*)G(1), s->lh[1], s->lw[1], lap, s->q_tmp, s->Kd);
+            else
+                hipLaunchKernelGGL((lapq_f64<double, FMA>), g, blk, 0, s->stream, (const double*)G(l), s->lh[l],
+                                   s->lw[l], (const double*)G(l + 1), s->lh[l + 1], s->lw[l + 1], lap, s->q_tmp, s->Kd);
+            hipLaunchKernelGGL((select_f64<FMA>), g, blk, 0, s->stream, s->q_tmp, (const double*)lap, s->lh[l],
+                               s->lw[l], idx, first, s->bestE[l], reinterpret_cast<double*>(s->bestLap[l]),
+                               s->bestIdx[l], s->K);
+        }
+    }
+    MI_HIP(hipGetLastError());
+    return MI_OK;
+}
+
+// base features in float64; the 256 / 65536-entry table log(count / npix) is filled on the host
+// (logl rounded to double, see kernels_f64.hpp)
+template <bool FMA>
+int process_base_f64(mi_stack* s, const double* base) {
+    ProfScope ps(s, MI_PROF_BASE, 0.0);
+    const int hb = s->lh[s->L], wb = s->lw[s->L], npix = hb * wb;
+    const int idx = s->first_index + s->n_pushed;
+    const int first = s->n_pushed == 0;
+    MI_HIP(hipMemsetAsync(s->cnt, 0, sizeof(uint32_t) * s->nlevels_hist, s->stream));
+    hipLaunchKernelGGL((base_gray_hist_f64<FMA>), dim3(cdiv(npix, 256)), dim3(256), 0, s->stream, base, npix,
+                       s->nlevels_hist, s->lev, s->cnt);
+    std::vector<uint32_t> cnt(s->nlevels_hist);
+    std::vector<double> lp(s->nlevels_hist, 0.0);
+    MI_HIP(hipMemcpyAsync(cnt.data(), s->cnt, cnt.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+    MI_HIP(hipStreamSynchronize(s->stream));
+    for (int l = 0; l < s->nlevels_hist; ++l)
+        if (cnt[l]) {
+            const double pr = (double)cnt[l] / (double)npix;   // counts.astype(float64) / counts.sum()
+            lp[l] = (double)logl((long double)pr);
+        }
+    MI_HIP(hipMemcpyAsync(s->logp, lp.data(), lp.size() * sizeof(double), hipMemcpyHostToDevice, s->stream));
+    MI_HIP(hipStreamSynchronize(s->stream));   // lp goes out of scope
+    const dim3 blk(32, 8);
+    hipLaunchKernelGGL(base_feat_select_f64, grid2d(wb, hb, blk), blk, 0, s->stream, s->lev,
+                       (const double*)s->logp, base, hb, wb, s->pad, idx, first, reinterpret_cast<double*>(s->bEnt),
+                       reinterpret_cast<double*>(s->bDev), s->idxE, s->idxD, reinterpret_cast<double*>(s->baseE),
+                       reinterpret_cast<double*>(s->baseD));
+    MI_HIP(hipGetLastError());
+    return MI_OK;
+}
+
+template <typename TIn, bool FMA>
+int push_device_frames_f64(mi_stack* s, const void* dev_frames, int n, size_t stride) {
+    for (int f = 0; f < n; ++f) {
+        const TIn* fr = (const TIn*)((const char*)dev_frames + (size_t)f * stride);
+        int rc;
+        if (s->L == 0) {
+            const size_t cnt = (size_t)s->lh[0] * s->lw[0] * 3;
+            hipLaunchKernelGGL((frame_to_f64<TIn>), dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s->stream, fr,
+                               cnt, reinterpret_cast<double*>(s->colA));
+            rc = process_base_f64<FMA>(s, reinterpret_cast<const double*>(s->colA));
+        } else {
+            rc = process_frame_f64<TIn, FMA>(s, fr);
+            if (rc) return rc;
+            rc = process_base_f64<FMA>(s, reinterpret_cast<const double*>(s->G[s->L]));
+        }
+        if (rc) return rc;
+        s->n_pushed++;
+    }
+    return MI_OK;
+}
+
+template <bool FMA>
+int finish_f64(mi_stack* s) {
+    ProfScope ps(s, MI_PROF_COLLAPSE, 0.0);
+    const int L = s->L;
+    const size_t nb = (size_t)s->lh[L] * s->lw[L] * 3;
+    double* fused = reinterpret_cast<double*>(s->fusedBase);
+    hipLaunchKernelGGL(base_fuse_f64, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, s->stream,
+                       (const double*)s->baseE, (const double*)s->baseD, nb, fused);
+    const double* up = fused;
+    double* bufs[2] = {reinterpret_cast<double*>(s->colA), reinterpret_cast<double*>(s->colB)};
+    const dim3 blk(64, 4);
+    for (int l = L - 1; l >= 0; --l) {
+        double* out = bufs[l & 1];
+        hipLaunchKernelGGL((collapse_f64<FMA>), grid2d(s->lw[l], s->lh[l], blk), blk, 0, s->stream, up, s->lh[l + 1],
+                           s->lw[l + 1], (const double*)s->bestLap[l], s->lh[l], s->lw[l], out, s->Kd);
+        up = out;
+    }
+    const size_t n = (size_t)s->lh[0] * s->lw[0] * 3;
+    const dim3 g((unsigned)((n + 255) / 256));
+    double* clipped = reinterpret_cast<double*>(s->clipped);
+    if (s->p.out_dtype == MI_U8)
+        hipLaunchKernelGGL((finalize_cast_f64<uint8_t>), g, dim3(256), 0, s->stream, up, n, (double)s->maxv, clipped,
+                           (uint8_t*)s->out_dev);
+    else
+        hipLaunchKernelGGL((finalize_cast_f64<uint16_t>), g, dim3(256), 0, s->stream, up, n, (double)s->maxv, clipped,
+                           (uint16_t*)s->out_dev);
+    MI_HIP(hipGetLastError());
+    return MI_OK;
+}
+
 template <typename TIn, bool FMA>
 int push_device_frames(mi_stack* s, const void* dev_frames, int n, size_t stride) {
     for (int f = 0; f < n; ++f) {
@@ -258,6 +375,20 @@ int push_device_frames(mi_stack* s, const void* dev_frames, int n, size_t stride
 int mi::dispatch_push(mi_stack* s, const void* dev_frames, int n, size_t stride) {
     const bool fma = s->p.use_fma != 0;
     if (s->p.impl == MI_IMPL_TILED) return tiled_push(s, dev_frames, n, stride);
+    if (s->f64) {
+        switch (s->p.in_dtype) {
+            case MI_U8:
+                return fma ? push_device_frames_f64<uint8_t, true>(s, dev_frames, n, stride)
+                           : push_device_frames_f64<uint8_t, false>(s, dev_frames, n, stride);
+            case MI_U16:
+                return fma ? push_device_frames_f64<uint16_t, true>(s, dev_frames, n, stride)
+                           : push_device_frames_f64<uint16_t, false>(s, dev_frames, n, stride);
+            case MI_F32:
+                return fma ? push_device_frames_f64<float, true>(s, dev_frames, n, stride)
+                           : push_device_frames_f64<float, false>(s, dev_frames, n, stride);
+        }
+        return fail(MI_ERR_INVALID, "bad in_dtype %d", s->p.in_dtype);
+    }
     switch (s->p.in_dtype) {
         case MI_U8:
             return fma ? push_device_frames<uint8_t, true>(s, dev_frames, n, stride)
@@ -599,9 +730,7 @@ int mi_stack_create(mi_stack_t** out, const mi_stack_params_t* params) {
         return fail(MI_ERR_INVALID, "in_dtype must be MI_U8, MI_U16 or MI_F32");
     if (p.out_dtype != MI_U8 && p.out_dtype != MI_U16)
         return fail(MI_ERR_INVALID, "out_dtype must be MI_U8 or MI_U16");
-    if (p.float_type == MI_F64)
-        return fail(MI_ERR_UNSUPPORTED, "float_type float-64 is not implemented on the HIP path yet");
-    if (p.float_type != MI_F32) return fail(MI_ERR_INVALID, "bad float_type %d", p.float_type);
+    if (p.float_type != MI_F32 && p.float_type != MI_F64) return fail(MI_ERR_INVALID, "bad float_type %d", p.float_type);
     if (p.min_size < 1) return fail(MI_ERR_INVALID, "min_size must be >= 1");
     if (p.kernel_size < 1 || p.kernel_size > 12)
         return fail(MI_ERR_INVALID, "kernel_size must be in [1, 12] (base window <= 11x11)");
@@ -643,11 +772,16 @@ int mi_stack_create(mi_stack_t** out, const mi_stack_params_t* params) {
         s->L = (int)s->lh.size() - 1;
     }
     if (s->L == 0) s->p.impl = MI_IMPL_SIMPLE;  // base-only stacks (tiny frames): one frame at a time
+    s->f64 = p.float_type == MI_F64;
+    if (s->f64) s->p.impl = MI_IMPL_SIMPLE;     // the precision option runs the one-frame-at-a-time formulation
     {
         double a = p.gen_kernel;
         double k[5] = {0.25 - a / 2.0, 0.25, a, 0.25, 0.25 - a / 2.0};
         for (int i = 0; i < 5; ++i)
-            for (int j = 0; j < 5; ++j) s->K.k[i * 5 + j] = (float)(k[i] * k[j]);
+            for (int j = 0; j < 5; ++j) {
+                s->K.k[i * 5 + j] = (float)(k[i] * k[j]);
+                s->Kd.k[i * 5 + j] = k[i] * k[j];
+            }
     }
     s->pad = (p.kernel_size - 1) / 2;
     s->nlevels_hist = p.out_dtype == MI_U8 ? 256 : 65536;
@@ -668,38 +802,39 @@ int mi_stack_create(mi_stack_t** out, const mi_stack_params_t* params) {
     }
     const int L = s->L;
     const size_t P0 = (size_t)p.height * p.width;
+    const size_t fm = s->f64 ? 2 : 1;   // float_type-sized buffers are allocated in units of float
     TRY(dev_alloc(s, &s->frame_dev, P0 * 3 * dtype_size(p.in_dtype)));
     s->G.assign(L + 1, nullptr);
     s->bestE.assign(L, nullptr);
     s->bestLap.assign(L, nullptr);
     s->bestIdx.assign(L, nullptr);
-    for (int l = 1; l <= L; ++l) TRY(dev_alloc_t(s, &s->G[l], (size_t)s->lh[l] * s->lw[l] * 3));
+    for (int l = 1; l <= L; ++l) TRY(dev_alloc_t(s, &s->G[l], (size_t)s->lh[l] * s->lw[l] * 3 * fm));
     for (int l = 0; l < L; ++l) {
         size_t np = (size_t)s->lh[l] * s->lw[l];
         TRY(dev_alloc_t(s, &s->bestE[l], np));
-        TRY(dev_alloc_t(s, &s->bestLap[l], np * 3));
+        TRY(dev_alloc_t(s, &s->bestLap[l], np * 3 * fm));
         TRY(dev_alloc_t(s, &s->bestIdx[l], np));
     }
     if (s->p.impl == MI_IMPL_SIMPLE) {
-        TRY(dev_alloc_t(s, &s->lap_tmp, P0 * 3));
+        TRY(dev_alloc_t(s, &s->lap_tmp, P0 * 3 * fm));
         TRY(dev_alloc_t(s, &s->q_tmp, P0));
     }
     {
         size_t nb = (size_t)s->lh[L] * s->lw[L];
         TRY(dev_alloc_t(s, &s->lev, nb));
         TRY(dev_alloc_t(s, &s->cnt, (size_t)s->nlevels_hist));
-        TRY(dev_alloc_t(s, &s->logp, (size_t)s->nlevels_hist));
-        TRY(dev_alloc_t(s, &s->bEnt, nb));
-        TRY(dev_alloc_t(s, &s->bDev, nb));
+        TRY(dev_alloc_t(s, &s->logp, (size_t)s->nlevels_hist * fm));
+        TRY(dev_alloc_t(s, &s->bEnt, nb * fm));
+        TRY(dev_alloc_t(s, &s->bDev, nb * fm));
         TRY(dev_alloc_t(s, &s->idxE, nb));
         TRY(dev_alloc_t(s, &s->idxD, nb));
-        TRY(dev_alloc_t(s, &s->baseE, nb * 3));
-        TRY(dev_alloc_t(s, &s->baseD, nb * 3));
-        TRY(dev_alloc_t(s, &s->fusedBase, nb * 3));
+        TRY(dev_alloc_t(s, &s->baseE, nb * 3 * fm));
+        TRY(dev_alloc_t(s, &s->baseD, nb * 3 * fm));
+        TRY(dev_alloc_t(s, &s->fusedBase, nb * 3 * fm));
     }
-    TRY(dev_alloc_t(s, &s->colA, P0 * 3));
-    TRY(dev_alloc_t(s, &s->colB, L >= 2 ? (size_t)s->lh[1] * s->lw[1] * 3 : 1));
-    TRY(dev_alloc_t(s, &s->clipped, P0 * 3));
+    TRY(dev_alloc_t(s, &s->colA, P0 * 3 * fm));
+    TRY(dev_alloc_t(s, &s->colB, (L >= 2 ? (size_t)s->lh[1] * s->lw[1] * 3 : 1) * fm));
+    TRY(dev_alloc_t(s, &s->clipped, P0 * 3 * fm));
     TRY(dev_alloc(s, &s->out_dev, P0 * 3 * dtype_size(p.out_dtype)));
     TRY(tiled_create(s));
 #undef TRY
@@ -808,7 +943,8 @@ int mi_stack_finish_device(mi_stack_t* s, void* dev_out) {
     rc = tiled_flush(s);
     if (rc) return rc;
     if (s->n_pushed == 0) return fail(MI_ERR_STATE, "finish with no frames pushed");
-    rc = s->p.use_fma ? finish_impl<true>(s) : finish_impl<false>(s);
+    if (s->f64) rc = s->p.use_fma ? finish_f64<true>(s) : finish_f64<false>(s);
+    else rc = s->p.use_fma ? finish_impl<true>(s) : finish_impl<false>(s);
     if (rc) return rc;
     s->finished = true;
     if (dev_out) {
@@ -842,15 +978,16 @@ int mi_stack_get_level(mi_stack_t* s, int level, int what, void* host_out, size_
     const void* src = nullptr;
     size_t bytes = 0;
     auto np = [&](int l) { return (size_t)s->lh[l] * s->lw[l]; };
+    const size_t fb = s->f64 ? 8 : 4;   // bytes of a float_type element
     switch (what) {
         case MI_TAP_GAUSS:
             if (level < 1 || level > L) return fail(MI_ERR_INVALID, "MI_TAP_GAUSS: level in [1, %d]", L);
             src = tiled_last_gauss(s, level);
-            bytes = np(level) * 12;
+            bytes = np(level) * 3 * fb;
             break;
         case MI_TAP_FUSED_LAP:
             if (level < 0 || level >= L) return fail(MI_ERR_INVALID, "bad level %d", level);
-            src = s->bestLap[level]; bytes = np(level) * 12; break;
+            src = s->bestLap[level]; bytes = np(level) * 3 * fb; break;
         case MI_TAP_ENERGY:
             if (level < 0 || level >= L) return fail(MI_ERR_INVALID, "bad level %d", level);
             src = s->bestE[level]; bytes = np(level) * 4; break;
@@ -859,14 +996,14 @@ int mi_stack_get_level(mi_stack_t* s, int level, int what, void* host_out, size_
             src = s->bestIdx[level]; bytes = np(level) * 4; break;
         case MI_TAP_FUSED_BASE:
             if (!s->finished) return fail(MI_ERR_STATE, "fused base is available after finish");
-            src = s->fusedBase; bytes = np(L) * 12; break;
+            src = s->fusedBase; bytes = np(L) * 3 * fb; break;
         case MI_TAP_BASE_IDX_E: src = s->idxE; bytes = np(L) * 4; break;
         case MI_TAP_BASE_IDX_D: src = s->idxD; bytes = np(L) * 4; break;
-        case MI_TAP_BASE_ENT: src = s->bEnt; bytes = np(L) * 4; break;
-        case MI_TAP_BASE_DEV: src = s->bDev; bytes = np(L) * 4; break;
+        case MI_TAP_BASE_ENT: src = s->bEnt; bytes = np(L) * fb; break;
+        case MI_TAP_BASE_DEV: src = s->bDev; bytes = np(L) * fb; break;
         case MI_TAP_COLLAPSED:
             if (!s->finished) return fail(MI_ERR_STATE, "collapsed image is available after finish");
-            src = s->clipped; bytes = np(0) * 12; break;
+            src = s->clipped; bytes = np(0) * 3 * fb; break;
         default: return fail(MI_ERR_INVALID, "unknown tap %d", what);
     }
     if (out_bytes < bytes) return fail(MI_ERR_INVALID, "output buffer too small: need %zu bytes", bytes);
@@ -886,6 +1023,7 @@ int mi_stack_state(mi_stack_t* s, int level, void** dev_energy, void** dev_lap, 
     rc = tiled_sync_all(s);
     if (rc) return rc;
     MI_HIP(hipStreamSynchronize(s->stream));
+    if (s->f64) return fail(MI_ERR_UNSUPPORTED, "the frame-sharded combine works on float-32 state only");
     const int L = s->L;
     void *e = nullptr, *l = nullptr, *i = nullptr;
     size_t n = 0;

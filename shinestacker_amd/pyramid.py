@@ -75,9 +75,6 @@ class PyramidStack(BaseStackAlgo):
                  float_type=constants.DEFAULT_PY_FLOAT, *, device=0, use_fma=True,
                  impl=_lib.IMPL_AUTO, batch_frames=0):
         super().__init__("pyramid", 2, float_type)
-        if self.float_type is np.float64:
-            raise InvalidOptionError("float_type", float_type,
-                                     details=" float-64 is not implemented on the MI355X path")
         self.min_size = min_size
         self.kernel_size = kernel_size
         self.pad_amount = (kernel_size - 1) // 2
@@ -105,7 +102,8 @@ class PyramidStack(BaseStackAlgo):
                                  min_size=self.min_size, kernel_size=self.kernel_size,
                                  gen_kernel=self.gen_kernel_a, use_fma=self.use_fma,
                                  device=self.device, impl=self.impl,
-                                 batch_frames=self.batch_frames)
+                                 batch_frames=self.batch_frames,
+                                 float_type=_lib.MI_F64 if self.float_type is np.float64 else _lib.MI_F32)
         self._stack_key = key
         return self._stack
 

@@ -42,6 +42,10 @@ def fusion_cases():
     return ["g1_u8", "g2_u16", "g3_ties", "g1b_nofma", "g1c_smooth", "g8_nolevels"]
 
 
+def f64_cases():
+    return ["g9_f64", "g9_f64_u16"]
+
+
 def stack_kwargs(params):
     kw = {k: params[k] for k in ("min_size", "kernel_size", "gen_kernel") if k in params}
     kw["use_fma"] = params.get("use_fma", True)

@@ -7,7 +7,7 @@ import shutil
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, fusion_cases, load_golden, stack_kwargs
+from conftest import GOLDEN, f64_cases, fusion_cases, load_golden, stack_kwargs
 
 pytestmark = pytest.mark.gpu
 
@@ -50,6 +50,50 @@ def test_golden_fusion(L, case, impl):
     assert np.array_equal(st.tap(L.TAP_COLLAPSED), g["collapsed"])
     assert out.dtype == g["final"].dtype and np.array_equal(out, g["final"])
     st.close()
+
+
+@pytest.mark.parametrize("case", f64_cases())
+def test_golden_fusion_float64(L, case):
+    """float_type='float-64' against the reference's own float-64 run: float64 Laplacians / base / collapse,
+    float32 energies, float64 entropy and deviation."""
+    g = load_golden(case)
+    fr = g["frames"]
+    st = L.Stack(fr.shape[1], fr.shape[2], in_dtype=fr.dtype, float_type=L.MI_F64, **stack_kwargs(g["params"]))
+    for f in fr:
+        st.push_frame(f)
+    assert st.levels == int(g["levels"])
+    for lv in range(st.levels):
+        assert np.array_equal(st.tap(L.TAP_ENERGY, lv), g[f"energy_{lv}"]), f"energy {lv}"
+        assert np.array_equal(st.tap(L.TAP_INDEX, lv), g[f"best_{lv}"]), f"index {lv}"
+        lap = st.tap(L.TAP_FUSED_LAP, lv)
+        assert lap.dtype == np.float64 and np.array_equal(lap, g[f"fused_{lv}"]), f"lap {lv}"
+    assert np.array_equal(st.tap(L.TAP_BASE_IDX_E), g["base_idx_e"])
+    assert np.array_equal(st.tap(L.TAP_BASE_IDX_D), g["base_idx_d"])
+    assert np.array_equal(st.tap(L.TAP_BASE_ENT), g["base_ent"].max(axis=0))
+    assert np.array_equal(st.tap(L.TAP_BASE_DEV), g["base_dev"].max(axis=0))
+    out = st.finish()
+    assert np.array_equal(st.tap(L.TAP_FUSED_BASE), g["fused_base"])
+    assert np.array_equal(st.tap(L.TAP_COLLAPSED), g["collapsed"])
+    assert out.dtype == g["final"].dtype and np.array_equal(out, g["final"])
+    st.close()
+
+
+@pytest.mark.parametrize("shape,dtype,n,kw", [
+    ((90, 131), np.uint16, 4, {"min_size": 16}),
+    ((40, 52), np.uint8, 3, {}),                         # no Laplacian levels
+    ((77, 64), np.uint8, 2, {"min_size": 8, "kernel_size": 3, "use_fma": False}),
+])
+def test_float64_random_vs_ref_shaped(L, oracle, shape, dtype, n, kw):
+    from shinestacker_amd.pyramid import PyramidStack
+    rng = np.random.default_rng(shape[0] * 3 + n)
+    hi = 256 if dtype == np.uint8 else 65536
+    frames = [rng.integers(0, hi, shape + (3,)).astype(dtype) for _ in range(n)]
+    want = oracle.RefShaped(float_type=np.float64, **kw).stack(frames)
+    got = PyramidStack(float_type="float-64", **kw).focus_stack_arrays(frames)
+    assert got.dtype == want.dtype and np.array_equal(got, want)
+    # and it is not the float-32 result in general (different rounding of the pyramid)
+    f32 = PyramidStack(**kw).focus_stack_arrays(frames)
+    assert f32.shape == got.shape
 
 
 @pytest.mark.parametrize("impl", [1, 2, 3])

@@ -139,8 +139,7 @@ def test_output_dir_scratched_and_chained(oracle, workdir):
 def test_option_errors():
     with pytest.raises(InvalidOptionError):
         PyramidStack(float_type="float-16")
-    with pytest.raises(InvalidOptionError):
-        PyramidStack(float_type="float-64")  # documented gap of the HIP path
+    assert PyramidStack(float_type="float-64").float_type is np.float64   # base_stack_algo.py:16-17
     with pytest.raises(InvalidOptionError):
         FocusStackBunch("b", PyramidStack(), frames=3, overlap=3)
     algo = PyramidStack()

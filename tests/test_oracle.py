@@ -8,7 +8,7 @@ import zlib
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, fusion_cases, load_golden, stack_kwargs
+from conftest import GOLDEN, f64_cases, fusion_cases, load_golden, stack_kwargs
 
 
 @pytest.mark.parametrize("case", fusion_cases())
@@ -25,6 +25,23 @@ def test_ref_shaped_matches_golden(oracle, case):
         assert np.array_equal(d["energy"][lv], g[f"energy_{lv}"])
     assert np.array_equal(d["fused"][-1], g["fused_base"])
     assert np.array_equal(d["ent"].max(axis=0), g["base_ent"].max(axis=0))
+
+
+@pytest.mark.parametrize("case", f64_cases())
+def test_ref_shaped_float64_matches_golden(oracle, case):
+    """float_type='float-64': the reference's own run (oracle/gen_golden.py f64_case) vs RefShaped(float64)."""
+    g = load_golden(case)
+    rs = oracle.RefShaped(float_type=np.float64, **stack_kwargs(g["params"]))
+    out, d = rs.stack(list(g["frames"]), want_detail=True)
+    assert np.array_equal(out, g["final"])
+    assert d["collapsed"].dtype == np.float64 and np.array_equal(d["collapsed"], g["collapsed"])
+    for lv in range(int(g["levels"])):
+        assert np.array_equal(d["fused"][lv], g[f"fused_{lv}"])
+        assert np.array_equal(d["best"][lv], g[f"best_{lv}"])
+        assert d["energy"][lv].dtype == np.float32 and np.array_equal(d["energy"][lv], g[f"energy_{lv}"])
+    assert np.array_equal(d["fused"][-1], g["fused_base"])
+    assert d["ent"].dtype == np.float64 and np.array_equal(d["ent"], g["base_ent"])
+    assert np.array_equal(d["dev"], g["base_dev"])
 
 
 @pytest.mark.parametrize("case", fusion_cases())
