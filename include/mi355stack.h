@@ -108,6 +108,7 @@ MI_API int mi_device_free(int device, void* dev_ptr);
 MI_API int mi_memcpy_h2d(int device, void* dev_dst, const void* host_src, size_t bytes);
 MI_API int mi_memcpy_d2h(int device, void* host_dst, const void* dev_src, size_t bytes);
 MI_API int mi_memcpy_d2d(int device, void* dev_dst, const void* dev_src, size_t bytes);
+MI_API int mi_memcpy_d2d_async(int device, void* stream, void* dev_dst, const void* dev_src, size_t bytes);
 MI_API int mi_device_synchronize(int device);
 
 /* ---- stacker handle ---- */
@@ -198,7 +199,9 @@ MI_API int mi_ecc_similarity(int device, const void* host_ref, const void* host_
  * moving frame costs one pyramid build plus the Gauss-Newton iterations.  `subsample` folds the
  * reference's fast sub-sampling img[::s, ::s] (utils.py img_subsample) into the first kernel; the
  * returned M is in full-resolution pixels (translation scaled back as align.py:224-231 does).
- * dev_ref / dev_mov: H x W x 3 device images of the handle's dtype.  The kernels run on `stream`;
+ * dev_ref / dev_mov: H x W x 3 device images of the handle's dtype.  The kernels run on `stream`, or on
+ * a stream the handle owns when `stream` is NULL (handles driven from different host threads then
+ * run side by side);
  * mi_aligner_estimate returns after the last iteration (it reads 28 sums back per iteration). */
 typedef struct mi_aligner* mi_aligner_t;
 MI_API int mi_aligner_create(mi_aligner_t* out, int device, int height, int width, int dtype, int subsample,
@@ -207,6 +210,11 @@ MI_API int mi_aligner_destroy(mi_aligner_t al);
 MI_API int mi_aligner_set_reference(mi_aligner_t al, void* stream, const void* dev_ref);
 MI_API int mi_aligner_estimate(mi_aligner_t al, void* stream, const void* dev_mov, int max_iters, double eps,
                         double* M_out, double* cc_out, int* iters_out);
+/* n <= 16 moving frames against the same reference in one batched Gauss-Newton: one launch and one host
+ * round trip per iteration for the whole batch.  M_out: n x 6, cc_out / iters_out: n entries; a frame
+ * the method fails on (no overlap, constant image) gets cc = -2 and an identity matrix. */
+MI_API int mi_aligner_estimate_batch(mi_aligner_t al, void* stream, const void* const* dev_movs, int n, int max_iters,
+                              double eps, double* M_out, double* cc_out, int* iters_out);
 
 /* ---- BalanceFrames device steps (reference algorithms/balance.py).
  * mi_histogram: histogram of an H x W x 3 uint8/uint16 BGR image as balance.py:158-180

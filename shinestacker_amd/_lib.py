@@ -47,6 +47,7 @@ SIGNATURES = {
     "mi_memcpy_h2d": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]),
     "mi_memcpy_d2h": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]),
     "mi_memcpy_d2d": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "mi_memcpy_d2d_async": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "mi_device_synchronize": (C.c_int, [C.c_int]),
     "mi_stack_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(StackParams)]),
     "mi_stack_destroy": (None, [C.c_void_p]),
@@ -94,6 +95,9 @@ SIGNATURES = {
                                C.c_int]),
     "mi_apply_lut_device": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int,
                                       C.c_void_p, C.c_int]),
+    "mi_aligner_estimate_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int,
+                                            C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                            C.POINTER(C.c_int)]),
     "mi_synth_frames_device": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.c_int, C.c_int, C.c_uint32]),
 }
@@ -400,6 +404,20 @@ class Aligner:
         check(load().mi_aligner_estimate(self._h, stream, dev_ptr, int(max_iters), float(eps), m,
                                          C.byref(cc), C.byref(it)))
         return np.array(list(m), dtype=np.float64).reshape(2, 3), cc.value, it.value
+
+    MAX_BATCH = 16
+
+    def estimate_batch(self, dev_ptrs, max_iters=60, eps=1e-9, stream=None):
+        """Up to 16 moving frames in one batched Gauss-Newton (mi_aligner_estimate_batch).
+        -> (M n x 2 x 3 float64, cc n float64 [-2 where the method failed], iterations n int32)"""
+        n = len(dev_ptrs)
+        ptrs = (C.c_void_p * n)(*dev_ptrs)
+        m = (C.c_double * (6 * n))()
+        cc = (C.c_double * n)()
+        it = (C.c_int * n)()
+        check(load().mi_aligner_estimate_batch(self._h, stream, ptrs, n, int(max_iters), float(eps), m, cc, it))
+        return (np.array(list(m), dtype=np.float64).reshape(n, 2, 3), np.array(list(cc), dtype=np.float64),
+                np.array(list(it), dtype=np.int32))
 
     def close(self):
         if self._h:

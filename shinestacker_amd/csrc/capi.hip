@@ -527,26 +527,69 @@ struct EccLevel {
 struct mi_aligner {
     int device = 0, height = 0, width = 0, dtype = 0, subsample = 1;
     int h = 0, w = 0;  // size of the sub-sampled images the estimate works on
-    std::vector<EccLevel> lv;
+    std::vector<EccLevel> lv;   // tmpl: one image; img / gx / gy: `cap` images each (frame f at + f * h * w)
     float* gray = nullptr;
-    double* partial = nullptr;       // [ECC_MAX_BLOCKS][ECC_NSUM]
-    unsigned int* ticket = nullptr;
-    double* hsums = nullptr;         // pinned, device-visible: the last block writes the 28 sums here
-    std::vector<void*> bufs;
+    int cap = 0;                     // moving frames the per-frame buffers hold
+    double* partial = nullptr;       // [cap][ECC_MAX_BLOCKS][ECC_NSUM]
+    unsigned int* ticket = nullptr;  // [cap]
+    double* hsums = nullptr;         // pinned, device-visible [cap][ECC_NSUM]: written by each frame's last block
+    std::vector<void*> bufs;         // template pyramid + gray scratch
+    std::vector<void*> fbufs;        // per-frame buffers (re-allocated when the capacity grows)
+    hipStream_t own = nullptr;       // used when the caller passes no stream: handles on different host
+                                     // threads then run side by side instead of serialising on stream 0
     bool have_ref = false;
 };
 
 namespace {
 
-void aligner_free(mi_aligner* al) {
-    for (void* b : al->bufs) (void)hipFree(b);
-    al->bufs.clear();
+void aligner_free_frames(mi_aligner* al) {
+    for (void* b : al->fbufs) (void)hipFree(b);
+    al->fbufs.clear();
     if (al->hsums) (void)hipHostFree(al->hsums);
     al->hsums = nullptr;
+    al->cap = 0;
 }
 
-int aligner_build(mi_aligner* al, hipStream_t st, const void* dev_img, bool is_tmpl) {
-    const size_t npx = (size_t)al->h * al->w;
+void aligner_free(mi_aligner* al) {
+    aligner_free_frames(al);
+    for (void* b : al->bufs) (void)hipFree(b);
+    al->bufs.clear();
+    if (al->own) (void)hipStreamDestroy(al->own);
+    al->own = nullptr;
+}
+
+// per-frame buffers for `n` moving frames
+int aligner_reserve(mi_aligner* al, int n) {
+    if (n <= al->cap) return MI_OK;
+    MI_HIP(hipDeviceSynchronize());
+    aligner_free_frames(al);
+    auto dalloc = [&](size_t bytes) -> void* {
+        void* p = nullptr;
+        if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+        al->fbufs.push_back(p);
+        return p;
+    };
+    bool ok = true;
+    for (auto& L : al->lv) {
+        const size_t nb = (size_t)L.h * L.w * 4 * n;
+        L.img = (float*)dalloc(nb); L.gx = (float*)dalloc(nb); L.gy = (float*)dalloc(nb);
+        ok = ok && L.img && L.gx && L.gy;
+    }
+    al->partial = (double*)dalloc((size_t)n * ECC_MAX_BLOCKS * ECC_NSUM * sizeof(double));
+    al->ticket = (unsigned int*)dalloc(sizeof(unsigned int) * n);
+    ok = ok && al->partial && al->ticket;
+    if (ok) ok = hipMemset(al->ticket, 0, sizeof(unsigned int) * n) == hipSuccess;
+    if (ok) ok = hipHostMalloc((void**)&al->hsums, (size_t)n * ECC_NSUM * sizeof(double), hipHostMallocDefault) == hipSuccess;
+    if (!ok) {
+        aligner_free_frames(al);
+        return fail(MI_ERR_NOMEM, "out of device memory");
+    }
+    al->cap = n;
+    return MI_OK;
+}
+
+// gray + pyramid (+ gradients) of one image: the template, or moving frame `slot`
+int aligner_build(mi_aligner* al, hipStream_t st, const void* dev_img, bool is_tmpl, int slot) {
     const dim3 blk(64, 4), g0(cdiv(al->w, 64), cdiv(al->h, 4));
     if (al->dtype == MI_U8)
         hipLaunchKernelGGL((ecc_gray<uint8_t>), g0, blk, 0, st, (const uint8_t*)dev_img, al->width, al->h, al->w,
@@ -554,93 +597,122 @@ int aligner_build(mi_aligner* al, hipStream_t st, const void* dev_img, bool is_t
     else
         hipLaunchKernelGGL((ecc_gray<uint16_t>), g0, blk, 0, st, (const uint16_t*)dev_img, al->width, al->h, al->w,
                            al->subsample, al->gray);
-    (void)npx;
     auto& lv = al->lv;
+    auto at = [&](float* base, size_t l) { return base + (size_t)slot * lv[l].h * lv[l].w; };
     for (size_t l = 0; l < lv.size(); ++l) {
-        float* dst = is_tmpl ? lv[l].tmpl : lv[l].img;
-        const float* src = l == 0 ? al->gray : (is_tmpl ? lv[l - 1].tmpl : lv[l - 1].img);
+        float* dst = is_tmpl ? lv[l].tmpl : at(lv[l].img, l);
+        const float* src = l == 0 ? al->gray : (is_tmpl ? lv[l - 1].tmpl : at(lv[l - 1].img, l - 1));
         const int sh = l == 0 ? al->h : lv[l - 1].h, sw = l == 0 ? al->w : lv[l - 1].w;
         hipLaunchKernelGGL(ecc_blur_down, dim3(cdiv(lv[l].w, 64), cdiv(lv[l].h, 4)), blk, 0, st, src, sh, sw, dst,
                            lv[l].h, lv[l].w, l == 0 ? 0 : 1);
         if (!is_tmpl)
             hipLaunchKernelGGL(ecc_gradient, dim3(cdiv(lv[l].w, 64), cdiv(lv[l].h, 4)), blk, 0, st, dst, lv[l].h,
-                               lv[l].w, lv[l].gx, lv[l].gy);
+                               lv[l].w, at(lv[l].gx, l), at(lv[l].gy, l));
     }
     MI_HIP(hipGetLastError());
     return MI_OK;
 }
 
-// coarse-to-fine forward-additive ECC on the pyramids held by `al`; M_out in FULL-resolution
-// pixel coordinates (translation scaled by the sub-sampling factor, as align.py:224-231 does)
-int aligner_solve(mi_aligner* al, hipStream_t st, int max_iters, double eps, double* M_out, double* cc_out,
+// Coarse-to-fine forward-additive ECC of `n` <= ECC_MAXF moving frames (pyramids in slots 0..n-1)
+// against the template: one launch and one host round trip per Gauss-Newton iteration for the whole
+// batch; frames that converged on a level sit out the rest of it.  M_out[f] in FULL-resolution pixel
+// coordinates (translation scaled by the sub-sampling factor, as align.py:224-231 does).  A frame
+// the method fails on (no overlap, constant image, degenerate transform) gets cc = -2.
+struct EccFrame {
+    double a = 1.0, b = 0.0, T0 = 0.0, T1 = 0.0, rho = -1.0;
+    double tx = 0.0, ty = 0.0, last_rho = -2.0;
+    int iters = 0;
+    bool failed = false, active = false;
+};
+
+int aligner_solve(mi_aligner* al, hipStream_t st, int n, int max_iters, double eps, double* M_out, double* cc_out,
                   int* iters_out) {
     if (max_iters < 1) max_iters = 50;
     if (!(eps > 0)) eps = 1e-8;
     auto& lv = al->lv;
-    // W in origin coordinates of the current level: u = A x + T, A = [a -b; b a]
-    double a = 1.0, b = 0.0, T0 = 0.0, T1 = 0.0, rho = -1.0;
-    int total_iters = 0;
+    std::vector<EccFrame> fr(n);
     for (int l = (int)lv.size() - 1; l >= 0; --l) {
         const EccLevel& L = lv[l];
         const double cx = 0.5 * (L.w - 1), cy = 0.5 * (L.h - 1);
-        // centred parameters: t = T - c + A c
-        double tx = T0 - cx + (a * cx - b * cy), ty = T1 - cy + (b * cx + a * cy);
         const size_t np = (size_t)L.h * L.w;
         const int step = np > (size_t)6000000 ? 2 : 1;
-        double last_rho = -2.0;
-        for (int it = 0; it < max_iters; ++it) {
-            EccParams p{a, b, tx, ty};
-            // ~8 pixels per thread, at most ECC_MAX_BLOCKS blocks (4 per CU)
-            const size_t work = (np / ((size_t)step * step) + 2047) / 2048;
-            const unsigned nblk = (unsigned)(work < 1 ? 1 : (work > (size_t)ECC_MAX_BLOCKS ? ECC_MAX_BLOCKS : work));
-            hipLaunchKernelGGL(ecc_accumulate, dim3(nblk), dim3(256), 0, st, L.tmpl, L.img, L.gx, L.gy, L.h, L.w, p,
-                               step, al->partial, al->ticket, al->hsums);
-            MI_HIP(hipStreamSynchronize(st));
-            double S[ECC_NSUM];
-            for (int k = 0; k < ECC_NSUM; ++k) S[k] = ((volatile double*)al->hsums)[k];
-            ++total_iters;
-            const double n = S[0];
-            if (n < 64) return fail(MI_ERR_STATE, "ECC: the images do not overlap");
-            const double mw = S[1] / n, mr = S[2] / n;
-            const double wn2 = S[3] - n * mw * mw, rn2 = S[4] - n * mr * mr, corr = S[5] - n * mw * mr;
-            if (!(wn2 > 0) || !(rn2 > 0)) return fail(MI_ERR_STATE, "ECC: constant image");
-            rho = corr / std::sqrt(wn2 * rn2);
-            double ip[4], tp[4], Hi_ip[4];
-            for (int k = 0; k < 4; ++k) {
-                ip[k] = S[10 + k] - mw * S[6 + k];
-                tp[k] = S[14 + k] - mr * S[6 + k];
-            }
-            if (!solve4(&S[18], ip, Hi_ip)) break;
-            double ipH = 0, tpH = 0;
-            for (int k = 0; k < 4; ++k) { ipH += ip[k] * Hi_ip[k]; tpH += tp[k] * Hi_ip[k]; }
-            const double lam_n = wn2 - ipH, lam_d = corr - tpH;
-            if (!(lam_d > 0)) break;  // the algorithm stopped before its convergence
-            const double lam = lam_n / lam_d;
-            double ep[4], dp[4];
-            for (int k = 0; k < 4; ++k) ep[k] = lam * tp[k] - ip[k];
-            if (!solve4(&S[18], ep, dp)) break;
-            a += dp[0]; b += dp[1]; tx += dp[2]; ty += dp[3];
-            // converged when the update moves no pixel of this level by more than 0.002 px
-            // (the image corners move the most), or when rho stalls
-            const double move = (std::fabs(dp[0]) + std::fabs(dp[1])) * std::hypot(cx, cy) +
-                                std::fabs(dp[2]) + std::fabs(dp[3]);
-            if (move < 2e-3 || std::fabs(rho - last_rho) < eps) break;
-            last_rho = rho;
+        // ~8 pixels per thread, at most ECC_MAX_BLOCKS blocks (4 per CU)
+        const size_t work = (np / ((size_t)step * step) + 2047) / 2048;
+        const unsigned nblk = (unsigned)(work < 1 ? 1 : (work > (size_t)ECC_MAX_BLOCKS ? ECC_MAX_BLOCKS : work));
+        for (auto& f : fr) {
+            // W in origin coordinates u = A x + T, A = [a -b; b a]; centred parameters t = T - c + A c
+            f.tx = f.T0 - cx + (f.a * cx - f.b * cy);
+            f.ty = f.T1 - cy + (f.b * cx + f.a * cy);
+            f.last_rho = -2.0;
+            f.active = !f.failed;
         }
-        // back to origin coordinates, then up to the next finer level (u_f = 2 u_c, x_f = 2 x_c)
-        T0 = tx + cx - (a * cx - b * cy);
-        T1 = ty + cy - (b * cx + a * cy);
-        if (l > 0) { T0 *= 2.0; T1 *= 2.0; }
+        for (int it = 0; it < max_iters; ++it) {
+            EccBatch pb{};
+            int nact = 0;
+            for (int k = 0; k < n; ++k) {
+                pb.p[k] = EccParams{fr[k].a, fr[k].b, fr[k].tx, fr[k].ty};
+                pb.active[k] = fr[k].active ? 1 : 0;
+                nact += pb.active[k];
+            }
+            if (!nact) break;
+            hipLaunchKernelGGL(ecc_accumulate, dim3(nblk, n), dim3(256), 0, st, L.tmpl, L.img, L.gx, L.gy, np, L.h, L.w,
+                               pb, step, al->partial, al->ticket, al->hsums);
+            MI_HIP(hipStreamSynchronize(st));
+            for (int k = 0; k < n; ++k) {
+                EccFrame& f = fr[k];
+                if (!f.active) continue;
+                double S[ECC_NSUM];
+                for (int q = 0; q < ECC_NSUM; ++q) S[q] = ((volatile double*)al->hsums)[(size_t)k * ECC_NSUM + q];
+                ++f.iters;
+                const double cnt = S[0];
+                if (cnt < 64) { f.failed = true; f.active = false; continue; }   // the images do not overlap
+                const double mw = S[1] / cnt, mr = S[2] / cnt;
+                const double wn2 = S[3] - cnt * mw * mw, rn2 = S[4] - cnt * mr * mr, corr = S[5] - cnt * mw * mr;
+                if (!(wn2 > 0) || !(rn2 > 0)) { f.failed = true; f.active = false; continue; }   // constant image
+                f.rho = corr / std::sqrt(wn2 * rn2);
+                double ip[4], tp[4], Hi_ip[4];
+                for (int q = 0; q < 4; ++q) {
+                    ip[q] = S[10 + q] - mw * S[6 + q];
+                    tp[q] = S[14 + q] - mr * S[6 + q];
+                }
+                if (!solve4(&S[18], ip, Hi_ip)) { f.active = false; continue; }
+                double ipH = 0, tpH = 0;
+                for (int q = 0; q < 4; ++q) { ipH += ip[q] * Hi_ip[q]; tpH += tp[q] * Hi_ip[q]; }
+                const double lam_n = wn2 - ipH, lam_d = corr - tpH;
+                if (!(lam_d > 0)) { f.active = false; continue; }  // the algorithm stopped before its convergence
+                const double lam = lam_n / lam_d;
+                double ep[4], dp[4];
+                for (int q = 0; q < 4; ++q) ep[q] = lam * tp[q] - ip[q];
+                if (!solve4(&S[18], ep, dp)) { f.active = false; continue; }
+                f.a += dp[0]; f.b += dp[1]; f.tx += dp[2]; f.ty += dp[3];
+                // converged when the update moves no pixel of this level by more than 0.002 px
+                // (the image corners move the most), or when rho stalls
+                const double move = (std::fabs(dp[0]) + std::fabs(dp[1])) * std::hypot(cx, cy) +
+                                    std::fabs(dp[2]) + std::fabs(dp[3]);
+                if (move < 2e-3 || std::fabs(f.rho - f.last_rho) < eps) f.active = false;
+                f.last_rho = f.rho;
+            }
+        }
+        for (auto& f : fr) {
+            // back to origin coordinates, then up to the next finer level (u_f = 2 u_c, x_f = 2 x_c)
+            f.T0 = f.tx + cx - (f.a * cx - f.b * cy);
+            f.T1 = f.ty + cy - (f.b * cx + f.a * cy);
+            if (l > 0) { f.T0 *= 2.0; f.T1 *= 2.0; }
+        }
     }
-    // M (moving -> reference) = W^-1, translation back to full-resolution pixels
-    const double det = a * a + b * b;
-    if (!(det > 1e-12)) return fail(MI_ERR_STATE, "ECC: degenerate transform");
-    const double ia = a / det, ib = -b / det;  // A^-1 = [ia -ib; ib ia]
     const double s = (double)al->subsample;
-    M_out[0] = ia;  M_out[1] = -ib; M_out[2] = -(ia * T0 - ib * T1) * s;
-    M_out[3] = ib;  M_out[4] = ia;  M_out[5] = -(ib * T0 + ia * T1) * s;
-    if (cc_out) *cc_out = rho;
-    if (iters_out) *iters_out = total_iters;
+    for (int k = 0; k < n; ++k) {
+        const EccFrame& f = fr[k];
+        double* M = M_out + 6 * k;
+        // M (moving -> reference) = W^-1, translation back to full-resolution pixels
+        const double det = f.a * f.a + f.b * f.b;
+        const bool bad = f.failed || !(det > 1e-12);
+        const double ia = bad ? 1.0 : f.a / det, ib = bad ? 0.0 : -f.b / det;  // A^-1 = [ia -ib; ib ia]
+        M[0] = ia;  M[1] = -ib; M[2] = bad ? 0.0 : -(ia * f.T0 - ib * f.T1) * s;
+        M[3] = ib;  M[4] = ia;  M[5] = bad ? 0.0 : -(ib * f.T0 + ia * f.T1) * s;
+        if (cc_out) cc_out[k] = bad ? -2.0 : f.rho;
+        if (iters_out) iters_out[k] = f.iters;
+    }
     return MI_OK;
 }
 
@@ -713,6 +785,13 @@ int mi_memcpy_d2d(int device, void* dev_dst, const void* dev_src, size_t bytes) 
     if (!dev_dst || !dev_src) return fail(MI_ERR_INVALID, "null pointer");
     MI_HIP(hipSetDevice(device));
     MI_HIP(hipMemcpy(dev_dst, dev_src, bytes, hipMemcpyDeviceToDevice));
+    return MI_OK;
+}
+
+int mi_memcpy_d2d_async(int device, void* stream, void* dev_dst, const void* dev_src, size_t bytes) {
+    if (!dev_dst || !dev_src) return fail(MI_ERR_INVALID, "null pointer");
+    MI_HIP(hipSetDevice(device));
+    MI_HIP(hipMemcpyAsync(dev_dst, dev_src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return MI_OK;
 }
 int mi_device_synchronize(int device) {
@@ -1190,11 +1269,7 @@ int mi_aligner_create(mi_aligner_t* out, int device, int height, int width, int 
     };
     bool ok = true;
     al->gray = (float*)dalloc((size_t)h * w * 4);
-    al->partial = (double*)dalloc((size_t)ECC_MAX_BLOCKS * ECC_NSUM * sizeof(double));
-    al->ticket = (unsigned int*)dalloc(sizeof(unsigned int));
-    ok = al->gray && al->partial && al->ticket;
-    if (ok) ok = hipMemset(al->ticket, 0, sizeof(unsigned int)) == hipSuccess;
-    if (ok) ok = hipHostMalloc((void**)&al->hsums, ECC_NSUM * sizeof(double), hipHostMallocDefault) == hipSuccess;
+    ok = al->gray != nullptr;
     // pyramid geometry: halve while the short side stays >= 48 pixels
     {
         int lh = h, lw = w;
@@ -1206,11 +1281,11 @@ int mi_aligner_create(mi_aligner_t* out, int device, int height, int width, int 
         }
     }
     for (auto& L : al->lv) {
-        const size_t n = (size_t)L.h * L.w * 4;
-        L.tmpl = (float*)dalloc(n); L.img = (float*)dalloc(n); L.gx = (float*)dalloc(n); L.gy = (float*)dalloc(n);
-        ok = ok && L.tmpl && L.img && L.gx && L.gy;
+        L.tmpl = (float*)dalloc((size_t)L.h * L.w * 4);
+        ok = ok && L.tmpl;
     }
-    if (!ok) {
+    if (ok) ok = hipStreamCreateWithFlags(&al->own, hipStreamNonBlocking) == hipSuccess;
+    if (!ok || aligner_reserve(al, 1)) {
         aligner_free(al);
         delete al;
         return fail(MI_ERR_NOMEM, "out of device memory");
@@ -1231,20 +1306,37 @@ int mi_aligner_destroy(mi_aligner_t al) {
 int mi_aligner_set_reference(mi_aligner_t al, void* stream, const void* dev_ref) {
     if (!al || !dev_ref) return fail(MI_ERR_INVALID, "null argument");
     MI_HIP(hipSetDevice(al->device));
-    int rc = aligner_build(al, (hipStream_t)stream, dev_ref, true);
+    int rc = aligner_build(al, stream ? (hipStream_t)stream : al->own, dev_ref, true, 0);
     if (rc) return rc;
     al->have_ref = true;
     return MI_OK;
 }
 
+int mi_aligner_estimate_batch(mi_aligner_t al, void* stream, const void* const* dev_movs, int n, int max_iters,
+                              double eps, double* M_out, double* cc_out, int* iters_out) {
+    if (!al || !dev_movs || !M_out) return fail(MI_ERR_INVALID, "null argument");
+    if (n < 1 || n > ECC_MAXF) return fail(MI_ERR_INVALID, "batch of %d frames (1..%d)", n, ECC_MAXF);
+    if (!al->have_ref) return fail(MI_ERR_STATE, "mi_aligner_set_reference has not been called");
+    for (int k = 0; k < n; ++k)
+        if (!dev_movs[k]) return fail(MI_ERR_INVALID, "null frame %d", k);
+    MI_HIP(hipSetDevice(al->device));
+    hipStream_t st = stream ? (hipStream_t)stream : al->own;
+    int rc = aligner_reserve(al, n);
+    if (rc) return rc;
+    for (int k = 0; k < n; ++k)
+        if ((rc = aligner_build(al, st, dev_movs[k], false, k))) return rc;
+    return aligner_solve(al, st, n, max_iters, eps, M_out, cc_out, iters_out);
+}
+
 int mi_aligner_estimate(mi_aligner_t al, void* stream, const void* dev_mov, int max_iters, double eps,
                         double* M_out, double* cc_out, int* iters_out) {
-    if (!al || !dev_mov || !M_out) return fail(MI_ERR_INVALID, "null argument");
-    if (!al->have_ref) return fail(MI_ERR_STATE, "mi_aligner_set_reference has not been called");
-    MI_HIP(hipSetDevice(al->device));
-    int rc = aligner_build(al, (hipStream_t)stream, dev_mov, false);
+    if (!dev_mov) return fail(MI_ERR_INVALID, "null argument");
+    double cc = -2.0;
+    int rc = mi_aligner_estimate_batch(al, stream, &dev_mov, 1, max_iters, eps, M_out, &cc, iters_out);
     if (rc) return rc;
-    return aligner_solve(al, (hipStream_t)stream, max_iters, eps, M_out, cc_out, iters_out);
+    if (cc_out) *cc_out = cc;
+    if (cc == -2.0) return fail(MI_ERR_STATE, "ECC: no overlap, constant image or degenerate transform");
+    return MI_OK;
 }
 
 int mi_ecc_similarity(int device, const void* host_ref, const void* host_mov, int height, int width,
@@ -1264,7 +1356,7 @@ int mi_ecc_similarity(int device, const void* host_ref, const void* host_mov, in
         MI_HIP(hipMemcpy(raw, host_ref, nb, hipMemcpyHostToDevice));
         int r = mi_aligner_set_reference(al, nullptr, raw);
         if (r) return r;
-        MI_HIP(hipDeviceSynchronize());
+        MI_HIP(hipStreamSynchronize(al->own));   // the pyramid is built before `raw` is reused
         MI_HIP(hipMemcpy(raw, host_mov, nb, hipMemcpyHostToDevice));
         return mi_aligner_estimate(al, nullptr, raw, max_iters, eps, M_out, cc_out, iters_out);
     };

@@ -77,16 +77,32 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 
 constexpr int ECC_MAX_BLOCKS = 1024;
+constexpr int ECC_MAXF = 16;  // moving frames per batched launch
 
-// One Gauss-Newton accumulation pass: every reference pixel samples the moving image (and its
-// gradients) at W(x) and adds its terms to 28 sums (double).  `step`: pixel stride (sub-sampling
-// of the sum at the finest levels).  Deterministic two-stage reduction in one launch: each block
-// writes its 28 partial sums to partial[block][28]; the block that draws the last ticket adds
-// the partials in block order and writes `sums` (host-visible memory), then re-arms the ticket.
+struct EccBatch {
+    EccParams p[ECC_MAXF];
+    int active[ECC_MAXF];
+};
+
+// One Gauss-Newton accumulation pass for up to ECC_MAXF moving frames against one template
+// (blockIdx.y = frame; frames whose `active` flag is 0 return at once): every reference pixel
+// samples the moving image (and its gradients) at W(x) and adds its terms to 28 sums (double).
+// `step`: pixel stride (sub-sampling of the sum at the finest levels).  Deterministic two-stage
+// reduction in one launch: each block writes its 28 partial sums to partial[frame][block][28];
+// the block that draws the frame's last ticket adds the partials in block order and writes
+// sums[frame][28] (host-visible memory), then re-arms the ticket.
+// img / gx / gy: frame f at base + f * fstride.
 __global__ __launch_bounds__(256) void ecc_accumulate(const float* __restrict__ tmpl, const float* __restrict__ img,
-                               const float* __restrict__ gx, const float* __restrict__ gy, int h, int w,
-                               EccParams p, int step, double* __restrict__ partial,
+                               const float* __restrict__ gx, const float* __restrict__ gy, size_t fstride, int h,
+                               int w, EccBatch pb, int step, double* __restrict__ partial,
                                unsigned int* __restrict__ ticket, double* __restrict__ sums) {
+    const int f = blockIdx.y;
+    if (!pb.active[f]) return;
+    const EccParams p = pb.p[f];
+    img += (size_t)f * fstride; gx += (size_t)f * fstride; gy += (size_t)f * fstride;
+    partial += (size_t)f * ECC_MAX_BLOCKS * ECC_NSUM;
+    ticket += f;
+    sums += (size_t)f * ECC_NSUM;
     double acc[ECC_NSUM];
 #pragma unroll
     for (int i = 0; i < ECC_NSUM; ++i) acc[i] = 0.0;

@@ -109,12 +109,18 @@ def align_and_stack(frames, ref_idx=-1, estimator=None, alignment_config=None, f
 
 def align_and_stack_device(dev_frames, n_frames, height, width, dtype, ref_idx=-1, alignment_config=None,
                            min_correlation=0.5, max_iters=60, device=0, batch_frames=16, out_dev=None,
-                           balance=None, **stack_kwargs):
+                           balance=None, ecc_batch=16, **stack_kwargs):
     """BASELINE config 4 with every frame resident in HBM: `dev_frames` is the device address of
     `n_frames` contiguous H x W x 3 frames.  Each frame is registered against frames[ref_idx] by
     the device ECC estimator (mi_aligner_*), warped with the blurred replicate border of
     align.py:238-251 straight into the stacker's input batch, and fused.  No frame crosses PCIe;
     per frame the host sees 28 doubles per Gauss-Newton iteration.
+
+    The transforms are estimated `ecc_batch` (<= 16) frames at a time in one batched Gauss-Newton
+    (mi_aligner_estimate_batch: one launch and one host round trip per iteration for the whole batch --
+    a single frame's chain of small kernels leaves the GPU mostly idle), then the frames are warped and
+    fused in order.  (Estimating on helper threads, one handle each or one batch ahead, measured no
+    faster: the round trips serialise in the runtime.)
 
     `balance`: optional dict of BalanceFrames options (channel, corr_map, subsample, fast_subsampling,
     mask_size, intensity_interval): every aligned frame is then balanced against the reference frame
@@ -140,6 +146,7 @@ def align_and_stack_device(dev_frames, n_frames, height, width, dtype, ref_idx=-
     stack = _lib.Stack(height, width, in_dtype=dt, out_dtype=dt, device=device, batch_frames=batch_frames,
                        **stack_kwargs)
     aligner = _lib.Aligner(height, width, dt, subsample=max(1, int(cfg['subsample'])), device=device)
+    ecc_batch = max(1, min(int(ecc_batch), _lib.Aligner.MAX_BATCH))
     tmp = _lib.DeviceBuffer(fb, device)
     mask = _lib.DeviceBuffer(height * width, device)
     # two batches of warped frames: one is being fused while the next is being filled
@@ -148,7 +155,17 @@ def align_and_stack_device(dev_frames, n_frames, height, width, dtype, ref_idx=-
     bv = (C.c_double * 4)(*(list(cfg['border_value']) + [0, 0, 0, 0])[:4])
     transforms, ccs = [], []
     cur, filled = 0, 0
+    st = stack.stream   # warps, balance and the reference-frame copy run on the stacker's own stream
     aligner.set_reference(dev_frames + ref_idx * fb)
+    estimates = {}
+
+    def estimate_from(i):
+        """transforms of the next `ecc_batch` moving frames starting at frame i"""
+        idx = [k for k in range(i, n_frames) if k != ref_idx][:ecc_batch]
+        ms, cs, _ = aligner.estimate_batch([dev_frames + k * fb for k in idx], max_iters=max_iters)
+        for k, m, c in zip(idx, ms, cs):
+            estimates[k] = (m, float(c))
+
     corr = None
     if balance is not None:
         from .balance import LumiCorrection, RGBCorrection
@@ -165,7 +182,7 @@ def align_and_stack_device(dev_frames, n_frames, height, width, dtype, ref_idx=-
     def flush():
         nonlocal cur, filled
         if filled:
-            lib.mi_device_synchronize(device)   # warps ran on the default stream; previous fuse done
+            stack.sync()   # the warps (on the stacker's stream) and the previous fuse are done
             stack.push_frames_device(batches[cur].ptr, filled, fb)
             cur ^= 1
             filled = 0
@@ -175,19 +192,21 @@ def align_and_stack_device(dev_frames, n_frames, height, width, dtype, ref_idx=-
             src = dev_frames + i * fb
             dst = batches[cur].ptr + filled * fb
             if i == ref_idx:
-                _lib.check(lib.mi_memcpy_d2d(device, dst, src, fb))   # align.py:279-280
+                _lib.check(lib.mi_memcpy_d2d_async(device, st, dst, src, fb))   # align.py:279-280
                 transforms.append(None)
                 ccs.append(1.0)
             else:
-                m, cc, _ = aligner.estimate(src, max_iters=max_iters)
+                if i not in estimates:
+                    estimate_from(i)
+                m, cc = estimates.pop(i)
                 if not cc >= min_correlation:
                     raise AlignmentError(i, f"correlation {cc:.3f} < {min_correlation}")
                 mm = (C.c_double * 6)(*m.reshape(6))
-                _lib.check(lib.mi_warp_affine_device(device, None, src, dst, tmp.ptr, mask.ptr, height, width,
+                _lib.check(lib.mi_warp_affine_device(device, st, src, dst, tmp.ptr, mask.ptr, height, width,
                                                      _lib.DTYPE_CODE[dt], mm, mode, bv, 21,
                                                      float(cfg['border_blur'])))
                 if corr is not None:
-                    corr.apply_correction_device(i, dst)
+                    corr.apply_correction_device(i, dst, st)
                 transforms.append(m)
                 ccs.append(cc)
             filled += 1

@@ -165,3 +165,32 @@ def test_align_and_stack_device_equals_host_pipeline(L, oracle):
                                         out_dev=out.ptr)
     assert none is None
     np.testing.assert_array_equal(out.download((h, w, 3), np.uint8), fused_dev)
+
+
+def test_batched_estimate_equals_single_estimates(L, oracle):
+    """mi_aligner_estimate_batch: every frame gets exactly what a single estimate gives (the per-frame
+    sums are reduced in the same order), including a frame the method fails on."""
+    h, w = 384, 512
+    frames, truth = [], []
+    for k, (th, s, tx, ty) in enumerate([(0.2, 1.001, 3.0, -2.0), (-0.4, 0.998, -5.5, 4.25), (0.0, 1.0, 0.0, 0.0),
+                                          (1.0, 1.004, 8.0, 6.0)]):
+        T = similarity(th, s, tx, ty, (w - 1) / 2, (h - 1) / 2)
+        ref, mov = make_pair(oracle, T, h=h, w=w, seed=9)
+        frames.append(mov)
+    flat = np.full_like(frames[0], 77)
+    frames.insert(2, flat)
+    buf = L.DeviceBuffer((len(frames) + 1) * ref.nbytes)
+    buf.upload(ref)
+    for k, fr in enumerate(frames):
+        buf.upload(fr, (k + 1) * ref.nbytes)
+    al = L.Aligner(h, w, np.uint8, subsample=1)
+    al.set_reference(buf.ptr)
+    ptrs = [buf.ptr + (k + 1) * ref.nbytes for k in range(len(frames))]
+    ms, ccs, its = al.estimate_batch(ptrs)
+    assert ccs[2] == -2.0 and np.array_equal(ms[2], [[1, 0, 0], [0, 1, 0]])
+    for k in (0, 1, 3, 4):
+        m1, cc1, it1 = al.estimate(ptrs[k])
+        assert np.array_equal(ms[k], m1) and ccs[k] == cc1 and its[k] == it1, k
+    with pytest.raises(Exception):
+        al.estimate(ptrs[2])
+    al.close()
