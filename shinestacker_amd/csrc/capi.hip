@@ -463,13 +463,22 @@ int round_sat(double v, int hi) {
 }
 
 template <typename T>
-int warp_launch(hipStream_t st, const void* src, void* warp, void* out, uint8_t* valid, int h, int w,
+int warp_launch(hipStream_t st, const void* src, void* side, void* out, uint8_t* valid, int h, int w,
                 const AffineArgs& a, bool blur, const GaussArgs& g) {
-    const dim3 blk(64, 4), grid(cdiv(w, 64), cdiv(h, 4));
-    hipLaunchKernelGGL((warp_affine_kernel<T>), grid, blk, 0, st, (const T*)src, (T*)warp, valid, a);
-    if (blur)
-        hipLaunchKernelGGL((border_blur_composite_kernel<T>), grid, blk, 0, st, (const T*)warp, valid,
-                           (T*)out, h, w, g);
+    // four pixels per thread; whole-dword stores when every row starts 4-byte aligned
+    const bool vec = (w % 4) == 0 && ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(valid)) & 3) == 0;
+    const dim3 blk(64, 4), grid(cdiv(cdiv(w, 4), 64), cdiv(h, 4));
+    if (vec) hipLaunchKernelGGL((warp_affine_kernel<T, true>), grid, blk, 0, st, (const T*)src, (T*)out, valid, a);
+    else hipLaunchKernelGGL((warp_affine_kernel<T, false>), grid, blk, 0, st, (const T*)src, (T*)out, valid, a);
+    if (blur) {
+        // the warped image goes straight to `out`; the few pixels outside the source frame are blurred
+        // from it into `side` and copied back (two sparse passes over the mask)
+        const size_t n = (size_t)h * w;
+        hipLaunchKernelGGL((border_blur_collect<T>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st,
+                           (const T*)out, valid, (T*)side, h, w, g);
+        hipLaunchKernelGGL((border_blur_scatter<T>), dim3((unsigned)((n / 16 + 256) / 256)), dim3(256), 0, st,
+                           (T*)out, valid, (const T*)side, h, w);
+    }
     MI_HIP(hipGetLastError());
     return MI_OK;
 }
@@ -1205,7 +1214,7 @@ int mi_warp_affine_device(int device, void* stream, const void* dev_src, void* d
         sum = 1.0 / sum;
         for (int i = 0; i < blur_ksize; ++i) g.k[i] = (float)(t[i] * sum);
     }
-    void* warp = blur ? dev_tmp : dev_dst;
+    void* warp = dev_tmp;
     if (dtype == MI_U8)
         return warp_launch<uint8_t>((hipStream_t)stream, dev_src, warp, dev_dst, (uint8_t*)dev_mask, height, width, a, blur, g);
     return warp_launch<uint16_t>((hipStream_t)stream, dev_src, warp, dev_dst, (uint8_t*)dev_mask, height, width, a, blur, g);

@@ -21,15 +21,11 @@ __device__ __forceinline__ int cv_round_d(double v) {
     return (int)rint(v);  // round half to even, as cvRound / lrint
 }
 
+// one destination pixel: the 3 channel values and the mask bit
 template <typename T>
-__global__ void warp_affine_kernel(const T* __restrict__ src, T* __restrict__ dst,
-                                   uint8_t* __restrict__ valid, AffineArgs a) {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+__device__ __forceinline__ void warp_pixel(const T* __restrict__ src, const AffineArgs& a, int x, int X0, int Y0,
+                                           int out[3], int& ok) {
     const int h = a.h, w = a.w;
-    if (x >= w || y >= h) return;
-    const int X0 = cv_round_d((a.iM[1] * y + a.iM[2]) * 1024.0) + 16;
-    const int Y0 = cv_round_d((a.iM[4] * y + a.iM[5]) * 1024.0) + 16;
     const int X = (X0 + cv_round_d(a.iM[0] * x * 1024.0)) >> 5;
     const int Y = (Y0 + cv_round_d(a.iM[3] * x * 1024.0)) >> 5;
     const int sx = X >> 5, sy = Y >> 5, fx = X & 31, fy = Y & 31;
@@ -38,38 +34,117 @@ __global__ void warp_affine_kernel(const T* __restrict__ src, T* __restrict__ ds
     const bool in00 = inx0 && iny0, in01 = inx1 && iny0, in10 = inx0 && iny1, in11 = inx1 && iny1;
     int iw0 = (32 - fy) * (32 - fx) * 32, iw1 = (32 - fy) * fx * 32, iw2 = fy * (32 - fx) * 32, iw3 = fy * fx * 32;
     if (fx == 0 && fy == 0) { iw0 = 32767; iw3 = 1; }
-    if (valid) {
+    {
         const int s = (in00 ? iw0 : 0) + (in01 ? iw1 : 0) + (in10 ? iw2 : 0) + (in11 ? iw3 : 0);
-        valid[(size_t)y * w + x] = (uint8_t)(((s + 16384) >> 15) != 0);
+        ok = ((s + 16384) >> 15) != 0;
     }
     const bool all_out = !(in00 || in01 || in10 || in11);
     const int x0 = min(max(sx, 0), w - 1), x1 = min(max(sx + 1, 0), w - 1);
     const int y0 = min(max(sy, 0), h - 1), y1 = min(max(sy + 1, 0), h - 1);
     const bool rep = a.mode == 1;
+    // replicate: clamped taps; constant: in-image taps or the border value.  A tap's three channels
+    // come in with one (unaligned) 32-bit load -- the byte loads were the bottleneck (12 per pixel
+    // through the texture-address unit); the very last pixel of the image is read one byte early so
+    // the load never leaves the buffer.
+    const size_t last = (size_t)h * w - 1;
+    auto tap = [&](int yy, int xx, int t[3]) {
+        const size_t pi = (size_t)yy * w + xx;
+        if constexpr (sizeof(T) == 1) {
+            uint32_t u;
+            if (pi != last) {
+                __builtin_memcpy(&u, src + pi * 3, 4);
+            } else {
+                __builtin_memcpy(&u, src + pi * 3 - 1, 4);
+                u >>= 8;
+            }
+            t[0] = u & 255u; t[1] = (u >> 8) & 255u; t[2] = (u >> 16) & 255u;
+        } else {
+            uint32_t u;
+            uint16_t v2;
+            __builtin_memcpy(&u, src + pi * 3, 4);
+            __builtin_memcpy(&v2, src + pi * 3 + 2, 2);
+            t[0] = u & 65535u; t[1] = u >> 16; t[2] = v2;
+        }
+    };
+    int q00[3], q01[3], q10[3], q11[3];
+    tap(rep ? y0 : min(max(sy, 0), h - 1), rep ? x0 : min(max(sx, 0), w - 1), q00);
+    tap(rep ? y0 : min(max(sy, 0), h - 1), rep ? x1 : min(max(sx + 1, 0), w - 1), q01);
+    tap(rep ? y1 : min(max(sy + 1, 0), h - 1), rep ? x0 : min(max(sx, 0), w - 1), q10);
+    tap(rep ? y1 : min(max(sy + 1, 0), h - 1), rep ? x1 : min(max(sx + 1, 0), w - 1), q11);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        const size_t o = ((size_t)y * w + x) * 3 + c;
         const int cb = a.border[c];
-        // replicate: clamped taps; constant: in-image taps or the border value
-        const T t00 = (rep || in00) ? src[((size_t)(rep ? y0 : sy) * w + (rep ? x0 : sx)) * 3 + c] : (T)cb;
-        const T t01 = (rep || in01) ? src[((size_t)(rep ? y0 : sy) * w + (rep ? x1 : sx + 1)) * 3 + c] : (T)cb;
-        const T t10 = (rep || in10) ? src[((size_t)(rep ? y1 : sy + 1) * w + (rep ? x0 : sx)) * 3 + c] : (T)cb;
-        const T t11 = (rep || in11) ? src[((size_t)(rep ? y1 : sy + 1) * w + (rep ? x1 : sx + 1)) * 3 + c] : (T)cb;
+        const T t00 = (rep || in00) ? (T)q00[c] : (T)cb;
+        const T t01 = (rep || in01) ? (T)q01[c] : (T)cb;
+        const T t10 = (rep || in10) ? (T)q10[c] : (T)cb;
+        const T t11 = (rep || in11) ? (T)q11[c] : (T)cb;
         int r;
         if constexpr (sizeof(T) == 1) {
             r = ((int)t00 * iw0 + (int)t01 * iw1 + (int)t10 * iw2 + (int)t11 * iw3 + 16384) >> 15;
             r = min(max(r, 0), 255);
         } else {
             const float wx1 = fx * (1.0f / 32), wx0 = 1.0f - wx1, wy1 = fy * (1.0f / 32), wy0 = 1.0f - wy1;
-            const float p0 = (float)t00 * (wy0 * wx0), p1 = (float)t01 * (wy0 * wx1);
-            const float p2 = (float)t10 * (wy1 * wx0), p3 = (float)t11 * (wy1 * wx1);
-            float s = p0 + p1;
-            s = s + p2;
-            s = s + p3;
+            const float q0 = (float)t00 * (wy0 * wx0), q1 = (float)t01 * (wy0 * wx1);
+            const float q2 = (float)t10 * (wy1 * wx0), q3 = (float)t11 * (wy1 * wx1);
+            float s = q0 + q1;
+            s = s + q2;
+            s = s + q3;
             r = min(max((int)rintf(s), 0), 65535);
         }
         if (!rep && all_out) r = cb;
-        dst[o] = (T)r;
+        out[c] = r;
+    }
+}
+
+// Four consecutive destination pixels per thread: 12 (uint8) / 24 (uint16) contiguous output bytes
+// and the 4 mask bytes leave as whole dwords when the row start allows it (VEC: w % 4 == 0 and
+// 4-byte aligned images).
+template <typename T, bool VEC>
+__global__ __launch_bounds__(256) void warp_affine_kernel(const T* __restrict__ src, T* __restrict__ dst,
+                                                          uint8_t* __restrict__ valid, AffineArgs a) {
+    const int xq = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    const int h = a.h, w = a.w;
+    if (xq >= w || y >= h) return;
+    const int X0 = cv_round_d((a.iM[1] * y + a.iM[2]) * 1024.0) + 16;
+    const int Y0 = cv_round_d((a.iM[4] * y + a.iM[5]) * 1024.0) + 16;
+    int v[4][3], ok[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        ok[p] = 0;
+        v[p][0] = v[p][1] = v[p][2] = 0;
+        if (xq + p < w) warp_pixel<T>(src, a, xq + p, X0, Y0, v[p], ok[p]);
+    }
+    const size_t px = (size_t)y * w + xq;
+    if constexpr (VEC) {
+        if constexpr (sizeof(T) == 1) {
+            uint32_t o[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                o[d] = 0;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) o[d] |= (uint32_t)v[(4 * d + b) / 3][(4 * d + b) % 3] << (8 * b);
+            }
+            uint32_t* d4 = reinterpret_cast<uint32_t*>(dst + px * 3);
+            d4[0] = o[0]; d4[1] = o[1]; d4[2] = o[2];
+        } else {
+            uint32_t* d4 = reinterpret_cast<uint32_t*>(dst + px * 3);
+#pragma unroll
+            for (int d = 0; d < 6; ++d)
+                d4[d] = (uint32_t)v[(2 * d) / 3][(2 * d) % 3] | ((uint32_t)v[(2 * d + 1) / 3][(2 * d + 1) % 3] << 16);
+        }
+        if (valid)
+            *reinterpret_cast<uint32_t*>(valid + px) =
+                (uint32_t)ok[0] | ((uint32_t)ok[1] << 8) | ((uint32_t)ok[2] << 16) | ((uint32_t)ok[3] << 24);
+    } else {
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+            if (xq + p < w) {
+                dst[(px + p) * 3 + 0] = (T)v[p][0];
+                dst[(px + p) * 3 + 1] = (T)v[p][1];
+                dst[(px + p) * 3 + 2] = (T)v[p][2];
+                if (valid) valid[px + p] = (uint8_t)ok[p];
+            }
     }
 }
 
@@ -78,21 +153,11 @@ struct GaussArgs {
     int ksize;
 };
 
-// out = valid ? warp : gaussian_blur(warp); blur = horizontal pass then vertical pass in float32,
-// taps in index order, REFLECT101, round-half-even + saturate (align_oracle.c).
+// gaussian_blur(img) at one pixel: horizontal pass then vertical pass in float32, taps in index
+// order, REFLECT101, round-half-even + saturate (align_oracle.c)
 template <typename T>
-__global__ void border_blur_composite_kernel(const T* __restrict__ warp, const uint8_t* __restrict__ valid,
-                                             T* __restrict__ out, int h, int w, GaussArgs g) {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y * blockDim.y + threadIdx.y;
-    if (x >= w || y >= h) return;
-    const size_t px = (size_t)y * w + x;
-    if (valid[px]) {
-        out[px * 3 + 0] = warp[px * 3 + 0];
-        out[px * 3 + 1] = warp[px * 3 + 1];
-        out[px * 3 + 2] = warp[px * 3 + 2];
-        return;
-    }
+__device__ __forceinline__ void blur_at(const T* __restrict__ img, int h, int w, int y, int x, const GaussArgs& g,
+                                        int out[3]) {
     const int r = g.ksize / 2;
     const int maxv = sizeof(T) == 1 ? 255 : 65535;
     float acc[3] = {0.f, 0.f, 0.f};
@@ -101,7 +166,7 @@ __global__ void border_blur_composite_kernel(const T* __restrict__ warp, const u
         float row[3] = {0.f, 0.f, 0.f};
         for (int dx = 0; dx < g.ksize; ++dx) {
             const int xx = r101_loop(x + dx - r, w);
-            const T* p = warp + ((size_t)yy * w + xx) * 3;
+            const T* p = img + ((size_t)yy * w + xx) * 3;
             const float k = g.k[dx];
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
@@ -116,7 +181,119 @@ __global__ void border_blur_composite_kernel(const T* __restrict__ warp, const u
         }
     }
 #pragma unroll
-    for (int c = 0; c < 3; ++c) out[px * 3 + c] = (T)min(max((int)rintf(acc[c]), 0), maxv);
+    for (int c = 0; c < 3; ++c) out[c] = min(max((int)rintf(acc[c]), 0), maxv);
+}
+
+// out = valid ? warp : gaussian_blur(warp), in place on `img` in two sparse passes: the pixels whose
+// mask is 0 (a frame along the borders: a few columns at the sides, wedges where the frame rotated)
+// get their blurred value computed from the untouched image into `side` (same index), then copied back.
+//
+// Pass 0 (collect), one wave per 64 consecutive pixels.  A wave with no masked pixel leaves at once.
+// A wave with many does one pixel per lane (blur_at).  A wave with few (the side columns: 1-3 lanes)
+// works through them 64 / ksize at a time instead of idling 60 lanes for 441 taps: ksize lanes per
+// pixel, lane r does the horizontal pass of window row r (taps in index order), the first lane of the
+// group adds the ksize row results in row order (shuffles, no LDS) -- the same float32 operations in
+// the same order as align_oracle.c either way.
+template <typename T>
+__global__ __launch_bounds__(64) void border_blur_collect(const T* __restrict__ img, const uint8_t* __restrict__ valid,
+                                                          T* __restrict__ side, int h, int w, GaussArgs g) {
+    const int lane = threadIdx.x;
+    const size_t n = (size_t)h * w;
+    const size_t base = (size_t)blockIdx.x * 64;
+    const size_t pi = base + lane;
+    const bool masked = pi < n && valid[pi] == 0;
+    const unsigned long long ballot = __ballot(masked);
+    if (ballot == 0) return;
+    const int nm = __popcll(ballot);
+    const int ks = g.ksize, r = ks / 2;
+    const int maxv = sizeof(T) == 1 ? 255 : 65535;
+    const int per = 64 / ks;  // pixels per cooperative round
+    if (nm > 4 * per) {
+        if (masked) {
+            const int y = (int)(pi / w), x = (int)(pi - (size_t)y * w);
+            int o[3];
+            blur_at<T>(img, h, w, y, x, g, o);
+            side[pi * 3 + 0] = (T)o[0]; side[pi * 3 + 1] = (T)o[1]; side[pi * 3 + 2] = (T)o[2];
+        }
+        return;
+    }
+    const int slot = lane / ks, wr = lane - slot * ks;
+    unsigned long long rest = ballot;
+    while (rest) {   // wave-uniform
+        // the next `per` masked lanes: group `slot` takes the slot-th of them
+        unsigned long long pick = rest;
+        int src_lane = -1;
+        for (int k = 0; k < per; ++k) {
+            if (!pick) break;
+            const int b = __ffsll((long long)pick) - 1;
+            if (k == slot) src_lane = b;
+            pick &= pick - 1;
+        }
+        rest = pick;
+        const bool act = slot < per && src_lane >= 0;
+        const size_t qi = base + (act ? src_lane : 0);
+        float q[3] = {0.f, 0.f, 0.f};
+        if (act) {
+            const int y = (int)(qi / w), x = (int)(qi - (size_t)y * w);
+            const int yy = r101_loop(y + wr - r, h);
+            float row[3] = {0.f, 0.f, 0.f};
+            for (int dx = 0; dx < ks; ++dx) {
+                const int xx = r101_loop(x + dx - r, w);
+                const T* p = img + ((size_t)yy * w + xx) * 3;
+                const float k = g.k[dx];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float pr = k * (float)p[c];
+                    row[c] = row[c] + pr;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) q[c] = g.k[wr] * row[c];
+        }
+        // vertical pass: the group's first lane adds the row results in row order
+        float acc[3] = {0.f, 0.f, 0.f};
+        for (int dy = 0; dy < ks; ++dy) {
+            const int from = min(slot * ks + dy, 63);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float v = __shfl(q[c], from, 64);
+                acc[c] = acc[c] + v;
+            }
+        }
+        if (act && wr == 0) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) side[qi * 3 + c] = (T)min(max((int)rintf(acc[c]), 0), maxv);
+        }
+    }
+}
+
+// Pass 1 (scatter): masked pixels take their blurred value from `side`.
+template <typename T>
+__global__ __launch_bounds__(256) void border_blur_scatter(T* __restrict__ img, const uint8_t* __restrict__ valid,
+                                                           const T* __restrict__ side, int h, int w) {
+    const size_t n = (size_t)h * w;
+    const size_t i0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
+    if (i0 >= n) return;
+    uint32_t m[4];
+    if (i0 + 16 <= n && (reinterpret_cast<uintptr_t>(valid) & 15) == 0) {
+        const uint4 q = *reinterpret_cast<const uint4*>(valid + i0);
+        m[0] = q.x; m[1] = q.y; m[2] = q.z; m[3] = q.w;
+        if (m[0] == 0x01010101u && m[1] == 0x01010101u && m[2] == 0x01010101u && m[3] == 0x01010101u)
+            return;  // all 16 valid: the common case
+    } else {
+        for (int k = 0; k < 4; ++k) {
+            m[k] = 0;
+            for (int b = 0; b < 4; ++b) {
+                const size_t i = i0 + 4 * k + b;
+                m[k] |= (uint32_t)(i < n ? valid[i] : 1) << (8 * b);
+            }
+        }
+    }
+    for (int k = 0; k < 16; ++k) {
+        if ((m[k >> 2] >> (8 * (k & 3))) & 0xffu) continue;
+        const size_t i = i0 + k;
+        img[i * 3 + 0] = side[i * 3 + 0]; img[i * 3 + 1] = side[i * 3 + 1]; img[i * 3 + 2] = side[i * 3 + 2];
+    }
 }
 
 }  // namespace mi
