@@ -644,7 +644,7 @@ int aligner_solve(mi_aligner* al, hipStream_t st, int n, int max_iters, double e
         const EccLevel& L = lv[l];
         const double cx = 0.5 * (L.w - 1), cy = 0.5 * (L.h - 1);
         const size_t np = (size_t)L.h * L.w;
-        const int step = np > (size_t)6000000 ? 2 : 1;
+        const int step = np >= (size_t)4000000 ? 2 : 1;   // 1M+ samples are plenty for 4 parameters
         // ~8 pixels per thread, at most ECC_MAX_BLOCKS blocks (4 per CU)
         const size_t work = (np / ((size_t)step * step) + 2047) / 2048;
         const unsigned nblk = (unsigned)(work < 1 ? 1 : (work > (size_t)ECC_MAX_BLOCKS ? ECC_MAX_BLOCKS : work));
