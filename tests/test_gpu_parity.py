@@ -325,3 +325,40 @@ def test_sharded_state_combine_on_one_gpu(L):
     for p in parts:
         p.close()
     whole.close()
+
+
+def test_combiner_under_rccl_world_1(tmp_path):
+    """Combiner.combine() (flat all-levels exchange over torch.distributed / RCCL) in a fresh process
+    -- torch's HIP runtime has to be loaded before libmi355stack.so -- with a world of one rank: the
+    exchange, the HIP select and the copy back must leave the stack's result unchanged."""
+    import subprocess
+    import sys
+    script = r'''
+import os, sys
+import numpy as np
+import torch, torch.distributed as dist
+torch.cuda.init()
+sys.path.insert(0, os.getcwd())
+from shinestacker_amd import _lib as L
+from shinestacker_amd.multigpu import Combiner
+dist.init_process_group("nccl", rank=0, world_size=1)
+rng = np.random.default_rng(5)
+frames = [rng.integers(0, 256, (200, 296, 3), dtype=np.uint8) for _ in range(5)]
+ref = L.Stack(200, 296)
+for f in frames: ref.push_frame(f)
+want = ref.finish()
+st = L.Stack(200, 296)
+st.set_first_index(0)
+for f in frames: st.push_frame(f)
+Combiner(st).combine()
+got = st.finish()
+assert np.array_equal(got, want), int((got != want).sum())
+for lv in range(st.levels):
+    assert np.array_equal(st.tap(L.TAP_INDEX, lv), ref.tap(L.TAP_INDEX, lv))
+dist.destroy_process_group()
+print("COMBINE_OK")
+'''
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=600,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert "COMBINE_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]

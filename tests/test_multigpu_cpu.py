@@ -70,15 +70,22 @@ def _worker(rank, world, port, ret):
         base_d = bases[so.idx_d - first, yy, xx]
         levels.append((so.b_ent, base_e, so.idx_e))
         levels.append((so.b_dev, base_d, so.idx_d))
-        out = []
-        for e, l, i in levels:
-            te = torch.from_numpy(np.ascontiguousarray(e).ravel().copy())
-            tl = torch.from_numpy(np.ascontiguousarray(l).ravel().copy())
-            ti = torch.from_numpy(np.ascontiguousarray(i).ravel().copy())
+        def tensors():
+            return [(torch.from_numpy(np.ascontiguousarray(e).ravel().copy()),
+                     torch.from_numpy(np.ascontiguousarray(l).ravel().copy()),
+                     torch.from_numpy(np.ascontiguousarray(i).ravel().copy())) for e, l, i in levels]
+        # level by level ...
+        per_level = tensors()
+        for te, tl, ti in per_level:
             multigpu.combine_state(te, tl, ti, dist.group.WORLD, _torch_select)
-            out.append((te.numpy(), tl.numpy(), ti.numpy()))
+        # ... and all levels in one flat exchange (what Combiner.combine uses): identical result
+        flat = tensors()
+        multigpu.combine_all(flat, dist.group.WORLD, _torch_select)
         if rank == 0:
-            ret["state"] = out
+            for a, b in zip(per_level, flat):
+                for x, y in zip(a, b):
+                    assert torch.equal(x, y)
+            ret["state"] = [(te.numpy(), tl.numpy(), ti.numpy()) for te, tl, ti in flat]
     finally:
         dist.destroy_process_group()
 
