@@ -11,8 +11,14 @@ CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(CSRC, "libmi355stack.so")
 SOURCES = ["capi.hip"]
-DEPS = ["capi.hip", "common.hpp", "kernels_simple.hpp", "kernels_tiled.hpp", "tiled_host.hpp",
-        os.path.join(ROOT, "include", "mi355stack.h")]
+
+
+def _deps():
+    """every source the library is built from: csrc/*.hip, csrc/*.hpp and the public header"""
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp"))) + \
+        [os.path.join(ROOT, "include", "mi355stack.h"), os.path.abspath(__file__)]
+
+
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
                "-fno-fast-math", "-fno-slp-vectorize", "-shared", "-fPIC", "-fvisibility=hidden",
                "-Wall", "-Wno-unused-function"]
@@ -29,14 +35,15 @@ def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    for d in DEPS:
-        p = d if os.path.isabs(d) else os.path.join(CSRC, d)
+    for p in _deps():
         if os.path.exists(p) and os.path.getmtime(p) > t:
             return True
     return False
 
 
 def build_extension(force=False, verbose=False):
+    # tuning flags from the environment always rebuild (they are not part of the time stamps)
+    force = force or bool(os.environ.get("MI_TILE_CFG") or os.environ.get("MI_EXTRA_FLAGS"))
     if not force and not needs_build():
         return LIB
     extra = []
