@@ -80,16 +80,18 @@ def combine_state(energy, lap, index, group, select_fn, width=3):
         dist.send(win_i.contiguous(), dst=root, group=group)
 
 
-def combine_all(states, group, select_fn, width=3):
+def combine_all(states, group, select_fn, width=3, with_index=True):
     """Combine the state of all levels at once.  `states`: list of (energy (n_l,), lap (n_l*width,),
     index (n_l,)) tensors of this rank; on return rank 0's tensors hold the combined state.
     Same arithmetic as `combine_state` level by level (the pixel chunks just run across level
-    boundaries), with 6 collectives in total."""
+    boundaries), with 6 collectives in total -- 4 with `with_index=False`, which leaves the winner
+    indices of rank 0 stale (they only feed the debug taps; the fused image needs E and lap alone)
+    and moves 16 instead of 20 bytes per pixel."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     e_all = torch.cat([e.reshape(-1) for e, _, _ in states])
     l_all = torch.cat([lp.reshape(-1) for _, lp, _ in states])
-    i_all = torch.cat([ix.reshape(-1) for _, _, ix in states])
+    i_all = torch.cat([ix.reshape(-1) for _, _, ix in states]) if with_index else None
     n = e_all.numel()
     bounds = chunk_bounds(n, world)
     sizes = [b - a for a, b in bounds]
@@ -101,7 +103,8 @@ def combine_all(states, group, select_fn, width=3):
                                input_split_sizes=[s_ * w for s_ in sizes], group=group)
         return out.view(world, mine * w)
 
-    win_e, win_l, win_i = select_fn(exchange(e_all, 1), exchange(l_all, width), exchange(i_all, 1))
+    win_e, win_l, win_i = select_fn(exchange(e_all, 1), exchange(l_all, width),
+                                    exchange(i_all, 1) if with_index else None)
 
     def to_root(win, full, w):
         # every rank's winners to rank 0: an all-to-all in which only rank 0 receives
@@ -112,14 +115,16 @@ def combine_all(states, group, select_fn, width=3):
 
     to_root(win_e, e_all, 1)
     to_root(win_l, l_all, width)
-    to_root(win_i, i_all, 1)
+    if with_index:
+        to_root(win_i, i_all, 1)
     if rank == 0:
         off = 0
         for e, lp, ix in states:
             m = e.numel()
             e.reshape(-1).copy_(e_all[off:off + m])
             lp.reshape(-1).copy_(l_all[off * width:(off + m) * width])
-            ix.reshape(-1).copy_(i_all[off:off + m])
+            if with_index:
+                ix.reshape(-1).copy_(i_all[off:off + m])
             off += m
 
 
@@ -148,15 +153,17 @@ class Combiner:
         world, m = cand_e.shape
         out_e = torch.empty(m, dtype=torch.float32, device=cand_e.device)
         out_l = torch.empty(cand_l.shape[1], dtype=torch.float32, device=cand_e.device)
-        out_i = torch.empty(m, dtype=torch.int32, device=cand_e.device)
+        out_i = torch.empty(m, dtype=torch.int32, device=cand_e.device) if cand_i is not None else None
         stream = torch.cuda.current_stream(cand_e.device).cuda_stream
         _lib.check(_lib.load().mi_combine_select(
             self.device, C.c_void_p(stream), world, cand_e.data_ptr(), cand_l.data_ptr(),
-            cand_i.data_ptr(), m, out_e.data_ptr(), out_l.data_ptr(), out_i.data_ptr()))
+            cand_i.data_ptr() if cand_i is not None else None, m, out_e.data_ptr(), out_l.data_ptr(),
+            out_i.data_ptr() if out_i is not None else None))
         return out_e, out_l, out_i
 
-    def combine(self):
-        """Call on every rank after its frames were pushed; rank 0 may then finish()."""
+    def combine(self, with_index=True):
+        """Call on every rank after its frames were pushed; rank 0 may then finish().
+        `with_index=False`: do not exchange the winner indices (debug taps only)."""
         st = self.stack
         st.sync()  # the library's streams are not torch's
         states = []
@@ -165,5 +172,5 @@ class Combiner:
             states.append((wrap_device(e_ptr, n, torch.float32, self.device),
                            wrap_device(l_ptr, n * 3, torch.float32, self.device),
                            wrap_device(i_ptr, n, torch.int32, self.device)))
-        combine_all(states, self.group, self._select_hip)
+        combine_all(states, self.group, self._select_hip, with_index=with_index)
         torch.cuda.current_stream(torch.device("cuda", self.device)).synchronize()

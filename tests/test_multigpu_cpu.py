@@ -39,7 +39,7 @@ def _torch_select(cand_e, cand_l, cand_i):
         best = torch.where(win, torch.full_like(best, r), best)
     ar = torch.arange(m)
     lap = cand_l.view(world, m, -1)[best, ar].reshape(-1)
-    return be, lap, cand_i[best, ar]
+    return be, lap, (cand_i[best, ar] if cand_i is not None else None)
 
 
 def _worker(rank, world, port, ret):
@@ -81,10 +81,14 @@ def _worker(rank, world, port, ret):
         # ... and all levels in one flat exchange (what Combiner.combine uses): identical result
         flat = tensors()
         multigpu.combine_all(flat, dist.group.WORLD, _torch_select)
+        # without the indices: energies and laps identical, indices untouched
+        noidx = tensors()
+        multigpu.combine_all(noidx, dist.group.WORLD, _torch_select, with_index=False)
         if rank == 0:
-            for a, b in zip(per_level, flat):
+            for a, b, c, orig in zip(per_level, flat, noidx, tensors()):
                 for x, y in zip(a, b):
                     assert torch.equal(x, y)
+                assert torch.equal(c[0], a[0]) and torch.equal(c[1], a[1]) and torch.equal(c[2], orig[2])
             ret["state"] = [(te.numpy(), tl.numpy(), ti.numpy()) for te, tl, ti in flat]
     finally:
         dist.destroy_process_group()
