@@ -184,6 +184,12 @@ int launch_level(mi_stack* s, int l, int set, const void* src, size_t src_stride
         a.ix0 = cdiv(8, BW) * BW;
         a.iy1 = (a.h - 8) / BH * BH;
         a.ix1 = (a.w - 8) / BW * BW;
+    } else if (TH % BH == 0 && TW % BW == 0) {
+        // origin on the border tiling, whole interior tiles from there
+        a.iy0 = cdiv(6, BH) * BH;
+        a.ix0 = cdiv(6, BW) * BW;
+        a.iy1 = a.iy0 + (a.h - 6 - a.iy0 > 0 ? (a.h - 6 - a.iy0) / TH * TH : 0);
+        a.ix1 = a.ix0 + (a.w - 6 - a.ix0 > 0 ? (a.w - 6 - a.ix0) / TW * TW : 0);
     } else {
         a.iy0 = cdiv(6, AY) * AY;
         a.ix0 = cdiv(6, AX) * AX;
