@@ -362,3 +362,39 @@ print("COMBINE_OK")
     r = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=600,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert "COMBINE_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_bunches_of_16bit_tiff_frames(L, oracle, tmp_path):
+    """BASELINE config 5 in miniature: 16-bit frames on disk, FocusStackBunch (frames=5, overlap=2) reusing
+    one stacker handle for every bunch, frames decoded on the host and pushed through the pinned async
+    upload path -- every bunch's output file equals the oracle's stack of that bunch, bit for bit."""
+    from shinestacker_amd import FocusStackBunch, PyramidStack, StackJob, get_bunches
+    from shinestacker_amd.imageio import read_img, write_img
+    rng = np.random.default_rng(50)
+    work = str(tmp_path)
+    os.makedirs(os.path.join(work, "in16"))
+    base = rng.integers(0, 65536, (136, 200, 3)).astype(np.uint16)
+    frames, names = [], []
+    for f in range(12):
+        fr = base.copy()
+        y0 = 10 * f
+        band = fr[y0:y0 + 30]
+        band[...] = rng.integers(0, 65536, band.shape)   # a band of fresh detail per frame
+        fr[: max(y0 - 5, 0)] //= 3
+        frames.append(fr)
+        names.append(f"f{f:02d}.tif")
+        write_img(os.path.join(work, "in16", names[-1]), fr)
+        assert np.array_equal(read_img(os.path.join(work, "in16", names[-1])), fr)   # lossless 16-bit round trip
+    job = StackJob("job", work, input_path="in16")
+    job.add_action(FocusStackBunch("bunches", PyramidStack(min_size=16, batch_frames=4), output_path="out16",
+                                   frames=5, overlap=2))
+    job.run()
+    outs = sorted(os.listdir(os.path.join(work, "out16")))
+    chunks = get_bunches(list(range(12)), 5, 2)
+    assert len(outs) == len(chunks) >= 3
+    for fname, idx in zip(outs, chunks):
+        so = oracle.StreamingOracle(136, 200, np.uint16, min_size=16, keep_gauss=False)
+        for k in idx:
+            so.push_frame(frames[k])
+        got = read_img(os.path.join(work, "out16", fname))
+        assert got.dtype == np.uint16 and np.array_equal(got, so.finish()), fname
