@@ -98,3 +98,28 @@ def test_u16_full_range_values(L, oracle):
     frames = [np.full((96, 96, 3), 65535, np.uint16), np.zeros((96, 96, 3), np.uint16)]
     frames[1][::2, ::2] = 65535
     check(L, oracle, frames)
+
+
+@pytest.mark.parametrize("h,w,off,pad", [(211, 333, 4, 12), (256, 512, 8, 0), (130, 262, 12, 36), (300, 1000, 0, 4000)])
+@pytest.mark.parametrize("src_dt", [np.float32, np.uint8, np.uint16])
+def test_device_frames_with_odd_alignment_and_stride(L, oracle, h, w, off, pad, src_dt):
+    """Frames resident on the device at a base address that is only 4-byte aligned and with a frame
+    stride larger than a frame: the vector staging paths (16-byte loads, dword loads of packed 8/16-bit
+    rows) must not assume more alignment than they check."""
+    rng = np.random.default_rng(h + w + off)
+    dt = np.uint8 if src_dt == np.float32 else src_dt
+    frames = make_frames(rng, (h, w), dt, 5)
+    so = oracle.StreamingOracle(h, w, dt, keep_gauss=False)
+    for f in frames:
+        so.push_frame(f)
+    want = so.finish()
+    per = h * w * 3 * np.dtype(src_dt).itemsize
+    stride = per + pad
+    buf = L.DeviceBuffer(off + stride * len(frames) + 64)
+    for i, f in enumerate(frames):
+        buf.upload(f.astype(src_dt), off + i * stride)
+    for impl in (L.IMPL_TILED, L.IMPL_STREAM, L.IMPL_SIMPLE):
+        st = L.Stack(h, w, in_dtype=src_dt, out_dtype=dt, impl=impl, batch_frames=3)
+        st.push_frames_device(buf.ptr + off, len(frames), stride)
+        assert np.array_equal(st.finish(), want), (impl, off, pad)
+        st.close()
