@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""One-off randomised differential stress: many random shapes / dtypes / batch sizes / options through
+the tiled (default) path against the streaming oracle.  Not part of the test suite (minutes on a GPU box):
+    python tools/stress_parity.py [n_cases] [seed]"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+
+
+def main():
+    from oracle import oracle
+    from shinestacker_amd import _lib as L
+    from test_gpu_fuzz import make_frames
+    oracle.build()
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1234)
+    bad = 0
+    for case in range(n_cases):
+        h = int(rng.integers(40, 700))
+        w = int(rng.integers(40, 900))
+        if case % 7 == 0:   # widths around the tile / border arithmetic
+            w = int(rng.choice([64 + 6 + 32, 32 + 64 + 5, 32 + 64 + 6, 32 + 64 + 7, 32 + 128 + 6, 134, 166, 198, 230]))
+        dt = [np.uint8, np.uint16][int(rng.integers(0, 2))]
+        n = int(rng.integers(1, 9))
+        kw = {"min_size": int(rng.choice([8, 16, 32])), "use_fma": bool(rng.integers(0, 2)),
+              "kernel_size": int(rng.choice([3, 5, 7]))}
+        batch = int(rng.integers(0, 5))
+        frames = make_frames(rng, (h, w), dt, n)
+        so = oracle.StreamingOracle(h, w, dt, keep_gauss=False, **kw)
+        for f in frames:
+            so.push_frame(f)
+        want = so.finish()
+        for impl in (L.IMPL_TILED, L.IMPL_STREAM):
+            st = L.Stack(h, w, in_dtype=dt, impl=impl, batch_frames=batch, **kw)
+            for f in frames:
+                st.push_frame(f)
+            ok = all(np.array_equal(st.tap(L.TAP_ENERGY, lv), so.best_e[lv]) and
+                     np.array_equal(st.tap(L.TAP_FUSED_LAP, lv), so.best_lap[lv]) for lv in range(st.levels))
+            got = st.finish()
+            ok = ok and np.array_equal(got, want)
+            st.close()
+            if not ok:
+                bad += 1
+                print("MISMATCH", case, impl, h, w, dt.__name__, n, kw, batch)
+    print(f"{n_cases} cases x 2 implementations: {bad} mismatches")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
