@@ -526,7 +526,7 @@ bool solve4(const double Hs[10], const double r[4], double d[4]) {
 
 struct EccLevel {
     int h, w;
-    float *tmpl, *img, *gx, *gy;
+    float *tmpl, *img;
 };
 
 }  // namespace
@@ -536,7 +536,7 @@ struct EccLevel {
 struct mi_aligner {
     int device = 0, height = 0, width = 0, dtype = 0, subsample = 1;
     int h = 0, w = 0;  // size of the sub-sampled images the estimate works on
-    std::vector<EccLevel> lv;   // tmpl: one image; img / gx / gy: `cap` images each (frame f at + f * h * w)
+    std::vector<EccLevel> lv;   // tmpl: one image; img: `cap` images (frame f at + f * h * w)
     float* gray = nullptr;
     int cap = 0;                     // moving frames the per-frame buffers hold
     double* partial = nullptr;       // [cap][ECC_MAX_BLOCKS][ECC_NSUM]
@@ -581,8 +581,8 @@ int aligner_reserve(mi_aligner* al, int n) {
     bool ok = true;
     for (auto& L : al->lv) {
         const size_t nb = (size_t)L.h * L.w * 4 * n;
-        L.img = (float*)dalloc(nb); L.gx = (float*)dalloc(nb); L.gy = (float*)dalloc(nb);
-        ok = ok && L.img && L.gx && L.gy;
+        L.img = (float*)dalloc(nb);
+        ok = ok && L.img;
     }
     al->partial = (double*)dalloc((size_t)n * ECC_MAX_BLOCKS * ECC_NSUM * sizeof(double));
     al->ticket = (unsigned int*)dalloc(sizeof(unsigned int) * n);
@@ -614,9 +614,6 @@ int aligner_build(mi_aligner* al, hipStream_t st, const void* dev_img, bool is_t
         const int sh = l == 0 ? al->h : lv[l - 1].h, sw = l == 0 ? al->w : lv[l - 1].w;
         hipLaunchKernelGGL(ecc_blur_down, dim3(cdiv(lv[l].w, 64), cdiv(lv[l].h, 4)), blk, 0, st, src, sh, sw, dst,
                            lv[l].h, lv[l].w, l == 0 ? 0 : 1);
-        if (!is_tmpl)
-            hipLaunchKernelGGL(ecc_gradient, dim3(cdiv(lv[l].w, 64), cdiv(lv[l].h, 4)), blk, 0, st, dst, lv[l].h,
-                               lv[l].w, at(lv[l].gx, l), at(lv[l].gy, l));
     }
     MI_HIP(hipGetLastError());
     return MI_OK;
@@ -664,7 +661,7 @@ int aligner_solve(mi_aligner* al, hipStream_t st, int n, int max_iters, double e
                 nact += pb.active[k];
             }
             if (!nact) break;
-            hipLaunchKernelGGL(ecc_accumulate, dim3(nblk, n), dim3(256), 0, st, L.tmpl, L.img, L.gx, L.gy, np, L.h, L.w,
+            hipLaunchKernelGGL(ecc_accumulate, dim3(nblk, n), dim3(256), 0, st, L.tmpl, L.img, np, L.h, L.w,
                                pb, step, al->partial, al->ticket, al->hsums);
             MI_HIP(hipStreamSynchronize(st));
             for (int k = 0; k < n; ++k) {
@@ -1283,7 +1280,7 @@ int mi_aligner_create(mi_aligner_t* out, int device, int height, int width, int 
     {
         int lh = h, lw = w;
         for (int l = 0; l < (max_levels > 0 ? max_levels : 8); ++l) {
-            al->lv.push_back({lh, lw, nullptr, nullptr, nullptr, nullptr});
+            al->lv.push_back({lh, lw, nullptr, nullptr});
             if ((lh < lw ? lh : lw) / 2 < 48) break;
             lh = (lh + 1) / 2;
             lw = (lw + 1) / 2;

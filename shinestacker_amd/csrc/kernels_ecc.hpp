@@ -46,17 +46,6 @@ __global__ void ecc_blur_down(const float* __restrict__ src, int h, int w, float
     dst[(size_t)y * wo + x] = acc;
 }
 
-// central-difference gradients
-__global__ void ecc_gradient(const float* __restrict__ src, int h, int w, float* __restrict__ gx,
-                             float* __restrict__ gy) {
-    int x = blockIdx.x * blockDim.x + threadIdx.x;
-    int y = blockIdx.y * blockDim.y + threadIdx.y;
-    if (x >= w || y >= h) return;
-    const int xm = max(x - 1, 0), xp = min(x + 1, w - 1), ym = max(y - 1, 0), yp = min(y + 1, h - 1);
-    gx[(size_t)y * w + x] = 0.5f * (src[(size_t)y * w + xp] - src[(size_t)y * w + xm]);
-    gy[(size_t)y * w + x] = 0.5f * (src[(size_t)yp * w + x] - src[(size_t)ym * w + x]);
-}
-
 __device__ __forceinline__ float bilerp(const float* __restrict__ im, int w, int x0, int y0, float fx, float fy) {
     const float* p = im + (size_t)y0 * w + x0;
     const float a = p[0] + fx * (p[1] - p[0]);
@@ -91,15 +80,16 @@ struct EccBatch {
 // reduction in one launch: each block writes its 28 partial sums to partial[frame][block][28];
 // the block that draws the frame's last ticket adds the partials in block order and writes
 // sums[frame][28] (host-visible memory), then re-arms the ticket.
-// img / gx / gy: frame f at base + f * fstride.
+// img: frame f at base + f * fstride.  The image gradients (central differences) are taken on the fly
+// from the 4x4 neighbourhood of the sample point -- 12 loads from one array instead of 4 from each of
+// three, and no gradient images to build or keep.
 __global__ __launch_bounds__(256) void ecc_accumulate(const float* __restrict__ tmpl, const float* __restrict__ img,
-                               const float* __restrict__ gx, const float* __restrict__ gy, size_t fstride, int h,
-                               int w, EccBatch pb, int step, double* __restrict__ partial,
+                               size_t fstride, int h, int w, EccBatch pb, int step, double* __restrict__ partial,
                                unsigned int* __restrict__ ticket, double* __restrict__ sums) {
     const int f = blockIdx.y;
     if (!pb.active[f]) return;
     const EccParams p = pb.p[f];
-    img += (size_t)f * fstride; gx += (size_t)f * fstride; gy += (size_t)f * fstride;
+    img += (size_t)f * fstride;
     partial += (size_t)f * ECC_MAX_BLOCKS * ECC_NSUM;
     ticket += f;
     sums += (size_t)f * ECC_NSUM;
@@ -117,8 +107,21 @@ __global__ __launch_bounds__(256) void ecc_accumulate(const float* __restrict__ 
         const int x0 = (int)floorf(u), y0 = (int)floorf(v);
         if (x0 < 1 || y0 < 1 || x0 >= w - 2 || y0 >= h - 2) continue;
         const float fx = u - x0, fy = v - y0;
-        const float iw = bilerp(img, w, x0, y0, fx, fy);
-        const float dgx = bilerp(gx, w, x0, y0, fx, fy), dgy = bilerp(gy, w, x0, y0, fx, fy);
+        // rows y0-1 .. y0+2, columns x0-1 .. x0+2 (all inside the image by the test above)
+        const float* r1 = img + (size_t)y0 * w + x0;   // (y0, x0)
+        const float* r0 = r1 - w;
+        const float* r2 = r1 + w;
+        const float* r3 = r2 + w;
+        const float a_m = r1[-1], a_0 = r1[0], a_1 = r1[1], a_2 = r1[2];
+        const float b_m = r2[-1], b_0 = r2[0], b_1 = r2[1], b_2 = r2[2];
+        const float t_0 = r0[0], t_1 = r0[1], u_0 = r3[0], u_1 = r3[1];
+        const float iw = (a_0 + fx * (a_1 - a_0)) + fy * ((b_0 + fx * (b_1 - b_0)) - (a_0 + fx * (a_1 - a_0)));
+        // gx at the four corners: 0.5 * (right - left); gy: 0.5 * (below - above)
+        const float gxa0 = 0.5f * (a_1 - a_m), gxa1 = 0.5f * (a_2 - a_0), gxb0 = 0.5f * (b_1 - b_m), gxb1 = 0.5f * (b_2 - b_0);
+        const float gya0 = 0.5f * (b_0 - t_0), gya1 = 0.5f * (b_1 - t_1), gyb0 = 0.5f * (u_0 - a_0), gyb1 = 0.5f * (u_1 - a_1);
+        const float gxt = gxa0 + fx * (gxa1 - gxa0), gxb = gxb0 + fx * (gxb1 - gxb0);
+        const float gyt = gya0 + fx * (gya1 - gya0), gyb = gyb0 + fx * (gyb1 - gyb0);
+        const float dgx = gxt + fy * (gxb - gxt), dgy = gyt + fy * (gyb - gyt);
         const float ir = tmpl[(size_t)y * w + x];
         const float J[4] = {dgx * xc + dgy * yc, -dgx * yc + dgy * xc, dgx, dgy};
         acc[0] += 1.0;
