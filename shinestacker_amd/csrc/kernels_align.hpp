@@ -153,6 +153,29 @@ struct GaussArgs {
     int ksize;
 };
 
+// the three channels of pixel `pi` as floats: one (unaligned) 32-bit load for 8-bit images -- three byte
+// loads per tap kept the texture-address unit busier than the arithmetic -- the very last pixel of the
+// image is read one byte early so the load never leaves the buffer; 16-bit: a 32-bit and a 16-bit load
+template <typename T>
+__device__ __forceinline__ void load_px3(const T* __restrict__ img, size_t pi, size_t last, float out[3]) {
+    if constexpr (sizeof(T) == 1) {
+        uint32_t u;
+        if (pi != last) {
+            __builtin_memcpy(&u, img + pi * 3, 4);
+        } else {
+            __builtin_memcpy(&u, img + pi * 3 - 1, 4);
+            u >>= 8;
+        }
+        out[0] = (float)(u & 255u); out[1] = (float)((u >> 8) & 255u); out[2] = (float)((u >> 16) & 255u);
+    } else {
+        uint32_t u;
+        uint16_t v2;
+        __builtin_memcpy(&u, img + pi * 3, 4);
+        __builtin_memcpy(&v2, img + pi * 3 + 2, 2);
+        out[0] = (float)(u & 65535u); out[1] = (float)(u >> 16); out[2] = (float)v2;
+    }
+}
+
 // gaussian_blur(img) at one pixel: horizontal pass then vertical pass in float32, taps in index
 // order, REFLECT101, round-half-even + saturate (align_oracle.c)
 template <typename T>
@@ -160,17 +183,19 @@ __device__ __forceinline__ void blur_at(const T* __restrict__ img, int h, int w,
                                         int out[3]) {
     const int r = g.ksize / 2;
     const int maxv = sizeof(T) == 1 ? 255 : 65535;
+    const size_t last = (size_t)h * w - 1;
     float acc[3] = {0.f, 0.f, 0.f};
     for (int dy = 0; dy < g.ksize; ++dy) {
         const int yy = r101_loop(y + dy - r, h);
         float row[3] = {0.f, 0.f, 0.f};
         for (int dx = 0; dx < g.ksize; ++dx) {
             const int xx = r101_loop(x + dx - r, w);
-            const T* p = img + ((size_t)yy * w + xx) * 3;
+            float p[3];
+            load_px3<T>(img, (size_t)yy * w + xx, last, p);
             const float k = g.k[dx];
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                const float pr = k * (float)p[c];
+                const float pr = k * p[c];
                 row[c] = row[c] + pr;
             }
         }
@@ -239,11 +264,12 @@ __global__ __launch_bounds__(64) void border_blur_collect(const T* __restrict__ 
             float row[3] = {0.f, 0.f, 0.f};
             for (int dx = 0; dx < ks; ++dx) {
                 const int xx = r101_loop(x + dx - r, w);
-                const T* p = img + ((size_t)yy * w + xx) * 3;
+                float p[3];
+                load_px3<T>(img, (size_t)yy * w + xx, n - 1, p);
                 const float k = g.k[dx];
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
-                    const float pr = k * (float)p[c];
+                    const float pr = k * p[c];
                     row[c] = row[c] + pr;
                 }
             }
