@@ -46,6 +46,19 @@ def build_extension(force=False, verbose=False):
     force = force or bool(os.environ.get("MI_TILE_CFG") or os.environ.get("MI_EXTRA_FLAGS"))
     if not force and not needs_build():
         return LIB
+    # one builder at a time (bench.py is started once per GPU): the others wait, then find it built
+    import fcntl
+    with open(os.path.join(CSRC, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not needs_build():
+                return LIB
+            return _build_locked(verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(verbose):
     extra = []
     cfg = os.environ.get("MI_TILE_CFG")  # "TH0,TW0,NT0,TH,TW,NT,PAD[,RU]" -- tuning builds only
     if cfg:
@@ -54,10 +67,11 @@ def build_extension(force=False, verbose=False):
         extra = [f"-D{n}={v}" for n, v in zip(names, cfg.split(","))]
     extra += os.environ.get("MI_EXTRA_FLAGS", "").split()
     cmd = [_hipcc(), *HIPCC_FLAGS, *extra, "-I", os.path.join(ROOT, "include"),
-           *[os.path.join(CSRC, s) for s in SOURCES], "-o", LIB]
+           *[os.path.join(CSRC, s) for s in SOURCES], "-o", LIB + ".tmp"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    os.replace(LIB + ".tmp", LIB)   # readers never see a half-written library
     return LIB
 
 
