@@ -56,8 +56,10 @@ class BaseStackAlgo:
     def print_message(self, msg):
         self.process.sub_message_r(_cyan(msg))
 
-    def read_image_and_update_metadata(self, img_path, metadata):
-        img = read_img(img_path)
+    def read_image_and_update_metadata(self, img_path, metadata, img=None):
+        """base_stack_algo.py:33-42; `img`: the already decoded file (decode-ahead), else it is read here."""
+        if img is None:
+            img = read_img(img_path)
         if img is None:
             raise ImageLoadError(img_path)
         updated = metadata is None
@@ -73,7 +75,7 @@ class PyramidStack(BaseStackAlgo):
                  kernel_size=constants.DEFAULT_PY_KERNEL_SIZE,
                  gen_kernel=constants.DEFAULT_PY_GEN_KERNEL,
                  float_type=constants.DEFAULT_PY_FLOAT, *, device=0, use_fma=True,
-                 impl=_lib.IMPL_AUTO, batch_frames=0):
+                 impl=_lib.IMPL_AUTO, batch_frames=0, decode_threads=4):
         super().__init__("pyramid", 2, float_type)
         self.min_size = min_size
         self.kernel_size = kernel_size
@@ -84,6 +86,7 @@ class PyramidStack(BaseStackAlgo):
         self.use_fma = use_fma
         self.impl = impl
         self.batch_frames = batch_frames
+        self.decode_threads = decode_threads   # files are decoded this many at a time, ahead of the GPU
         self.dtype = None
         self.num_pixel_values = None
         self.max_pixel_value = None
@@ -135,9 +138,10 @@ class PyramidStack(BaseStackAlgo):
         # pass 1: decode + validate every file (as pyramid.py:155-169) and hand each
         # frame to the device right away, so decoding overlaps the GPU work.  A
         # validation error still aborts the whole stack before any result exists.
-        for i, img_path in enumerate(filenames):
+        for i, (img_path, decoded) in enumerate(self._decode_ahead(filenames)):
             self.print_message(f": validating file {img_path.split('/')[-1]}")
-            img, metadata, updated = self.read_image_and_update_metadata(img_path, metadata)
+            img, metadata, updated = self.read_image_and_update_metadata(
+                img_path, metadata, decoded.result() if decoded is not None else None)
             if updated:
                 self._set_dtype(metadata[1])
                 stack = self._handle(metadata[0], metadata[1])
@@ -150,6 +154,37 @@ class PyramidStack(BaseStackAlgo):
             self._step(i + n)
         self.print_message(': pyramids fusion completed')
         return stack.finish()
+
+    def _decode_ahead(self, filenames):
+        """(path, future-or-None) in file order.  With decode_threads > 1 the files are decoded on a
+        thread pool a few frames ahead of the consumer (image codecs release the GIL): a 24 MP JPEG
+        takes the host far longer to decode than the GPU needs to fuse it.  Errors surface in order,
+        at the file that caused them, as in the sequential loop (pyramid.py:155-169)."""
+        n = int(self.decode_threads or 0)
+        if n <= 1 or len(filenames) <= 1:
+            for p in filenames:
+                yield p, None
+            return
+        from collections import deque
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=n) as pool:
+            window = deque()
+            it = iter(filenames)
+            for p in it:
+                window.append((p, pool.submit(read_img, p)))
+                if len(window) >= 2 * n:
+                    break
+            while window:
+                p, fut = window.popleft()
+                nxt = next(it, None)
+                if nxt is not None:
+                    window.append((nxt, pool.submit(read_img, nxt)))
+                try:
+                    yield p, fut
+                except GeneratorExit:
+                    for _, f in window:
+                        f.cancel()
+                    raise
 
     def focus_stack_arrays(self, frames):
         """In-memory variant (no file I/O): `frames` is a sequence of H x W x 3 uint8/uint16

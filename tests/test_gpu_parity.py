@@ -398,3 +398,47 @@ def test_bunches_of_16bit_tiff_frames(L, oracle, tmp_path):
             so.push_frame(frames[k])
         got = read_img(os.path.join(work, "out16", fname))
         assert got.dtype == np.uint16 and np.array_equal(got, so.finish()), fname
+
+
+def test_decode_ahead_keeps_order_output_and_error_position(L, tmp_path):
+    """PyramidStack(decode_threads=N) decodes files on a thread pool ahead of the GPU: same fused image,
+    same callback sequence as the sequential loop, and a bad file stops the stack at ITS position."""
+    from shinestacker_amd import PyramidStack
+    from shinestacker_amd.errors import ShapeError
+    from shinestacker_amd.imageio import write_img
+    rng = np.random.default_rng(3)
+    names = []
+    for i in range(9):
+        names.append(str(tmp_path / f"im{i:02d}.png"))
+        write_img(names[-1], rng.integers(0, 256, (96, 160, 3)).astype(np.uint8))
+
+    class Proc:
+        id, name = 7, "p"
+
+        def __init__(self):
+            self.trace = []
+
+        def callback(self, key, *a):
+            self.trace.append((key,) + a)
+            return True
+
+        def sub_message_r(self, *_a, **_k):
+            pass
+
+    outs, traces = [], []
+    for nthreads in (1, 4):
+        algo = PyramidStack(decode_threads=nthreads)
+        algo.process = Proc()
+        algo.do_step_callback = True
+        outs.append(algo.focus_stack(names))
+        traces.append(algo.process.trace)
+    assert np.array_equal(outs[0], outs[1]) and traces[0] == traces[1]
+    assert [t[3] for t in traces[1] if t[0] == "after_step"] == list(range(18))
+    # a frame of another shape at index 5
+    write_img(names[5], rng.integers(0, 256, (96, 128, 3)).astype(np.uint8))
+    algo = PyramidStack(decode_threads=4)
+    algo.process = Proc()
+    algo.do_step_callback = True
+    with pytest.raises(ShapeError):
+        algo.focus_stack(names)
+    assert [t[3] for t in algo.process.trace if t[0] == "after_step"] == [0, 1, 2, 3, 4]
