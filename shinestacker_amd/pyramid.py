@@ -75,7 +75,7 @@ class PyramidStack(BaseStackAlgo):
                  kernel_size=constants.DEFAULT_PY_KERNEL_SIZE,
                  gen_kernel=constants.DEFAULT_PY_GEN_KERNEL,
                  float_type=constants.DEFAULT_PY_FLOAT, *, device=0, use_fma=True,
-                 impl=_lib.IMPL_AUTO, batch_frames=0, decode_threads=4):
+                 impl=_lib.IMPL_AUTO, batch_frames=0, decode_threads=8):
         super().__init__("pyramid", 2, float_type)
         self.min_size = min_size
         self.kernel_size = kernel_size
