@@ -333,12 +333,20 @@ class CombinedActions(StepList, FrameDirectory):
     (stack_framework.py:191-232 FramesRefActions + :246-302 CombinedActions)."""
 
     def __init__(self, name, actions=None, enabled=True, ref_idx=-1, step_process=False,
-                 **kwargs):
+                 io_threads=2, **kwargs):
         FrameDirectory.__init__(self, name, **kwargs)
         StepList.__init__(self, name, enabled)
         self._actions = list(actions or [])
         self.ref_idx = ref_idx
         self.step_process = step_process
+        # codec work off the critical path (not in the reference, which reads, processes and writes one
+        # file at a time): the next input file is decoded while the current frame is processed, and
+        # output files are encoded in the background.  0 = strictly sequential.  With step_process the
+        # next step reads the previous OUTPUT file, so writes stay synchronous there.
+        self.io_threads = io_threads
+        self._pool = None
+        self._ahead = {}
+        self._writes = []
         self.dtype = None
         self.shape = None
         self._idx = self._ref_idx = self._idx_step = None
@@ -357,10 +365,44 @@ class CombinedActions(StepList, FrameDirectory):
                 a.begin(self)
 
     def end(self):
+        self._drain_writes()
+        if self._pool is not None:
+            self._pool.shutdown(wait=True)
+            self._pool = None
+        self._ahead = {}
         for a in self._actions:
             if a.enabled:
                 a.end()
         StepList.end(self)
+
+    # -- background codec work
+    def _io_pool(self):
+        if self._pool is None and self.io_threads and self.io_threads > 0:
+            from concurrent.futures import ThreadPoolExecutor
+            self._pool = ThreadPoolExecutor(max_workers=int(self.io_threads))
+        return self._pool
+
+    def _drain_writes(self):
+        writes, self._writes = self._writes, []
+        for w in writes:
+            w.result()   # re-raises an encoder / file-system error of a background write
+
+    def _read_input(self, idx):
+        fut = self._ahead.pop(idx, None)
+        path = f"{self.input_full_path}/{self.filenames[idx]}"
+        return fut.result() if fut is not None else read_img(path)
+
+    def _decode_next(self, idx, idx_step):
+        """Start decoding the file the next step will ask for (same order as run_step)."""
+        pool = self._io_pool()
+        if pool is None:
+            return
+        n = len(self.filenames)
+        nxt = idx + idx_step
+        if nxt == n:
+            nxt = self.ref_idx - 1
+        if 0 <= nxt < n and nxt not in self._ahead and not (self.step_process and nxt == self.ref_idx):
+            self._ahead[nxt] = pool.submit(read_img, f"{self.input_full_path}/{self.filenames[nxt]}")
 
     def img_ref(self, idx):
         base = self.output_dir if self.step_process else self.input_full_path
@@ -393,7 +435,8 @@ class CombinedActions(StepList, FrameDirectory):
     def run_frame(self, idx, ref_idx):
         filename = self.filenames[idx]
         self.sub_message_r(': read input image')
-        img = read_img(f"{self.input_full_path}/{filename}")
+        img = self._read_input(idx)
+        self._decode_next(idx, self._idx_step if self._idx_step is not None else +1)
         if img is None:
             raise RuntimeError(f"Invalid file: {self.input_full_path}/{filename}")
         if self.dtype is not None and img.dtype != self.dtype:
@@ -411,7 +454,14 @@ class CombinedActions(StepList, FrameDirectory):
             img = a.run_frame(idx, ref_idx, img)
         self.sub_message_r(': write output image')
         if img is not None:
-            write_img(self.output_dir + "/" + filename, np.ascontiguousarray(img))
+            out = np.ascontiguousarray(img)
+            pool = self._io_pool()
+            if pool is None or self.step_process:
+                write_img(self.output_dir + "/" + filename, out)
+            else:
+                if len(self._writes) >= 2 * int(self.io_threads):
+                    self._writes.pop(0).result()
+                self._writes.append(pool.submit(write_img, self.output_dir + "/" + filename, out))
         else:
             self.print_message("No output file resulted from processing input file: "
                                f"{self.input_full_path}/{filename}", level=logging.WARNING)

@@ -1,5 +1,7 @@
 """GPU: the alignment apply step (mi_warp_affine) against oracle/align_oracle.c -- bit-exact --
 plus analytic known answers."""
+import os
+
 import numpy as np
 import pytest
 
@@ -129,3 +131,45 @@ def test_align_and_stack_pipeline_equals_two_step_path(L, oracle):
         so.push_frame(f)
     assert matches == [500, 500, 0, 500, 500]
     assert np.array_equal(fused, so.finish())
+
+
+def test_project_align_balance_stack_on_files(hiplib, oracle, tmp_path):
+    """A whole example-project shape (stack-from-frames.fsp): CombinedActions[AlignFrames(GPU ECC), BalanceFrames]
+    -> FocusStack, on files, with the codec work in the background (io_threads / decode_threads) and strictly
+    sequential: identical output files."""
+    from shinestacker_amd import (AlignFrames, BalanceFrames, CombinedActions, FocusStack, PyramidStack, StackJob)
+    from shinestacker_amd.align import ecc_estimator
+    from shinestacker_amd.imageio import read_img, write_img
+    from test_gpu_ecc import make_pair, similarity
+    hiplib.require_device()
+    work = str(tmp_path)
+    os.makedirs(os.path.join(work, "in"))
+    h, w = 256, 384
+    for f in range(5):
+        d = f - 2
+        T = similarity(0.15 * d, 1 + 4e-4 * d, 1.3 * d, -0.9 * d, (w - 1) / 2, (h - 1) / 2)
+        ref, mov = make_pair(oracle, T, h=h, w=w, seed=31, noise=2.0)
+        fr = ref if d == 0 else mov
+        write_img(os.path.join(work, "in", f"f{f}.png"), np.clip(fr * (1.0 + 0.1 * d), 0, 255).astype(np.uint8))
+    results = []
+    for tag, io_threads, dec in (("bg", 2, 4), ("seq", 0, 1)):
+        job = StackJob("job", work, input_path="in")
+        job.add_action(CombinedActions(f"align-{tag}", [AlignFrames(estimator=ecc_estimator(), subsample=1),
+                                                        BalanceFrames(subsample=1)],
+                                       output_path=f"aligned-{tag}", io_threads=io_threads))
+        job.add_action(FocusStack(f"stack-{tag}", PyramidStack(decode_threads=dec), input_path=f"aligned-{tag}",
+                                  output_path=f"stack-{tag}"))
+        job.run()
+        aligned = [read_img(os.path.join(work, f"aligned-{tag}", n))
+                   for n in sorted(os.listdir(os.path.join(work, f"aligned-{tag}")))]
+        out = sorted(os.listdir(os.path.join(work, f"stack-{tag}")))
+        assert len(aligned) == 5 and len(out) == 1
+        results.append((aligned, read_img(os.path.join(work, f"stack-{tag}", out[0]))))
+    for a, b in zip(results[0][0], results[1][0]):
+        assert np.array_equal(a, b)
+    assert np.array_equal(results[0][1], results[1][1])
+    # and the stack of the aligned files is what the oracle makes of them
+    so = oracle.StreamingOracle(h, w, np.uint8, keep_gauss=False)
+    for a in results[0][0]:
+        so.push_frame(a)
+    assert np.array_equal(results[0][1], so.finish())
