@@ -358,7 +358,11 @@ for lv in range(st.levels):
 dist.destroy_process_group()
 print("COMBINE_OK")
 '''
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=600,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert "COMBINE_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
