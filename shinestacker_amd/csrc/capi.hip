@@ -811,6 +811,10 @@ int mi_stack_create(mi_stack_t** out, const mi_stack_params_t* params) {
     *out = nullptr;
     const mi_stack_params_t& p = *params;
     if (p.height < 1 || p.width < 1) return fail(MI_ERR_INVALID, "bad frame size %dx%d", p.width, p.height);
+    // the kernels address pixels inside a frame with 32-bit byte offsets (12 bytes per float pixel)
+    if ((uint64_t)p.height * (uint64_t)p.width * 12ull >= (1ull << 32))
+        return fail(MI_ERR_UNSUPPORTED, "frames of %dx%d exceed the 357-megapixel limit of the 32-bit in-frame addressing",
+                    p.width, p.height);
     if (p.in_dtype != MI_U8 && p.in_dtype != MI_U16 && p.in_dtype != MI_F32)
         return fail(MI_ERR_INVALID, "in_dtype must be MI_U8, MI_U16 or MI_F32");
     if (p.out_dtype != MI_U8 && p.out_dtype != MI_U16)
