@@ -446,3 +446,24 @@ def test_decode_ahead_keeps_order_output_and_error_position(L, tmp_path):
     with pytest.raises(ShapeError):
         algo.focus_stack(names)
     assert [t[3] for t in algo.process.trace if t[0] == "after_step"] == [0, 1, 2, 3, 4]
+
+
+def test_frames_beyond_24_bit_pixel_counts(L, oracle):
+    """108-megapixel frames: level 1 alone has more than 2^24 pixels, which the 24-bit index
+    multiplies of the kernels must not see (they are used for in-tile / per-row arithmetic only)."""
+    H, W = 9000, 12040
+    frames = [oracle.synth_frame_u8(H, W, f, 2) for f in range(2)]
+    so = oracle.StreamingOracle(H, W, np.uint8, keep_gauss=False)
+    st = L.Stack(H, W)
+    for f in frames:
+        so.push_frame(f)
+        st.push_frame(f)
+    want = so.finish()
+    assert st.levels == so.levels == 8
+    for lv in (0, 1, 2):
+        assert np.array_equal(st.tap(L.TAP_ENERGY, lv), so.best_e[lv]), lv
+        assert np.array_equal(st.tap(L.TAP_FUSED_LAP, lv), so.best_lap[lv]), lv
+    assert np.array_equal(st.finish(), want)
+    st.close()
+    with pytest.raises(Exception):
+        L.Stack(20000, 20000)   # 400 MP: beyond the 32-bit in-frame addressing, rejected at create
