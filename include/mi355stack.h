@@ -140,7 +140,10 @@ MI_API int mi_stack_get_level(mi_stack_t* s, int level, int what, void* host_out
 
 /* Device pointers of the running selection state of one level (level ==
  * levels addresses the base: energy -> entropy max, lap -> base_e; the
- * deviation twin comes from level == levels + 1).  For the cross-GPU combine.
+ * deviation twin comes from level == levels + 1).  level == -1: the state of ALL levels and of both
+ * base twins at once -- float-32 stacks keep it in three contiguous slabs (per-level segments padded
+ * to 64 pixels; npixels counts the padding) so that the combine can move it as one flat vector.
+ * For the cross-GPU combine.
  * Synchronises the handle: on return all enqueued work has finished, so the pointers may be
  * used from any other stream. */
 MI_API int mi_stack_state(mi_stack_t* s, int level, void** dev_energy, void** dev_lap, void** dev_index,

@@ -73,6 +73,11 @@ struct mi_stack {
     float* q_tmp = nullptr;
     std::vector<float*> bestE, bestLap;
     std::vector<int32_t*> bestIdx;
+    // float-32 stacks: the selection state of all levels and of the two base features lives in three
+    // contiguous slabs (segments padded to 64 pixels), so the cross-GPU combine sees one flat vector
+    float *slabE = nullptr, *slabL = nullptr;
+    int32_t* slabI = nullptr;
+    size_t slab_px = 0;
 
     int32_t* lev = nullptr;
     uint32_t* cnt = nullptr;
@@ -898,8 +903,30 @@ int mi_stack_create(mi_stack_t** out, const mi_stack_params_t* params) {
     s->bestLap.assign(L, nullptr);
     s->bestIdx.assign(L, nullptr);
     for (int l = 1; l <= L; ++l) TRY(dev_alloc_t(s, &s->G[l], (size_t)s->lh[l] * s->lw[l] * 3 * fm));
+    std::vector<size_t> seg_off(L + 2, 0);
+    if (!s->f64) {
+        size_t off = 0;
+        for (int k = 0; k < L + 2; ++k) {
+            seg_off[k] = off;
+            const int lv = k < L ? k : L;
+            off += (((size_t)s->lh[lv] * s->lw[lv]) + 63) / 64 * 64;
+        }
+        s->slab_px = off;
+        TRY(dev_alloc_t(s, &s->slabE, off));
+        TRY(dev_alloc_t(s, &s->slabI, off));
+        TRY(dev_alloc_t(s, &s->slabL, off * 3));
+        MI_HIP(hipMemset(s->slabE, 0, off * 4));
+        MI_HIP(hipMemset(s->slabI, 0, off * 4));
+        MI_HIP(hipMemset(s->slabL, 0, off * 12));
+    }
     for (int l = 0; l < L; ++l) {
         size_t np = (size_t)s->lh[l] * s->lw[l];
+        if (!s->f64) {
+            s->bestE[l] = s->slabE + seg_off[l];
+            s->bestLap[l] = s->slabL + seg_off[l] * 3;
+            s->bestIdx[l] = s->slabI + seg_off[l];
+            continue;
+        }
         TRY(dev_alloc_t(s, &s->bestE[l], np));
         TRY(dev_alloc_t(s, &s->bestLap[l], np * 3 * fm));
         TRY(dev_alloc_t(s, &s->bestIdx[l], np));
@@ -913,12 +940,18 @@ int mi_stack_create(mi_stack_t** out, const mi_stack_params_t* params) {
         TRY(dev_alloc_t(s, &s->lev, nb));
         TRY(dev_alloc_t(s, &s->cnt, (size_t)s->nlevels_hist));
         TRY(dev_alloc_t(s, &s->logp, (size_t)s->nlevels_hist * fm));
-        TRY(dev_alloc_t(s, &s->bEnt, nb * fm));
-        TRY(dev_alloc_t(s, &s->bDev, nb * fm));
-        TRY(dev_alloc_t(s, &s->idxE, nb));
-        TRY(dev_alloc_t(s, &s->idxD, nb));
-        TRY(dev_alloc_t(s, &s->baseE, nb * 3 * fm));
-        TRY(dev_alloc_t(s, &s->baseD, nb * 3 * fm));
+        if (!s->f64) {
+            s->bEnt = s->slabE + seg_off[L];      s->bDev = s->slabE + seg_off[L + 1];
+            s->idxE = s->slabI + seg_off[L];      s->idxD = s->slabI + seg_off[L + 1];
+            s->baseE = s->slabL + seg_off[L] * 3; s->baseD = s->slabL + seg_off[L + 1] * 3;
+        } else {
+            TRY(dev_alloc_t(s, &s->bEnt, nb * fm));
+            TRY(dev_alloc_t(s, &s->bDev, nb * fm));
+            TRY(dev_alloc_t(s, &s->idxE, nb));
+            TRY(dev_alloc_t(s, &s->idxD, nb));
+            TRY(dev_alloc_t(s, &s->baseE, nb * 3 * fm));
+            TRY(dev_alloc_t(s, &s->baseD, nb * 3 * fm));
+        }
         TRY(dev_alloc_t(s, &s->fusedBase, nb * 3 * fm));
     }
     TRY(dev_alloc_t(s, &s->colA, P0 * 3 * fm));
@@ -1116,7 +1149,9 @@ int mi_stack_state(mi_stack_t* s, int level, void** dev_energy, void** dev_lap, 
     const int L = s->L;
     void *e = nullptr, *l = nullptr, *i = nullptr;
     size_t n = 0;
-    if (level >= 0 && level < L) {
+    if (level == -1) {   // everything at once: the contiguous slabs (padding pixels included)
+        e = s->slabE; l = s->slabL; i = s->slabI; n = s->slab_px;
+    } else if (level >= 0 && level < L) {
         e = s->bestE[level]; l = s->bestLap[level]; i = s->bestIdx[level];
         n = (size_t)s->lh[level] * s->lw[level];
     } else if (level == L) {

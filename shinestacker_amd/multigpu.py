@@ -89,9 +89,14 @@ def combine_all(states, group, select_fn, width=3, with_index=True):
     and moves 16 instead of 20 bytes per pixel."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    e_all = torch.cat([e.reshape(-1) for e, _, _ in states])
-    l_all = torch.cat([lp.reshape(-1) for _, lp, _ in states])
-    i_all = torch.cat([ix.reshape(-1) for _, _, ix in states]) if with_index else None
+    single = len(states) == 1   # the library's contiguous slabs: exchanged in place, no packing copies
+    if single:
+        e_all, l_all = states[0][0].reshape(-1), states[0][1].reshape(-1)
+        i_all = states[0][2].reshape(-1) if with_index else None
+    else:
+        e_all = torch.cat([e.reshape(-1) for e, _, _ in states])
+        l_all = torch.cat([lp.reshape(-1) for _, lp, _ in states])
+        i_all = torch.cat([ix.reshape(-1) for _, _, ix in states]) if with_index else None
     n = e_all.numel()
     bounds = chunk_bounds(n, world)
     sizes = [b - a for a, b in bounds]
@@ -117,7 +122,7 @@ def combine_all(states, group, select_fn, width=3, with_index=True):
     to_root(win_l, l_all, width)
     if with_index:
         to_root(win_i, i_all, 1)
-    if rank == 0:
+    if rank == 0 and not single:
         off = 0
         for e, lp, ix in states:
             m = e.numel()
@@ -166,11 +171,10 @@ class Combiner:
         `with_index=False`: do not exchange the winner indices (debug taps only)."""
         st = self.stack
         st.sync()  # the library's streams are not torch's
-        states = []
-        for level in range(st.levels + 2):  # levels, then base entropy twin, base deviation twin
-            e_ptr, l_ptr, i_ptr, n = st.state_ptrs(level)
-            states.append((wrap_device(e_ptr, n, torch.float32, self.device),
-                           wrap_device(l_ptr, n * 3, torch.float32, self.device),
-                           wrap_device(i_ptr, n, torch.int32, self.device)))
+        # all levels, then base entropy twin, base deviation twin: one contiguous slab per array
+        e_ptr, l_ptr, i_ptr, n = st.state_ptrs(-1)
+        states = [(wrap_device(e_ptr, n, torch.float32, self.device),
+                   wrap_device(l_ptr, n * 3, torch.float32, self.device),
+                   wrap_device(i_ptr, n, torch.int32, self.device))]
         combine_all(states, self.group, self._select_hip, with_index=with_index)
         torch.cuda.current_stream(torch.device("cuda", self.device)).synchronize()

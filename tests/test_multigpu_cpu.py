@@ -81,6 +81,14 @@ def _worker(rank, world, port, ret):
         # ... and all levels in one flat exchange (what Combiner.combine uses): identical result
         flat = tensors()
         multigpu.combine_all(flat, dist.group.WORLD, _torch_select)
+        # one contiguous slab per array (what Combiner.combine hands over): exchanged in place
+        t = tensors()
+        slab = [(torch.cat([a for a, _, _ in t]), torch.cat([b for _, b, _ in t]), torch.cat([c for _, _, c in t]))]
+        multigpu.combine_all(slab, dist.group.WORLD, _torch_select)
+        if rank == 0:
+            assert torch.equal(slab[0][0], torch.cat([a for a, _, _ in flat]))
+            assert torch.equal(slab[0][1], torch.cat([b for _, b, _ in flat]))
+            assert torch.equal(slab[0][2], torch.cat([c for _, _, c in flat]))
         # without the indices: energies and laps identical, indices untouched
         noidx = tensors()
         multigpu.combine_all(noidx, dist.group.WORLD, _torch_select, with_index=False)
