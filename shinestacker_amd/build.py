@@ -21,7 +21,7 @@ def _deps():
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
                "-fno-fast-math", "-fno-slp-vectorize", "-shared", "-fPIC", "-fvisibility=hidden",
-               "-Wall", "-Wno-unused-function"]
+               "-Wall", "-Wno-unused-function", "-pthread"]
 
 
 def _hipcc():

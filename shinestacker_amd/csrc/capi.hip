@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <thread>
 #include <vector>
 
 #include "common.hpp"

@@ -400,10 +400,26 @@ int tiled_push_host(mi_stack* s, const void* host_bgr, size_t row_stride_bytes) 
         const int slot = (int)(t->pin_no % TiledState::NPIN);
         MI_HIP(hipEventSynchronize(t->evPin[slot]));  // bounce buffer free again? (no-op when unused)
         char* pb = (char*)t->pin[slot];
-        if (row_stride_bytes == rb) memcpy(pb, host_bgr, rb * s->p.height);
-        else
-            for (int y = 0; y < s->p.height; ++y)
-                memcpy(pb + (size_t)y * rb, (const char*)host_bgr + (size_t)y * row_stride_bytes, rb);
+        // One thread copies ~25 GB/s into pinned memory -- half of what the PCIe link then moves; big
+        // frames are copied by a few threads, in row bands.
+        {
+            const int H = s->p.height;
+            const size_t total = rb * (size_t)H;
+            const int nthr = total >= ((size_t)32 << 20) ? 4 : 1;
+            auto band = [&](int y0, int y1) {
+                if (row_stride_bytes == rb) memcpy(pb + (size_t)y0 * rb, (const char*)host_bgr + (size_t)y0 * rb, rb * (size_t)(y1 - y0));
+                else
+                    for (int y = y0; y < y1; ++y)
+                        memcpy(pb + (size_t)y * rb, (const char*)host_bgr + (size_t)y * row_stride_bytes, rb);
+            };
+            if (nthr == 1) band(0, H);
+            else {
+                std::thread th[3];
+                for (int k = 1; k < nthr; ++k) th[k - 1] = std::thread(band, H * k / nthr, H * (k + 1) / nthr);
+                band(0, H / nthr);
+                for (int k = 1; k < nthr; ++k) th[k - 1].join();
+            }
+        }
         MI_HIP(hipMemcpyAsync(dst, pb, t->frame_bytes, hipMemcpyHostToDevice, t->stc));
         MI_HIP(hipEventRecord(t->evPin[slot], t->stc));
         t->pin_no++;
