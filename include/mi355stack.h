@@ -241,6 +241,42 @@ MI_API int mi_apply_lut(int device, const void* host_src, void* host_dst, int he
 MI_API int mi_apply_lut_device(int device, void* stream, const void* dev_src, void* dev_dst, size_t npixels,
                         int dtype, const void* dev_lut, int nlut);
 
+/* ---- DepthMapStack: the second stacker behind the same plug-in boundary ----
+ * Replaces the arithmetic of DepthMapStack.focus_stack (reference algorithms/depth_map.py:64-123) for
+ * float_type float-32: push = the first file loop (:67-75: read, img_bw, then per frame get_sobel_map :28-34
+ * or get_laplacian_map :36-41 and the running np.max :88); finish = energies / max (:90), smooth_energy
+ * (:43-52), get_focus_map (:54-62), the per-frame pyrDown / pyrUp weighted Laplacian pyramids (:94-112),
+ * the collapse and np.clip(np.absolute()).astype (:117-123).  The handle keeps every pushed frame and one
+ * float32 plane per frame in device memory (the reference re-reads every file in its second loop).
+ * Parity: oracle/depth_map_oracle.py (OpenCV primitives restated, unpinned -- see DESIGN.md). */
+enum { MI_DM_MAP_AVERAGE = 0, MI_DM_MAP_MAX = 1 };          /* constants.py:147-148 */
+enum { MI_DM_ENERGY_LAPLACIAN = 0, MI_DM_ENERGY_SOBEL = 1 };  /* constants.py:145-146 */
+typedef struct mi_dmap mi_dmap_t;
+typedef struct mi_dmap_params {
+    int32_t height, width;
+    int32_t dtype;         /* MI_U8 / MI_U16: frames in, fused frame out                       */
+    int32_t device;
+    int32_t map_type;      /* MI_DM_MAP_*       (depth_map.py:11)                              */
+    int32_t energy;        /* MI_DM_ENERGY_*    (:12)                                          */
+    int32_t kernel_size;   /* cv2.Laplacian aperture, odd, <= 15 (:13)                         */
+    int32_t blur_size;     /* cv2.GaussianBlur size, odd, <= 31 (:14)                          */
+    int32_t smooth_size;   /* cv2.bilateralFilter diameter, <= 0: no smoothing, <= 31 (:15)    */
+    int32_t levels;        /* blend pyramid levels, >= 1 (:17)                                 */
+    float temperature;     /* softmax temperature of the MAX map (:16)                         */
+} mi_dmap_params_t;
+MI_API void mi_dmap_default_params(mi_dmap_params_t* p);   /* constants.py:151-157 */
+MI_API int mi_dmap_create(mi_dmap_t** out, const mi_dmap_params_t* params);
+MI_API void mi_dmap_destroy(mi_dmap_t* d);
+MI_API int mi_dmap_reset(mi_dmap_t* d);                    /* forget the frames, keep the buffers */
+MI_API int mi_dmap_frames_pushed(const mi_dmap_t* d, int* n);
+/* H x W x 3 BGR frame of `dtype`; row_stride_bytes 0 = packed.  The host form returns once the caller's
+ * buffer may be reused; the device form copies on the handle's stream. */
+MI_API int mi_dmap_push_frame(mi_dmap_t* d, const void* host_bgr, size_t row_stride_bytes);
+MI_API int mi_dmap_push_frame_device(mi_dmap_t* d, const void* dev_bgr);
+/* fused frame (dtype, H x W x 3) to host / device memory; both return after the work has completed */
+MI_API int mi_dmap_finish(mi_dmap_t* d, void* host_out, size_t row_stride_bytes);
+MI_API int mi_dmap_finish_device(mi_dmap_t* d, void* dev_out);
+
 /* ---- synthetic stack generator, device side ---- */
 MI_API int mi_synth_frames_device(int device, void* dev_out, int dtype, int height, int width,
                            int first_frame, int n_frames, int stack_size, uint32_t seed);

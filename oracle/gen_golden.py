@@ -341,10 +341,71 @@ def nolevels_case():
     fusion_case("g8_nolevels", frames)
 
 
+def _dm_frames(rng, n, h, w, dtype):
+    """A textured scene whose sharp region moves from frame to frame (so the weights differ)."""
+    top = 255 if dtype == np.uint8 else 65535
+    yy, xx = np.mgrid[0:h, 0:w]
+    scene = rng.random((h, w, 3)) * 0.6 + 0.2 * np.sin(xx / 3.0)[..., None] + 0.2 * np.cos(yy / 4.0)[..., None]
+    out = []
+    for i in range(n):
+        focus = np.exp(-((xx - w * (i + 0.5) / n) / (w / n)) ** 2)[..., None]
+        smooth = (scene + np.roll(scene, 1, 0) + np.roll(scene, 1, 1) + np.roll(scene, -1, 0) + np.roll(scene, -1, 1)) / 5
+        img = focus * scene + (1 - focus) * smooth
+        out.append(np.clip(img * top, 0, top).astype(dtype))
+    return out
+
+
+def depth_map_case():
+    """The reference's DepthMapStack.focus_stack itself (depth_map.py:64-123) over the cv2 shim; the streaming
+    restatement oracle/depth_map_oracle.depth_map_stack must reproduce every recording bit for bit."""
+    from . import depth_map_oracle as dmo
+    rng = np.random.default_rng(61)
+    cases = [
+        ("dm_default_u8", np.uint8, (5, 45, 70), {}),
+        ("dm_max_u8", np.uint8, (4, 37, 51), {"map_type": "max"}),
+        ("dm_sobel_l4_u16", np.uint16, (3, 64, 49), {"energy": "sobel", "levels": 4}),
+        ("dm_nosmooth_k3_u8", np.uint8, (3, 33, 40), {"smooth_size": 0, "kernel_size": 3, "blur_size": 3}),
+        ("dm_max_t05_l1_u16", np.uint16, (3, 30, 44), {"map_type": "max", "temperature": 0.5, "levels": 1,
+                                                       "smooth_size": 5}),
+        ("dm_k7_b9_u8", np.uint8, (3, 40, 40), {"kernel_size": 7, "blur_size": 9, "smooth_size": 9, "levels": 2}),
+    ]
+    store = {}
+    meta = {}
+    for name, dt, (n, h, w), kw in cases:
+        frames = _dm_frames(rng, n, h, w, dt)
+        if name == "dm_default_u8":
+            frames[1][:, :20] = frames[0][:, :20] = 60   # a flat patch in every frame: zero energy, zero total
+            for f in frames[2:]:
+                f[:, :20] = 60
+        out, trace = ri.reference_depth_map(frames, **kw)
+        mine = dmo.depth_map_stack(frames, **kw)
+        flat = None
+        if name == "dm_default_u8":
+            # where every energy is 0 the reference's weights are uninitialised memory (np.divide where=)
+            flat = np.zeros(out.shape[:2], bool)
+            flat[:, :20] = True   # zero totals up to column 8, spread by two pyrDown / pyrUp rounds to column 18
+            assert np.array_equal(out[~flat], mine[~flat]), name
+        else:
+            assert np.array_equal(out, mine), name
+        store[name + "_frames"] = np.stack(frames)
+        store[name + "_out"] = out
+        if flat is not None:
+            store[name + "_undefined"] = flat
+        meta[name] = {"kwargs": kw, "trace_len": len(trace),
+                      "trace_head": [list(map(str, t)) for t in trace[:4]]}
+        print("  ", name, out.shape, out.dtype, "oracle == reference run")
+    np.savez_compressed(os.path.join(OUT, "depth_map.npz"), **store)
+    with open(os.path.join(OUT, "depth_map.json"), "w") as fh:
+        json.dump(meta, fh, indent=1)
+
+
 def main():
     assert ri.available(), "needs /root/reference"
     os.makedirs(OUT, exist_ok=True)
     orc.build()
+    if "--only-depth-map" in sys.argv:
+        depth_map_case()
+        return
     if "--only-nolevels" in sys.argv:
         nolevels_case()
         return
@@ -383,6 +444,8 @@ def main():
     f64_case()
     print("balance")
     balance_case()
+    print("depth map stacker")
+    depth_map_case()
     print("G5 primitives")
     primitive_cases()
     print("G7 base")

@@ -77,11 +77,43 @@ def make_cv2_shim(use_fma=True):
     def _unavailable(*_a, **_k):
         raise RuntimeError("cv2 shim: function not available in the oracle container")
 
+    # DepthMapStack's primitives (oracle/depth_map_oracle.py; parity unpinned, see there)
+    from . import depth_map_oracle as dmo
+    cv2.CV_64F = 6
+
+    def Sobel(img, ddepth, dx, dy, ksize=3):
+        assert ddepth == cv2.CV_64F and img.dtype == np.float32 and (dx, dy) in ((1, 0), (0, 1))
+        kx, ky = dmo.sobel_kernels(dx, dy, ksize)
+        return dmo.filter2d_f64(img, np.outer(ky, kx))
+
+    def GaussianBlur(img, ksize, sigma):
+        assert sigma == 0 and ksize[0] == ksize[1] and img.dtype == np.float32
+        return dmo.gaussian_blur_f32(img, ksize[0])
+
+    def Laplacian(img, ddepth, ksize=1):
+        assert ddepth == cv2.CV_64F and img.dtype == np.float32
+        return dmo.filter2d_f64(img, dmo.laplacian_kernel2d(ksize))
+
+    def bilateralFilter(img, d, sigma_color, sigma_space):
+        assert img.dtype == np.float32 and img.ndim == 2
+        return dmo.bilateral_f32(img, d, sigma_color, sigma_space)
+
+    def pyrDown(img):
+        assert img.dtype == np.float32
+        return dmo.pyr_down(img)
+
+    def pyrUp(img, dstsize=None):
+        assert img.dtype == np.float32
+        return dmo.pyr_up(img, dstsize)
+
+    cv2.Sobel, cv2.Laplacian, cv2.bilateralFilter = Sobel, Laplacian, bilateralFilter
+    cv2.pyrDown, cv2.pyrUp = pyrDown, pyrUp
     cv2.filter2D = filter2D
     cv2.cvtColor = cvtColor
     cv2.copyMakeBorder = copyMakeBorder
     cv2.LUT, cv2.split, cv2.merge, cv2.resize = LUT, split, merge, resize
-    for name in ("imread", "imwrite", "warpAffine", "warpPerspective", "GaussianBlur",
+    cv2.GaussianBlur = GaussianBlur
+    for name in ("imread", "imwrite", "warpAffine", "warpPerspective",
                  "SIFT_create", "ORB_create", "AKAZE_create", "BRISK_create",
                  "FastFeatureDetector_create", "FlannBasedMatcher", "BFMatcher",
                  "findHomography", "estimateAffinePartial2D", "getPerspectiveTransform",
@@ -181,3 +213,41 @@ def load_balance_module():
     except Exception:  # noqa: BLE001
         pass
     return importlib.import_module("shinestacker.algorithms.balance")
+
+
+class _NumpyWithExactExp:
+    """`np` inside the reference's depth_map module: float32 exp is the correctly rounded one
+    (depth_map_oracle.exp_f32), for the same reason as _NumpyWithExactLog."""
+
+    def __getattr__(self, name):
+        return getattr(np, name)
+
+    @staticmethod
+    def exp(x):
+        x = np.asarray(x)
+        if x.dtype == np.float32:
+            return np.exp(x.astype(np.float64)).astype(np.float32)
+        return np.exp(x)
+
+
+def reference_depth_map(frames, **algo_kwargs):
+    """Run the reference's DepthMapStack.focus_stack (depth_map.py:64-123) on in-memory frames: the
+    file reads are replaced by look-ups ("file names" are the frame indices), everything else is the
+    reference's code over the cv2 shim.  Returns (fused frame, callback trace)."""
+    load_pyramid_module()
+    mod = importlib.import_module("shinestacker.algorithms.depth_map")
+    base = importlib.import_module("shinestacker.algorithms.base_stack_algo")
+    mod.np = _NumpyWithExactExp()
+    reader = lambda path: frames[int(path)].copy()  # noqa: E731
+    mod.read_img = reader
+    base.read_img = reader
+    algo = mod.DepthMapStack(**algo_kwargs)
+    trace = []
+
+    class Proc(FakeProcess):
+        def callback(self, key, *a):
+            trace.append((key,) + tuple(a[2:]))
+            return True
+    algo.process = Proc()
+    out = algo.focus_stack([str(i) for i in range(len(frames))])
+    return out, trace

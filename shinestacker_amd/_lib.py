@@ -35,6 +35,16 @@ class StackParams(C.Structure):
                 ("reserved", C.c_int32 * 5)]
 
 
+class DepthMapParams(C.Structure):
+    _fields_ = [("height", C.c_int32), ("width", C.c_int32), ("dtype", C.c_int32), ("device", C.c_int32),
+                ("map_type", C.c_int32), ("energy", C.c_int32), ("kernel_size", C.c_int32),
+                ("blur_size", C.c_int32), ("smooth_size", C.c_int32), ("levels", C.c_int32),
+                ("temperature", C.c_float)]
+
+
+DM_MAP_AVERAGE, DM_MAP_MAX = 0, 1
+DM_ENERGY_LAPLACIAN, DM_ENERGY_SOBEL = 0, 1
+
 # name -> (restype, argtypes); also the list the symbol-export test walks
 SIGNATURES = {
     "mi_abi_version": (C.c_int, []),
@@ -98,6 +108,15 @@ SIGNATURES = {
     "mi_aligner_estimate_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int,
                                             C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                             C.POINTER(C.c_int)]),
+    "mi_dmap_default_params": (None, [C.POINTER(DepthMapParams)]),
+    "mi_dmap_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(DepthMapParams)]),
+    "mi_dmap_destroy": (None, [C.c_void_p]),
+    "mi_dmap_reset": (C.c_int, [C.c_void_p]),
+    "mi_dmap_frames_pushed": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    "mi_dmap_push_frame": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "mi_dmap_push_frame_device": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mi_dmap_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "mi_dmap_finish_device": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mi_synth_frames_device": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.c_int, C.c_int, C.c_uint32]),
 }
@@ -339,6 +358,72 @@ class Stack:
         ms, n, b = C.c_double(), C.c_int64(), C.c_double()
         check(load().mi_stack_profile_get(self._h, kind, C.byref(ms), C.byref(n), C.byref(b)))
         return ms.value, n.value, b.value
+
+
+class DepthMap:
+    """Thin object wrapper over an mi_dmap_t handle (DepthMapStack's arithmetic, include/mi355stack.h)."""
+
+    def __init__(self, height, width, dtype=np.uint8, map_type=DM_MAP_AVERAGE, energy=DM_ENERGY_LAPLACIAN,
+                 kernel_size=5, blur_size=5, smooth_size=15, temperature=0.1, levels=3, device=0):
+        lib = load()
+        require_device()
+        p = DepthMapParams()
+        lib.mi_dmap_default_params(C.byref(p))
+        self.dtype = np.dtype(dtype)
+        p.height, p.width, p.dtype, p.device = int(height), int(width), DTYPE_CODE[self.dtype], int(device)
+        p.map_type, p.energy = int(map_type), int(energy)
+        p.kernel_size, p.blur_size, p.smooth_size = int(kernel_size), int(blur_size), int(smooth_size)
+        p.levels, p.temperature = int(levels), float(temperature)
+        self.height, self.width, self.device = p.height, p.width, p.device
+        h = C.c_void_p()
+        check(lib.mi_dmap_create(C.byref(h), C.byref(p)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load().mi_dmap_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def reset(self):
+        check(load().mi_dmap_reset(self._h))
+
+    @property
+    def frames_pushed(self):
+        n = C.c_int()
+        check(load().mi_dmap_frames_pushed(self._h, C.byref(n)))
+        return n.value
+
+    def push_frame(self, frame):
+        a = np.asarray(frame)
+        if a.shape != (self.height, self.width, 3):
+            raise ValueError(f"frame shape {a.shape} != {(self.height, self.width, 3)}")
+        if a.dtype != self.dtype:
+            raise ValueError(f"frame dtype {a.dtype} != {self.dtype}")
+        a = np.ascontiguousarray(a)
+        check(load().mi_dmap_push_frame(self._h, a.ctypes.data, 0))
+
+    def push_frame_device(self, dev_ptr):
+        check(load().mi_dmap_push_frame_device(self._h, dev_ptr))
+
+    def finish(self):
+        out = np.empty((self.height, self.width, 3), self.dtype)
+        check(load().mi_dmap_finish(self._h, out.ctypes.data, 0))
+        return out
+
+    def finish_device(self, dev_ptr=None):
+        check(load().mi_dmap_finish_device(self._h, dev_ptr))
 
 
 def synth_frames_device(dev_ptr, dtype, height, width, first_frame, n_frames, stack_size,

@@ -1549,3 +1549,6 @@ int mi_synth_frames_device(int device, void* dev_out, int dtype, int height, int
 }
 
 }  // extern "C"
+
+// DepthMapStack handle (mi_dmap_*)
+#include "depthmap_host.hpp"

@@ -1,0 +1,396 @@
+// depthmap_host.hpp -- the mi_dmap_* handle: DepthMapStack (reference algorithms/depth_map.py:10-123) with the
+// frames and their energy planes resident in HBM.  Included by capi.hip (one translation unit).
+//
+// The reference keeps N gray planes, N energy planes and N weight planes in host memory and reads every file
+// twice; here the frame (input dtype) and one float32 plane per frame stay on the device -- 24 MP x 256 frames
+// of 8-bit input are 18 + 25 GB of the 288 -- and everything else is per-frame scratch.
+#pragma once
+#include "kernels_depthmap.hpp"
+
+struct mi_dmap {
+    mi_dmap_params_t p{};
+    size_t esz = 1;                  // bytes per input element
+    hipStream_t stream = nullptr;
+    std::vector<void*> frames;       // device copies of the pushed frames (kept across reset for reuse)
+    std::vector<float*> en;          // energy -> smoothed energy -> relative weight of frame i
+    float* spare = nullptr;          // the plane the bilateral filter writes into (swapped with en[i])
+    float *tmpA = nullptr, *tmpB = nullptr, *tmpC = nullptr;
+    float *tot = nullptr, *mx = nullptr;
+    float* scal = nullptr;           // [0] global max, [1..2] frame min / max, [3..4] bilateral scale / flat flag
+    float* lut = nullptr;
+    int8_t* offs = nullptr;
+    float* sw = nullptr;
+    int radius = 0, ntaps = 0;
+    double color_coeff = 0.0;
+    std::vector<int> lh, lw;         // level shapes, 0 .. levels-1
+    std::vector<float*> G, W, B;     // Gaussian levels of the current frame (G[0] unused), weights, blend sums
+    void* out_dev = nullptr;
+    mi::DmTaps taps{};
+    mi::DmK2 k2{};
+    int n = 0;
+    bool finished = false;
+    std::vector<void*> allocs;
+};
+
+namespace {
+
+using namespace mi;
+
+void dmap_free(mi_dmap* d) {
+    for (void* p : d->allocs) (void)hipFree(p);
+    d->allocs.clear();
+    if (d->stream) (void)hipStreamDestroy(d->stream);
+    d->stream = nullptr;
+}
+
+template <typename T>
+int dmap_alloc(mi_dmap* d, T** p, size_t count) {
+    void* q = nullptr;
+    MI_HIP(hipMalloc(&q, count * sizeof(T) ? count * sizeof(T) : 1));
+    d->allocs.push_back(q);
+    *p = (T*)q;
+    return MI_OK;
+}
+
+// cv2.getGaussianKernel(ksize, 0, CV_32F) (oracle/depth_map_oracle.py gaussian_kernel_f32)
+void dmap_gauss_taps(int ksize, DmTaps& t) {
+    static const float s1[] = {1.f}, s3[] = {0.25f, 0.5f, 0.25f}, s5[] = {0.0625f, 0.25f, 0.375f, 0.25f, 0.0625f},
+                       s7[] = {0.03125f, 0.109375f, 0.21875f, 0.28125f, 0.21875f, 0.109375f, 0.03125f};
+    t.ksize = ksize;
+    const float* tab = ksize == 1 ? s1 : ksize == 3 ? s3 : ksize == 5 ? s5 : ksize == 7 ? s7 : nullptr;
+    if (tab) {
+        for (int i = 0; i < ksize; ++i) t.k[i] = tab[i];
+        return;
+    }
+    const double sigma = 0.3 * ((ksize - 1) * 0.5 - 1) + 0.8, scale = -0.5 / (sigma * sigma);
+    double sum = 0.0;
+    for (int i = 0; i < ksize; ++i) {
+        const double x = i - (ksize - 1) * 0.5;
+        t.k[i] = (float)std::exp(scale * x * x);
+        sum += (double)t.k[i];
+    }
+    sum = 1.0 / sum;
+    for (int i = 0; i < ksize; ++i) t.k[i] = (float)((double)t.k[i] * sum);
+}
+
+// cv2.getDerivKernels (Sobel family): ksize - order - 1 steps [1 1], `order` steps [-1 1]
+void dmap_sobel_kernel(int order, int ksize, double* out) {
+    std::vector<double> k{1.0};
+    auto conv = [&](double a, double b) {
+        std::vector<double> r(k.size() + 1, 0.0);
+        for (size_t i = 0; i < k.size(); ++i) {
+            r[i] += k[i] * a;
+            r[i + 1] += k[i] * b;
+        }
+        k = r;
+    };
+    for (int i = 0; i < ksize - order - 1; ++i) conv(1.0, 1.0);
+    for (int i = 0; i < order; ++i) conv(1.0, -1.0);
+    for (int i = 0; i < ksize; ++i) out[i] = (order & 1) ? k[ksize - 1 - i] : k[i];
+}
+
+void dmap_laplacian_kernel(int ksize, DmK2& K) {
+    if (ksize == 1 || ksize == 3) {
+        static const double a1[9] = {0, 1, 0, 1, -4, 1, 0, 1, 0}, a3[9] = {2, 0, 2, 0, -8, 0, 2, 0, 2};
+        K.ksize = 3;
+        for (int i = 0; i < 9; ++i) K.k[i] = ksize == 1 ? a1[i] : a3[i];
+        return;
+    }
+    double kd[15], ks[15];
+    dmap_sobel_kernel(2, ksize, kd);
+    dmap_sobel_kernel(0, ksize, ks);
+    K.ksize = ksize;
+    for (int i = 0; i < ksize; ++i)
+        for (int j = 0; j < ksize; ++j) K.k[i * ksize + j] = ks[i] * kd[j] + kd[i] * ks[j];
+}
+
+inline dim3 dm_grid2(int h, int w) { return dim3(cdiv(w, 64), cdiv(h, 4)); }
+inline dim3 dm_grid1(size_t n) { return dim3((unsigned)((n + 255) / 256)); }
+
+// pass 1 for the frame just stored in d->frames[i]
+template <typename T>
+int dmap_energy(mi_dmap* d, int i) {
+    const int h = d->p.height, w = d->p.width;
+    const size_t np = (size_t)h * w;
+    hipStream_t st = d->stream;
+    hipLaunchKernelGGL((dm_gray<T>), dm_grid1(np), dim3(256), 0, st, (const T*)d->frames[i], np, d->tmpA);
+    if (d->p.energy == MI_DM_ENERGY_SOBEL) {
+        hipLaunchKernelGGL(dm_sobel, dm_grid2(h, w), dim3(256), 0, st, d->tmpA, h, w, d->en[i], d->scal);
+    } else {
+        hipLaunchKernelGGL((dm_blur<true>), dm_grid2(h, w), dim3(256), 0, st, d->tmpA, h, w, d->tmpB, d->taps);
+        hipLaunchKernelGGL((dm_blur<false>), dm_grid2(h, w), dim3(256), 0, st, d->tmpB, h, w, d->tmpC, d->taps);
+        hipLaunchKernelGGL(dm_laplacian, dm_grid2(h, w), dim3(256), 0, st, d->tmpC, h, w, d->en[i], d->scal, d->k2);
+    }
+    MI_HIP(hipGetLastError());
+    return MI_OK;
+}
+
+int dmap_new_slot(mi_dmap* d) {
+    if ((size_t)d->n < d->frames.size()) return MI_OK;   // reuse after reset
+    const size_t np = (size_t)d->p.height * d->p.width;
+    void* f = nullptr;
+    float* e = nullptr;
+    MI_HIP(hipMalloc(&f, np * 3 * d->esz));
+    d->allocs.push_back(f);
+    int rc = dmap_alloc(d, &e, np);
+    if (rc) return rc;
+    d->frames.push_back(f);
+    d->en.push_back(e);
+    return MI_OK;
+}
+
+template <typename T>
+int dmap_finish_t(mi_dmap* d) {
+    const int h = d->p.height, w = d->p.width, L = d->p.levels, N = d->n;
+    const size_t np = (size_t)h * w;
+    hipStream_t st = d->stream;
+    const bool avg = d->p.map_type == MI_DM_MAP_AVERAGE;
+    static const uint32_t mm_init[2] = {0x7f800000u, 0u};
+    // energies / max, smoothing, running sum (AVERAGE) or maximum (MAX) over the frames
+    for (int i = 0; i < N; ++i) {
+        MI_HIP(hipMemcpyAsync(d->scal + 1, mm_init, 8, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(dm_normalise, dm_grid1(np), dim3(256), 0, st, d->en[i], np, d->scal, d->scal + 1);
+        float* acc = avg ? d->tot : d->mx;
+        if (d->p.smooth_size > 0) {
+            hipLaunchKernelGGL(dm_bilateral_lut, dim3(1), dim3(1024), 0, st, d->scal + 1, d->color_coeff, d->lut,
+                               d->scal + 3);
+            DmBilateral a{d->en[i], d->spare, h, w, d->radius, d->ntaps, d->offs, d->sw, d->lut, d->scal + 3,
+                          acc, avg ? 0 : 1, i == 0};
+            hipLaunchKernelGGL(dm_bilateral, dim3(cdiv(w, 64), cdiv(h, 16)), dim3(256), 0, st, a);
+            std::swap(d->en[i], d->spare);
+        } else {
+            hipLaunchKernelGGL(dm_accumulate, dm_grid1(np), dim3(256), 0, st, d->en[i], np, acc, avg ? 0 : 1, i == 0);
+        }
+    }
+    if (!avg)
+        for (int i = 0; i < N; ++i)
+            hipLaunchKernelGGL(dm_relative, dm_grid1(np), dim3(256), 0, st, d->en[i], d->mx, np, d->p.temperature,
+                               d->tot, i == 0);
+    MI_HIP(hipGetLastError());
+    // weighted Laplacian pyramids
+    for (int i = 0; i < N; ++i) {
+        const T* frame = (const T*)d->frames[i];
+        const int first = i == 0;
+        hipLaunchKernelGGL(dm_weight, dm_grid1(np), dim3(256), 0, st, d->en[i], d->tot, np, avg ? 1 : 0, d->W[0]);
+        for (int l = 1; l < L; ++l) {
+            const dim3 g = dm_grid2(d->lh[l], d->lw[l]);
+            if (l == 1)
+                hipLaunchKernelGGL((dm_pyrdown<T, 3>), g, dim3(256), 0, st, frame, h, w, d->G[1], d->lh[1], d->lw[1]);
+            else
+                hipLaunchKernelGGL((dm_pyrdown<float, 3>), g, dim3(256), 0, st, d->G[l - 1], d->lh[l - 1], d->lw[l - 1],
+                                   d->G[l], d->lh[l], d->lw[l]);
+            hipLaunchKernelGGL((dm_pyrdown<float, 1>), g, dim3(256), 0, st, d->W[l - 1], d->lh[l - 1], d->lw[l - 1],
+                               d->W[l], d->lh[l], d->lw[l]);
+        }
+        const size_t ntop = (size_t)d->lh[L - 1] * d->lw[L - 1];
+        if (L == 1)
+            hipLaunchKernelGGL((dm_top_blend<T>), dm_grid1(ntop), dim3(256), 0, st, frame, ntop, d->W[0], d->B[0], first);
+        else
+            hipLaunchKernelGGL((dm_top_blend<float>), dm_grid1(ntop), dim3(256), 0, st, d->G[L - 1], ntop, d->W[L - 1],
+                               d->B[L - 1], first);
+        for (int l = L - 2; l >= 0; --l) {
+            const dim3 g = dm_grid2(d->lh[l], d->lw[l]);
+            if (l == 0)
+                hipLaunchKernelGGL((dm_lap_blend<T>), g, dim3(256), 0, st, frame, h, w, d->G[1], d->lh[1], d->lw[1],
+                                   d->W[0], d->B[0], first);
+            else
+                hipLaunchKernelGGL((dm_lap_blend<float>), g, dim3(256), 0, st, d->G[l], d->lh[l], d->lw[l], d->G[l + 1],
+                                   d->lh[l + 1], d->lw[l + 1], d->W[l], d->B[l], first);
+        }
+    }
+    // collapse in place (level l takes pyrUp of the finished level l+1), clip, cast
+    for (int l = L - 2; l >= 0; --l)
+        hipLaunchKernelGGL(dm_collapse, dm_grid2(d->lh[l], d->lw[l]), dim3(256), 0, st, d->B[l + 1], d->lh[l + 1],
+                           d->lw[l + 1], d->B[l], d->lh[l], d->lw[l], d->B[l]);
+    hipLaunchKernelGGL((dm_finalize<T>), dm_grid1(np * 3), dim3(256), 0, st, d->B[0], np * 3,
+                       sizeof(T) == 1 ? 255.f : 65535.f, (T*)d->out_dev);
+    MI_HIP(hipGetLastError());
+    return MI_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void mi_dmap_default_params(mi_dmap_params_t* p) {
+    if (!p) return;
+    memset(p, 0, sizeof *p);
+    p->dtype = MI_U8;
+    p->map_type = MI_DM_MAP_AVERAGE;     // constants.py:151-157
+    p->energy = MI_DM_ENERGY_LAPLACIAN;
+    p->kernel_size = 5;
+    p->blur_size = 5;
+    p->smooth_size = 15;
+    p->temperature = 0.1f;
+    p->levels = 3;
+}
+
+int mi_dmap_create(mi_dmap_t** out, const mi_dmap_params_t* params) {
+    if (!out || !params) return fail(MI_ERR_INVALID, "null argument");
+    *out = nullptr;
+    const mi_dmap_params_t p = *params;
+    if (p.height < 1 || p.width < 1) return fail(MI_ERR_INVALID, "bad frame size %dx%d", p.width, p.height);
+    if ((size_t)p.height * p.width > ((size_t)1 << 30)) return fail(MI_ERR_UNSUPPORTED, "frame too large");
+    if (p.dtype != MI_U8 && p.dtype != MI_U16) return fail(MI_ERR_INVALID, "dtype must be MI_U8 or MI_U16");
+    if (p.map_type != MI_DM_MAP_AVERAGE && p.map_type != MI_DM_MAP_MAX) return fail(MI_ERR_INVALID, "bad map_type %d", p.map_type);
+    if (p.energy != MI_DM_ENERGY_LAPLACIAN && p.energy != MI_DM_ENERGY_SOBEL) return fail(MI_ERR_INVALID, "bad energy %d", p.energy);
+    if (p.energy == MI_DM_ENERGY_LAPLACIAN) {
+        if (p.kernel_size < 1 || p.kernel_size > 15 || p.kernel_size % 2 == 0)
+            return fail(MI_ERR_INVALID, "kernel_size must be odd and in [1, 15]");
+        if (p.blur_size < 1 || p.blur_size > 31 || p.blur_size % 2 == 0)
+            return fail(MI_ERR_INVALID, "blur_size must be odd and in [1, 31]");
+    }
+    if (p.smooth_size > 31) return fail(MI_ERR_UNSUPPORTED, "smooth_size above 31 (bilateral radius above 15)");
+    if (p.levels < 1 || p.levels > 16) return fail(MI_ERR_INVALID, "levels must be in [1, 16]");
+    if (p.map_type == MI_DM_MAP_MAX && !(p.temperature != 0.f)) return fail(MI_ERR_INVALID, "temperature must not be 0");
+    int ndev = 0;
+    int rc = mi_device_count(&ndev);
+    if (rc) return rc;
+    if (ndev == 0) return fail(MI_ERR_NO_DEVICE, "no HIP device visible");
+    if (p.device < 0 || p.device >= ndev) return fail(MI_ERR_INVALID, "bad device %d", p.device);
+    MI_HIP(hipSetDevice(p.device));
+    mi_dmap* d = new (std::nothrow) mi_dmap();
+    if (!d) return fail(MI_ERR_NOMEM, "out of host memory");
+    d->p = p;
+    d->esz = p.dtype == MI_U8 ? 1 : 2;
+    if (p.energy == MI_DM_ENERGY_LAPLACIAN) {
+        dmap_gauss_taps(p.blur_size, d->taps);
+        dmap_laplacian_kernel(p.kernel_size, d->k2);
+    }
+    const size_t np = (size_t)p.height * p.width;
+    auto body = [&]() -> int {
+        MI_HIP(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
+        int r;
+        if ((r = dmap_alloc(d, &d->tmpA, np)) || (r = dmap_alloc(d, &d->tmpB, np)) || (r = dmap_alloc(d, &d->tmpC, np)) ||
+            (r = dmap_alloc(d, &d->spare, np)) || (r = dmap_alloc(d, &d->tot, np)) || (r = dmap_alloc(d, &d->scal, 8)) ||
+            (r = dmap_alloc(d, &d->lut, DM_LUT_BINS + 2)))
+            return r;
+        if (p.map_type == MI_DM_MAP_MAX && (r = dmap_alloc(d, &d->mx, np))) return r;
+        void* o = nullptr;
+        MI_HIP(hipMalloc(&o, np * 3 * d->esz));
+        d->allocs.push_back(o);
+        d->out_dev = o;
+        if (p.smooth_size > 0) {   // bilateral disc, cv2.bilateralFilter(e, smooth_size, 25, 25) (depth_map.py:50)
+            const double sigma_color = 25.0, sigma_space = 25.0;
+            d->radius = std::max(p.smooth_size / 2, 1);
+            d->color_coeff = -0.5 / (sigma_color * sigma_color);
+            const double cs = -0.5 / (sigma_space * sigma_space);
+            std::vector<int8_t> offs;
+            std::vector<float> sw;
+            for (int i = -d->radius; i <= d->radius; ++i)
+                for (int j = -d->radius; j <= d->radius; ++j) {
+                    const double r = std::sqrt((double)i * i + (double)j * j);
+                    if (r > d->radius) continue;
+                    offs.push_back((int8_t)i);
+                    offs.push_back((int8_t)j);
+                    sw.push_back((float)std::exp(r * r * cs));
+                }
+            d->ntaps = (int)sw.size();
+            if ((r = dmap_alloc(d, &d->offs, offs.size())) || (r = dmap_alloc(d, &d->sw, sw.size()))) return r;
+            MI_HIP(hipMemcpy(d->offs, offs.data(), offs.size(), hipMemcpyHostToDevice));
+            MI_HIP(hipMemcpy(d->sw, sw.data(), sw.size() * 4, hipMemcpyHostToDevice));
+        }
+        int lh = p.height, lw = p.width;
+        for (int l = 0; l < p.levels; ++l) {
+            d->lh.push_back(lh);
+            d->lw.push_back(lw);
+            float *g = nullptr, *wgt = nullptr, *b = nullptr;
+            const size_t n = (size_t)lh * lw;
+            if (l > 0 && (r = dmap_alloc(d, &g, n * 3))) return r;
+            if ((r = dmap_alloc(d, &wgt, n)) || (r = dmap_alloc(d, &b, n * 3))) return r;
+            d->G.push_back(g);
+            d->W.push_back(wgt);
+            d->B.push_back(b);
+            lh = (lh + 1) / 2;
+            lw = (lw + 1) / 2;
+        }
+        MI_HIP(hipMemsetAsync(d->scal, 0, 32, d->stream));
+        return MI_OK;
+    };
+    rc = body();
+    if (rc) {
+        dmap_free(d);
+        delete d;
+        return rc;
+    }
+    *out = d;
+    return MI_OK;
+}
+
+void mi_dmap_destroy(mi_dmap_t* d) {
+    if (!d) return;
+    (void)hipSetDevice(d->p.device);
+    if (d->stream) (void)hipStreamSynchronize(d->stream);
+    dmap_free(d);
+    delete d;
+}
+
+int mi_dmap_reset(mi_dmap_t* d) {
+    if (!d) return fail(MI_ERR_INVALID, "null handle");
+    MI_HIP(hipSetDevice(d->p.device));
+    d->n = 0;
+    d->finished = false;
+    MI_HIP(hipMemsetAsync(d->scal, 0, 32, d->stream));
+    return MI_OK;
+}
+
+int mi_dmap_frames_pushed(const mi_dmap_t* d, int* n) {
+    if (!d || !n) return fail(MI_ERR_INVALID, "null argument");
+    *n = d->n;
+    return MI_OK;
+}
+
+static int dmap_push_common(mi_dmap_t* d, const void* src, size_t row_stride_bytes, bool on_device) {
+    if (!d) return fail(MI_ERR_INVALID, "null handle");
+    if (!src) return fail(MI_ERR_INVALID, "null frame");
+    if (d->finished) return fail(MI_ERR_STATE, "push after finish; call mi_dmap_reset first");
+    MI_HIP(hipSetDevice(d->p.device));
+    int rc = dmap_new_slot(d);
+    if (rc) return rc;
+    const size_t rb = (size_t)d->p.width * 3 * d->esz;
+    if (row_stride_bytes == 0) row_stride_bytes = rb;
+    if (row_stride_bytes < rb) return fail(MI_ERR_INVALID, "row stride smaller than a row");
+    MI_HIP(hipMemcpy2DAsync(d->frames[d->n], rb, src, row_stride_bytes, rb, d->p.height,
+                            on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, d->stream));
+    if (!on_device) MI_HIP(hipStreamSynchronize(d->stream));   // the caller may reuse its buffer
+    rc = d->p.dtype == MI_U8 ? dmap_energy<uint8_t>(d, d->n) : dmap_energy<uint16_t>(d, d->n);
+    if (rc) return rc;
+    d->n++;
+    return MI_OK;
+}
+
+int mi_dmap_push_frame(mi_dmap_t* d, const void* host_bgr, size_t row_stride_bytes) {
+    return dmap_push_common(d, host_bgr, row_stride_bytes, false);
+}
+
+int mi_dmap_push_frame_device(mi_dmap_t* d, const void* dev_bgr) {
+    return dmap_push_common(d, dev_bgr, 0, true);
+}
+
+int mi_dmap_finish_device(mi_dmap_t* d, void* dev_out) {
+    if (!d) return fail(MI_ERR_INVALID, "null handle");
+    if (d->finished) return fail(MI_ERR_STATE, "finish called twice; call mi_dmap_reset first");
+    if (d->n == 0) return fail(MI_ERR_STATE, "finish with no frames pushed");
+    MI_HIP(hipSetDevice(d->p.device));
+    int rc = d->p.dtype == MI_U8 ? dmap_finish_t<uint8_t>(d) : dmap_finish_t<uint16_t>(d);
+    if (rc) return rc;
+    d->finished = true;
+    if (dev_out)
+        MI_HIP(hipMemcpyAsync(dev_out, d->out_dev, (size_t)d->p.height * d->p.width * 3 * d->esz, hipMemcpyDeviceToDevice,
+                              d->stream));
+    MI_HIP(hipStreamSynchronize(d->stream));
+    return MI_OK;
+}
+
+int mi_dmap_finish(mi_dmap_t* d, void* host_out, size_t row_stride_bytes) {
+    if (!host_out) return fail(MI_ERR_INVALID, "null output buffer");
+    int rc = mi_dmap_finish_device(d, nullptr);
+    if (rc) return rc;
+    const size_t rb = (size_t)d->p.width * 3 * d->esz;
+    if (row_stride_bytes == 0) row_stride_bytes = rb;
+    if (row_stride_bytes < rb) return fail(MI_ERR_INVALID, "row stride smaller than a row");
+    MI_HIP(hipMemcpy2D(host_out, row_stride_bytes, d->out_dev, rb, rb, d->p.height, hipMemcpyDeviceToHost));
+    return MI_OK;
+}
+
+}  // extern "C"

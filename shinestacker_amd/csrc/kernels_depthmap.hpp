@@ -1,0 +1,403 @@
+// kernels_depthmap.hpp -- DepthMapStack (reference algorithms/depth_map.py:10-123; SURVEY.md 8(f)
+// rank 4), float-32 mode, frame at a time:
+//
+//   pass 1 (at push)   gray -> energy: |Sobel_x| + |Sobel_y| (:28-34) or |Laplacian(GaussianBlur)| (:36-41),
+//                      running global maximum (:88)
+//   finish             energies / max (:90), bilateral smoothing (:43-52), focus map: e / sum_i e (:55-57)
+//                      or softmax((e - max_i e) / T) (:58-61);
+//   pass 2             per frame: Gaussian pyramids of the frame and of its weight (pyrDown), Laplacian
+//                      pyramid of the frame (pyrUp), weighted accumulation (:94-112); collapse, clip, cast
+//                      (:117-123)
+//
+// Every kernel is one thread per output with the operation order of oracle/depth_map_oracle.py (the
+// OpenCV primitives restated there: parity unpinned, stated in DESIGN.md).  With the default parameters
+// the energies are exact whatever the order (integer gray levels, dyadic 5-tap Gaussian, integer
+// derivative kernels, float64 accumulation as cv2's CV_64F output implies).
+#pragma once
+#include "common.hpp"
+#include "kernels_balance.hpp"
+
+namespace mi {
+
+struct DmTaps {
+    float k[32];  // symmetric Gaussian, float32 (cv2.getGaussianKernel(ksize, 0, CV_32F))
+    int ksize;
+};
+struct DmK2 {
+    double k[15 * 15];  // 2-D Laplacian aperture (integers), row-major
+    int ksize;
+};
+
+__device__ __forceinline__ void atomic_max_pos(float* addr, float v) {  // v >= 0: the bit patterns order like the values
+    atomicMax(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
+}
+__device__ __forceinline__ void atomic_min_pos(float* addr, float v) {
+    atomicMin(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+    return v;
+}
+
+// img_bw (utils.py:46-47): integer BGR2GRAY, then np.array(..., dtype=float32) (:77)
+template <typename T>
+__global__ __launch_bounds__(256) void dm_gray(const T* __restrict__ img, size_t npix, float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npix) return;
+    out[i] = (float)bgr2gray_int(img[3 * i], img[3 * i + 1], img[3 * i + 2]);
+}
+
+// one axis of cv2.GaussianBlur on float32: k[c]*S[0] + sum_j k[c+j]*(S[-j] + S[j])
+template <bool ROWS>
+__global__ __launch_bounds__(256) void dm_blur(const float* __restrict__ src, int h, int w, float* __restrict__ dst,
+                                               DmTaps t) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    const int r = t.ksize / 2;
+    auto at = [&](int o) {
+        return ROWS ? src[(size_t)y * w + r101_loop(x + o, w)] : src[(size_t)r101_loop(y + o, h) * w + x];
+    };
+    float acc = t.k[r] * at(0);
+    for (int j = 1; j <= r; ++j) {
+        const float pr = t.k[r + j] * (at(-j) + at(j));
+        acc = acc + pr;
+    }
+    dst[(size_t)y * w + x] = acc;
+}
+
+__device__ __forceinline__ void block_max_to(float v, float* gmax) {
+    v = wave_max(v);
+    if ((threadIdx.x & 63) == 0 && v > 0.f) atomic_max_pos(gmax, v);
+}
+
+// |cv2.Laplacian(blurred, CV_64F, ksize)| -> float32, and the running global maximum
+__global__ __launch_bounds__(256) void dm_laplacian(const float* __restrict__ src, int h, int w,
+                                                    float* __restrict__ out, float* __restrict__ gmax, DmK2 K) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    float e = 0.f;
+    if (x < w && y < h) {
+        const int r = K.ksize / 2;
+        double s = 0.0;
+        for (int i = 0; i < K.ksize; ++i) {
+            const float* row = src + (size_t)r101_loop(y + i - r, h) * w;
+            for (int j = 0; j < K.ksize; ++j) {
+                const double k = K.k[i * K.ksize + j];
+                if (k == 0.0) continue;
+                const double pr = k * (double)row[r101_loop(x + j - r, w)];
+                s = s + pr;
+            }
+        }
+        e = (float)fabs(s);
+        out[(size_t)y * w + x] = e;
+    }
+    block_max_to(e, gmax);
+}
+
+// |Sobel_x| + |Sobel_y| (3x3, CV_64F) -> float32
+__global__ __launch_bounds__(256) void dm_sobel(const float* __restrict__ src, int h, int w, float* __restrict__ out,
+                                                float* __restrict__ gmax) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    float e = 0.f;
+    if (x < w && y < h) {
+        double p[3][3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const float* row = src + (size_t)r101_loop(y + i - 1, h) * w;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) p[i][j] = (double)row[r101_loop(x + j - 1, w)];
+        }
+        // row-major over the non-zero taps of outer([1 2 1], [-1 0 1]) and outer([-1 0 1], [1 2 1])
+        double gx = 0.0 + -1.0 * p[0][0];
+        gx = gx + 1.0 * p[0][2];
+        gx = gx + -2.0 * p[1][0];
+        gx = gx + 2.0 * p[1][2];
+        gx = gx + -1.0 * p[2][0];
+        gx = gx + 1.0 * p[2][2];
+        double gy = 0.0 + -1.0 * p[0][0];
+        gy = gy + -2.0 * p[0][1];
+        gy = gy + -1.0 * p[0][2];
+        gy = gy + 1.0 * p[2][0];
+        gy = gy + 2.0 * p[2][1];
+        gy = gy + 1.0 * p[2][2];
+        e = (float)(fabs(gx) + fabs(gy));
+        out[(size_t)y * w + x] = e;
+    }
+    block_max_to(e, gmax);
+}
+
+// energies / max_energy (float32 division, :90) in place, and the frame's own min / max (the bilateral
+// filter scales its range table with them).  mm[0] = min, mm[1] = max, preset to +inf bits / 0.
+__global__ __launch_bounds__(256) void dm_normalise(float* __restrict__ e, size_t n, const float* __restrict__ gmax,
+                                                    float* __restrict__ mm) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const float m = *gmax;
+    float v = 0.f, lo = __uint_as_float(0x7f800000u);
+    if (i < n) {
+        v = e[i];
+        if (m > 0.f) {
+            v = v / m;
+            e[i] = v;
+        }
+        lo = v;
+    }
+    const float hi = wave_max(v);
+    lo = wave_min(lo);
+    if ((threadIdx.x & 63) == 0) {
+        atomic_max_pos(mm + 1, hi);
+        atomic_min_pos(mm, lo);
+    }
+}
+
+constexpr int DM_LUT_BINS = 4096;
+
+// expLUT of cv2.bilateralFilter (float32 images).  bp[0] = scale_index, bp[1] = 1 if the image is constant.
+__global__ __launch_bounds__(1024) void dm_bilateral_lut(const float* __restrict__ mm, double color_coeff,
+                                                         float* __restrict__ lut, float* __restrict__ bp) {
+    const float lo = mm[0], hi = mm[1];
+    const bool flat = fabs((double)lo - (double)hi) < (double)1.1920928955078125e-07f;
+    const float len = (float)((double)hi - (double)lo);
+    const float scale_index = (float)DM_LUT_BINS / len;
+    if (threadIdx.x == 0) {
+        bp[0] = scale_index;
+        bp[1] = flat ? 1.f : 0.f;
+    }
+    if (flat) return;
+    auto entry = [&](int i) {
+        const double val = (double)((float)i / scale_index);
+        return (float)exp(val * val * color_coeff);
+    };
+    for (int i = threadIdx.x; i < DM_LUT_BINS + 2; i += 1024)
+        lut[i] = (i == 0 || entry(i - 1) > 0.f) ? entry(i) : 0.f;   // the table stops at its first zero
+}
+
+struct DmBilateral {
+    const float* src;
+    float* dst;
+    int h, w, radius, ntaps;
+    const int8_t* offs;   // ntaps x (dy, dx), raster order of the disc
+    const float* sw;      // space weights
+    const float* lut;
+    const float* bp;
+    float* acc;           // AVERAGE: running sum of the smoothed energies; MAX: running maximum
+    int mode;             // 0 = sum, 1 = max
+    int first;
+};
+
+// cv2.bilateralFilter(e, d, 25, 25) on a float32 plane; the smoothed plane also goes into the running
+// sum / maximum over frames (np.sum / np.max over axis 0 add the planes in frame order).
+// 16 x 64 pixels per workgroup; the patch (radius <= 15) and the range table live in LDS.
+__global__ __launch_bounds__(256) void dm_bilateral(DmBilateral a) {
+    constexpr int TH = 16, TW = 64, RMAX = 15;
+    __shared__ float sP[(TH + 2 * RMAX) * (TW + 2 * RMAX)];
+    __shared__ float sL[DM_LUT_BINS + 2];
+    const int t = threadIdx.x, r = a.radius;
+    const int y0 = blockIdx.y * TH, x0 = blockIdx.x * TW;
+    const bool flat = a.bp[1] != 0.f;
+    const int pw = TW + 2 * r, ph = TH + 2 * r;
+    if (!flat) {
+        for (int i = t; i < DM_LUT_BINS + 2; i += 256) sL[i] = a.lut[i];
+        for (int i = t; i < ph * pw; i += 256) {
+            const int py = i / pw, px = i - py * pw;
+            sP[i] = a.src[(size_t)r101_loop(y0 + py - r, a.h) * a.w + r101_loop(x0 + px - r, a.w)];
+        }
+    }
+    __syncthreads();
+    const float scale_index = a.bp[0];
+    const int tx = t & 63, tq = t >> 6;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int ty = tq + 4 * k, y = y0 + ty, x = x0 + tx;
+        if (y >= a.h || x >= a.w) continue;
+        const size_t pi = (size_t)y * a.w + x;
+        float res;
+        if (flat) {
+            res = a.src[pi];
+        } else {
+            const float* c = sP + (ty + r) * pw + (tx + r);
+            const float v0 = *c;
+            float sum = 0.f, wsum = 0.f;
+            for (int n = 0; n < a.ntaps; ++n) {
+                const int dy = a.offs[2 * n], dx = a.offs[2 * n + 1];
+                const float val = c[dy * pw + dx];
+                float alpha = fabsf(val - v0) * scale_index;
+                const int idx = (int)floorf(alpha);
+                alpha = alpha - (float)idx;
+                const float l0 = sL[idx], l1 = sL[idx + 1];
+                const float d = l1 - l0;
+                const float ad = alpha * d;
+                const float cw = l0 + ad;
+                const float wk = a.sw[n] * cw;
+                const float vw = val * wk;
+                sum = sum + vw;
+                wsum = wsum + wk;
+            }
+            res = sum / wsum;
+        }
+        a.dst[pi] = res;
+        if (a.mode == 0) a.acc[pi] = a.first ? 0.f + res : a.acc[pi] + res;
+        else a.acc[pi] = a.first ? res : fmaxf(a.acc[pi], res);
+    }
+}
+
+// smooth_size <= 0: no smoothing, only the running sum / maximum
+__global__ __launch_bounds__(256) void dm_accumulate(const float* __restrict__ e, size_t n, float* __restrict__ acc,
+                                                     int mode, int first) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float v = e[i];
+    if (mode == 0) acc[i] = first ? 0.f + v : acc[i] + v;
+    else acc[i] = first ? v : fmaxf(acc[i], v);
+}
+
+// MAX map (:59-60): relative = exp((e - max_e) / T) in place (float32 exp, correctly rounded through the
+// double exp), running sum of the relatives
+__global__ __launch_bounds__(256) void dm_relative(float* __restrict__ e, const float* __restrict__ mx, size_t n,
+                                                   float temperature, float* __restrict__ tot, int first) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float d = e[i] - mx[i];
+    const float q = d / temperature;
+    const float rel = (float)exp((double)q);
+    e[i] = rel;
+    tot[i] = first ? 0.f + rel : tot[i] + rel;
+}
+
+// weights (:57, :61): e / total; the AVERAGE map leaves pixels whose total is 0 undefined in the
+// reference (np.divide(..., where=) without out=) -- 0 here
+__global__ __launch_bounds__(256) void dm_weight(const float* __restrict__ e, const float* __restrict__ tot, size_t n,
+                                                 int guard_zero, float* __restrict__ wgt) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float t = tot[i];
+    wgt[i] = (guard_zero && t == 0.f) ? 0.f : e[i] / t;
+}
+
+// cv2.pyrDown on float32 data with C interleaved channels: rows s[2x]*6 + (s[2x-1] + s[2x+1])*4 + s[2x-2] +
+// s[2x+2], the same down the columns, * 1/256.  TSrc = the frame's integer type for level 0.
+template <typename TSrc, int C>
+__global__ __launch_bounds__(256) void dm_pyrdown(const TSrc* __restrict__ src, int h, int w, float* __restrict__ dst,
+                                                  int ho, int wo) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= wo || y >= ho) return;
+    int xs[5], ys[5];
+#pragma unroll
+    for (int o = 0; o < 5; ++o) {
+        xs[o] = r101_loop(2 * x + o - 2, w);
+        ys[o] = r101_loop(2 * y + o - 2, h);
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        float rowv[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const TSrc* row = src + (size_t)ys[i] * w * C + c;
+            const float m2 = (float)row[xs[0] * C], m1 = (float)row[xs[1] * C], c0 = (float)row[xs[2] * C],
+                        p1 = (float)row[xs[3] * C], p2 = (float)row[xs[4] * C];
+            float s = c0 * 6.f;
+            const float pr = (m1 + p1) * 4.f;
+            s = s + pr;
+            s = s + m2;
+            rowv[i] = s + p2;
+        }
+        float s = rowv[2] * 6.f;
+        const float pr = (rowv[1] + rowv[3]) * 4.f;
+        s = s + pr;
+        s = s + rowv[0];
+        s = s + rowv[4];
+        dst[((size_t)y * wo + x) * C + c] = s * (1.0f / 256.0f);
+    }
+}
+
+// one axis of cv2.pyrUp, unnormalised: sample i of a destination of nd samples from n source samples
+template <typename F>
+__device__ __forceinline__ float up_axis(int n, int nd, int i, F at) {
+    if (i >= 2 * n) i = 2 * n - 1;  // an odd destination repeats its last sample
+    const int s = i >> 1;
+    if (i & 1) {
+        if (s == n - 1) return at(s) * 8.f;
+        return (at(s) + at(s + 1)) * 4.f;
+    }
+    if (n == 1) return at(0) * 8.f;
+    if (s == 0) {
+        const float a = at(0) * 6.f, b = at(1) * 2.f;
+        return a + b;
+    }
+    if (s == n - 1) {
+        const float b = at(s) * 7.f;
+        return at(s - 1) + b;
+    }
+    const float m = at(s) * 6.f;
+    const float l = at(s - 1) + m;
+    return l + at(s + 1);
+}
+
+// cv2.pyrUp(src, dstsize=(wd, hd)) at destination (y, x), channel c: columns first, then rows, * 1/64
+template <int C>
+__device__ __forceinline__ float pyrup_at(const float* __restrict__ src, int hs, int ws, int hd, int wd, int y, int x,
+                                          int c) {
+    const float v = up_axis(hs, hd, y, [&](int r) {
+        const float* row = src + (size_t)r * ws * C + c;
+        return up_axis(ws, wd, x, [&](int q) { return row[q * C]; });
+    });
+    return v * (1.0f / 64.0f);
+}
+
+// Laplacian level (fine - pyrUp(coarse)) times the weight plane of that level, accumulated over frames (:104-110)
+template <typename TFine>
+__global__ __launch_bounds__(256) void dm_lap_blend(const TFine* __restrict__ fine, int h, int w,
+                                                    const float* __restrict__ coarse, int hc, int wc,
+                                                    const float* __restrict__ wgt, float* __restrict__ blend, int first) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    const size_t p = (size_t)y * w + x;
+    const float wv = wgt[p];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float lap = (float)fine[p * 3 + c] - pyrup_at<3>(coarse, hc, wc, h, w, y, x, c);
+        const float cur = lap * wv;
+        blend[p * 3 + c] = first ? cur : blend[p * 3 + c] + cur;
+    }
+}
+
+// coarsest level: the Gaussian level itself times its weight plane
+template <typename TFine>
+__global__ __launch_bounds__(256) void dm_top_blend(const TFine* __restrict__ top, size_t npix,
+                                                    const float* __restrict__ wgt, float* __restrict__ blend, int first) {
+    const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= npix) return;
+    const float wv = wgt[p];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float cur = (float)top[p * 3 + c] * wv;
+        blend[p * 3 + c] = first ? cur : blend[p * 3 + c] + cur;
+    }
+}
+
+// result = pyrUp(result) + blended level (:119-121)
+__global__ __launch_bounds__(256) void dm_collapse(const float* __restrict__ coarse, int hc, int wc,
+                                                   const float* __restrict__ blend, int h, int w, float* __restrict__ out) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    const size_t p = (size_t)y * w + x;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) out[p * 3 + c] = pyrup_at<3>(coarse, hc, wc, h, w, y, x, c) + blend[p * 3 + c];
+}
+
+// np.clip(np.absolute(result), 0, n_values).astype(dtype) (:122-123)
+template <typename TOut>
+__global__ __launch_bounds__(256) void dm_finalize(const float* __restrict__ img, size_t n, float maxv,
+                                                   TOut* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float v = fabsf(img[i]);
+    v = v < 0.f ? 0.f : (v > maxv ? maxv : v);
+    out[i] = (TOut)v;
+}
+
+}  // namespace mi

@@ -39,6 +39,7 @@ class BaseStackAlgo:
         self._name = name
         self._steps_per_frame = steps_per_frame
         self.process = None
+        self.decode_threads = 8   # files are decoded this many at a time, ahead of the GPU (_decode_ahead)
         if float_type == constants.FLOAT_32:
             self.float_type = np.float32
         elif float_type == constants.FLOAT_64:
@@ -68,6 +69,37 @@ class BaseStackAlgo:
         else:
             validate_image(img, *metadata)
         return img, metadata, updated
+
+    def _decode_ahead(self, filenames):
+        """(path, future-or-None) in file order.  With decode_threads > 1 the files are decoded on a
+        thread pool a few frames ahead of the consumer (image codecs release the GIL): a 24 MP JPEG
+        takes the host far longer to decode than the GPU needs to fuse it.  Errors surface in order,
+        at the file that caused them, as in the sequential loop (pyramid.py:155-169)."""
+        n = int(self.decode_threads or 0)
+        if n <= 1 or len(filenames) <= 1:
+            for p in filenames:
+                yield p, None
+            return
+        from collections import deque
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=n) as pool:
+            window = deque()
+            it = iter(filenames)
+            for p in it:
+                window.append((p, pool.submit(read_img, p)))
+                if len(window) >= 2 * n:
+                    break
+            while window:
+                p, fut = window.popleft()
+                nxt = next(it, None)
+                if nxt is not None:
+                    window.append((nxt, pool.submit(read_img, nxt)))
+                try:
+                    yield p, fut
+                except GeneratorExit:
+                    for _, f in window:
+                        f.cancel()
+                    raise
 
 
 class PyramidStack(BaseStackAlgo):
@@ -154,37 +186,6 @@ class PyramidStack(BaseStackAlgo):
             self._step(i + n)
         self.print_message(': pyramids fusion completed')
         return stack.finish()
-
-    def _decode_ahead(self, filenames):
-        """(path, future-or-None) in file order.  With decode_threads > 1 the files are decoded on a
-        thread pool a few frames ahead of the consumer (image codecs release the GIL): a 24 MP JPEG
-        takes the host far longer to decode than the GPU needs to fuse it.  Errors surface in order,
-        at the file that caused them, as in the sequential loop (pyramid.py:155-169)."""
-        n = int(self.decode_threads or 0)
-        if n <= 1 or len(filenames) <= 1:
-            for p in filenames:
-                yield p, None
-            return
-        from collections import deque
-        from concurrent.futures import ThreadPoolExecutor
-        with ThreadPoolExecutor(max_workers=n) as pool:
-            window = deque()
-            it = iter(filenames)
-            for p in it:
-                window.append((p, pool.submit(read_img, p)))
-                if len(window) >= 2 * n:
-                    break
-            while window:
-                p, fut = window.popleft()
-                nxt = next(it, None)
-                if nxt is not None:
-                    window.append((nxt, pool.submit(read_img, nxt)))
-                try:
-                    yield p, fut
-                except GeneratorExit:
-                    for _, f in window:
-                        f.cancel()
-                    raise
 
     def focus_stack_arrays(self, frames):
         """In-memory variant (no file I/O): `frames` is a sequence of H x W x 3 uint8/uint16
