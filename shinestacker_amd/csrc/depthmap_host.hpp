@@ -18,8 +18,7 @@ struct mi_dmap {
     float *tot = nullptr, *mx = nullptr;
     float* scal = nullptr;           // [0] global max, [1..2] frame min / max, [3..4] bilateral scale / flat flag
     float* lut = nullptr;
-    int8_t* offs = nullptr;
-    float* sw = nullptr;
+    int2* disc = nullptr;            // bilateral disc: (LDS patch offset, space weight bits) per tap
     int radius = 0, ntaps = 0;
     double color_coeff = 0.0;
     std::vector<int> lh, lw;         // level shapes, 0 .. levels-1
@@ -119,7 +118,12 @@ int dmap_energy(mi_dmap* d, int i) {
     } else {
         hipLaunchKernelGGL((dm_blur<true>), dm_grid2(h, w), dim3(256), 0, st, d->tmpA, h, w, d->tmpB, d->taps);
         hipLaunchKernelGGL((dm_blur<false>), dm_grid2(h, w), dim3(256), 0, st, d->tmpB, h, w, d->tmpC, d->taps);
-        hipLaunchKernelGGL(dm_laplacian, dm_grid2(h, w), dim3(256), 0, st, d->tmpC, h, w, d->en[i], d->scal, d->k2);
+        if (d->k2.ksize == 5)
+            hipLaunchKernelGGL((dm_laplacian<5>), dm_grid2(h, w), dim3(256), 0, st, d->tmpC, h, w, d->en[i], d->scal, d->k2);
+        else if (d->k2.ksize == 3)
+            hipLaunchKernelGGL((dm_laplacian<3>), dm_grid2(h, w), dim3(256), 0, st, d->tmpC, h, w, d->en[i], d->scal, d->k2);
+        else
+            hipLaunchKernelGGL((dm_laplacian<0>), dm_grid2(h, w), dim3(256), 0, st, d->tmpC, h, w, d->en[i], d->scal, d->k2);
     }
     MI_HIP(hipGetLastError());
     return MI_OK;
@@ -149,12 +153,13 @@ int dmap_finish_t(mi_dmap* d) {
     // energies / max, smoothing, running sum (AVERAGE) or maximum (MAX) over the frames
     for (int i = 0; i < N; ++i) {
         MI_HIP(hipMemcpyAsync(d->scal + 1, mm_init, 8, hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(dm_normalise, dm_grid1(np), dim3(256), 0, st, d->en[i], np, d->scal, d->scal + 1);
+        hipLaunchKernelGGL(dm_normalise, dim3((unsigned)std::min<size_t>((np + 255) / 256, 4096)), dim3(256), 0, st, d->en[i], np,
+                           d->scal, d->scal + 1);
         float* acc = avg ? d->tot : d->mx;
         if (d->p.smooth_size > 0) {
             hipLaunchKernelGGL(dm_bilateral_lut, dim3(1), dim3(1024), 0, st, d->scal + 1, d->color_coeff, d->lut,
                                d->scal + 3);
-            DmBilateral a{d->en[i], d->spare, h, w, d->radius, d->ntaps, d->offs, d->sw, d->lut, d->scal + 3,
+            DmBilateral a{d->en[i], d->spare, h, w, d->radius, d->ntaps, d->disc, d->lut, d->scal + 3,
                           acc, avg ? 0 : 1, i == 0};
             hipLaunchKernelGGL(dm_bilateral, dim3(cdiv(w, 64), cdiv(h, 16)), dim3(256), 0, st, a);
             std::swap(d->en[i], d->spare);
@@ -275,20 +280,20 @@ int mi_dmap_create(mi_dmap_t** out, const mi_dmap_params_t* params) {
             d->radius = std::max(p.smooth_size / 2, 1);
             d->color_coeff = -0.5 / (sigma_color * sigma_color);
             const double cs = -0.5 / (sigma_space * sigma_space);
-            std::vector<int8_t> offs;
-            std::vector<float> sw;
+            std::vector<int2> taps;
+            const int pw = 64 + 2 * d->radius;   // patch row length of dm_bilateral's 16 x 64 tile
             for (int i = -d->radius; i <= d->radius; ++i)
                 for (int j = -d->radius; j <= d->radius; ++j) {
                     const double r = std::sqrt((double)i * i + (double)j * j);
                     if (r > d->radius) continue;
-                    offs.push_back((int8_t)i);
-                    offs.push_back((int8_t)j);
-                    sw.push_back((float)std::exp(r * r * cs));
+                    const float sw = (float)std::exp(r * r * cs);
+                    int bits;
+                    memcpy(&bits, &sw, 4);
+                    taps.push_back(make_int2(i * pw + j, bits));
                 }
-            d->ntaps = (int)sw.size();
-            if ((r = dmap_alloc(d, &d->offs, offs.size())) || (r = dmap_alloc(d, &d->sw, sw.size()))) return r;
-            MI_HIP(hipMemcpy(d->offs, offs.data(), offs.size(), hipMemcpyHostToDevice));
-            MI_HIP(hipMemcpy(d->sw, sw.data(), sw.size() * 4, hipMemcpyHostToDevice));
+            d->ntaps = (int)taps.size();
+            if ((r = dmap_alloc(d, &d->disc, taps.size()))) return r;
+            MI_HIP(hipMemcpy(d->disc, taps.data(), taps.size() * sizeof(int2), hipMemcpyHostToDevice));
         }
         int lh = p.height, lw = p.width;
         for (int l = 0; l < p.levels; ++l) {

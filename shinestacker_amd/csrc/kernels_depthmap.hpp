@@ -19,6 +19,8 @@
 
 namespace mi {
 
+typedef float dm_v2f __attribute__((ext_vector_type(2)));
+
 struct DmTaps {
     float k[32];  // symmetric Gaussian, float32 (cv2.getGaussianKernel(ksize, 0, CV_32F))
     int ksize;
@@ -71,25 +73,47 @@ __global__ __launch_bounds__(256) void dm_blur(const float* __restrict__ src, in
     dst[(size_t)y * w + x] = acc;
 }
 
+// workgroup maximum -> one atomic per workgroup, and none when the global value is already as large (the
+// running maximum only grows, so a stale read can cost an extra atomic but never lose one)
 __device__ __forceinline__ void block_max_to(float v, float* gmax) {
+    __shared__ float sm[16];
     v = wave_max(v);
-    if ((threadIdx.x & 63) == 0 && v > 0.f) atomic_max_pos(gmax, v);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < (int)(blockDim.x >> 6); ++i) v = fmaxf(v, sm[i]);
+        if (v > __hip_atomic_load(gmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomic_max_pos(gmax, v);
+    }
+}
+__device__ __forceinline__ void block_min_to(float v, float* gmin) {
+    __shared__ float sm[16];
+    v = wave_min(v);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < (int)(blockDim.x >> 6); ++i) v = fminf(v, sm[i]);
+        if (v < __hip_atomic_load(gmin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomic_min_pos(gmin, v);
+    }
 }
 
-// |cv2.Laplacian(blurred, CV_64F, ksize)| -> float32, and the running global maximum
+// |cv2.Laplacian(blurred, CV_64F, ksize)| -> float32, and the running global maximum.  KS = the aperture as a
+// compile-time constant (taps unrolled, kernel in registers) or 0 for any size; pixels whose window lies inside the
+// image skip the reflection maps.
+template <int KS>
 __global__ __launch_bounds__(256) void dm_laplacian(const float* __restrict__ src, int h, int w,
                                                     float* __restrict__ out, float* __restrict__ gmax, DmK2 K) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     float e = 0.f;
     if (x < w && y < h) {
-        const int r = K.ksize / 2;
+        const int ks = KS ? KS : K.ksize, r = ks / 2;
+        const bool inside = x >= r && y >= r && x + r < w && y + r < h;
         double s = 0.0;
-        for (int i = 0; i < K.ksize; ++i) {
-            const float* row = src + (size_t)r101_loop(y + i - r, h) * w;
-            for (int j = 0; j < K.ksize; ++j) {
-                const double k = K.k[i * K.ksize + j];
+        for (int i = 0; i < ks; ++i) {
+            const float* row = src + (size_t)(inside ? y + i - r : r101_loop(y + i - r, h)) * w;
+            for (int j = 0; j < ks; ++j) {
+                const double k = K.k[i * ks + j];
                 if (k == 0.0) continue;
-                const double pr = k * (double)row[r101_loop(x + j - r, w)];
+                const double pr = k * (double)row[inside ? x + j - r : r101_loop(x + j - r, w)];
                 s = s + pr;
             }
         }
@@ -135,23 +159,19 @@ __global__ __launch_bounds__(256) void dm_sobel(const float* __restrict__ src, i
 // filter scales its range table with them).  mm[0] = min, mm[1] = max, preset to +inf bits / 0.
 __global__ __launch_bounds__(256) void dm_normalise(float* __restrict__ e, size_t n, const float* __restrict__ gmax,
                                                     float* __restrict__ mm) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     const float m = *gmax;
-    float v = 0.f, lo = __uint_as_float(0x7f800000u);
-    if (i < n) {
-        v = e[i];
+    float hi = 0.f, lo = __uint_as_float(0x7f800000u);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        float v = e[i];
         if (m > 0.f) {
             v = v / m;
             e[i] = v;
         }
-        lo = v;
+        hi = fmaxf(hi, v);
+        lo = fminf(lo, v);
     }
-    const float hi = wave_max(v);
-    lo = wave_min(lo);
-    if ((threadIdx.x & 63) == 0) {
-        atomic_max_pos(mm + 1, hi);
-        atomic_min_pos(mm, lo);
-    }
+    block_max_to(hi, mm + 1);
+    block_min_to(lo, mm);
 }
 
 constexpr int DM_LUT_BINS = 4096;
@@ -180,8 +200,7 @@ struct DmBilateral {
     const float* src;
     float* dst;
     int h, w, radius, ntaps;
-    const int8_t* offs;   // ntaps x (dy, dx), raster order of the disc
-    const float* sw;      // space weights
+    const int2* taps;     // ntaps x (dy * patch_width + dx, bits of the space weight), raster order of the disc
     const float* lut;
     const float* bp;
     float* acc;           // AVERAGE: running sum of the smoothed energies; MAX: running maximum
@@ -195,13 +214,17 @@ struct DmBilateral {
 __global__ __launch_bounds__(256) void dm_bilateral(DmBilateral a) {
     constexpr int TH = 16, TW = 64, RMAX = 15;
     __shared__ float sP[(TH + 2 * RMAX) * (TW + 2 * RMAX)];
-    __shared__ float sL[DM_LUT_BINS + 2];
+    __shared__ __attribute__((aligned(8))) float sL[2 * (DM_LUT_BINS + 1)];   // (lut[i], lut[i+1] - lut[i]) pairs
     const int t = threadIdx.x, r = a.radius;
     const int y0 = blockIdx.y * TH, x0 = blockIdx.x * TW;
     const bool flat = a.bp[1] != 0.f;
     const int pw = TW + 2 * r, ph = TH + 2 * r;
     if (!flat) {
-        for (int i = t; i < DM_LUT_BINS + 2; i += 256) sL[i] = a.lut[i];
+        for (int i = t; i < DM_LUT_BINS + 1; i += 256) {
+            const float l0 = a.lut[i], l1 = a.lut[i + 1];
+            sL[2 * i] = l0;
+            sL[2 * i + 1] = l1 - l0;
+        }
         for (int i = t; i < ph * pw; i += 256) {
             const int py = i / pw, px = i - py * pw;
             sP[i] = a.src[(size_t)r101_loop(y0 + py - r, a.h) * a.w + r101_loop(x0 + px - r, a.w)];
@@ -210,35 +233,39 @@ __global__ __launch_bounds__(256) void dm_bilateral(DmBilateral a) {
     __syncthreads();
     const float scale_index = a.bp[0];
     const int tx = t & 63, tq = t >> 6;
+    // the thread's four pixels (rows tq, tq+4, tq+8, tq+12 of column tx) go through the taps together: four
+    // independent chains hide the LDS latency of the patch read and of the range-table gather
+    const float* c = sP + (tq + r) * pw + (tx + r);
+    float v0[4], sum[4] = {0.f, 0.f, 0.f, 0.f}, wsum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v0[k] = c[4 * k * pw];
+    if (!flat) {
+#pragma unroll 2
+        for (int n = 0; n < a.ntaps; ++n) {
+            const int2 tap = a.taps[n];                // (dy * pw + dx, bits of the space weight): a scalar load
+            const float swn = __int_as_float(tap.y);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float val = c[4 * k * pw + tap.x];
+                const float alpha = fabsf(val - v0[k]) * scale_index;   // 0 <= alpha <= DM_LUT_BINS
+                const int idx = (int)alpha;                               // floor of a non-negative value
+                const float fr = __builtin_amdgcn_fractf(alpha);          // alpha - floor(alpha), exact
+                const dm_v2f l = *reinterpret_cast<const dm_v2f*>(sL + 2 * idx);
+                const float ad = fr * l.y;
+                const float cw = l.x + ad;
+                const float wk = swn * cw;
+                const float vw = val * wk;
+                sum[k] = sum[k] + vw;
+                wsum[k] = wsum[k] + wk;
+            }
+        }
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const int ty = tq + 4 * k, y = y0 + ty, x = x0 + tx;
+        const int y = y0 + tq + 4 * k, x = x0 + tx;
         if (y >= a.h || x >= a.w) continue;
         const size_t pi = (size_t)y * a.w + x;
-        float res;
-        if (flat) {
-            res = a.src[pi];
-        } else {
-            const float* c = sP + (ty + r) * pw + (tx + r);
-            const float v0 = *c;
-            float sum = 0.f, wsum = 0.f;
-            for (int n = 0; n < a.ntaps; ++n) {
-                const int dy = a.offs[2 * n], dx = a.offs[2 * n + 1];
-                const float val = c[dy * pw + dx];
-                float alpha = fabsf(val - v0) * scale_index;
-                const int idx = (int)floorf(alpha);
-                alpha = alpha - (float)idx;
-                const float l0 = sL[idx], l1 = sL[idx + 1];
-                const float d = l1 - l0;
-                const float ad = alpha * d;
-                const float cw = l0 + ad;
-                const float wk = a.sw[n] * cw;
-                const float vw = val * wk;
-                sum = sum + vw;
-                wsum = wsum + wk;
-            }
-            res = sum / wsum;
-        }
+        const float res = flat ? a.src[pi] : sum[k] / wsum[k];
         a.dst[pi] = res;
         if (a.mode == 0) a.acc[pi] = a.first ? 0.f + res : a.acc[pi] + res;
         else a.acc[pi] = a.first ? res : fmaxf(a.acc[pi], res);

@@ -2,11 +2,14 @@
 weights, blend) timed separately.  python tools/depthmap_time.py [--frames 32] [--dtype u8] [--map max] ..."""
 import argparse
 import json
+import os
+import sys
 import time
 
 import numpy as np
 
-from shinestacker_amd import _lib as L
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from shinestacker_amd import _lib as L  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--frames", type=int, default=32)
@@ -29,7 +32,6 @@ dm = L.DepthMap(H, W, dtype=dt, map_type={"average": 0, "max": 1}[a.map], energy
 best = None
 for rep in range(a.reps + 1):
     dm.reset()
-    L.device_synchronize(0) if hasattr(L, "device_synchronize") else None
     t0 = time.perf_counter()
     for i in range(N):
         dm.push_frame_device(buf.ptr + i * fb)
