@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """One-off randomised differential stress: many random shapes / dtypes / batch sizes / options through
 the tiled (default) path against the streaming oracle.  Not part of the test suite (minutes on a GPU box):
-    python tools/stress_parity.py [n_cases] [seed]"""
+    python tests/stress_parity.py [n_cases] [seed]"""
 import os
 import sys
 
