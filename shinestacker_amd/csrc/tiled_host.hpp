@@ -209,6 +209,28 @@ int launch_level(mi_stack* s, int l, int set, const void* src, size_t src_stride
         const char* ab = getenv("MI_ABLATE");  // timing studies only; results are wrong when set
         a.ablate = ab ? atoi(ab) : 0;
     }
+#ifdef MI_PHASE_CLOCK
+    static unsigned long long* dbg_dev = nullptr;
+    if (l == 0) {
+        if (!dbg_dev) {
+            MI_HIP(hipMalloc(&dbg_dev, 16 * 16 * 8));
+            MI_HIP(hipMemset(dbg_dev, 0, 16 * 16 * 8));
+        } else {   // print the previous launch's numbers
+            unsigned long long hbuf[16 * 16];
+            MI_HIP(hipMemcpy(hbuf, dbg_dev, sizeof hbuf, hipMemcpyDeviceToHost));
+            MI_HIP(hipMemset(dbg_dev, 0, 16 * 16 * 8));
+            static const char* nm[9] = {"stage", "bar1", "prefetch", "reduce", "bar2", "gnstore", "lapq", "bar3", "energy"};
+            for (int wv = 0; wv < NT / 64; ++wv) {
+                if (!hbuf[wv * 16 + 15]) continue;
+                fprintf(stderr, "wave %d:", wv);
+                for (int i = 0; i < 9; ++i)
+                    fprintf(stderr, " %s %.0f", nm[i], (double)hbuf[wv * 16 + i] / (double)hbuf[wv * 16 + 15] / nb);
+                fprintf(stderr, "  (cycles per frame)\n");
+            }
+        }
+        a.dbg = dbg_dev;
+    } else a.dbg = nullptr;
+#endif
     const size_t ldsA = (size_t)GA::LDS_FLOATS * sizeof(float), ldsB = (size_t)GB::LDS_FLOATS * sizeof(float);
     auto kin = level_fused<TIn, FMA, true, TH, TW, NT, PADA>;
     auto kbd = level_fused<TIn, FMA, false, BH, BW, BNT, false>;
