@@ -480,7 +480,7 @@ int warp_launch(hipStream_t st, const void* src, void* side, void* out, uint8_t*
         // the warped image goes straight to `out`; the few pixels outside the source frame are blurred
         // from it into `side` and copied back (two sparse passes over the mask)
         const size_t n = (size_t)h * w;
-        hipLaunchKernelGGL((border_blur_collect<T>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st,
+        hipLaunchKernelGGL((border_blur_collect<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
                            (const T*)out, valid, (T*)side, h, w, g);
         hipLaunchKernelGGL((border_blur_scatter<T>), dim3((unsigned)((n / 16 + 256) / 256)), dim3(256), 0, st,
                            (T*)out, valid, (const T*)side, h, w);

@@ -213,18 +213,20 @@ __device__ __forceinline__ void blur_at(const T* __restrict__ img, int h, int w,
 // mask is 0 (a frame along the borders: a few columns at the sides, wedges where the frame rotated)
 // get their blurred value computed from the untouched image into `side` (same index), then copied back.
 //
-// Pass 0 (collect), one wave per 64 consecutive pixels.  A wave with no masked pixel leaves at once.
+// Pass 0 (collect), one wave per 64 consecutive pixels (four waves per workgroup).  A wave with no masked pixel leaves at once.
 // A wave with many does one pixel per lane (blur_at).  A wave with few (the side columns: 1-3 lanes)
 // works through them 64 / ksize at a time instead of idling 60 lanes for 441 taps: ksize lanes per
 // pixel, lane r does the horizontal pass of window row r (taps in index order), the first lane of the
 // group adds the ksize row results in row order (shuffles, no LDS) -- the same float32 operations in
 // the same order as align_oracle.c either way.
 template <typename T>
-__global__ __launch_bounds__(64) void border_blur_collect(const T* __restrict__ img, const uint8_t* __restrict__ valid,
-                                                          T* __restrict__ side, int h, int w, GaussArgs g) {
-    const int lane = threadIdx.x;
+__global__ __launch_bounds__(256) void border_blur_collect(const T* __restrict__ img, const uint8_t* __restrict__ valid,
+                                                           T* __restrict__ side, int h, int w, GaussArgs g) {
+    // four independent waves per workgroup (one 64-pixel chunk each): a quarter of the workgroups to dispatch --
+    // with one-wave workgroups the launch of the 375 000 of a 24 MP frame alone took 80 us
+    const int lane = threadIdx.x & 63;
     const size_t n = (size_t)h * w;
-    const size_t base = (size_t)blockIdx.x * 64;
+    const size_t base = ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
     const size_t pi = base + lane;
     const bool masked = pi < n && valid[pi] == 0;
     const unsigned long long ballot = __ballot(masked);
