@@ -283,14 +283,41 @@ def get_bunches(collection, n_frames, n_overlap):
     return [collection[x:x + n_frames] for x in range(0, len(collection) - n_overlap, step)]
 
 
-class FocusStackBunch(StepList, _FocusStackCommon):
-    """stack.py:67-97."""
+def shard_steps(n_steps, rank, world):
+    """Contiguous block of step indices for `rank`: sizes differ by at most one, every step exactly once."""
+    per, extra = divmod(n_steps, world)
+    lo = rank * per + min(rank, extra)
+    return range(lo, lo + per + (1 if rank < extra else 0))
 
-    def __init__(self, name, stack_algo, enabled=True, **kwargs):
+
+class FocusStackBunch(StepList, _FocusStackCommon):
+    """stack.py:67-97.
+
+    Multi-GPU ("bunch mode: whole bunches per GPU, no collective"): bunches are independent
+    stacks, so with ``shard=(rank, world)`` -- or ``shard='env'``, which reads RANK / WORLD_SIZE / LOCAL_RANK
+    as torch.distributed.run sets them and puts the stacker on device LOCAL_RANK -- every process fuses a
+    contiguous block of the bunch steps and writes those output files; file names, contents and the
+    'bunch: NNNN' plot titles are the ones the single-process run produces.  Only rank 0 scratches the output
+    directory; the other ranks wait for it (torch.distributed barrier when a process group exists, else a marker
+    file), so that no rank writes into a directory that is still being emptied."""
+
+    def __init__(self, name, stack_algo, enabled=True, shard=None, **kwargs):
+        self.rank, self.world = 0, 1
+        if shard == 'env':
+            self.rank, self.world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+            if hasattr(stack_algo, "device"):
+                stack_algo.device = int(os.environ.get("LOCAL_RANK", "0"))
+        elif shard is not None:
+            self.rank, self.world = int(shard[0]), int(shard[1])
+        if not 0 <= self.rank < self.world:
+            raise InvalidOptionError("shard", shard, "rank must be in [0, world)")
+        if self.rank > 0:
+            kwargs['scratch_output_dir'] = False
         StepList.__init__(self, name, enabled)
         FrameDirectory.__init__(self, name, **kwargs)
         self._init_stack(stack_algo, kwargs)
         self._chunks = None
+        self._steps = None
         self.frame_count = 0
         self.frames = kwargs.get('frames', constants.DEFAULT_FRAMES)
         self.overlap = kwargs.get('overlap', constants.DEFAULT_OVERLAP)
@@ -302,16 +329,45 @@ class FocusStackBunch(StepList, _FocusStackCommon):
     def init(self, job, _working_path=''):
         self.init_paths(job)
 
+    def _marker(self):
+        run = os.environ.get("TORCHELASTIC_RUN_ID") or os.environ.get("MASTER_PORT") or "0"
+        return os.path.join(self.output_dir, f".shard_ready_{run}")
+
+    def _wait_for_rank0(self, timeout=600.0):
+        """Rank 0 has emptied the output directory (init_paths) before any rank writes into it."""
+        if self.world == 1:
+            return
+        try:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                dist.barrier()
+                return
+        except ImportError:
+            pass
+        import time
+        if self.rank == 0:
+            open(self._marker(), "w").close()
+            return
+        t0 = time.monotonic()
+        while not os.path.exists(self._marker()):
+            if time.monotonic() - t0 > timeout:
+                raise RuntimeError(f"rank {self.rank}: rank 0 did not prepare {self.output_dir}")
+            time.sleep(0.01)
+
     def begin(self):
         StepList.begin(self)
         self._chunks = get_bunches(self.folder_filelist(), self.frames, self.overlap)
-        self.set_counts(len(self._chunks))
+        self._steps = list(shard_steps(len(self._chunks), self.rank, self.world))
+        self.set_counts(len(self._steps))
+        self._wait_for_rank0()
 
     def run_step(self):
-        self.print_message_r(f"fusing bunch: {self.count + 1}/{self.counts}")
+        step = self._steps[self.count]
+        self.frame_count = step   # the 'bunch: NNNN' title numbers bunches by their global step
+        self.print_message_r(f"fusing bunch: {step + 1}/{len(self._chunks)}")
         # the reference indexes chunks[count - 1] with count starting at 0 (stack.py:97):
         # the last bunch goes first; every bunch is still fused exactly once.
-        self.focus_stack(self._chunks[self.count - 1])
+        self.focus_stack(self._chunks[step - 1])
 
 
 # ------------------------------------------------------------------------------ per-frame actions

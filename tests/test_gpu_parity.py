@@ -467,3 +467,28 @@ def test_frames_beyond_24_bit_pixel_counts(L, oracle):
     st.close()
     with pytest.raises(Exception):
         L.Stack(20000, 20000)   # 400 MP: beyond the 32-bit in-frame addressing, rejected at create
+
+
+def test_bunches_sharded_over_two_ranks_on_one_gpu(L, tmp_path):
+    """SURVEY 8(e) bunch mode with the HIP stacker: the two ranks' blocks of bunches (run one after the other on
+    this GPU) give the files of the single-process job, bit for bit."""
+    from shinestacker_amd import FocusStackBunch, PyramidStack, StackJob
+    from shinestacker_amd.imageio import read_img, write_img
+    rng = np.random.default_rng(21)
+    work = str(tmp_path)
+    os.makedirs(os.path.join(work, "in"))
+    for i in range(11):
+        write_img(os.path.join(work, "in", f"f{i:02d}.png"), rng.integers(0, 256, (80, 112, 3)).astype(np.uint8))
+
+    def run(shard, out):
+        job = StackJob("job", work, input_path="in")
+        job.add_action(FocusStackBunch("b", PyramidStack(min_size=16), output_path=out, frames=4, overlap=1,
+                                       shard=shard))
+        job.run()
+    run(None, "single")
+    for rank in (0, 1):
+        run((rank, 2), "sharded")
+    names = sorted(os.listdir(os.path.join(work, "single")))
+    assert names == sorted(f for f in os.listdir(os.path.join(work, "sharded")) if not f.startswith(".")) and len(names) == 4
+    for f in names:
+        assert np.array_equal(read_img(os.path.join(work, "single", f)), read_img(os.path.join(work, "sharded", f)))

@@ -197,3 +197,75 @@ def test_combined_actions_iteration_order(workdir, step_process, want):
     job.run()
     assert rec.seen == want
     assert len(os.listdir(os.path.join(workdir, "aligned"))) == 6
+
+
+def test_bunches_sharded_over_ranks(oracle, workdir, tmp_path):
+    """SURVEY 8(e) bunch mode: whole bunches per process, no collective.  Two ranks (run one after the other
+    here) produce exactly the files of the single-process job, each bunch fused once, same 'bunch: NNNN' titles."""
+    from shinestacker_amd.actions import shard_steps
+    for n, world in ((7, 2), (5, 8), (16, 4), (0, 3)):
+        got = [i for r in range(world) for i in shard_steps(n, r, world)]
+        assert got == list(range(n))
+        sizes = [len(shard_steps(n, r, world)) for r in range(world)]
+        assert max(sizes) - min(sizes) <= 1
+
+    def run(shard, out, cbs=None):
+        job = StackJob("job", workdir, input_path="input", callbacks=cbs or {})
+        job.add_action(FocusStackBunch("bunches", OracleStacker(oracle), output_path=out, frames=3, overlap=1,
+                                       shard=shard))
+        job.run()
+        return job
+
+    trace1, cbs1 = recorder()
+    run(None, "single", cbs1)
+    titles1 = sorted(t[2] for t in trace1 if t[0] == "save_plot")
+    files1 = sorted(os.listdir(os.path.join(workdir, "single")))
+    assert len(files1) >= 2
+    titles2 = []
+    os.makedirs(os.path.join(workdir, "sharded"))
+    open(os.path.join(workdir, "sharded", "stale.png"), "w").close()   # rank 0 (and only rank 0) empties the dir
+    for rank in (0, 1):
+        tr, cbs = recorder()
+        job = run((rank, 2), "sharded", cbs)
+        titles2 += [t[2] for t in tr if t[0] == "save_plot"]
+        assert job is not None
+    files2 = sorted(f for f in os.listdir(os.path.join(workdir, "sharded")) if not f.startswith("."))
+    assert files2 == files1 and sorted(titles2) == titles1
+    for f in files1:
+        assert np.array_equal(read_img(os.path.join(workdir, "single", f)), read_img(os.path.join(workdir, "sharded", f)))
+    with pytest.raises(InvalidOptionError):
+        FocusStackBunch("b", OracleStacker(oracle), shard=(2, 2))
+
+
+def test_bunches_sharded_two_processes(workdir):
+    """The same with two real processes started the way torch.distributed.run starts ranks (RANK / WORLD_SIZE /
+    LOCAL_RANK in the environment, shard='env'): rank 1 waits for rank 0's marker before it writes."""
+    import subprocess
+    import sys
+    script = (
+        "import os, sys, time\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from conftest import *\n"
+        "from oracle import oracle as orc\n"
+        "orc.build()\n"
+        "from test_host_logic import OracleStacker\n"
+        "from shinestacker_amd import FocusStackBunch, StackJob\n"
+        "if os.environ['RANK'] == '0': time.sleep(0.5)\n"     # rank 1 must wait for rank 0's scratch
+        "job = StackJob('job', %r, input_path='input')\n"
+        "algo = OracleStacker(orc); algo.device = -1\n"
+        "job.add_action(FocusStackBunch('bunches', algo, output_path='out2p', frames=3, overlap=1, shard='env'))\n"
+        "job.run()\n"
+        "assert algo.device == int(os.environ['LOCAL_RANK'])\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)), workdir)
+    os.makedirs(os.path.join(workdir, "out2p"))
+    open(os.path.join(workdir, "out2p", "stale.png"), "w").close()
+    procs = []
+    for rank in (0, 1):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_PORT="29511")
+        procs.append(subprocess.Popen([sys.executable, "-c", script], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    files = sorted(f for f in os.listdir(os.path.join(workdir, "out2p")) if not f.startswith("."))
+    n_in = len(os.listdir(os.path.join(workdir, "input")))
+    assert len(files) == len(get_bunches(list(range(n_in)), 3, 1)) and "stale.png" not in files

@@ -2,7 +2,12 @@
 """BASELINE config 5 on one GPU at reduced length: 16-bit 50 MP frames in HOST memory, stacked in
 bunches (FocusStackBunch geometry: frames=10, overlap=2, stack.py:61-64) through the pinned asynchronous
 upload path of mi_stack_push_frame -- PCIe, the bounce copy and the kernels overlap.  One stacker handle
-serves every bunch (reset between bunches), as FocusStackBunch does."""
+serves every bunch (reset between bunches), as FocusStackBunch does.
+
+Several GPUs (SURVEY 8(e) bunch mode, no collective in the data path): start it with
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 tools/config5.py
+Every rank fuses a contiguous block of the bunches on GPU LOCAL_RANK (actions.shard_steps, what
+FocusStackBunch(shard='env') does); a gloo group is used for the two barriers and the max-over-ranks time only."""
 import argparse
 import json
 import os
@@ -20,17 +25,25 @@ def main():
     ap.add_argument("--height", type=int, default=5792)
     ap.add_argument("--width", type=int, default=8640)
     args = ap.parse_args()
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    dev = int(os.environ.get("MI_TOOL_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     from shinestacker_amd import _lib as L
-    from shinestacker_amd.actions import get_bunches
+    from shinestacker_amd.actions import get_bunches, shard_steps
     N, H, W = args.frames, args.height, args.width
     per = H * W * 3 * 2
     ndist = 8   # distinct host frames, cycled
-    buf = L.DeviceBuffer(per * ndist)
-    L.synth_frames_device(buf.ptr, np.uint16, H, W, 0, ndist, ndist)
+    buf = L.DeviceBuffer(per * ndist, dev)
+    L.synth_frames_device(buf.ptr, np.uint16, H, W, 0, ndist, ndist, device=dev)
     host = [buf.download((H, W, 3), np.uint16, offset=i * per) for i in range(ndist)]
-    bunches = get_bunches(list(range(N)), 10, 2)
-    st = L.Stack(H, W, in_dtype=np.uint16, out_dtype=np.uint16)
-    out = L.DeviceBuffer(per)
+    all_bunches = get_bunches(list(range(N)), 10, 2)
+    bunches = [all_bunches[i] for i in shard_steps(len(all_bunches), rank, world)]
+    st = L.Stack(H, W, in_dtype=np.uint16, out_dtype=np.uint16, device=dev)
+    out = L.DeviceBuffer(per, dev)
 
     def run():
         pushed = 0
@@ -43,12 +56,25 @@ def main():
         st.sync()
         return pushed
     run()
+    if dist is not None:
+        dist.barrier()
     t0 = time.perf_counter()
     pushed = run()
     dt = time.perf_counter() - t0
-    print(json.dumps({"config": f"{N} x {W}x{H} u16 frames from host memory, {len(bunches)} bunches of <= 10 (overlap 2)",
-                      "frames_pushed": pushed, "seconds": dt, "Mpixels_per_s": pushed * H * W / dt / 1e6,
-                      "host_to_device_GB_per_s": pushed * per / dt / 1e9}))
+    if dist is not None:
+        t = torch.tensor([dt, float(pushed)], dtype=torch.float64)
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        dt, pushed = float(tmax[0]), int(t[1])
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({"config": f"{N} x {W}x{H} u16 frames from host memory, {len(all_bunches)} bunches of <= 10 "
+                                    f"(overlap 2) over {world} process(es)",
+                          "frames_pushed": pushed, "seconds": dt, "Mpixels_per_s": pushed * H * W / dt / 1e6,
+                          "host_to_device_GB_per_s": pushed * per / dt / 1e9}))
+    if dist is not None:
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
