@@ -290,44 +290,22 @@ def shard_steps(n_steps, rank, world):
     return range(lo, lo + per + (1 if rank < extra else 0))
 
 
-class FocusStackBunch(StepList, _FocusStackCommon):
-    """stack.py:67-97.
+class _Sharded:
+    """Rank bookkeeping of the actions that split their independent steps over processes (one per GPU)."""
+    rank, world = 0, 1
 
-    Multi-GPU (SURVEY.md 8(e), "bunch mode: whole bunches per GPU, no collective"): bunches are independent
-    stacks, so with ``shard=(rank, world)`` -- or ``shard='env'``, which reads RANK / WORLD_SIZE / LOCAL_RANK
-    as torch.distributed.run sets them and puts the stacker on device LOCAL_RANK -- every process fuses a
-    contiguous block of the bunch steps and writes those output files; file names, contents and the
-    'bunch: NNNN' plot titles are the ones the single-process run produces.  Only rank 0 scratches the output
-    directory; the other ranks wait for it (torch.distributed barrier when a process group exists, else a marker
-    file), so that no rank writes into a directory that is still being emptied."""
-
-    def __init__(self, name, stack_algo, enabled=True, shard=None, **kwargs):
-        self.rank, self.world = 0, 1
+    def _shard_setup(self, shard, kwargs, device_holders=()):
         if shard == 'env':
             self.rank, self.world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
-            if hasattr(stack_algo, "device"):
-                stack_algo.device = int(os.environ.get("LOCAL_RANK", "0"))
+            for obj in device_holders:
+                if hasattr(obj, "device"):
+                    obj.device = int(os.environ.get("LOCAL_RANK", "0"))
         elif shard is not None:
             self.rank, self.world = int(shard[0]), int(shard[1])
         if not 0 <= self.rank < self.world:
             raise InvalidOptionError("shard", shard, "rank must be in [0, world)")
         if self.rank > 0:
-            kwargs['scratch_output_dir'] = False
-        StepList.__init__(self, name, enabled)
-        FrameDirectory.__init__(self, name, **kwargs)
-        self._init_stack(stack_algo, kwargs)
-        self._chunks = None
-        self._steps = None
-        self.frame_count = 0
-        self.frames = kwargs.get('frames', constants.DEFAULT_FRAMES)
-        self.overlap = kwargs.get('overlap', constants.DEFAULT_OVERLAP)
-        self.stack_algo.do_step_callback = False
-        if self.overlap >= self.frames:
-            raise InvalidOptionError("overlap", self.overlap,
-                                     "overlap must be smaller than batch size")
-
-    def init(self, job, _working_path=''):
-        self.init_paths(job)
+            kwargs['scratch_output_dir'] = False   # only rank 0 empties the shared output directory
 
     def _marker(self):
         run = os.environ.get("TORCHELASTIC_RUN_ID") or os.environ.get("MASTER_PORT") or "0"
@@ -353,6 +331,36 @@ class FocusStackBunch(StepList, _FocusStackCommon):
             if time.monotonic() - t0 > timeout:
                 raise RuntimeError(f"rank {self.rank}: rank 0 did not prepare {self.output_dir}")
             time.sleep(0.01)
+
+
+class FocusStackBunch(StepList, _FocusStackCommon, _Sharded):
+    """stack.py:67-97.
+
+    Multi-GPU (SURVEY.md 8(e), "bunch mode: whole bunches per GPU, no collective"): bunches are independent
+    stacks, so with ``shard=(rank, world)`` -- or ``shard='env'``, which reads RANK / WORLD_SIZE / LOCAL_RANK
+    as torch.distributed.run sets them and puts the stacker on device LOCAL_RANK -- every process fuses a
+    contiguous block of the bunch steps and writes those output files; file names, contents and the
+    'bunch: NNNN' plot titles are the ones the single-process run produces.  Only rank 0 scratches the output
+    directory; the other ranks wait for it (torch.distributed barrier when a process group exists, else a marker
+    file), so that no rank writes into a directory that is still being emptied."""
+
+    def __init__(self, name, stack_algo, enabled=True, shard=None, **kwargs):
+        self._shard_setup(shard, kwargs, (stack_algo,))
+        StepList.__init__(self, name, enabled)
+        FrameDirectory.__init__(self, name, **kwargs)
+        self._init_stack(stack_algo, kwargs)
+        self._chunks = None
+        self._steps = None
+        self.frame_count = 0
+        self.frames = kwargs.get('frames', constants.DEFAULT_FRAMES)
+        self.overlap = kwargs.get('overlap', constants.DEFAULT_OVERLAP)
+        self.stack_algo.do_step_callback = False
+        if self.overlap >= self.frames:
+            raise InvalidOptionError("overlap", self.overlap,
+                                     "overlap must be smaller than batch size")
+
+    def init(self, job, _working_path=''):
+        self.init_paths(job)
 
     def begin(self):
         StepList.begin(self)
@@ -384,15 +392,21 @@ class SubAction:
         pass
 
 
-class CombinedActions(StepList, FrameDirectory):
+class CombinedActions(StepList, FrameDirectory, _Sharded):
     """Per-frame sub-action pipeline with a reference frame
     (stack_framework.py:191-232 FramesRefActions + :246-302 CombinedActions)."""
 
     def __init__(self, name, actions=None, enabled=True, ref_idx=-1, step_process=False,
-                 io_threads=2, **kwargs):
+                 io_threads=2, shard=None, **kwargs):
+        # SURVEY.md 8(e), alignment: without step_process every frame depends on the reference frame only, so
+        # the frames split over processes like bunches do (shard=(rank, world) or 'env'; every rank reads the
+        # reference frame itself, no collective); with step_process the frames form two serial chains
+        self._actions = list(actions or [])
+        self._shard_setup(shard, kwargs, self._actions)
+        if self.world > 1 and step_process:
+            raise InvalidOptionError("shard", shard, "step_process chains frames; they cannot be sharded")
         FrameDirectory.__init__(self, name, **kwargs)
         StepList.__init__(self, name, enabled)
-        self._actions = list(actions or [])
         self.ref_idx = ref_idx
         self.step_process = step_process
         # codec work off the critical path (not in the reference, which reads, processes and writes one
@@ -413,12 +427,14 @@ class CombinedActions(StepList, FrameDirectory):
     def begin(self):
         StepList.begin(self)
         self.set_filelist()
-        self.set_counts(len(self.filenames))
+        self._block = shard_steps(len(self.filenames), self.rank, self.world)
+        self.set_counts(len(self._block))
         if self.ref_idx == -1:
             self.ref_idx = len(self.filenames) // 2
         for a in self._actions:
             if a.enabled:
                 a.begin(self)
+        self._wait_for_rank0()
 
     def end(self):
         self._drain_writes()
@@ -457,6 +473,8 @@ class CombinedActions(StepList, FrameDirectory):
         nxt = idx + idx_step
         if nxt == n:
             nxt = self.ref_idx - 1
+        if self.world > 1 and nxt not in self._block:
+            return
         if 0 <= nxt < n and nxt not in self._ahead and not (self.step_process and nxt == self.ref_idx):
             self._ahead[nxt] = pool.submit(read_img, f"{self.input_full_path}/{self.filenames[nxt]}")
 
@@ -471,10 +489,10 @@ class CombinedActions(StepList, FrameDirectory):
     def run_step(self):
         n = len(self.filenames)
         if self.count == 0:
-            self._idx = self.ref_idx if self.step_process else 0
+            self._idx = self.ref_idx if self.step_process else self._block.start
             self._ref_idx = self.ref_idx
             self._idx_step = +1
-        self.print_message_r(f"step {self.count + 1}/{n}: process file: "
+        self.print_message_r(f"step {self.count + 1}/{self.counts}: process file: "
                              f"{self.filenames[self._idx]}, reference: "
                              f"{self.filenames[self._ref_idx]}")
         self.run_frame(self._idx, self._ref_idx)

@@ -269,3 +269,24 @@ def test_bunches_sharded_two_processes(workdir):
     files = sorted(f for f in os.listdir(os.path.join(workdir, "out2p")) if not f.startswith("."))
     n_in = len(os.listdir(os.path.join(workdir, "input")))
     assert len(files) == len(get_bunches(list(range(n_in)), 3, 1)) and "stale.png" not in files
+
+
+def test_combined_actions_sharded_over_ranks(workdir):
+    """SURVEY 8(e) alignment without step_process: frames depend on the reference frame only, so they split over
+    processes; every rank sees the same reference index, the union of the ranks' frames is every frame once."""
+    seen, files = [], None
+    os.makedirs(os.path.join(workdir, "aligned"))
+    open(os.path.join(workdir, "aligned", "stale.png"), "w").close()
+    for rank in range(3):
+        rec = Recorder()
+        rec.device = -1
+        job = StackJob("job", workdir, input_path="input")
+        job.add_action(CombinedActions("combo", [rec], output_path="aligned", shard=(rank, 3)))
+        job.run()
+        seen += rec.seen
+        assert len(rec.seen) == 2 and rec.device == -1
+    assert seen == [(0, 3), (1, 3), (2, 3), (3, 3), (4, 3), (5, 3)]
+    files = sorted(f for f in os.listdir(os.path.join(workdir, "aligned")) if not f.startswith("."))
+    assert files == sorted(os.listdir(os.path.join(workdir, "input")))
+    with pytest.raises(InvalidOptionError):
+        CombinedActions("combo", [Recorder()], step_process=True, shard=(0, 2))
