@@ -88,6 +88,8 @@ struct mi_stack {
     float* fusedBase = nullptr;
 
     float *colA = nullptr, *colB = nullptr, *clipped = nullptr;
+    const float* collapse_src = nullptr;   // float-32 stacks: input of the finest collapse step (set by finish)
+    bool have_clipped = true;              // `clipped` holds the collapsed image (else the tap rebuilds it)
     void* out_dev = nullptr;
 
     int stream_levels = 0;    // levels 0..stream_levels-1 run their interior on the streaming kernel
@@ -420,13 +422,27 @@ int finish_impl(mi_stack* s) {
     const float* up = s->fusedBase;
     float* bufs[2] = {s->colA, s->colB};
     const dim3 blk(64, 4);
-    for (int l = L - 1; l >= 0; --l) {
+    for (int l = L - 1; l >= 1; --l) {
         float* out = bufs[l & 1];
         hipLaunchKernelGGL((collapse_simple<FMA>), grid2d(s->lw[l], s->lh[l], blk), blk, 0,
                            s->stream, up, s->lh[l + 1], s->lw[l + 1], s->bestLap[l], s->lh[l],
                            s->lw[l], out, s->K);
         up = out;
     }
+    s->collapse_src = up;     // level-1 image (or the fused base): what the collapsed-image tap restarts from
+    s->have_clipped = false;
+    if (L >= 1) {             // finest step fused with clip(abs) and the cast
+        const dim3 g0 = grid2d(s->lw[0], s->lh[0], blk);
+        if (s->p.out_dtype == MI_U8)
+            hipLaunchKernelGGL((collapse_final<FMA, uint8_t>), g0, blk, 0, s->stream, up, s->lh[1], s->lw[1], s->bestLap[0],
+                               s->lh[0], s->lw[0], s->maxv, (uint8_t*)s->out_dev, s->K);
+        else
+            hipLaunchKernelGGL((collapse_final<FMA, uint16_t>), g0, blk, 0, s->stream, up, s->lh[1], s->lw[1], s->bestLap[0],
+                               s->lh[0], s->lw[0], s->maxv, (uint16_t*)s->out_dev, s->K);
+        MI_HIP(hipGetLastError());
+        return MI_OK;
+    }
+    s->have_clipped = true;
     size_t n = (size_t)s->lh[0] * s->lw[0] * 3;
     dim3 g((unsigned)((n + 255) / 256));
     if (s->p.out_dtype == MI_U8)
@@ -1126,6 +1142,25 @@ int mi_stack_get_level(mi_stack_t* s, int level, int what, void* host_out, size_
         case MI_TAP_BASE_DEV: src = s->bDev; bytes = np(L) * fb; break;
         case MI_TAP_COLLAPSED:
             if (!s->finished) return fail(MI_ERR_STATE, "collapsed image is available after finish");
+            if (!s->f64 && !s->have_clipped) {   // finish fused the finest collapse step with the cast: redo it unfused
+                const dim3 blk(64, 4);
+                if (s->p.use_fma)
+                    hipLaunchKernelGGL((collapse_simple<true>), grid2d(s->lw[0], s->lh[0], blk), blk, 0, s->stream,
+                                       s->collapse_src, s->lh[1], s->lw[1], s->bestLap[0], s->lh[0], s->lw[0], s->colA, s->K);
+                else
+                    hipLaunchKernelGGL((collapse_simple<false>), grid2d(s->lw[0], s->lh[0], blk), blk, 0, s->stream,
+                                       s->collapse_src, s->lh[1], s->lw[1], s->bestLap[0], s->lh[0], s->lw[0], s->colA, s->K);
+                const size_t n = np(0) * 3;
+                const dim3 g((unsigned)((n + 255) / 256));
+                if (s->p.out_dtype == MI_U8)
+                    hipLaunchKernelGGL((finalize_cast<uint8_t>), g, dim3(256), 0, s->stream, s->colA, n, s->maxv, s->clipped,
+                                       (uint8_t*)s->out_dev);
+                else
+                    hipLaunchKernelGGL((finalize_cast<uint16_t>), g, dim3(256), 0, s->stream, s->colA, n, s->maxv, s->clipped,
+                                       (uint16_t*)s->out_dev);
+                MI_HIP(hipGetLastError());
+                s->have_clipped = true;
+            }
             src = s->clipped; bytes = np(0) * 3 * fb; break;
         default: return fail(MI_ERR_INVALID, "unknown tap %d", what);
     }

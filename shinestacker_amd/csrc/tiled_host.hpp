@@ -29,6 +29,7 @@ struct TiledState {
     int32_t* lev[2] = {nullptr, nullptr};   // base batch scratch, per set
     uint32_t* cnt[2] = {nullptr, nullptr};
     float* logp[2] = {nullptr, nullptr};
+    float* feat[2] = {nullptr, nullptr};    // (entropy, deviation) of every (frame, pixel) of the batch
     hipStream_t st1 = nullptr, st2 = nullptr;
     hipEvent_t evL0i[2] = {nullptr, nullptr}, evL0b[2] = {nullptr, nullptr}, evRest[2] = {nullptr, nullptr};
     std::vector<hipEvent_t> evLvl;  // [set][level][interior|border]: per-level joins of st2 and st1
@@ -86,6 +87,7 @@ int tiled_create(mi_stack* s) {
         if ((rc = dev_alloc_t(s, &t->lev[set], nb * t->bcap))) return rc;
         if ((rc = dev_alloc_t(s, &t->cnt[set], (size_t)s->nlevels_hist * t->bcap))) return rc;
         if ((rc = dev_alloc_t(s, &t->logp[set], (size_t)s->nlevels_hist * t->bcap))) return rc;
+        if ((rc = dev_alloc_t(s, &t->feat[set], 2 * nb * t->bcap))) return rc;
     }
     return MI_OK;
 }
@@ -314,9 +316,12 @@ int run_batch(mi_stack* s, const void* frames, size_t stride, int nb) {
         hipLaunchKernelGGL(base_logp_batch, dim3(cdiv(s->nlevels_hist, 256), nb), dim3(256), 0, st2,
                            t->cnt[set], s->nlevels_hist, npix, t->logp[set]);
         const dim3 blk(16, 4);
-        hipLaunchKernelGGL(base_feat_select_batch, grid2d(wb, hb, blk), blk, 0, st2, t->lev[set],
-                           t->logp[set], t->Gb[set][L], t->gstride[L], s->nlevels_hist, nb, hb, wb,
-                           s->pad, s->first_index + s->n_pushed, s->n_pushed == 0, s->bEnt, s->bDev,
+        dim3 grd = grid2d(wb, hb, blk);
+        grd.z = nb;
+        hipLaunchKernelGGL(base_feat_batch, grd, blk, 0, st2, t->lev[set], t->logp[set], s->nlevels_hist, hb, wb, s->pad,
+                           t->feat[set]);
+        hipLaunchKernelGGL(base_select_batch, dim3(cdiv(npix, 64)), dim3(64), 0, st2, t->feat[set], t->Gb[set][L],
+                           t->gstride[L], nb, npix, s->first_index + s->n_pushed, s->n_pushed == 0, s->bEnt, s->bDev,
                            s->idxE, s->idxD, s->baseE, s->baseD);
         MI_HIP(hipGetLastError());
     }
