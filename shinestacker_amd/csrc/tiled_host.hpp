@@ -297,8 +297,17 @@ int run_batch(mi_stack* s, const void* frames, size_t stride, int nb) {
     // coarser levels: interior tiles on st2, border tiles on st1 (disjoint tiles of one level run
     // side by side); both streams join after every level because level l+1 reads all of G_{l+1}
     for (int l = 1; l < L; ++l) {
-        if ((rc = launch_level<float, FMA, MI_TILE_H, MI_TILE_W, MI_TILE_NT, false, MI_TILE_H, MI_TILE_W, MI_TILE_NT>(
-                 s, l, set, t->Gb[set][l], t->gstride[l] * sizeof(float), nb, st2, st1)))
+        // coarser levels that still have thousands of tiles (4 MP and more: level 1 of a 24 MP frame) run on
+        // level 0's tile configuration -- less halo per tile: +2 % on the 256 x 24 MP job; MI_WIDE_LEVELS overrides
+        static const int wide_levels = getenv("MI_WIDE_LEVELS") ? atoi(getenv("MI_WIDE_LEVELS")) : -1;
+        const bool wide = wide_levels >= 0 ? l <= wide_levels : (size_t)s->lh[l] * s->lw[l] >= ((size_t)4 << 20);
+        if (wide)
+            rc = launch_level<float, FMA, MI_TILE0_H, MI_TILE0_W, MI_TILE0_NT, MI_TILE_PAD != 0, MI_TILE_H, MI_TILE_W, MI_TILE_NT>(
+                s, l, set, t->Gb[set][l], t->gstride[l] * sizeof(float), nb, st2, st1);
+        else
+            rc = launch_level<float, FMA, MI_TILE_H, MI_TILE_W, MI_TILE_NT, false, MI_TILE_H, MI_TILE_W, MI_TILE_NT>(
+                s, l, set, t->Gb[set][l], t->gstride[l] * sizeof(float), nb, st2, st1);
+        if (rc)
             return rc;
         hipEvent_t ei = t->evLvl[(set * (L + 1) + l) * 2], eb = t->evLvl[(set * (L + 1) + l) * 2 + 1];
         MI_HIP(hipEventRecord(ei, st2));
@@ -357,7 +366,9 @@ int tiled_push(mi_stack* s, const void* dev_frames, int n, size_t stride) {
         // levels, which is latency-bound and scales with the batch length.
         const int left = n - f0;
         int nb = left > t->bcap ? t->bcap : left;
-        if (left <= t->bcap && left >= 16 && n > t->bcap) nb = (left / 2 + 3) & ~3;
+        static const int taper = getenv("MI_TAPER") ? atoi(getenv("MI_TAPER")) : 1;   // 0 / 2: timing studies
+        if (taper == 1 && left <= t->bcap && left >= 16 && n > t->bcap) nb = (left / 2 + 3) & ~3;
+        if (taper == 2 && left == t->bcap && n > t->bcap) nb = t->bcap / 2;
         const void* fr = (const char*)dev_frames + (size_t)f0 * stride;
         switch (s->p.in_dtype) {
             case MI_U8: rc = fma ? run_batch<uint8_t, true>(s, fr, stride, nb) : run_batch<uint8_t, false>(s, fr, stride, nb); break;
