@@ -157,7 +157,7 @@ constexpr int ilcm(int a, int b) {
 //   interior kernel: tile config A (TH, TW, NT, padded LDS), stream st_in
 //   border kernel  : tile config B (BH, BW, BNT, unpadded LDS: small enough to co-reside
 //                    with two level-0 interior workgroups on one CU), stream st_bd
-template <typename TIn, bool FMA, int TH, int TW, int NT, bool PADA, int BH, int BW, int BNT>
+template <typename TIn, bool FMA, int TH, int TW, int NT, bool PADA, int BH, int BW, int BNT, bool COARSE_NAME = false>
 int launch_level(mi_stack* s, int l, int set, const void* src, size_t src_stride, int nb,
                  hipStream_t st_in, hipStream_t st_bd) {
     using GA = TileGeom<TH, TW, NT, PADA>;
@@ -234,7 +234,7 @@ int launch_level(mi_stack* s, int l, int set, const void* src, size_t src_stride
     } else a.dbg = nullptr;
 #endif
     const size_t ldsA = (size_t)GA::LDS_FLOATS * sizeof(float), ldsB = (size_t)GB::LDS_FLOATS * sizeof(float);
-    auto kin = level_fused<TIn, FMA, true, TH, TW, NT, PADA>;
+    auto kin = COARSE_NAME ? level_fused_coarse<TIn, FMA, true, TH, TW, NT, PADA> : level_fused<TIn, FMA, true, TH, TW, NT, PADA>;
     auto kbd = level_fused<TIn, FMA, false, BH, BW, BNT, false>;
     static thread_local bool attr_set = false;
     if (!attr_set) {
@@ -302,7 +302,7 @@ int run_batch(mi_stack* s, const void* frames, size_t stride, int nb) {
         static const int wide_levels = getenv("MI_WIDE_LEVELS") ? atoi(getenv("MI_WIDE_LEVELS")) : -1;
         const bool wide = wide_levels >= 0 ? l <= wide_levels : (size_t)s->lh[l] * s->lw[l] >= ((size_t)4 << 20);
         if (wide)
-            rc = launch_level<float, FMA, MI_TILE0_H, MI_TILE0_W, MI_TILE0_NT, MI_TILE_PAD != 0, MI_TILE_H, MI_TILE_W, MI_TILE_NT>(
+            rc = launch_level<float, FMA, MI_TILE0_H, MI_TILE0_W, MI_TILE0_NT, MI_TILE_PAD != 0, MI_TILE_H, MI_TILE_W, MI_TILE_NT, true>(
                 s, l, set, t->Gb[set][l], t->gstride[l] * sizeof(float), nb, st2, st1);
         else
             rc = launch_level<float, FMA, MI_TILE_H, MI_TILE_W, MI_TILE_NT, false, MI_TILE_H, MI_TILE_W, MI_TILE_NT>(
