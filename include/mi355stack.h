@@ -243,7 +243,7 @@ MI_API int mi_apply_lut_device(int device, void* stream, const void* dev_src, vo
 
 /* ---- DepthMapStack: the second stacker behind the same plug-in boundary ----
  * Replaces the arithmetic of DepthMapStack.focus_stack (reference algorithms/depth_map.py:64-123) for
- * float_type float-32: push = the first file loop (:67-75: read, img_bw, then per frame get_sobel_map :28-34
+ * both float types: push = the first file loop (:67-75: read, img_bw, then per frame get_sobel_map :28-34
  * or get_laplacian_map :36-41 and the running np.max :88); finish = energies / max (:90), smooth_energy
  * (:43-52), get_focus_map (:54-62), the per-frame pyrDown / pyrUp weighted Laplacian pyramids (:94-112),
  * the collapse and np.clip(np.absolute()).astype (:117-123).  The handle keeps every pushed frame and one
@@ -263,6 +263,7 @@ typedef struct mi_dmap_params {
     int32_t smooth_size;   /* cv2.bilateralFilter diameter, <= 0: no smoothing, <= 31 (:15)    */
     int32_t levels;        /* blend pyramid levels, >= 1 (:17)                                 */
     float temperature;     /* softmax temperature of the MAX map (:16)                         */
+    int32_t float_type;    /* MI_F32 / MI_F64 (:18, base_stack_algo.py:14-17)                  */
 } mi_dmap_params_t;
 MI_API void mi_dmap_default_params(mi_dmap_params_t* p);   /* constants.py:151-157 */
 MI_API int mi_dmap_create(mi_dmap_t** out, const mi_dmap_params_t* params);

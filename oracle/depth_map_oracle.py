@@ -45,21 +45,26 @@ _SMALL_GAUSS = {1: [1.0], 3: [0.25, 0.5, 0.25], 5: [0.0625, 0.25, 0.375, 0.25, 0
                 7: [0.03125, 0.109375, 0.21875, 0.28125, 0.21875, 0.109375, 0.03125]}
 
 
-def gaussian_kernel_f32(ksize, sigma=0.0):
-    """cv2.getGaussianKernel(ksize, sigma, CV_32F): fixed table for ksize <= 7 with sigma <= 0,
-    else exp(-x^2 / 2 sigma^2) with sigma = 0.3*((ksize-1)*0.5 - 1) + 0.8, evaluated in double,
-    rounded to float32, normalised by the sum of the rounded values."""
+def gaussian_kernel(ksize, dtype=F32, sigma=0.0):
+    """cv2.getGaussianKernel(ksize, sigma, CV_32F / CV_64F): fixed table for ksize <= 7 with sigma <= 0,
+    else exp(-x^2 / 2 sigma^2) with sigma = 0.3*((ksize-1)*0.5 - 1) + 0.8, evaluated in double, (CV_32F: rounded
+    to float32,) normalised by the sum of the stored values."""
+    dtype = np.dtype(dtype).type
     if sigma <= 0 and ksize in _SMALL_GAUSS:
-        return np.array(_SMALL_GAUSS[ksize], F32)
+        return np.array(_SMALL_GAUSS[ksize], dtype)
     if sigma <= 0:
         sigma = 0.3 * ((ksize - 1) * 0.5 - 1) + 0.8
     scale = -0.5 / (sigma * sigma)
-    k = np.array([math.exp(scale * (i - (ksize - 1) * 0.5) ** 2) for i in range(ksize)], np.float64).astype(F32)
+    k = np.array([math.exp(scale * (i - (ksize - 1) * 0.5) ** 2) for i in range(ksize)], np.float64).astype(dtype)
     s = 0.0
     for v in k:
         s += float(v)
     s = 1.0 / s
-    return np.array([F32(float(v) * s) for v in k], F32)
+    return np.array([dtype(float(v) * s) for v in k], dtype)
+
+
+def gaussian_kernel_f32(ksize, sigma=0.0):
+    return gaussian_kernel(ksize, F32, sigma)
 
 
 def sobel_kernels(dx, dy, ksize):
@@ -88,8 +93,8 @@ def laplacian_kernel2d(ksize):
 
 # --------------------------------------------------------------------------- primitives
 def filter2d_f64(img, k2d):
-    """Correlation of a float32 image with a 2-D kernel, accumulated in float64 in row-major tap
-    order, REFLECT_101.  (Sobel / Laplacian with ddepth CV_64F work in double.)"""
+    """Correlation of a float32 / float64 image with a 2-D kernel, accumulated in float64 in row-major
+    tap order, REFLECT_101.  (Sobel / Laplacian with ddepth CV_64F work in double.)"""
     kh, kw = k2d.shape
     ry, rx = kh // 2, kw // 2
     h, w = img.shape
@@ -112,10 +117,11 @@ def sobel_energy(gray, float_type=F32):
     return (np.abs(gx) + np.abs(gy)).astype(float_type)
 
 
-def gaussian_blur_f32(img, ksize):
-    """cv2.GaussianBlur(img, (ksize, ksize), 0) on float32: separable, rows then columns, each as
-    k[c]*S[0] + sum_j k[c+j]*(S[-j] + S[j]) in float32 (the symmetric row / column filters)."""
-    k = gaussian_kernel_f32(ksize)
+def gaussian_blur(img, ksize):
+    """cv2.GaussianBlur(img, (ksize, ksize), 0) on float32 / float64: separable, rows then columns, each as
+    k[c]*S[0] + sum_j k[c+j]*(S[-j] + S[j]) in the image's type (the symmetric row / column filters)."""
+    ft = img.dtype.type
+    k = gaussian_kernel(ksize, ft)
     r = ksize // 2
     h, w = img.shape
 
@@ -129,15 +135,19 @@ def gaussian_blur_f32(img, ksize):
         for j in range(1, r + 1):
             acc = acc + k[r + j] * (at(-j) + at(j))
         return acc
-    p = img.astype(F32)[:, reflect101(np.arange(-r, w + r), w)]
+    p = img[:, reflect101(np.arange(-r, w + r), w)]
     rows = sym(p, 1, w)
     p = rows[reflect101(np.arange(-r, h + r), h)]
     return sym(p, 0, h)
 
 
+def gaussian_blur_f32(img, ksize):
+    return gaussian_blur(np.asarray(img, F32), ksize)
+
+
 def laplacian_energy(gray, blur_size, kernel_size, float_type=F32):
     """depth_map.py:39-40."""
-    blurred = gaussian_blur_f32(gray, blur_size)
+    blurred = gaussian_blur(gray, blur_size)
     return np.abs(filter2d_f64(blurred, laplacian_kernel2d(kernel_size))).astype(float_type)
 
 
@@ -196,38 +206,45 @@ def bilateral_f32(img, d, sigma_color=25.0, sigma_space=25.0):
     return s / ws
 
 
+def _ft(img):
+    a = np.asarray(img)
+    return a if a.dtype in (np.float32, np.float64) else a.astype(F32)
+
+
 def pyr_down(img):
-    """cv2.pyrDown on float32 (any channel count): 5-tap [1 4 6 4 1] rows
+    """cv2.pyrDown on float32 / float64 (any channel count): 5-tap [1 4 6 4 1] rows
     (s[2x]*6 + (s[2x-1] + s[2x+1])*4 + s[2x-2] + s[2x+2]), the same across rows, then * 1/256.
     REFLECT_101 on the source indices; destination ((h+1)//2, (w+1)//2)."""
-    a = np.asarray(img, F32)
+    a = _ft(img)
+    T = a.dtype.type
     h, w = a.shape[:2]
     ho, wo = (h + 1) // 2, (w + 1) // 2
     cols = [reflect101(2 * np.arange(wo) + o, w) for o in (-2, -1, 0, 1, 2)]
-    row = a[:, cols[2]] * F32(6) + (a[:, cols[1]] + a[:, cols[3]]) * F32(4) + a[:, cols[0]] + a[:, cols[4]]
+    row = a[:, cols[2]] * T(6) + (a[:, cols[1]] + a[:, cols[3]]) * T(4) + a[:, cols[0]] + a[:, cols[4]]
     rws = [reflect101(2 * np.arange(ho) + o, h) for o in (-2, -1, 0, 1, 2)]
-    out = row[rws[2]] * F32(6) + (row[rws[1]] + row[rws[3]]) * F32(4) + row[rws[0]] + row[rws[4]]
-    return out * F32(1.0 / 256.0)
+    out = row[rws[2]] * T(6) + (row[rws[1]] + row[rws[3]]) * T(4) + row[rws[0]] + row[rws[4]]
+    return out * T(1.0 / 256.0)
 
 
 def _up_axis(a, n_dst, axis):
     """One axis of pyrUp (unnormalised): even = s[i-1] + 6 s[i] + s[i+1], odd = 4 (s[i] + s[i+1]);
     ends: first even 6 s[0] + 2 s[1], last even s[n-2] + 7 s[n-1], last odd 8 s[n-1]; an odd destination
     repeats its last sample, one of 2n - 1 drops the last odd sample."""
+    T = a.dtype.type
     a = np.moveaxis(a, axis, 0)
     n = a.shape[0]
-    out = np.empty((max(n_dst, 2 * n),) + a.shape[1:], F32)
+    out = np.empty((max(n_dst, 2 * n),) + a.shape[1:], a.dtype)
     if n == 1:
-        out[0] = a[0] * F32(8)
-        out[1] = a[0] * F32(8)
+        out[0] = a[0] * T(8)
+        out[1] = a[0] * T(8)
     else:
         ev = np.empty_like(a)
         od = np.empty_like(a)
-        ev[0] = a[0] * F32(6) + a[1] * F32(2)
-        ev[1:-1] = a[:-2] + a[1:-1] * F32(6) + a[2:]
-        ev[-1] = a[-2] + a[-1] * F32(7)
-        od[:-1] = (a[:-1] + a[1:]) * F32(4)
-        od[-1] = a[-1] * F32(8)
+        ev[0] = a[0] * T(6) + a[1] * T(2)
+        ev[1:-1] = a[:-2] + a[1:-1] * T(6) + a[2:]
+        ev[-1] = a[-2] + a[-1] * T(7)
+        od[:-1] = (a[:-1] + a[1:]) * T(4)
+        od[-1] = a[-1] * T(8)
         out[0:2 * n:2] = ev
         out[1:2 * n:2] = od
     if n_dst > 2 * n:
@@ -236,36 +253,40 @@ def _up_axis(a, n_dst, axis):
 
 
 def pyr_up(img, dstsize):
-    """cv2.pyrUp(img, dstsize=(w, h)) on float32: columns then rows by _up_axis, then * 1/64."""
-    a = np.asarray(img, F32)
+    """cv2.pyrUp(img, dstsize=(w, h)) on float32 / float64: columns then rows by _up_axis, then * 1/64."""
+    a = _ft(img)
     wd, hd = dstsize
     h, w = a.shape[:2]
     assert abs(wd - 2 * w) == wd % 2 and abs(hd - 2 * h) == hd % 2, "pyrUp: bad dstsize"
     t = _up_axis(a, wd, 1)
     t = _up_axis(t, hd, 0)
-    return t * F32(1.0 / 64.0)
+    return t * a.dtype.type(1.0 / 64.0)
 
 
 # --------------------------------------------------------------------------- the stacker
 def depth_map_stack(frames, map_type="average", energy="laplacian", kernel_size=5, blur_size=5,
-                    smooth_size=15, temperature=0.1, levels=3, gray_fn=None):
-    """DepthMapStack.focus_stack (depth_map.py:64-123) for float_type float-32, frame at a time.
-    `frames`: list of H x W x 3 uint8 / uint16 BGR arrays.  Returns the fused frame."""
+                    smooth_size=15, temperature=0.1, levels=3, float_type="float-32", gray_fn=None):
+    """DepthMapStack.focus_stack (depth_map.py:64-123), frame at a time, for float_type 'float-32' / 'float-64'.
+    `frames`: list of H x W x 3 uint8 / uint16 BGR arrays.  Returns the fused frame.
+    float-64: gray / energy planes and the image pyramids are float64; the bilateral filter still runs on
+    float32 copies and its output array is float32 (depth_map.py:46-51), so with smoothing the weights are float32."""
     from . import oracle as orc
     gray_fn = gray_fn or orc.bgr2gray_int
+    FT = {"float-32": np.float32, "float-64": np.float64}[float_type]
     dtype = frames[0].dtype
-    grays = [gray_fn(f).astype(F32) for f in frames]                              # :70-71, :77
+    grays = [gray_fn(f).astype(FT) for f in frames]                               # :70-71, :77
     if energy == "sobel":
-        en = [sobel_energy(g) for g in grays]                                     # :28-34
+        en = [sobel_energy(g, FT) for g in grays]                                 # :28-34
     elif energy == "laplacian":
-        en = [laplacian_energy(g, blur_size, kernel_size) for g in grays]         # :36-41
+        en = [laplacian_energy(g, blur_size, kernel_size, FT) for g in grays]     # :36-41
     else:
         raise ValueError("energy")
-    mx = max(F32(e.max()) for e in en)                                            # :88
+    mx = max(e.max() for e in en)                                                 # :88
     if mx > 0:
         en = [e / mx for e in en]                                                 # :90
     if smooth_size > 0:
-        en = [bilateral_f32(e, smooth_size, 25, 25) for e in en]                  # :43-52
+        en = [bilateral_f32(e.astype(F32), smooth_size, 25, 25) for e in en]      # :43-52 (float32 result array)
+    WT = en[0].dtype.type
     if map_type == "average":                                                     # :55-57
         tot = np.zeros_like(en[0])
         for e in en:
@@ -276,7 +297,7 @@ def depth_map_stack(frames, map_type="average", energy="laplacian", kernel_size=
         m = en[0]
         for e in en[1:]:
             m = np.maximum(m, e)
-        rel = [exp_f32((e - m) / F32(temperature)) for e in en]
+        rel = [exp_rounded((e - m) / WT(temperature)) for e in en]
         tot = np.zeros_like(rel[0])
         for r in rel:
             tot = tot + r
@@ -285,7 +306,7 @@ def depth_map_stack(frames, map_type="average", energy="laplacian", kernel_size=
         raise ValueError("map_type")
     blended = None
     for f, wgt in zip(frames, weights):                                           # :94-112
-        gp_img, gp_w = [f.astype(F32)], [wgt]
+        gp_img, gp_w = [f.astype(FT)], [wgt]
         for _ in range(levels - 1):
             gp_img.append(pyr_down(gp_img[-1]))
             gp_w.append(pyr_down(gp_w[-1]))
@@ -303,8 +324,15 @@ def depth_map_stack(frames, map_type="average", energy="laplacian", kernel_size=
     return np.clip(np.absolute(result), 0, n_values).astype(dtype)               # :122-123
 
 
+def exp_rounded(x):
+    """exp in x's type as the correctly rounded value (NumPy's SIMD exp is CPU-dispatch dependent within 1 ulp, so it
+    cannot be a parity target; ref_import patches the reference's np.exp to this one when recording golden vectors):
+    float32 through float64, float64 through the x87 long double."""
+    x = np.asarray(x)
+    if x.dtype == np.float32:
+        return np.exp(x.astype(np.float64)).astype(F32)
+    return np.exp(x.astype(np.longdouble)).astype(np.float64)
+
+
 def exp_f32(x):
-    """float32 exp as the correctly rounded value (NumPy's SIMD float32 exp is CPU-dispatch
-    dependent within 1 ulp, so it cannot be a parity target; ref_import patches the reference's
-    np.exp to this one when recording golden vectors)."""
-    return np.exp(np.asarray(x, F32).astype(np.float64)).astype(F32)
+    return exp_rounded(np.asarray(x, F32))

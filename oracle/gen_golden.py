@@ -368,6 +368,11 @@ def depth_map_case():
         ("dm_max_t05_l1_u16", np.uint16, (3, 30, 44), {"map_type": "max", "temperature": 0.5, "levels": 1,
                                                        "smooth_size": 5}),
         ("dm_k7_b9_u8", np.uint8, (3, 40, 40), {"kernel_size": 7, "blur_size": 9, "smooth_size": 9, "levels": 2}),
+        ("dm_f64_default_u8", np.uint8, (4, 45, 70), {"float_type": "float-64"}),
+        ("dm_f64_max_nosmooth_u16", np.uint16, (3, 37, 51), {"float_type": "float-64", "map_type": "max",
+                                                             "smooth_size": 0, "blur_size": 9}),
+        ("dm_f64_sobel_l4_u16", np.uint16, (3, 64, 49), {"float_type": "float-64", "energy": "sobel", "levels": 4,
+                                                         "map_type": "max", "temperature": 0.3}),
     ]
     store = {}
     meta = {}

@@ -82,16 +82,16 @@ def make_cv2_shim(use_fma=True):
     cv2.CV_64F = 6
 
     def Sobel(img, ddepth, dx, dy, ksize=3):
-        assert ddepth == cv2.CV_64F and img.dtype == np.float32 and (dx, dy) in ((1, 0), (0, 1))
+        assert ddepth == cv2.CV_64F and img.dtype in (np.float32, np.float64) and (dx, dy) in ((1, 0), (0, 1))
         kx, ky = dmo.sobel_kernels(dx, dy, ksize)
         return dmo.filter2d_f64(img, np.outer(ky, kx))
 
     def GaussianBlur(img, ksize, sigma):
-        assert sigma == 0 and ksize[0] == ksize[1] and img.dtype == np.float32
-        return dmo.gaussian_blur_f32(img, ksize[0])
+        assert sigma == 0 and ksize[0] == ksize[1] and img.dtype in (np.float32, np.float64)
+        return dmo.gaussian_blur(img, ksize[0])
 
     def Laplacian(img, ddepth, ksize=1):
-        assert ddepth == cv2.CV_64F and img.dtype == np.float32
+        assert ddepth == cv2.CV_64F and img.dtype in (np.float32, np.float64)
         return dmo.filter2d_f64(img, dmo.laplacian_kernel2d(ksize))
 
     def bilateralFilter(img, d, sigma_color, sigma_space):
@@ -99,11 +99,11 @@ def make_cv2_shim(use_fma=True):
         return dmo.bilateral_f32(img, d, sigma_color, sigma_space)
 
     def pyrDown(img):
-        assert img.dtype == np.float32
+        assert img.dtype in (np.float32, np.float64)
         return dmo.pyr_down(img)
 
     def pyrUp(img, dstsize=None):
-        assert img.dtype == np.float32
+        assert img.dtype in (np.float32, np.float64)
         return dmo.pyr_up(img, dstsize)
 
     cv2.Sobel, cv2.Laplacian, cv2.bilateralFilter = Sobel, Laplacian, bilateralFilter
@@ -227,6 +227,8 @@ class _NumpyWithExactExp:
         x = np.asarray(x)
         if x.dtype == np.float32:
             return np.exp(x.astype(np.float64)).astype(np.float32)
+        if x.dtype == np.float64:
+            return np.exp(x.astype(np.longdouble)).astype(np.float64)
         return np.exp(x)
 
 

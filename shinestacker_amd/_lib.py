@@ -39,7 +39,7 @@ class DepthMapParams(C.Structure):
     _fields_ = [("height", C.c_int32), ("width", C.c_int32), ("dtype", C.c_int32), ("device", C.c_int32),
                 ("map_type", C.c_int32), ("energy", C.c_int32), ("kernel_size", C.c_int32),
                 ("blur_size", C.c_int32), ("smooth_size", C.c_int32), ("levels", C.c_int32),
-                ("temperature", C.c_float)]
+                ("temperature", C.c_float), ("float_type", C.c_int32)]
 
 
 DM_MAP_AVERAGE, DM_MAP_MAX = 0, 1
@@ -364,7 +364,8 @@ class DepthMap:
     """Thin object wrapper over an mi_dmap_t handle (DepthMapStack's arithmetic, include/mi355stack.h)."""
 
     def __init__(self, height, width, dtype=np.uint8, map_type=DM_MAP_AVERAGE, energy=DM_ENERGY_LAPLACIAN,
-                 kernel_size=5, blur_size=5, smooth_size=15, temperature=0.1, levels=3, device=0):
+                 kernel_size=5, blur_size=5, smooth_size=15, temperature=0.1, levels=3, device=0,
+                 float_type=MI_F32):
         lib = load()
         require_device()
         p = DepthMapParams()
@@ -373,7 +374,7 @@ class DepthMap:
         p.height, p.width, p.dtype, p.device = int(height), int(width), DTYPE_CODE[self.dtype], int(device)
         p.map_type, p.energy = int(map_type), int(energy)
         p.kernel_size, p.blur_size, p.smooth_size = int(kernel_size), int(blur_size), int(smooth_size)
-        p.levels, p.temperature = int(levels), float(temperature)
+        p.levels, p.temperature, p.float_type = int(levels), float(temperature), int(float_type)
         self.height, self.width, self.device = p.height, p.width, p.device
         h = C.c_void_p()
         check(lib.mi_dmap_create(C.byref(h), C.byref(p)))

@@ -2,7 +2,7 @@
 // frames and their energy planes resident in HBM.  Included by capi.hip (one translation unit).
 //
 // The reference keeps N gray planes, N energy planes and N weight planes in host memory and reads every file
-// twice; here the frame (input dtype) and one float32 plane per frame stay on the device -- 24 MP x 256 frames
+// twice; here the frame (input dtype) and one float_type plane per frame stay on the device -- 24 MP x 256 frames
 // of 8-bit input are 18 + 25 GB of the 288 -- and everything else is per-frame scratch.
 #pragma once
 #include "kernels_depthmap.hpp"
@@ -12,19 +12,25 @@ struct mi_dmap {
     size_t esz = 1;                  // bytes per input element
     hipStream_t stream = nullptr;
     std::vector<void*> frames;       // device copies of the pushed frames (kept across reset for reuse)
-    std::vector<float*> en;          // energy -> smoothed energy -> relative weight of frame i
-    float* spare = nullptr;          // the plane the bilateral filter writes into (swapped with en[i])
-    float *tmpA = nullptr, *tmpB = nullptr, *tmpC = nullptr;
-    float *tot = nullptr, *mx = nullptr;
-    float* scal = nullptr;           // [0] global max, [1..2] frame min / max, [3..4] bilateral scale / flat flag
+    // F = float_type (float / double), W = type of the weights (float when the bilateral filter ran, else F).
+    // Planes are raw allocations of fsz bytes per pixel; the typed views are made where they are used.
+    size_t fsz = 4;
+    bool f64 = false;
+    std::vector<void*> en;           // energy (F) -> smoothed energy (W) -> relative weight (W) of frame i
+    float* spare = nullptr;          // float-32: the plane the bilateral filter writes into (swapped with en[i])
+    void *tmpA = nullptr, *tmpB = nullptr, *tmpC = nullptr;   // gray / row-blurred / blurred plane (F)
+    void *tot = nullptr, *mx = nullptr;                       // running sum / maximum of the (smoothed) energies (W)
+    void* scalF = nullptr;           // F: [0] global max, [1..2] min / max written by dm_normalise<F>
+    float* scalf = nullptr;          // float: [0..1] min / max of the bilateral input, [2..3] scale / flat flag, [4] = 0
     float* lut = nullptr;
     int2* disc = nullptr;            // bilateral disc: (LDS patch offset, space weight bits) per tap
     int radius = 0, ntaps = 0;
     double color_coeff = 0.0;
     std::vector<int> lh, lw;         // level shapes, 0 .. levels-1
-    std::vector<float*> G, W, B;     // Gaussian levels of the current frame (G[0] unused), weights, blend sums
+    std::vector<void*> G, W, B;      // Gaussian levels of the current frame (F x 3, G[0] unused), weights (W), blend sums (F x 3)
     void* out_dev = nullptr;
-    mi::DmTaps taps{};
+    mi::DmTapsT<float> taps{};
+    mi::DmTapsT<double> tapsd{};
     mi::DmK2 k2{};
     int n = 0;
     bool finished = false;
@@ -51,25 +57,32 @@ int dmap_alloc(mi_dmap* d, T** p, size_t count) {
     return MI_OK;
 }
 
-// cv2.getGaussianKernel(ksize, 0, CV_32F) (oracle/depth_map_oracle.py gaussian_kernel_f32)
-void dmap_gauss_taps(int ksize, DmTaps& t) {
-    static const float s1[] = {1.f}, s3[] = {0.25f, 0.5f, 0.25f}, s5[] = {0.0625f, 0.25f, 0.375f, 0.25f, 0.0625f},
-                       s7[] = {0.03125f, 0.109375f, 0.21875f, 0.28125f, 0.21875f, 0.109375f, 0.03125f};
+int dmap_alloc_bytes(mi_dmap* d, void** p, size_t bytes) {
+    MI_HIP(hipMalloc(p, bytes ? bytes : 1));
+    d->allocs.push_back(*p);
+    return MI_OK;
+}
+
+// cv2.getGaussianKernel(ksize, 0, CV_32F / CV_64F) (oracle/depth_map_oracle.py gaussian_kernel)
+template <typename F>
+void dmap_gauss_taps(int ksize, DmTapsT<F>& t) {
+    static const double s1[] = {1.0}, s3[] = {0.25, 0.5, 0.25}, s5[] = {0.0625, 0.25, 0.375, 0.25, 0.0625},
+                        s7[] = {0.03125, 0.109375, 0.21875, 0.28125, 0.21875, 0.109375, 0.03125};
     t.ksize = ksize;
-    const float* tab = ksize == 1 ? s1 : ksize == 3 ? s3 : ksize == 5 ? s5 : ksize == 7 ? s7 : nullptr;
+    const double* tab = ksize == 1 ? s1 : ksize == 3 ? s3 : ksize == 5 ? s5 : ksize == 7 ? s7 : nullptr;
     if (tab) {
-        for (int i = 0; i < ksize; ++i) t.k[i] = tab[i];
+        for (int i = 0; i < ksize; ++i) t.k[i] = (F)tab[i];
         return;
     }
     const double sigma = 0.3 * ((ksize - 1) * 0.5 - 1) + 0.8, scale = -0.5 / (sigma * sigma);
     double sum = 0.0;
     for (int i = 0; i < ksize; ++i) {
         const double x = i - (ksize - 1) * 0.5;
-        t.k[i] = (float)std::exp(scale * x * x);
+        t.k[i] = (F)std::exp(scale * x * x);
         sum += (double)t.k[i];
     }
     sum = 1.0 / sum;
-    for (int i = 0; i < ksize; ++i) t.k[i] = (float)((double)t.k[i] * sum);
+    for (int i = 0; i < ksize; ++i) t.k[i] = (F)((double)t.k[i] * sum);
 }
 
 // cv2.getDerivKernels (Sobel family): ksize - order - 1 steps [1 1], `order` steps [-1 1]
@@ -107,23 +120,27 @@ inline dim3 dm_grid2(int h, int w) { return dim3(cdiv(w, 64), cdiv(h, 4)); }
 inline dim3 dm_grid1(size_t n) { return dim3((unsigned)((n + 255) / 256)); }
 
 // pass 1 for the frame just stored in d->frames[i]
-template <typename T>
+template <typename T, typename F>
 int dmap_energy(mi_dmap* d, int i) {
     const int h = d->p.height, w = d->p.width;
     const size_t np = (size_t)h * w;
     hipStream_t st = d->stream;
-    hipLaunchKernelGGL((dm_gray<T>), dm_grid1(np), dim3(256), 0, st, (const T*)d->frames[i], np, d->tmpA);
+    F *tA = (F*)d->tmpA, *tB = (F*)d->tmpB, *tC = (F*)d->tmpC, *en = (F*)d->en[i], *gmax = (F*)d->scalF;
+    const DmTapsT<F>& taps = [&]() -> const DmTapsT<F>& {
+        if constexpr (sizeof(F) == 4) return d->taps; else return d->tapsd;
+    }();
+    hipLaunchKernelGGL((dm_gray<T, F>), dm_grid1(np), dim3(256), 0, st, (const T*)d->frames[i], np, tA);
     if (d->p.energy == MI_DM_ENERGY_SOBEL) {
-        hipLaunchKernelGGL(dm_sobel, dm_grid2(h, w), dim3(256), 0, st, d->tmpA, h, w, d->en[i], d->scal);
+        hipLaunchKernelGGL((dm_sobel<F>), dm_grid2(h, w), dim3(256), 0, st, (const F*)tA, h, w, en, gmax);
     } else {
-        hipLaunchKernelGGL((dm_blur<true>), dm_grid2(h, w), dim3(256), 0, st, d->tmpA, h, w, d->tmpB, d->taps);
-        hipLaunchKernelGGL((dm_blur<false>), dm_grid2(h, w), dim3(256), 0, st, d->tmpB, h, w, d->tmpC, d->taps);
+        hipLaunchKernelGGL((dm_blur<true, F>), dm_grid2(h, w), dim3(256), 0, st, (const F*)tA, h, w, tB, taps);
+        hipLaunchKernelGGL((dm_blur<false, F>), dm_grid2(h, w), dim3(256), 0, st, (const F*)tB, h, w, tC, taps);
         if (d->k2.ksize == 5)
-            hipLaunchKernelGGL((dm_laplacian<5>), dm_grid2(h, w), dim3(256), 0, st, d->tmpC, h, w, d->en[i], d->scal, d->k2);
+            hipLaunchKernelGGL((dm_laplacian<5, F>), dm_grid2(h, w), dim3(256), 0, st, (const F*)tC, h, w, en, gmax, d->k2);
         else if (d->k2.ksize == 3)
-            hipLaunchKernelGGL((dm_laplacian<3>), dm_grid2(h, w), dim3(256), 0, st, d->tmpC, h, w, d->en[i], d->scal, d->k2);
+            hipLaunchKernelGGL((dm_laplacian<3, F>), dm_grid2(h, w), dim3(256), 0, st, (const F*)tC, h, w, en, gmax, d->k2);
         else
-            hipLaunchKernelGGL((dm_laplacian<0>), dm_grid2(h, w), dim3(256), 0, st, d->tmpC, h, w, d->en[i], d->scal, d->k2);
+            hipLaunchKernelGGL((dm_laplacian<0, F>), dm_grid2(h, w), dim3(256), 0, st, (const F*)tC, h, w, en, gmax, d->k2);
     }
     MI_HIP(hipGetLastError());
     return MI_OK;
@@ -132,85 +149,134 @@ int dmap_energy(mi_dmap* d, int i) {
 int dmap_new_slot(mi_dmap* d) {
     if ((size_t)d->n < d->frames.size()) return MI_OK;   // reuse after reset
     const size_t np = (size_t)d->p.height * d->p.width;
-    void* f = nullptr;
-    float* e = nullptr;
-    MI_HIP(hipMalloc(&f, np * 3 * d->esz));
-    d->allocs.push_back(f);
-    int rc = dmap_alloc(d, &e, np);
-    if (rc) return rc;
+    void *f = nullptr, *e = nullptr;
+    int rc = dmap_alloc_bytes(d, &f, np * 3 * d->esz);
+    if (rc || (rc = dmap_alloc_bytes(d, &e, np * d->fsz))) return rc;
     d->frames.push_back(f);
     d->en.push_back(e);
     return MI_OK;
 }
 
-template <typename T>
-int dmap_finish_t(mi_dmap* d) {
+// pass 2 and the collapse, with the weight planes already in en[i] (type W)
+template <typename T, typename F, typename W>
+int dmap_blend(mi_dmap* d) {
     const int h = d->p.height, w = d->p.width, L = d->p.levels, N = d->n;
     const size_t np = (size_t)h * w;
     hipStream_t st = d->stream;
     const bool avg = d->p.map_type == MI_DM_MAP_AVERAGE;
-    static const uint32_t mm_init[2] = {0x7f800000u, 0u};
-    // energies / max, smoothing, running sum (AVERAGE) or maximum (MAX) over the frames
-    for (int i = 0; i < N; ++i) {
-        MI_HIP(hipMemcpyAsync(d->scal + 1, mm_init, 8, hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(dm_normalise, dim3((unsigned)std::min<size_t>((np + 255) / 256, 4096)), dim3(256), 0, st, d->en[i], np,
-                           d->scal, d->scal + 1);
-        float* acc = avg ? d->tot : d->mx;
-        if (d->p.smooth_size > 0) {
-            hipLaunchKernelGGL(dm_bilateral_lut, dim3(1), dim3(1024), 0, st, d->scal + 1, d->color_coeff, d->lut,
-                               d->scal + 3);
-            DmBilateral a{d->en[i], d->spare, h, w, d->radius, d->ntaps, d->disc, d->lut, d->scal + 3,
-                          acc, avg ? 0 : 1, i == 0};
-            hipLaunchKernelGGL(dm_bilateral, dim3(cdiv(w, 64), cdiv(h, 16)), dim3(256), 0, st, a);
-            std::swap(d->en[i], d->spare);
-        } else {
-            hipLaunchKernelGGL(dm_accumulate, dm_grid1(np), dim3(256), 0, st, d->en[i], np, acc, avg ? 0 : 1, i == 0);
-        }
-    }
-    if (!avg)
-        for (int i = 0; i < N; ++i)
-            hipLaunchKernelGGL(dm_relative, dm_grid1(np), dim3(256), 0, st, d->en[i], d->mx, np, d->p.temperature,
-                               d->tot, i == 0);
-    MI_HIP(hipGetLastError());
-    // weighted Laplacian pyramids
+    auto Gl = [&](int l) { return (F*)d->G[l]; };
+    auto Wl = [&](int l) { return (W*)d->W[l]; };
+    auto Bl = [&](int l) { return (F*)d->B[l]; };
     for (int i = 0; i < N; ++i) {
         const T* frame = (const T*)d->frames[i];
         const int first = i == 0;
-        hipLaunchKernelGGL(dm_weight, dm_grid1(np), dim3(256), 0, st, d->en[i], d->tot, np, avg ? 1 : 0, d->W[0]);
+        hipLaunchKernelGGL((dm_weight<W>), dm_grid1(np), dim3(256), 0, st, (const W*)d->en[i], (const W*)d->tot, np,
+                           avg ? 1 : 0, Wl(0));
         for (int l = 1; l < L; ++l) {
             const dim3 g = dm_grid2(d->lh[l], d->lw[l]);
             if (l == 1)
-                hipLaunchKernelGGL((dm_pyrdown<T, 3>), g, dim3(256), 0, st, frame, h, w, d->G[1], d->lh[1], d->lw[1]);
+                hipLaunchKernelGGL((dm_pyrdown<T, 3, F>), g, dim3(256), 0, st, frame, h, w, Gl(1), d->lh[1], d->lw[1]);
             else
-                hipLaunchKernelGGL((dm_pyrdown<float, 3>), g, dim3(256), 0, st, d->G[l - 1], d->lh[l - 1], d->lw[l - 1],
-                                   d->G[l], d->lh[l], d->lw[l]);
-            hipLaunchKernelGGL((dm_pyrdown<float, 1>), g, dim3(256), 0, st, d->W[l - 1], d->lh[l - 1], d->lw[l - 1],
-                               d->W[l], d->lh[l], d->lw[l]);
+                hipLaunchKernelGGL((dm_pyrdown<F, 3, F>), g, dim3(256), 0, st, (const F*)Gl(l - 1), d->lh[l - 1], d->lw[l - 1],
+                                   Gl(l), d->lh[l], d->lw[l]);
+            hipLaunchKernelGGL((dm_pyrdown<W, 1, W>), g, dim3(256), 0, st, (const W*)Wl(l - 1), d->lh[l - 1], d->lw[l - 1],
+                               Wl(l), d->lh[l], d->lw[l]);
         }
         const size_t ntop = (size_t)d->lh[L - 1] * d->lw[L - 1];
         if (L == 1)
-            hipLaunchKernelGGL((dm_top_blend<T>), dm_grid1(ntop), dim3(256), 0, st, frame, ntop, d->W[0], d->B[0], first);
+            hipLaunchKernelGGL((dm_top_blend<T, F, W>), dm_grid1(ntop), dim3(256), 0, st, frame, ntop, (const W*)Wl(0), Bl(0),
+                               first);
         else
-            hipLaunchKernelGGL((dm_top_blend<float>), dm_grid1(ntop), dim3(256), 0, st, d->G[L - 1], ntop, d->W[L - 1],
-                               d->B[L - 1], first);
+            hipLaunchKernelGGL((dm_top_blend<F, F, W>), dm_grid1(ntop), dim3(256), 0, st, (const F*)Gl(L - 1), ntop,
+                               (const W*)Wl(L - 1), Bl(L - 1), first);
         for (int l = L - 2; l >= 0; --l) {
             const dim3 g = dm_grid2(d->lh[l], d->lw[l]);
             if (l == 0)
-                hipLaunchKernelGGL((dm_lap_blend<T>), g, dim3(256), 0, st, frame, h, w, d->G[1], d->lh[1], d->lw[1],
-                                   d->W[0], d->B[0], first);
+                hipLaunchKernelGGL((dm_lap_blend<T, F, W>), g, dim3(256), 0, st, frame, h, w, (const F*)Gl(1), d->lh[1],
+                                   d->lw[1], (const W*)Wl(0), Bl(0), first);
             else
-                hipLaunchKernelGGL((dm_lap_blend<float>), g, dim3(256), 0, st, d->G[l], d->lh[l], d->lw[l], d->G[l + 1],
-                                   d->lh[l + 1], d->lw[l + 1], d->W[l], d->B[l], first);
+                hipLaunchKernelGGL((dm_lap_blend<F, F, W>), g, dim3(256), 0, st, (const F*)Gl(l), d->lh[l], d->lw[l],
+                                   (const F*)Gl(l + 1), d->lh[l + 1], d->lw[l + 1], (const W*)Wl(l), Bl(l), first);
         }
     }
     // collapse in place (level l takes pyrUp of the finished level l+1), clip, cast
     for (int l = L - 2; l >= 0; --l)
-        hipLaunchKernelGGL(dm_collapse, dm_grid2(d->lh[l], d->lw[l]), dim3(256), 0, st, d->B[l + 1], d->lh[l + 1],
-                           d->lw[l + 1], d->B[l], d->lh[l], d->lw[l], d->B[l]);
-    hipLaunchKernelGGL((dm_finalize<T>), dm_grid1(np * 3), dim3(256), 0, st, d->B[0], np * 3,
-                       sizeof(T) == 1 ? 255.f : 65535.f, (T*)d->out_dev);
+        hipLaunchKernelGGL((dm_collapse<F>), dm_grid2(d->lh[l], d->lw[l]), dim3(256), 0, st, (const F*)Bl(l + 1), d->lh[l + 1],
+                           d->lw[l + 1], (const F*)Bl(l), d->lh[l], d->lw[l], Bl(l));
+    hipLaunchKernelGGL((dm_finalize<T, F>), dm_grid1(np * 3), dim3(256), 0, st, (const F*)Bl(0), np * 3,
+                       (F)(sizeof(T) == 1 ? 255 : 65535), (T*)d->out_dev);
     MI_HIP(hipGetLastError());
     return MI_OK;
+}
+
+// focus map: running sum / maximum of the energies of type W in en[i] (already accumulated by the caller for the
+// AVERAGE map); the MAX map turns them into relatives and sums those
+template <typename W>
+int dmap_focus_map(mi_dmap* d) {
+    const size_t np = (size_t)d->p.height * d->p.width;
+    if (d->p.map_type == MI_DM_MAP_MAX)
+        for (int i = 0; i < d->n; ++i)
+            hipLaunchKernelGGL((dm_relative<W>), dm_grid1(np), dim3(256), 0, d->stream, (W*)d->en[i], (const W*)d->mx, np,
+                               (W)d->p.temperature, (W*)d->tot, i == 0);
+    MI_HIP(hipGetLastError());
+    return MI_OK;
+}
+
+template <typename T, typename F>
+int dmap_finish_t(mi_dmap* d) {
+    const int h = d->p.height, w = d->p.width, N = d->n;
+    const size_t np = (size_t)h * w;
+    hipStream_t st = d->stream;
+    const bool avg = d->p.map_type == MI_DM_MAP_AVERAGE, smooth = d->p.smooth_size > 0;
+    static const uint32_t mm_init[2] = {0x7f800000u, 0u};
+    static const uint64_t mmd_init[2] = {0x7ff0000000000000ull, 0ull};
+    const dim3 gnorm((unsigned)std::min<size_t>((np + 255) / 256, 4096));
+    F* sF = (F*)d->scalF;
+    // energies / max, smoothing, running sum (AVERAGE) or maximum (MAX) over the frames
+    for (int i = 0; i < N; ++i) {
+        if (sizeof(F) == 4 && smooth) {   // float-32: min / max of the normalised plane feed the bilateral filter
+            MI_HIP(hipMemcpyAsync(d->scalf, mm_init, 8, hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL((dm_normalise<float>), gnorm, dim3(256), 0, st, (float*)d->en[i], np, (const float*)d->scalF,
+                               d->scalf);
+        } else {
+            if (sizeof(F) == 4) MI_HIP(hipMemcpyAsync(sF + 1, mm_init, 8, hipMemcpyHostToDevice, st));
+            else MI_HIP(hipMemcpyAsync(sF + 1, mmd_init, 16, hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL((dm_normalise<F>), gnorm, dim3(256), 0, st, (F*)d->en[i], np, (const F*)sF, sF + 1);
+        }
+        if (smooth) {
+            const float* bsrc = (const float*)d->en[i];
+            float* bdst = d->spare;
+            if (sizeof(F) == 8) {   // float-64: smoothing works on a float32 copy and returns float32 (depth_map.py:46-51)
+                hipLaunchKernelGGL(dm_to_f32, dm_grid1(np), dim3(256), 0, st, (const double*)d->en[i], np, (float*)d->tmpA);
+                MI_HIP(hipMemcpyAsync(d->scalf, mm_init, 8, hipMemcpyHostToDevice, st));
+                hipLaunchKernelGGL((dm_normalise<float>), gnorm, dim3(256), 0, st, (float*)d->tmpA, np,
+                                   (const float*)(d->scalf + 4), d->scalf);   // *gmax = 0: min / max only
+                bsrc = (const float*)d->tmpA;
+                bdst = (float*)d->en[i];
+            }
+            hipLaunchKernelGGL(dm_bilateral_lut, dim3(1), dim3(1024), 0, st, (const float*)d->scalf, d->color_coeff, d->lut,
+                               d->scalf + 2);
+            DmBilateral a{bsrc, bdst, h, w, d->radius, d->ntaps, d->disc, d->lut, d->scalf + 2,
+                          (float*)(avg ? d->tot : d->mx), avg ? 0 : 1, i == 0};
+            hipLaunchKernelGGL(dm_bilateral, dim3(cdiv(w, 64), cdiv(h, 16)), dim3(256), 0, st, a);
+            if (sizeof(F) == 4) {
+                void* t = d->en[i];
+                d->en[i] = d->spare;
+                d->spare = (float*)t;
+            }
+        } else {
+            hipLaunchKernelGGL((dm_accumulate<F>), dm_grid1(np), dim3(256), 0, st, (const F*)d->en[i], np,
+                               (F*)(avg ? d->tot : d->mx), avg ? 0 : 1, i == 0);
+        }
+    }
+    MI_HIP(hipGetLastError());
+    int rc;
+    if (smooth || sizeof(F) == 4) {   // weights are float32
+        if ((rc = dmap_focus_map<float>(d))) return rc;
+        return dmap_blend<T, F, float>(d);
+    }
+    if ((rc = dmap_focus_map<F>(d))) return rc;
+    return dmap_blend<T, F, F>(d);
 }
 
 }  // namespace
@@ -228,6 +294,7 @@ void mi_dmap_default_params(mi_dmap_params_t* p) {
     p->smooth_size = 15;
     p->temperature = 0.1f;
     p->levels = 3;
+    p->float_type = MI_F32;
 }
 
 int mi_dmap_create(mi_dmap_t** out, const mi_dmap_params_t* params) {
@@ -237,6 +304,7 @@ int mi_dmap_create(mi_dmap_t** out, const mi_dmap_params_t* params) {
     if (p.height < 1 || p.width < 1) return fail(MI_ERR_INVALID, "bad frame size %dx%d", p.width, p.height);
     if ((size_t)p.height * p.width > ((size_t)1 << 30)) return fail(MI_ERR_UNSUPPORTED, "frame too large");
     if (p.dtype != MI_U8 && p.dtype != MI_U16) return fail(MI_ERR_INVALID, "dtype must be MI_U8 or MI_U16");
+    if (p.float_type != MI_F32 && p.float_type != MI_F64) return fail(MI_ERR_INVALID, "float_type must be MI_F32 or MI_F64");
     if (p.map_type != MI_DM_MAP_AVERAGE && p.map_type != MI_DM_MAP_MAX) return fail(MI_ERR_INVALID, "bad map_type %d", p.map_type);
     if (p.energy != MI_DM_ENERGY_LAPLACIAN && p.energy != MI_DM_ENERGY_SOBEL) return fail(MI_ERR_INVALID, "bad energy %d", p.energy);
     if (p.energy == MI_DM_ENERGY_LAPLACIAN) {
@@ -258,23 +326,26 @@ int mi_dmap_create(mi_dmap_t** out, const mi_dmap_params_t* params) {
     if (!d) return fail(MI_ERR_NOMEM, "out of host memory");
     d->p = p;
     d->esz = p.dtype == MI_U8 ? 1 : 2;
+    d->f64 = p.float_type == MI_F64;
+    d->fsz = d->f64 ? 8 : 4;
     if (p.energy == MI_DM_ENERGY_LAPLACIAN) {
         dmap_gauss_taps(p.blur_size, d->taps);
+        dmap_gauss_taps(p.blur_size, d->tapsd);
         dmap_laplacian_kernel(p.kernel_size, d->k2);
     }
     const size_t np = (size_t)p.height * p.width;
     auto body = [&]() -> int {
         MI_HIP(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
         int r;
-        if ((r = dmap_alloc(d, &d->tmpA, np)) || (r = dmap_alloc(d, &d->tmpB, np)) || (r = dmap_alloc(d, &d->tmpC, np)) ||
-            (r = dmap_alloc(d, &d->spare, np)) || (r = dmap_alloc(d, &d->tot, np)) || (r = dmap_alloc(d, &d->scal, 8)) ||
+        const size_t fsz = d->fsz;
+        if ((r = dmap_alloc_bytes(d, &d->tmpA, np * fsz)) || (r = dmap_alloc_bytes(d, &d->tmpB, np * fsz)) ||
+            (r = dmap_alloc_bytes(d, &d->tmpC, np * fsz)) || (r = dmap_alloc_bytes(d, &d->tot, np * fsz)) ||
+            (r = dmap_alloc_bytes(d, &d->scalF, 64)) || (r = dmap_alloc(d, &d->scalf, 16)) ||
             (r = dmap_alloc(d, &d->lut, DM_LUT_BINS + 2)))
             return r;
-        if (p.map_type == MI_DM_MAP_MAX && (r = dmap_alloc(d, &d->mx, np))) return r;
-        void* o = nullptr;
-        MI_HIP(hipMalloc(&o, np * 3 * d->esz));
-        d->allocs.push_back(o);
-        d->out_dev = o;
+        if (!d->f64 && (r = dmap_alloc(d, &d->spare, np))) return r;
+        if (p.map_type == MI_DM_MAP_MAX && (r = dmap_alloc_bytes(d, &d->mx, np * fsz))) return r;
+        if ((r = dmap_alloc_bytes(d, &d->out_dev, np * 3 * d->esz))) return r;
         if (p.smooth_size > 0) {   // bilateral disc, cv2.bilateralFilter(e, smooth_size, 25, 25) (depth_map.py:50)
             const double sigma_color = 25.0, sigma_space = 25.0;
             d->radius = std::max(p.smooth_size / 2, 1);
@@ -299,17 +370,18 @@ int mi_dmap_create(mi_dmap_t** out, const mi_dmap_params_t* params) {
         for (int l = 0; l < p.levels; ++l) {
             d->lh.push_back(lh);
             d->lw.push_back(lw);
-            float *g = nullptr, *wgt = nullptr, *b = nullptr;
+            void *g = nullptr, *wgt = nullptr, *b = nullptr;
             const size_t n = (size_t)lh * lw;
-            if (l > 0 && (r = dmap_alloc(d, &g, n * 3))) return r;
-            if ((r = dmap_alloc(d, &wgt, n)) || (r = dmap_alloc(d, &b, n * 3))) return r;
+            if (l > 0 && (r = dmap_alloc_bytes(d, &g, n * 3 * fsz))) return r;
+            if ((r = dmap_alloc_bytes(d, &wgt, n * fsz)) || (r = dmap_alloc_bytes(d, &b, n * 3 * fsz))) return r;
             d->G.push_back(g);
             d->W.push_back(wgt);
             d->B.push_back(b);
             lh = (lh + 1) / 2;
             lw = (lw + 1) / 2;
         }
-        MI_HIP(hipMemsetAsync(d->scal, 0, 32, d->stream));
+        MI_HIP(hipMemsetAsync(d->scalF, 0, 64, d->stream));
+        MI_HIP(hipMemsetAsync(d->scalf, 0, 64, d->stream));
         return MI_OK;
     };
     rc = body();
@@ -335,7 +407,7 @@ int mi_dmap_reset(mi_dmap_t* d) {
     MI_HIP(hipSetDevice(d->p.device));
     d->n = 0;
     d->finished = false;
-    MI_HIP(hipMemsetAsync(d->scal, 0, 32, d->stream));
+    MI_HIP(hipMemsetAsync(d->scalF, 0, 64, d->stream));
     return MI_OK;
 }
 
@@ -358,7 +430,8 @@ static int dmap_push_common(mi_dmap_t* d, const void* src, size_t row_stride_byt
     MI_HIP(hipMemcpy2DAsync(d->frames[d->n], rb, src, row_stride_bytes, rb, d->p.height,
                             on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, d->stream));
     if (!on_device) MI_HIP(hipStreamSynchronize(d->stream));   // the caller may reuse its buffer
-    rc = d->p.dtype == MI_U8 ? dmap_energy<uint8_t>(d, d->n) : dmap_energy<uint16_t>(d, d->n);
+    if (d->f64) rc = d->p.dtype == MI_U8 ? dmap_energy<uint8_t, double>(d, d->n) : dmap_energy<uint16_t, double>(d, d->n);
+    else rc = d->p.dtype == MI_U8 ? dmap_energy<uint8_t, float>(d, d->n) : dmap_energy<uint16_t, float>(d, d->n);
     if (rc) return rc;
     d->n++;
     return MI_OK;
@@ -377,7 +450,9 @@ int mi_dmap_finish_device(mi_dmap_t* d, void* dev_out) {
     if (d->finished) return fail(MI_ERR_STATE, "finish called twice; call mi_dmap_reset first");
     if (d->n == 0) return fail(MI_ERR_STATE, "finish with no frames pushed");
     MI_HIP(hipSetDevice(d->p.device));
-    int rc = d->p.dtype == MI_U8 ? dmap_finish_t<uint8_t>(d) : dmap_finish_t<uint16_t>(d);
+    int rc;
+    if (d->f64) rc = d->p.dtype == MI_U8 ? dmap_finish_t<uint8_t, double>(d) : dmap_finish_t<uint16_t, double>(d);
+    else rc = d->p.dtype == MI_U8 ? dmap_finish_t<uint8_t, float>(d) : dmap_finish_t<uint16_t, float>(d);
     if (rc) return rc;
     d->finished = true;
     if (dev_out)

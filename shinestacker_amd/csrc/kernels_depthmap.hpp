@@ -1,5 +1,7 @@
 // kernels_depthmap.hpp -- DepthMapStack (reference algorithms/depth_map.py:10-123; SURVEY.md 8(f)
-// rank 4), float-32 mode, frame at a time:
+// rank 4), frame at a time; F = float (float_type 'float-32') or double ('float-64': gray / energy planes and
+// the image pyramids in float64; the bilateral filter still works on float32 copies and returns float32, so
+// with smoothing the weights W are float32 in both modes, depth_map.py:46-51):
 //
 //   pass 1 (at push)   gray -> energy: |Sobel_x| + |Sobel_y| (:28-34) or |Laplacian(GaussianBlur)| (:36-41),
 //                      running global maximum (:88)
@@ -21,8 +23,9 @@ namespace mi {
 
 typedef float dm_v2f __attribute__((ext_vector_type(2)));
 
-struct DmTaps {
-    float k[32];  // symmetric Gaussian, float32 (cv2.getGaussianKernel(ksize, 0, CV_32F))
+template <typename F>
+struct DmTapsT {
+    F k[32];  // symmetric Gaussian in the image's type (cv2.getGaussianKernel(ksize, 0, CV_32F / CV_64F))
     int ksize;
 };
 struct DmK2 {
@@ -30,44 +33,59 @@ struct DmK2 {
     int ksize;
 };
 
-__device__ __forceinline__ void atomic_max_pos(float* addr, float v) {  // v >= 0: the bit patterns order like the values
+// v >= 0: the bit patterns order like the values
+__device__ __forceinline__ void atomic_max_pos(float* addr, float v) {
     atomicMax(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
 }
 __device__ __forceinline__ void atomic_min_pos(float* addr, float v) {
     atomicMin(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
 }
-__device__ __forceinline__ float wave_max(float v) {
+__device__ __forceinline__ void atomic_max_pos(double* addr, double v) {
+    atomicMax(reinterpret_cast<unsigned long long*>(addr), (unsigned long long)__double_as_longlong(v));
+}
+__device__ __forceinline__ void atomic_min_pos(double* addr, double v) {
+    atomicMin(reinterpret_cast<unsigned long long*>(addr), (unsigned long long)__double_as_longlong(v));
+}
+template <typename F>
+__device__ __forceinline__ F wave_max(F v) {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    for (int o = 32; o > 0; o >>= 1) {
+        const F u = __shfl_xor(v, o);
+        v = u > v ? u : v;
+    }
     return v;
 }
-__device__ __forceinline__ float wave_min(float v) {
+template <typename F>
+__device__ __forceinline__ F wave_min(F v) {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+    for (int o = 32; o > 0; o >>= 1) {
+        const F u = __shfl_xor(v, o);
+        v = u < v ? u : v;
+    }
     return v;
 }
 
 // img_bw (utils.py:46-47): integer BGR2GRAY, then np.array(..., dtype=float32) (:77)
-template <typename T>
-__global__ __launch_bounds__(256) void dm_gray(const T* __restrict__ img, size_t npix, float* __restrict__ out) {
+template <typename T, typename F>
+__global__ __launch_bounds__(256) void dm_gray(const T* __restrict__ img, size_t npix, F* __restrict__ out) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= npix) return;
-    out[i] = (float)bgr2gray_int(img[3 * i], img[3 * i + 1], img[3 * i + 2]);
+    out[i] = (F)bgr2gray_int(img[3 * i], img[3 * i + 1], img[3 * i + 2]);
 }
 
-// one axis of cv2.GaussianBlur on float32: k[c]*S[0] + sum_j k[c+j]*(S[-j] + S[j])
-template <bool ROWS>
-__global__ __launch_bounds__(256) void dm_blur(const float* __restrict__ src, int h, int w, float* __restrict__ dst,
-                                               DmTaps t) {
+// one axis of cv2.GaussianBlur: k[c]*S[0] + sum_j k[c+j]*(S[-j] + S[j]) in the image's type
+template <bool ROWS, typename F>
+__global__ __launch_bounds__(256) void dm_blur(const F* __restrict__ src, int h, int w, F* __restrict__ dst,
+                                               DmTapsT<F> t) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= w || y >= h) return;
     const int r = t.ksize / 2;
     auto at = [&](int o) {
         return ROWS ? src[(size_t)y * w + r101_loop(x + o, w)] : src[(size_t)r101_loop(y + o, h) * w + x];
     };
-    float acc = t.k[r] * at(0);
+    F acc = t.k[r] * at(0);
     for (int j = 1; j <= r; ++j) {
-        const float pr = t.k[r + j] * (at(-j) + at(j));
+        const F pr = t.k[r + j] * (at(-j) + at(j));
         acc = acc + pr;
     }
     dst[(size_t)y * w + x] = acc;
@@ -75,23 +93,25 @@ __global__ __launch_bounds__(256) void dm_blur(const float* __restrict__ src, in
 
 // workgroup maximum -> one atomic per workgroup, and none when the global value is already as large (the
 // running maximum only grows, so a stale read can cost an extra atomic but never lose one)
-__device__ __forceinline__ void block_max_to(float v, float* gmax) {
-    __shared__ float sm[16];
+template <typename F>
+__device__ __forceinline__ void block_max_to(F v, F* gmax) {
+    __shared__ F sm[16];
     v = wave_max(v);
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int i = 1; i < (int)(blockDim.x >> 6); ++i) v = fmaxf(v, sm[i]);
+        for (int i = 1; i < (int)(blockDim.x >> 6); ++i) v = sm[i] > v ? sm[i] : v;
         if (v > __hip_atomic_load(gmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomic_max_pos(gmax, v);
     }
 }
-__device__ __forceinline__ void block_min_to(float v, float* gmin) {
-    __shared__ float sm[16];
+template <typename F>
+__device__ __forceinline__ void block_min_to(F v, F* gmin) {
+    __shared__ F sm[16];
     v = wave_min(v);
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int i = 1; i < (int)(blockDim.x >> 6); ++i) v = fminf(v, sm[i]);
+        for (int i = 1; i < (int)(blockDim.x >> 6); ++i) v = sm[i] < v ? sm[i] : v;
         if (v < __hip_atomic_load(gmin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomic_min_pos(gmin, v);
     }
 }
@@ -99,17 +119,17 @@ __device__ __forceinline__ void block_min_to(float v, float* gmin) {
 // |cv2.Laplacian(blurred, CV_64F, ksize)| -> float32, and the running global maximum.  KS = the aperture as a
 // compile-time constant (taps unrolled, kernel in registers) or 0 for any size; pixels whose window lies inside the
 // image skip the reflection maps.
-template <int KS>
-__global__ __launch_bounds__(256) void dm_laplacian(const float* __restrict__ src, int h, int w,
-                                                    float* __restrict__ out, float* __restrict__ gmax, DmK2 K) {
+template <int KS, typename F>
+__global__ __launch_bounds__(256) void dm_laplacian(const F* __restrict__ src, int h, int w,
+                                                    F* __restrict__ out, F* __restrict__ gmax, DmK2 K) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    float e = 0.f;
+    F e = 0;
     if (x < w && y < h) {
         const int ks = KS ? KS : K.ksize, r = ks / 2;
         const bool inside = x >= r && y >= r && x + r < w && y + r < h;
         double s = 0.0;
         for (int i = 0; i < ks; ++i) {
-            const float* row = src + (size_t)(inside ? y + i - r : r101_loop(y + i - r, h)) * w;
+            const F* row = src + (size_t)(inside ? y + i - r : r101_loop(y + i - r, h)) * w;
             for (int j = 0; j < ks; ++j) {
                 const double k = K.k[i * ks + j];
                 if (k == 0.0) continue;
@@ -117,22 +137,23 @@ __global__ __launch_bounds__(256) void dm_laplacian(const float* __restrict__ sr
                 s = s + pr;
             }
         }
-        e = (float)fabs(s);
+        e = (F)fabs(s);
         out[(size_t)y * w + x] = e;
     }
     block_max_to(e, gmax);
 }
 
-// |Sobel_x| + |Sobel_y| (3x3, CV_64F) -> float32
-__global__ __launch_bounds__(256) void dm_sobel(const float* __restrict__ src, int h, int w, float* __restrict__ out,
-                                                float* __restrict__ gmax) {
+// |Sobel_x| + |Sobel_y| (3x3, CV_64F) -> the energy plane's type
+template <typename F>
+__global__ __launch_bounds__(256) void dm_sobel(const F* __restrict__ src, int h, int w, F* __restrict__ out,
+                                                F* __restrict__ gmax) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    float e = 0.f;
+    F e = 0;
     if (x < w && y < h) {
         double p[3][3];
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            const float* row = src + (size_t)r101_loop(y + i - 1, h) * w;
+            const F* row = src + (size_t)r101_loop(y + i - 1, h) * w;
 #pragma unroll
             for (int j = 0; j < 3; ++j) p[i][j] = (double)row[r101_loop(x + j - 1, w)];
         }
@@ -149,29 +170,37 @@ __global__ __launch_bounds__(256) void dm_sobel(const float* __restrict__ src, i
         gy = gy + 1.0 * p[2][0];
         gy = gy + 2.0 * p[2][1];
         gy = gy + 1.0 * p[2][2];
-        e = (float)(fabs(gx) + fabs(gy));
+        e = (F)(fabs(gx) + fabs(gy));
         out[(size_t)y * w + x] = e;
     }
     block_max_to(e, gmax);
 }
 
-// energies / max_energy (float32 division, :90) in place, and the frame's own min / max (the bilateral
-// filter scales its range table with them).  mm[0] = min, mm[1] = max, preset to +inf bits / 0.
-__global__ __launch_bounds__(256) void dm_normalise(float* __restrict__ e, size_t n, const float* __restrict__ gmax,
-                                                    float* __restrict__ mm) {
-    const float m = *gmax;
-    float hi = 0.f, lo = __uint_as_float(0x7f800000u);
+// energies / max_energy (:90, a division in the plane's type) in place, and the plane's own min / max (the
+// bilateral filter scales its range table with them).  mm[0] = min, mm[1] = max, preset to +inf bits / 0.
+// A zero *gmax leaves the values as they are (used to take min / max only).
+template <typename F>
+__global__ __launch_bounds__(256) void dm_normalise(F* __restrict__ e, size_t n, const F* __restrict__ gmax,
+                                                    F* __restrict__ mm) {
+    const F m = *gmax;
+    F hi = 0, lo = INFINITY;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        float v = e[i];
-        if (m > 0.f) {
+        F v = e[i];
+        if (m > 0) {
             v = v / m;
             e[i] = v;
         }
-        hi = fmaxf(hi, v);
-        lo = fminf(lo, v);
+        hi = v > hi ? v : hi;
+        lo = v < lo ? v : lo;
     }
     block_max_to(hi, mm + 1);
     block_min_to(lo, mm);
+}
+
+// energy_map[i].astype(np.float32) (:48)
+__global__ __launch_bounds__(256) void dm_to_f32(const double* __restrict__ src, size_t n, float* __restrict__ dst) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = (float)src[i];
 }
 
 constexpr int DM_LUT_BINS = 4096;
@@ -272,43 +301,47 @@ __global__ __launch_bounds__(256) void dm_bilateral(DmBilateral a) {
     }
 }
 
-// smooth_size <= 0: no smoothing, only the running sum / maximum
-__global__ __launch_bounds__(256) void dm_accumulate(const float* __restrict__ e, size_t n, float* __restrict__ acc,
+// smooth_size <= 0: no smoothing, only the running sum / maximum (W = the energy planes' type)
+template <typename W>
+__global__ __launch_bounds__(256) void dm_accumulate(const W* __restrict__ e, size_t n, W* __restrict__ acc,
                                                      int mode, int first) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const float v = e[i];
-    if (mode == 0) acc[i] = first ? 0.f + v : acc[i] + v;
-    else acc[i] = first ? v : fmaxf(acc[i], v);
+    const W v = e[i];
+    if (mode == 0) acc[i] = first ? (W)0 + v : acc[i] + v;
+    else acc[i] = first ? v : (acc[i] > v ? acc[i] : v);
 }
 
-// MAX map (:59-60): relative = exp((e - max_e) / T) in place (float32 exp, correctly rounded through the
-// double exp), running sum of the relatives
-__global__ __launch_bounds__(256) void dm_relative(float* __restrict__ e, const float* __restrict__ mx, size_t n,
-                                                   float temperature, float* __restrict__ tot, int first) {
+// MAX map (:59-60): relative = exp((e - max_e) / T) in place, running sum of the relatives.  float32: the
+// correctly rounded exp (through the double one); float64: the device library's exp (the oracle's is correctly
+// rounded -- the last bit may differ, which the parity tolerance covers)
+template <typename W>
+__global__ __launch_bounds__(256) void dm_relative(W* __restrict__ e, const W* __restrict__ mx, size_t n,
+                                                   W temperature, W* __restrict__ tot, int first) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const float d = e[i] - mx[i];
-    const float q = d / temperature;
-    const float rel = (float)exp((double)q);
+    const W d = e[i] - mx[i];
+    const W q = d / temperature;
+    const W rel = (W)exp((double)q);
     e[i] = rel;
-    tot[i] = first ? 0.f + rel : tot[i] + rel;
+    tot[i] = first ? (W)0 + rel : tot[i] + rel;
 }
 
 // weights (:57, :61): e / total; the AVERAGE map leaves pixels whose total is 0 undefined in the
 // reference (np.divide(..., where=) without out=) -- 0 here
-__global__ __launch_bounds__(256) void dm_weight(const float* __restrict__ e, const float* __restrict__ tot, size_t n,
-                                                 int guard_zero, float* __restrict__ wgt) {
+template <typename W>
+__global__ __launch_bounds__(256) void dm_weight(const W* __restrict__ e, const W* __restrict__ tot, size_t n,
+                                                 int guard_zero, W* __restrict__ wgt) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const float t = tot[i];
-    wgt[i] = (guard_zero && t == 0.f) ? 0.f : e[i] / t;
+    const W t = tot[i];
+    wgt[i] = (guard_zero && t == 0) ? (W)0 : e[i] / t;
 }
 
-// cv2.pyrDown on float32 data with C interleaved channels: rows s[2x]*6 + (s[2x-1] + s[2x+1])*4 + s[2x-2] +
+// cv2.pyrDown with C interleaved channels, arithmetic in F: rows s[2x]*6 + (s[2x-1] + s[2x+1])*4 + s[2x-2] +
 // s[2x+2], the same down the columns, * 1/256.  TSrc = the frame's integer type for level 0.
-template <typename TSrc, int C>
-__global__ __launch_bounds__(256) void dm_pyrdown(const TSrc* __restrict__ src, int h, int w, float* __restrict__ dst,
+template <typename TSrc, int C, typename F>
+__global__ __launch_bounds__(256) void dm_pyrdown(const TSrc* __restrict__ src, int h, int w, F* __restrict__ dst,
                                                   int ho, int wo) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= wo || y >= ho) return;
@@ -320,110 +353,110 @@ __global__ __launch_bounds__(256) void dm_pyrdown(const TSrc* __restrict__ src, 
     }
 #pragma unroll
     for (int c = 0; c < C; ++c) {
-        float rowv[5];
+        F rowv[5];
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
             const TSrc* row = src + (size_t)ys[i] * w * C + c;
-            const float m2 = (float)row[xs[0] * C], m1 = (float)row[xs[1] * C], c0 = (float)row[xs[2] * C],
-                        p1 = (float)row[xs[3] * C], p2 = (float)row[xs[4] * C];
-            float s = c0 * 6.f;
-            const float pr = (m1 + p1) * 4.f;
+            const F m2 = (F)row[xs[0] * C], m1 = (F)row[xs[1] * C], c0 = (F)row[xs[2] * C],
+                    p1 = (F)row[xs[3] * C], p2 = (F)row[xs[4] * C];
+            F s = c0 * (F)6;
+            const F pr = (m1 + p1) * (F)4;
             s = s + pr;
             s = s + m2;
             rowv[i] = s + p2;
         }
-        float s = rowv[2] * 6.f;
-        const float pr = (rowv[1] + rowv[3]) * 4.f;
+        F s = rowv[2] * (F)6;
+        const F pr = (rowv[1] + rowv[3]) * (F)4;
         s = s + pr;
         s = s + rowv[0];
         s = s + rowv[4];
-        dst[((size_t)y * wo + x) * C + c] = s * (1.0f / 256.0f);
+        dst[((size_t)y * wo + x) * C + c] = s * (F)(1.0 / 256.0);
     }
 }
 
 // one axis of cv2.pyrUp, unnormalised: sample i of a destination of nd samples from n source samples
-template <typename F>
-__device__ __forceinline__ float up_axis(int n, int nd, int i, F at) {
+template <typename F, typename A>
+__device__ __forceinline__ F up_axis(int n, int nd, int i, A at) {
     if (i >= 2 * n) i = 2 * n - 1;  // an odd destination repeats its last sample
     const int s = i >> 1;
     if (i & 1) {
-        if (s == n - 1) return at(s) * 8.f;
-        return (at(s) + at(s + 1)) * 4.f;
+        if (s == n - 1) return at(s) * (F)8;
+        return (at(s) + at(s + 1)) * (F)4;
     }
-    if (n == 1) return at(0) * 8.f;
+    if (n == 1) return at(0) * (F)8;
     if (s == 0) {
-        const float a = at(0) * 6.f, b = at(1) * 2.f;
+        const F a = at(0) * (F)6, b = at(1) * (F)2;
         return a + b;
     }
     if (s == n - 1) {
-        const float b = at(s) * 7.f;
+        const F b = at(s) * (F)7;
         return at(s - 1) + b;
     }
-    const float m = at(s) * 6.f;
-    const float l = at(s - 1) + m;
+    const F m = at(s) * (F)6;
+    const F l = at(s - 1) + m;
     return l + at(s + 1);
 }
 
 // cv2.pyrUp(src, dstsize=(wd, hd)) at destination (y, x), channel c: columns first, then rows, * 1/64
-template <int C>
-__device__ __forceinline__ float pyrup_at(const float* __restrict__ src, int hs, int ws, int hd, int wd, int y, int x,
-                                          int c) {
-    const float v = up_axis(hs, hd, y, [&](int r) {
-        const float* row = src + (size_t)r * ws * C + c;
-        return up_axis(ws, wd, x, [&](int q) { return row[q * C]; });
+template <int C, typename F>
+__device__ __forceinline__ F pyrup_at(const F* __restrict__ src, int hs, int ws, int hd, int wd, int y, int x, int c) {
+    const F v = up_axis<F>(hs, hd, y, [&](int r) {
+        const F* row = src + (size_t)r * ws * C + c;
+        return up_axis<F>(ws, wd, x, [&](int q) { return row[q * C]; });
     });
-    return v * (1.0f / 64.0f);
+    return v * (F)(1.0 / 64.0);
 }
 
 // Laplacian level (fine - pyrUp(coarse)) times the weight plane of that level, accumulated over frames (:104-110)
-template <typename TFine>
+template <typename TFine, typename F, typename W>
 __global__ __launch_bounds__(256) void dm_lap_blend(const TFine* __restrict__ fine, int h, int w,
-                                                    const float* __restrict__ coarse, int hc, int wc,
-                                                    const float* __restrict__ wgt, float* __restrict__ blend, int first) {
+                                                    const F* __restrict__ coarse, int hc, int wc,
+                                                    const W* __restrict__ wgt, F* __restrict__ blend, int first) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= w || y >= h) return;
     const size_t p = (size_t)y * w + x;
-    const float wv = wgt[p];
+    const F wv = (F)wgt[p];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        const float lap = (float)fine[p * 3 + c] - pyrup_at<3>(coarse, hc, wc, h, w, y, x, c);
-        const float cur = lap * wv;
+        const F lap = (F)fine[p * 3 + c] - pyrup_at<3, F>(coarse, hc, wc, h, w, y, x, c);
+        const F cur = lap * wv;
         blend[p * 3 + c] = first ? cur : blend[p * 3 + c] + cur;
     }
 }
 
 // coarsest level: the Gaussian level itself times its weight plane
-template <typename TFine>
+template <typename TFine, typename F, typename W>
 __global__ __launch_bounds__(256) void dm_top_blend(const TFine* __restrict__ top, size_t npix,
-                                                    const float* __restrict__ wgt, float* __restrict__ blend, int first) {
+                                                    const W* __restrict__ wgt, F* __restrict__ blend, int first) {
     const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (p >= npix) return;
-    const float wv = wgt[p];
+    const F wv = (F)wgt[p];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        const float cur = (float)top[p * 3 + c] * wv;
+        const F cur = (F)top[p * 3 + c] * wv;
         blend[p * 3 + c] = first ? cur : blend[p * 3 + c] + cur;
     }
 }
 
 // result = pyrUp(result) + blended level (:119-121)
-__global__ __launch_bounds__(256) void dm_collapse(const float* __restrict__ coarse, int hc, int wc,
-                                                   const float* __restrict__ blend, int h, int w, float* __restrict__ out) {
+template <typename F>
+__global__ __launch_bounds__(256) void dm_collapse(const F* __restrict__ coarse, int hc, int wc,
+                                                   const F* __restrict__ blend, int h, int w, F* __restrict__ out) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= w || y >= h) return;
     const size_t p = (size_t)y * w + x;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) out[p * 3 + c] = pyrup_at<3>(coarse, hc, wc, h, w, y, x, c) + blend[p * 3 + c];
+    for (int c = 0; c < 3; ++c) out[p * 3 + c] = pyrup_at<3, F>(coarse, hc, wc, h, w, y, x, c) + blend[p * 3 + c];
 }
 
 // np.clip(np.absolute(result), 0, n_values).astype(dtype) (:122-123)
-template <typename TOut>
-__global__ __launch_bounds__(256) void dm_finalize(const float* __restrict__ img, size_t n, float maxv,
+template <typename TOut, typename F>
+__global__ __launch_bounds__(256) void dm_finalize(const F* __restrict__ img, size_t n, F maxv,
                                                    TOut* __restrict__ out) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    float v = fabsf(img[i]);
-    v = v < 0.f ? 0.f : (v > maxv ? maxv : v);
+    F v = img[i] < 0 ? -img[i] : img[i];
+    v = v < 0 ? (F)0 : (v > maxv ? maxv : v);
     out[i] = (TOut)v;
 }
 

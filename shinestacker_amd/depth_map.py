@@ -16,9 +16,9 @@ All arithmetic runs in libmi355stack.so (mi_dmap_*, csrc/kernels_depthmap.hpp); 
 Every frame is decoded once and stays on the device for the second loop (the reference reads each file
 twice, :69 and :96).
 
-Not implemented: float_type='float-64' (the reference's option that makes the gray / energy planes and the
-blend pyramids float64) -- InvalidOptionError at construction.  The AVERAGE map's value where all energies
-of a pixel are 0 is undefined in the reference (np.divide(..., where=...) without out=, :57); it is 0 here.
+Both float types (float-64: gray / energy planes and blend pyramids in float64; the bilateral filter still runs
+on float32 copies, as in the reference).  The AVERAGE map's value where all energies of a pixel are 0 is undefined
+in the reference (np.divide(..., where=...) without out=, :57); it is 0 here.
 """
 import numpy as np
 
@@ -39,9 +39,6 @@ class DepthMapStack(BaseStackAlgo):
                  levels=constants.DEFAULT_DM_LEVELS, float_type=constants.DEFAULT_DM_FLOAT, *, device=0,
                  decode_threads=8):
         super().__init__("depth map", 2, float_type)
-        if self.float_type is not np.float32:
-            raise InvalidOptionError("float_type", float_type,
-                                     details=" DepthMapStack on MI355X implements FLOAT_32 only")
         self.map_type = map_type
         self.energy = energy
         self.kernel_size = kernel_size
@@ -57,7 +54,7 @@ class DepthMapStack(BaseStackAlgo):
     # ------------------------------------------------------------------ device handle
     def _handle(self, shape, dtype):
         key = (tuple(shape[:2]), np.dtype(dtype), self.map_type, self.energy, self.kernel_size, self.blur_size,
-               self.smooth_size, self.temperature, self.levels)
+               self.smooth_size, self.temperature, self.levels, self.float_type)
         if self._dmap is not None and self._key == key:
             self._dmap.reset()
             return self._dmap
@@ -68,7 +65,8 @@ class DepthMapStack(BaseStackAlgo):
                                    energy=_ENERGY_CODE.get(self.energy, _lib.DM_ENERGY_LAPLACIAN),
                                    kernel_size=self.kernel_size, blur_size=self.blur_size,
                                    smooth_size=self.smooth_size, temperature=self.temperature,
-                                   levels=self.levels, device=self.device)
+                                   levels=self.levels, device=self.device,
+                                   float_type=_lib.MI_F64 if self.float_type is np.float64 else _lib.MI_F32)
         self._key = key
         return self._dmap
 

@@ -37,8 +37,9 @@ def close_enough(got, want, where=None):
 def run_gpu(L, frames, **kw):
     kw = dict(kw)
     h, w = frames[0].shape[:2]
+    ft = L.MI_F64 if kw.pop("float_type", "float-32") == "float-64" else L.MI_F32
     with L.DepthMap(h, w, dtype=frames[0].dtype, map_type=MAP[kw.pop("map_type", "average")],
-                    energy=ENERGY[kw.pop("energy", "laplacian")], **kw) as dm:
+                    energy=ENERGY[kw.pop("energy", "laplacian")], float_type=ft, **kw) as dm:
         for f in frames:
             dm.push_frame(f)
         assert dm.frames_pushed == len(frames)
@@ -87,6 +88,12 @@ CASES = [
     (np.uint8, 2, 5, 7, {"levels": 3}),            # tiny: every stencil reflects more than once
     (np.uint8, 2, 1, 9, {"levels": 2, "smooth_size": 5}),
     (np.uint16, 2, 130, 259, {"levels": 6}),
+    (np.uint8, 4, 61, 83, {"float_type": "float-64"}),
+    (np.uint16, 3, 50, 77, {"float_type": "float-64", "map_type": "max"}),
+    (np.uint16, 3, 47, 66, {"float_type": "float-64", "smooth_size": 0, "levels": 4}),
+    (np.uint8, 3, 39, 58, {"float_type": "float-64", "smooth_size": 0, "map_type": "max", "energy": "sobel"}),
+    (np.uint8, 2, 40, 40, {"float_type": "float-64", "kernel_size": 9, "blur_size": 11, "smooth_size": 7, "levels": 2}),
+    (np.uint8, 2, 3, 5, {"float_type": "float-64"}),
 ]
 
 
@@ -179,6 +186,9 @@ def test_plugin_protocol_on_files(L, tmp_path):
     # the same stacker object again (FocusStackBunch reuses it), other options
     algo.map_type, algo.energy = "max", "sobel"
     assert close_enough(algo.focus_stack(names[:4]), dmo.depth_map_stack(frames[:4], map_type="max", energy="sobel"))[0]
+    algo64 = DepthMapStack(float_type="float-64", levels=2)
+    algo64.process = Proc()
+    assert close_enough(algo64.focus_stack(names[:3]), dmo.depth_map_stack(frames[:3], float_type="float-64", levels=2))[0]
     # stop request during the first loop
     algo = DepthMapStack()
     algo.process = Proc(stop_at=2)
