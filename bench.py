@@ -88,6 +88,8 @@ def main():
         args.gpus = world
 
     dist = None
+    # the host driver only supports dmabuf IPC: without this RCCL's buffer sharing across processes fails
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     force_dist = os.environ.get("MI_BENCH_FORCE_COMBINE") == "1"  # exercise the combine at world 1
     if world > 1 or force_dist:
         # torch ships its own HIP runtime: it must be loaded BEFORE libmi355stack.so pulls in
