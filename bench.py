@@ -147,7 +147,9 @@ def main():
         else:
             st.push_frames_device(buf.ptr, F)
         if combiner is not None:
-            combiner.combine()          # arg-max-with-payload exchange over xGMI
+            # arg-max-with-payload exchange over xGMI; the fused image needs the winners' payloads only, so the
+            # winner indices are not exchanged and the winners' energies stay on the chunk owners
+            combiner.combine(with_index=False, root_energy=False)
             if rank == 0:
                 st.finish_device()
         else:
@@ -209,6 +211,11 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args)
+        if world > 1 or force_dist:
+            # RCCL prints its version banner through C stdio when NCCL_DEBUG is set (it is, on the GPU boxes): push
+            # that out first, so that the JSON line is the last line of rank 0's stdout
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
         print(json.dumps(line), flush=True)
     if world > 1 or force_dist:
         dist.destroy_process_group()

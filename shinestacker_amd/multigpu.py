@@ -80,13 +80,15 @@ def combine_state(energy, lap, index, group, select_fn, width=3):
         dist.send(win_i.contiguous(), dst=root, group=group)
 
 
-def combine_all(states, group, select_fn, width=3, with_index=True):
+def combine_all(states, group, select_fn, width=3, with_index=True, root_energy=True):
     """Combine the state of all levels at once.  `states`: list of (energy (n_l,), lap (n_l*width,),
     index (n_l,)) tensors of this rank; on return rank 0's tensors hold the combined state.
     Same arithmetic as `combine_state` level by level (the pixel chunks just run across level
     boundaries), with 6 collectives in total -- 4 with `with_index=False`, which leaves the winner
     indices of rank 0 stale (they only feed the debug taps; the fused image needs E and lap alone)
-    and moves 16 instead of 20 bytes per pixel."""
+    and moves 16 instead of 20 bytes per pixel.  `root_energy=False` also keeps the winners' energies on the
+    chunk owners (3 collectives, 12 instead of 20 bytes per pixel to rank 0): the collapse reads the fused Laplacians
+    and base pixels only, so the fused image is the same; rank 0's energy taps are then stale too."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     single = len(states) == 1   # the library's contiguous slabs: exchanged in place, no packing copies
@@ -118,7 +120,8 @@ def combine_all(states, group, select_fn, width=3, with_index=True):
                                output_split_sizes=[s_ * w for s_ in sizes] if rank == 0 else [0] * world,
                                input_split_sizes=[mine * w] + [0] * (world - 1), group=group)
 
-    to_root(win_e, e_all, 1)
+    if root_energy:
+        to_root(win_e, e_all, 1)
     to_root(win_l, l_all, width)
     if with_index:
         to_root(win_i, i_all, 1)
@@ -126,7 +129,8 @@ def combine_all(states, group, select_fn, width=3, with_index=True):
         off = 0
         for e, lp, ix in states:
             m = e.numel()
-            e.reshape(-1).copy_(e_all[off:off + m])
+            if root_energy:
+                e.reshape(-1).copy_(e_all[off:off + m])
             lp.reshape(-1).copy_(l_all[off * width:(off + m) * width])
             if with_index:
                 ix.reshape(-1).copy_(i_all[off:off + m])
@@ -166,9 +170,10 @@ class Combiner:
             out_i.data_ptr() if out_i is not None else None))
         return out_e, out_l, out_i
 
-    def combine(self, with_index=True):
+    def combine(self, with_index=True, root_energy=True):
         """Call on every rank after its frames were pushed; rank 0 may then finish().
-        `with_index=False`: do not exchange the winner indices (debug taps only)."""
+        `with_index=False`: do not exchange the winner indices (debug taps only); `root_energy=False`: do not send the
+        winners' energies to rank 0 either (the fused image needs the winners' Laplacians / base pixels alone)."""
         st = self.stack
         st.sync()  # the library's streams are not torch's
         # all levels, then base entropy twin, base deviation twin: one contiguous slab per array
@@ -176,5 +181,5 @@ class Combiner:
         states = [(wrap_device(e_ptr, n, torch.float32, self.device),
                    wrap_device(l_ptr, n * 3, torch.float32, self.device),
                    wrap_device(i_ptr, n, torch.int32, self.device))]
-        combine_all(states, self.group, self._select_hip, with_index=with_index)
+        combine_all(states, self.group, self._select_hip, with_index=with_index, root_energy=root_energy)
         torch.cuda.current_stream(torch.device("cuda", self.device)).synchronize()

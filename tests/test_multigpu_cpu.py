@@ -97,6 +97,12 @@ def _worker(rank, world, port, ret):
                 for x, y in zip(a, b):
                     assert torch.equal(x, y)
                 assert torch.equal(c[0], a[0]) and torch.equal(c[1], a[1]) and torch.equal(c[2], orig[2])
+        # payloads only (what bench.py uses): the winners' Laplacians reach rank 0, energies and indices stay local
+        pay = tensors()
+        multigpu.combine_all(pay, dist.group.WORLD, _torch_select, with_index=False, root_energy=False)
+        if rank == 0:
+            for a, c, orig in zip(per_level, pay, tensors()):
+                assert torch.equal(c[1], a[1]) and torch.equal(c[0], orig[0]) and torch.equal(c[2], orig[2])
             ret["state"] = [(te.numpy(), tl.numpy(), ti.numpy()) for te, tl, ti in flat]
     finally:
         dist.destroy_process_group()
