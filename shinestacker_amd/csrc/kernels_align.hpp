@@ -236,6 +236,45 @@ __global__ __launch_bounds__(256) void border_blur_collect(const T* __restrict__
     const int maxv = sizeof(T) == 1 ? 255 : 65535;
     const int per = 64 / ks;  // pixels per cooperative round
     if (nm > 4 * per) {
+        // A run of masked pixels (a row along the top or bottom edge).  When the 64 pixels lie in one image row the
+        // wave shares each window row through LDS: 64 + 2r pixels are loaded once (two loads per lane instead of
+        // ksize per lane, and the reflection map per loaded pixel instead of per tap) and every lane sums its ksize
+        // neighbours from there -- the operations of blur_at in the same order, a third of the instructions.
+        __shared__ float sRow[4][64 + 2 * 10][3];
+        const int y_first = (int)(base / w), x_first = (int)(base - (size_t)y_first * w);
+        if (r <= 10 && x_first + 63 < w && base + 63 < n) {
+            float (*s)[3] = sRow[threadIdx.x >> 6];
+            float acc[3] = {0.f, 0.f, 0.f};
+            for (int dy = 0; dy < ks; ++dy) {
+                const int yy = r101_loop(y_first + dy - r, h);
+                for (int j = lane; j < 64 + 2 * r; j += 64) {
+                    float p[3];
+                    load_px3<T>(img, (size_t)yy * w + r101_loop(x_first + j - r, w), n - 1, p);
+                    s[j][0] = p[0]; s[j][1] = p[1]; s[j][2] = p[2];
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the wave's own LDS writes have landed
+                float row[3] = {0.f, 0.f, 0.f};
+                for (int dx = 0; dx < ks; ++dx) {
+                    const float k = g.k[dx];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const float pr = k * s[lane + dx][c];
+                        row[c] = row[c] + pr;
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float q = g.k[dy] * row[c];
+                    acc[c] = acc[c] + q;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next row overwrites
+            }
+            if (masked) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) side[pi * 3 + c] = (T)min(max((int)rintf(acc[c]), 0), maxv);
+            }
+            return;
+        }
         if (masked) {
             const int y = (int)(pi / w), x = (int)(pi - (size_t)y * w);
             int o[3];
