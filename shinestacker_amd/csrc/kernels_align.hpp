@@ -176,11 +176,42 @@ __device__ __forceinline__ void load_px3(const T* __restrict__ img, size_t pi, s
     }
 }
 
+// the same pixel kept raw (8-bit: one dword, 16-bit: two), decoded later
+template <typename T>
+__device__ __forceinline__ uint2 load_px3_raw(const T* __restrict__ img, size_t pi, size_t last) {
+    uint2 v = {0u, 0u};
+    if constexpr (sizeof(T) == 1) {
+        if (pi != last) {
+            __builtin_memcpy(&v.x, img + pi * 3, 4);
+        } else {
+            __builtin_memcpy(&v.x, img + pi * 3 - 1, 4);
+            v.x >>= 8;
+        }
+    } else {
+        uint16_t v2;
+        __builtin_memcpy(&v.x, img + pi * 3, 4);
+        __builtin_memcpy(&v2, img + pi * 3 + 2, 2);
+        v.y = v2;
+    }
+    return v;
+}
+template <typename T>
+__device__ __forceinline__ void decode_px3(uint2 v, float out[3]) {
+    if constexpr (sizeof(T) == 1) {
+        out[0] = (float)(v.x & 255u); out[1] = (float)((v.x >> 8) & 255u); out[2] = (float)((v.x >> 16) & 255u);
+    } else {
+        out[0] = (float)(v.x & 65535u); out[1] = (float)(v.x >> 16); out[2] = (float)v.y;
+    }
+}
+
 // gaussian_blur(img) at one pixel: horizontal pass then vertical pass in float32, taps in index
 // order, REFLECT101, round-half-even + saturate (align_oracle.c)
-template <typename T>
+// `kof(i)` returns tap i of the Gaussian: the callers keep the taps in a VGPR (lane i holds tap i) and read them
+// with v_readlane -- indexing the kernel-argument array with a loop counter costs a scalar load and an lgkmcnt
+// wait per tap, ~0.15 us each, 441 of them per pixel
+template <typename T, typename KOf>
 __device__ __forceinline__ void blur_at(const T* __restrict__ img, int h, int w, int y, int x, const GaussArgs& g,
-                                        int out[3]) {
+                                        int out[3], KOf kof) {
     const int r = g.ksize / 2;
     const int maxv = sizeof(T) == 1 ? 255 : 65535;
     const size_t last = (size_t)h * w - 1;
@@ -188,20 +219,33 @@ __device__ __forceinline__ void blur_at(const T* __restrict__ img, int h, int w,
     for (int dy = 0; dy < g.ksize; ++dy) {
         const int yy = r101_loop(y + dy - r, h);
         float row[3] = {0.f, 0.f, 0.f};
-        for (int dx = 0; dx < g.ksize; ++dx) {
-            const int xx = r101_loop(x + dx - r, w);
-            float p[3];
-            load_px3<T>(img, (size_t)yy * w + xx, last, p);
-            const float k = g.k[dx];
+        // the window row's loads are issued together (groups of 8), not one per dependent multiply-add: a wave that
+        // comes here alone -- a run that crosses a row end -- otherwise pays 441 memory latencies in a row (~75 us)
+        for (int d0 = 0; d0 < g.ksize; d0 += 8) {
+            uint2 raw[8];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const float pr = k * p[c];
-                row[c] = row[c] + pr;
+            for (int u = 0; u < 8; ++u) {
+                const int dx = min(d0 + u, g.ksize - 1);
+                raw[u] = load_px3_raw<T>(img, (size_t)yy * w + r101_loop(x + dx - r, w), last);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (d0 + u < g.ksize) {
+                    float p[3];
+                    decode_px3<T>(raw[u], p);
+                    const float k = kof(d0 + u);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const float pr = k * p[c];
+                        row[c] = row[c] + pr;
+                    }
+                }
             }
         }
+        const float kd = kof(dy);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const float q = g.k[dy] * row[c];
+            const float q = kd * row[c];
             acc[c] = acc[c] + q;
         }
     }
@@ -235,6 +279,8 @@ __global__ __launch_bounds__(256) void border_blur_collect(const T* __restrict__
     const int ks = g.ksize, r = ks / 2;
     const int maxv = sizeof(T) == 1 ? 255 : 65535;
     const int per = 64 / ks;  // pixels per cooperative round
+    const float kreg = g.k[lane & 31];   // lane i holds tap i (ksize <= 31)
+    auto kof = [&](int i) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(kreg), i)); };
     if (nm > 4 * per) {
         // A run of masked pixels (a row along the top or bottom edge).  When the 64 pixels lie in one image row the
         // wave shares each window row through LDS: 64 + 2r pixels are loaded once (two loads per lane instead of
@@ -245,29 +291,50 @@ __global__ __launch_bounds__(256) void border_blur_collect(const T* __restrict__
         if (r <= 10 && x_first + 63 < w && base + 63 < n) {
             float (*s)[3] = sRow[threadIdx.x >> 6];
             float acc[3] = {0.f, 0.f, 0.f};
-            for (int dy = 0; dy < ks; ++dy) {
-                const int yy = r101_loop(y_first + dy - r, h);
-                for (int j = lane; j < 64 + 2 * r; j += 64) {
-                    float p[3];
-                    load_px3<T>(img, (size_t)yy * w + r101_loop(x_first + j - r, w), n - 1, p);
-                    s[j][0] = p[0]; s[j][1] = p[1]; s[j][2] = p[2];
+            // all window rows are requested before the first one is used: only a few hundred such waves exist per
+            // frame, so nothing else hides the latency of 21 load round trips in a row
+            uint2 pre[21][2];
+#pragma unroll
+            for (int dy = 0; dy < 21; ++dy) {
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const int j = lane + 64 * jj;
+                    pre[dy][jj] = uint2{0u, 0u};
+                    if (dy < ks && j < 64 + 2 * r)
+                        pre[dy][jj] = load_px3_raw<T>(img, (size_t)r101_loop(y_first + dy - r, h) * w +
+                                                               r101_loop(x_first + j - r, w), n - 1);
+                }
+            }
+#pragma unroll
+            for (int dy = 0; dy < 21; ++dy) {
+                if (dy < ks) {
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const int j = lane + 64 * jj;
+                    if (j < 64 + 2 * r) {
+                        float p[3];
+                        decode_px3<T>(pre[dy][jj], p);
+                        s[j][0] = p[0]; s[j][1] = p[1]; s[j][2] = p[2];
+                    }
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the wave's own LDS writes have landed
                 float row[3] = {0.f, 0.f, 0.f};
                 for (int dx = 0; dx < ks; ++dx) {
-                    const float k = g.k[dx];
+                    const float k = kof(dx);
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
                         const float pr = k * s[lane + dx][c];
                         row[c] = row[c] + pr;
                     }
                 }
+                const float kd = kof(dy);
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
-                    const float q = g.k[dy] * row[c];
+                    const float q = kd * row[c];
                     acc[c] = acc[c] + q;
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next row overwrites
+                }
             }
             if (masked) {
 #pragma unroll
@@ -278,7 +345,7 @@ __global__ __launch_bounds__(256) void border_blur_collect(const T* __restrict__
         if (masked) {
             const int y = (int)(pi / w), x = (int)(pi - (size_t)y * w);
             int o[3];
-            blur_at<T>(img, h, w, y, x, g, o);
+            blur_at<T>(img, h, w, y, x, g, o, kof);
             side[pi * 3 + 0] = (T)o[0]; side[pi * 3 + 1] = (T)o[1]; side[pi * 3 + 2] = (T)o[2];
         }
         return;
@@ -307,15 +374,16 @@ __global__ __launch_bounds__(256) void border_blur_collect(const T* __restrict__
                 const int xx = r101_loop(x + dx - r, w);
                 float p[3];
                 load_px3<T>(img, (size_t)yy * w + xx, n - 1, p);
-                const float k = g.k[dx];
+                const float k = kof(dx);
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     const float pr = k * p[c];
                     row[c] = row[c] + pr;
                 }
             }
+            const float kw = __shfl(kreg, wr, 64);   // tap of this lane's window row
 #pragma unroll
-            for (int c = 0; c < 3; ++c) q[c] = g.k[wr] * row[c];
+            for (int c = 0; c < 3; ++c) q[c] = kw * row[c];
         }
         // vertical pass: the group's first lane adds the row results in row order
         float acc[3] = {0.f, 0.f, 0.f};

@@ -15,7 +15,8 @@ src, dst, tmp, mask = (L.DeviceBuffer(nb) for _ in range(3)), None, None, None
 src, dst, tmp = src
 mask = L.DeviceBuffer(H * W)
 L.synth_frames_device(src.ptr, np.uint8, H, W, 0, 1, 4, 7)
-cases = {"identity": (1.0, 0.0, 0.0, 0.0), "shift3": (1.0, 0.0, 3.3, -2.2), "config4-like": (1.002, 0.0015, 9.0, -7.0),
+cases = {"identity": (1.0, 0.0, 0.0, 0.0), "xshift3": (1.0, 0.0, 3.3, 0.0), "yshift2": (1.0, 0.0, 0.0, -2.2),
+         "shift3": (1.0, 0.0, 3.3, -2.2), "config4-like": (1.002, 0.0015, 9.0, -7.0),
          "rot0.5deg": (1.0, 0.0087, 0.0, 0.0)}
 for name, (a, b, tx, ty) in cases.items():
     M = (C.c_double * 6)(a, -b, tx, b, a, ty)
