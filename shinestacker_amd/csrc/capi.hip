@@ -664,8 +664,10 @@ int aligner_solve(mi_aligner* al, hipStream_t st, int n, int max_iters, double e
         const double cx = 0.5 * (L.w - 1), cy = 0.5 * (L.h - 1);
         const size_t np = (size_t)L.h * L.w;
         const int step = np >= (size_t)4000000 ? 2 : 1;   // 1M+ samples are plenty for 4 parameters
-        // ~8 pixels per thread, at most ECC_MAX_BLOCKS blocks (4 per CU)
-        const size_t work = (np / ((size_t)step * step) + 2047) / 2048;
+        // ~24 samples per thread (the 28 double sums cost a thread ~500 instructions to reduce, as much as 5 samples),
+        // at most ECC_MAX_BLOCKS blocks (4 per CU)
+        static const size_t per_blk = getenv("MI_ECC_PER_BLOCK") ? (size_t)atoi(getenv("MI_ECC_PER_BLOCK")) : 6144;   // study knob
+        const size_t work = (np / ((size_t)step * step) + per_blk - 1) / per_blk;
         const unsigned nblk = (unsigned)(work < 1 ? 1 : (work > (size_t)ECC_MAX_BLOCKS ? ECC_MAX_BLOCKS : work));
         for (auto& f : fr) {
             // W in origin coordinates u = A x + T, A = [a -b; b a]; centred parameters t = T - c + A c

@@ -159,10 +159,24 @@ __global__ __launch_bounds__(256) void ecc_accumulate(const float* __restrict__ 
     __syncthreads();
     if (!last) return;
     __threadfence();
+    // 28 sums x 9 interleaved slices of the block list on 252 threads (one thread per sum walked up to 1024 partials
+    // one load latency at a time: ~220 us of the finest level's 340 us), then the slices in slice order: still one
+    // fixed summation order, independent of which block came last
+    constexpr int SLICES = 9;
+    __shared__ double slice[SLICES][ECC_NSUM];
+    if (threadIdx.x < ECC_NSUM * SLICES) {
+        const int sidx = threadIdx.x % ECC_NSUM, part = threadIdx.x / ECC_NSUM;
+        double t = 0.0;
+#pragma unroll 4
+        for (unsigned bk = part; bk < gridDim.x; bk += SLICES)
+            t += __builtin_nontemporal_load(&partial[(size_t)bk * ECC_NSUM + sidx]);
+        slice[part][sidx] = t;
+    }
+    __syncthreads();
     if (threadIdx.x < ECC_NSUM) {
         double t = 0.0;
-        for (unsigned bk = 0; bk < gridDim.x; ++bk)
-            t += __builtin_nontemporal_load(&partial[(size_t)bk * ECC_NSUM + threadIdx.x]);
+#pragma unroll
+        for (int part = 0; part < SLICES; ++part) t += slice[part][threadIdx.x];
         sums[threadIdx.x] = t;
     }
     if (threadIdx.x == 0) *ticket = 0;
