@@ -282,63 +282,84 @@ __global__ __launch_bounds__(256) void border_blur_collect(const T* __restrict__
     const float kreg = g.k[lane & 31];   // lane i holds tap i (ksize <= 31)
     auto kof = [&](int i) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(kreg), i)); };
     if (nm > 4 * per) {
-        // A run of masked pixels (a row along the top or bottom edge).  When the 64 pixels lie in one image row the
-        // wave shares each window row through LDS: 64 + 2r pixels are loaded once (two loads per lane instead of
+        // A run of masked pixels (a row along the top or bottom edge): the wave shares each window row through LDS: 64 + 2r pixels are loaded once (two loads per lane instead of
         // ksize per lane, and the reflection map per loaded pixel instead of per tap) and every lane sums its ksize
         // neighbours from there -- the operations of blur_at in the same order, a third of the instructions.
         __shared__ float sRow[4][64 + 2 * 10][3];
         const int y_first = (int)(base / w), x_first = (int)(base - (size_t)y_first * w);
-        if (r <= 10 && x_first + 63 < w && base + 63 < n) {
+        if (r <= 10) {
             float (*s)[3] = sRow[threadIdx.x >> 6];
-            float acc[3] = {0.f, 0.f, 0.f};
-            // all window rows are requested before the first one is used: only a few hundred such waves exist per
-            // frame, so nothing else hides the latency of 21 load round trips in a row
-            uint2 pre[21][2];
+            // a chunk that crosses a row end is two runs (the tail of row y_first, the head of the next row): the
+            // procedure runs once per run, with lane 0 at a virtual column xs of that row
+            const int nruns = x_first + 63 >= w ? 2 : 1;
+            for (int run = 0; run < nruns; ++run) {
+                const int yr = y_first + run;
+                if (yr >= h) break;
+                const int xs = run == 0 ? x_first : x_first - w;
+                const bool mine = masked && (run == 0 ? lane < w - x_first : lane >= w - x_first);
+                float acc[3] = {0.f, 0.f, 0.f};
+                // all window rows are requested before the first one is used: only a few hundred such waves exist
+                // per frame, so nothing else hides the latency of 21 load round trips in a row
+                uint2 pre[21][2];
 #pragma unroll
-            for (int dy = 0; dy < 21; ++dy) {
+                for (int dy = 0; dy < 21; ++dy) {
 #pragma unroll
-                for (int jj = 0; jj < 2; ++jj) {
-                    const int j = lane + 64 * jj;
-                    pre[dy][jj] = uint2{0u, 0u};
-                    if (dy < ks && j < 64 + 2 * r)
-                        pre[dy][jj] = load_px3_raw<T>(img, (size_t)r101_loop(y_first + dy - r, h) * w +
-                                                               r101_loop(x_first + j - r, w), n - 1);
-                }
-            }
-#pragma unroll
-            for (int dy = 0; dy < 21; ++dy) {
-                if (dy < ks) {
-#pragma unroll
-                for (int jj = 0; jj < 2; ++jj) {
-                    const int j = lane + 64 * jj;
-                    if (j < 64 + 2 * r) {
-                        float p[3];
-                        decode_px3<T>(pre[dy][jj], p);
-                        s[j][0] = p[0]; s[j][1] = p[1]; s[j][2] = p[2];
+                    for (int jj = 0; jj < 2; ++jj) {
+                        const int j = lane + 64 * jj;
+                        pre[dy][jj] = uint2{0u, 0u};
+                        if (dy < ks && j < 64 + 2 * r)
+                            pre[dy][jj] = load_px3_raw<T>(img, (size_t)r101_loop(yr + dy - r, h) * w +
+                                                                   r101_loop(xs + j - r, w), n - 1);
                     }
                 }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the wave's own LDS writes have landed
-                float row[3] = {0.f, 0.f, 0.f};
-                for (int dx = 0; dx < ks; ++dx) {
-                    const float k = kof(dx);
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        const float pr = k * s[lane + dx][c];
-                        row[c] = row[c] + pr;
+                for (int dy = 0; dy < 21; ++dy) {
+                    if (dy < ks) {
+#pragma unroll
+                        for (int jj = 0; jj < 2; ++jj) {
+                            const int j = lane + 64 * jj;
+                            if (j < 64 + 2 * r) {
+                                float p[3];
+                                decode_px3<T>(pre[dy][jj], p);
+                                s[j][0] = p[0]; s[j][1] = p[1]; s[j][2] = p[2];
+                            }
+                        }
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the wave's own LDS writes have landed
+                        float row[3] = {0.f, 0.f, 0.f};
+                        // seven taps' LDS reads are in flight at a time (a loop that waits for every read is a chain
+                        // of 1 323 LDS latencies per pixel)
+                        for (int d0 = 0; d0 < ks; d0 += 7) {
+                            float v[7][3];
+#pragma unroll
+                            for (int u = 0; u < 7; ++u) {
+                                const int jx = lane + min(d0 + u, ks - 1);
+                                v[u][0] = s[jx][0]; v[u][1] = s[jx][1]; v[u][2] = s[jx][2];
+                            }
+#pragma unroll
+                            for (int u = 0; u < 7; ++u) {
+                                if (d0 + u < ks) {
+                                    const float k = kof(d0 + u);
+#pragma unroll
+                                    for (int c = 0; c < 3; ++c) {
+                                        const float pr = k * v[u][c];
+                                        row[c] = row[c] + pr;
+                                    }
+                                }
+                            }
+                        }
+                        const float kd = kof(dy);
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            const float q = kd * row[c];
+                            acc[c] = acc[c] + q;
+                        }
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next row overwrites
                     }
                 }
-                const float kd = kof(dy);
+                if (mine) {
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const float q = kd * row[c];
-                    acc[c] = acc[c] + q;
+                    for (int c = 0; c < 3; ++c) side[pi * 3 + c] = (T)min(max((int)rintf(acc[c]), 0), maxv);
                 }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next row overwrites
-                }
-            }
-            if (masked) {
-#pragma unroll
-                for (int c = 0; c < 3; ++c) side[pi * 3 + c] = (T)min(max((int)rintf(acc[c]), 0), maxv);
             }
             return;
         }
