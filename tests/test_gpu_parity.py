@@ -492,3 +492,24 @@ def test_bunches_sharded_over_two_ranks_on_one_gpu(L, tmp_path):
     assert names == sorted(f for f in os.listdir(os.path.join(work, "sharded")) if not f.startswith(".")) and len(names) == 4
     for f in names:
         assert np.array_equal(read_img(os.path.join(work, "single", f)), read_img(os.path.join(work, "sharded", f)))
+
+
+@pytest.mark.parametrize("shape,dtype", [((4101, 4303), np.uint8), ((4210, 4097), np.uint16)])
+def test_large_coarse_levels_on_the_wide_tile(L, oracle, shape, dtype):
+    """Frames of 17 MP and more: level 1 (> 4 MP) runs on level 0's 32x64 tile configuration (level_fused_coarse) --
+    odd sizes at every level, state and image against the streaming oracle."""
+    H, W = shape
+    scale = 1 if dtype == np.uint8 else 257
+    frames = [(oracle.synth_frame_numpy(H, W, f, 2).astype(dtype) * scale).astype(dtype) for f in range(2)]
+    so = oracle.StreamingOracle(H, W, dtype, keep_gauss=False)
+    st = L.Stack(H, W, in_dtype=dtype)
+    for f in frames:
+        so.push_frame(f)
+        st.push_frame(f)
+    want = so.finish()
+    assert st.levels == so.levels == 7
+    for lv in range(so.levels):
+        assert np.array_equal(st.tap(L.TAP_ENERGY, lv), so.best_e[lv]), lv
+        assert np.array_equal(st.tap(L.TAP_FUSED_LAP, lv), so.best_lap[lv]), lv
+    assert np.array_equal(st.finish(), want)
+    st.close()
