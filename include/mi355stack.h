@@ -125,7 +125,9 @@ MI_API int mi_stack_set_first_index(mi_stack_t* s, int first_global_index);
  * Returns after the work is enqueued; the host buffer may be reused on return. */
 MI_API int mi_stack_push_frame(mi_stack_t* s, const void* host_bgr, size_t row_stride_bytes);
 /* n frames already resident in device memory (tightly packed rows, frames
- * frame_stride_bytes apart), dtype = params.in_dtype. */
+ * frame_stride_bytes apart), dtype = params.in_dtype.  The frames must be complete either on the host's
+ * timeline (a finished copy / kernel) or in the order of the handle's stream (mi_stack_stream): work the
+ * caller enqueued there -- a warp, a table apply -- is waited for on the device, not on the host. */
 MI_API int mi_stack_push_frames_device(mi_stack_t* s, const void* dev_frames, int n,
                                 size_t frame_stride_bytes);
 /* wait for everything enqueued so far */

@@ -42,6 +42,7 @@ struct TiledState {
     hipStream_t stc = nullptr;                              // copy stream
     hipEvent_t evCopied = nullptr;                          // all H2D of the staged batch done
     hipEvent_t evRingFree = nullptr;                        // level-0 kernels finished reading the ring
+    hipEvent_t evInput = nullptr;                           // device pushes: the frames are complete in s->stream order
     long pin_no = 0;
 };
 
@@ -69,6 +70,7 @@ int tiled_create(mi_stack* s) {
     MI_HIP(hipStreamCreateWithPriority(&t->st2, hipStreamNonBlocking, prio_hi));
     t->gstride.assign(L + 1, 0);
     int rc;
+    MI_HIP(hipEventCreateWithFlags(&t->evInput, hipEventDisableTiming));
     for (int set = 0; set < 2; ++set) {
         MI_HIP(hipEventCreateWithFlags(&t->evL0i[set], hipEventDisableTiming));
         MI_HIP(hipEventCreateWithFlags(&t->evL0b[set], hipEventDisableTiming));
@@ -117,6 +119,7 @@ void tiled_destroy(mi_stack* s) {
     }
     if (t->evCopied) (void)hipEventDestroy(t->evCopied);
     if (t->evRingFree) (void)hipEventDestroy(t->evRingFree);
+    if (t->evInput) (void)hipEventDestroy(t->evInput);
     if (t->stc) (void)hipStreamDestroy(t->stc);
     if (t->st1) (void)hipStreamDestroy(t->st1);
     if (t->st2) (void)hipStreamDestroy(t->st2);
@@ -286,6 +289,10 @@ int run_batch(mi_stack* s, const void* frames, size_t stride, int nb) {
     // Gb[set] is free once st2 finished batch k-2 (no-op for the first two batches)
     MI_HIP(hipStreamWaitEvent(st0, t->evRest[set], 0));
     MI_HIP(hipStreamWaitEvent(st1, t->evRest[set], 0));
+    // whatever produced the frames on s->stream (a warp, a table apply, a copy enqueued by the caller) is ordered
+    // before the level-0 interior kernel by the stream itself; the border kernel runs on st1 and needs the event
+    MI_HIP(hipEventRecord(t->evInput, st0));
+    MI_HIP(hipStreamWaitEvent(st1, t->evInput, 0));
     if ((rc = launch_level<TIn, FMA, MI_TILE0_H, MI_TILE0_W, MI_TILE0_NT, MI_TILE_PAD != 0, MI_TILE_H, MI_TILE_W, MI_TILE_NT>(
              s, 0, set, frames, stride, nb, st0, st1)))
         return rc;

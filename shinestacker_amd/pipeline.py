@@ -182,7 +182,10 @@ def align_and_stack_device(dev_frames, n_frames, height, width, dtype, ref_idx=-
     def flush():
         nonlocal cur, filled
         if filled:
-            stack.sync()   # the warps (on the stacker's stream) and the previous fuse are done
+            # No host synchronisation here: the warps run on the stacker's stream, where the level-0 kernels that read
+            # this batch are enqueued next, and the stacker joins its side streams into that stream after every push --
+            # so the batch buffer written two flushes later is free by stream order.  The host goes straight on to the
+            # next batch's estimate (its own stream), which then overlaps these warps and the fuse.
             stack.push_frames_device(batches[cur].ptr, filled, fb)
             cur ^= 1
             filled = 0
