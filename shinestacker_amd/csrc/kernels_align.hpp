@@ -96,6 +96,57 @@ __device__ __forceinline__ void warp_pixel(const T* __restrict__ src, const Affi
     }
 }
 
+// The same pixel when all four taps are known to lie inside the image (the caller checked the thread's first and last
+// pixel; an affine map keeps the ones between them between): no clamping, no per-tap in-image flags, mask = 1 -- the
+// kernel is instruction-bound, and that bookkeeping was a third of its instructions.  Same arithmetic, same results.
+template <typename T>
+__device__ __forceinline__ void warp_pixel_inside(const T* __restrict__ src, const AffineArgs& a, int x, int X0, int Y0,
+                                                  int out[3]) {
+    const int w = a.w;
+    const int X = (X0 + cv_round_d(a.iM[0] * x * 1024.0)) >> 5;
+    const int Y = (Y0 + cv_round_d(a.iM[3] * x * 1024.0)) >> 5;
+    const int sx = X >> 5, sy = Y >> 5, fx = X & 31, fy = Y & 31;
+    int iw0 = (32 - fy) * (32 - fx) * 32, iw1 = (32 - fy) * fx * 32, iw2 = fy * (32 - fx) * 32, iw3 = fy * fx * 32;
+    if (fx == 0 && fy == 0) { iw0 = 32767; iw3 = 1; }
+    const T* p0 = src + ((size_t)sy * w + sx) * 3;
+    const T* p1 = p0 + (size_t)w * 3;
+    int q[4][3];
+    if constexpr (sizeof(T) == 1) {
+        uint32_t u[4];
+        __builtin_memcpy(&u[0], p0, 4);     __builtin_memcpy(&u[1], p0 + 3, 4);
+        __builtin_memcpy(&u[2], p1, 4);     __builtin_memcpy(&u[3], p1 + 3, 4);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { q[t][0] = u[t] & 255u; q[t][1] = (u[t] >> 8) & 255u; q[t][2] = (u[t] >> 16) & 255u; }
+    } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const T* p = (t < 2 ? p0 : p1) + (t & 1) * 3;
+            uint32_t u;
+            uint16_t v2;
+            __builtin_memcpy(&u, p, 4);
+            __builtin_memcpy(&v2, p + 2, 2);
+            q[t][0] = u & 65535u; q[t][1] = u >> 16; q[t][2] = v2;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        int r;
+        if constexpr (sizeof(T) == 1) {
+            r = (q[0][c] * iw0 + q[1][c] * iw1 + q[2][c] * iw2 + q[3][c] * iw3 + 16384) >> 15;
+            r = min(max(r, 0), 255);
+        } else {
+            const float wx1 = fx * (1.0f / 32), wx0 = 1.0f - wx1, wy1 = fy * (1.0f / 32), wy0 = 1.0f - wy1;
+            const float q0 = (float)q[0][c] * (wy0 * wx0), q1 = (float)q[1][c] * (wy0 * wx1);
+            const float q2 = (float)q[2][c] * (wy1 * wx0), q3 = (float)q[3][c] * (wy1 * wx1);
+            float s = q0 + q1;
+            s = s + q2;
+            s = s + q3;
+            r = min(max((int)rintf(s), 0), 65535);
+        }
+        out[c] = r;
+    }
+}
+
 // Four consecutive destination pixels per thread: 12 (uint8) / 24 (uint16) contiguous output bytes
 // and the 4 mask bytes leave as whole dwords when the row start allows it (VEC: w % 4 == 0 and
 // 4-byte aligned images).
@@ -109,11 +160,28 @@ __global__ __launch_bounds__(256) void warp_affine_kernel(const T* __restrict__ 
     const int X0 = cv_round_d((a.iM[1] * y + a.iM[2]) * 1024.0) + 16;
     const int Y0 = cv_round_d((a.iM[4] * y + a.iM[5]) * 1024.0) + 16;
     int v[4][3], ok[4];
+    // source positions of the thread's first and last pixel: both (with their +1 taps, and not touching the image's
+    // very last pixel, whose 4-byte tap load would leave the buffer) inside the image -> the fast path for all four
+    bool inside = xq + 3 < w;
+    if (inside) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int x = xq + 3 * e;
+            const int sx = ((X0 + cv_round_d(a.iM[0] * x * 1024.0)) >> 5) >> 5;
+            const int sy = ((Y0 + cv_round_d(a.iM[3] * x * 1024.0)) >> 5) >> 5;
+            inside = inside && sx >= 0 && sx + 1 < w && sy >= 0 && sy + 1 < h - 1;
+        }
+    }
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         ok[p] = 0;
         v[p][0] = v[p][1] = v[p][2] = 0;
-        if (xq + p < w) warp_pixel<T>(src, a, xq + p, X0, Y0, v[p], ok[p]);
+        if (inside) {
+            warp_pixel_inside<T>(src, a, xq + p, X0, Y0, v[p]);
+            ok[p] = 1;
+        } else if (xq + p < w) {
+            warp_pixel<T>(src, a, xq + p, X0, Y0, v[p], ok[p]);
+        }
     }
     const size_t px = (size_t)y * w + xq;
     if constexpr (VEC) {
