@@ -35,7 +35,7 @@ def parse():
     ap.add_argument("--height", type=int, default=4000)
     ap.add_argument("--width", type=int, default=6000)
     ap.add_argument("--dtype", default="f32", choices=["u8", "u16", "f32"])
-    ap.add_argument("--impl", default="auto", choices=["auto", "simple", "tiled", "stream"])
+    ap.add_argument("--impl", default="auto", choices=["auto", "simple", "tiled"])
     ap.add_argument("--batch", type=int, default=0, help="frames per fused launch (0 = library default)")
     ap.add_argument("--source", default="device", choices=["device", "host"],
                     help="host: frames are pushed from host memory one by one (PCIe-inclusive rate; "
@@ -117,7 +117,7 @@ def main():
     total_frames = F * world
     buf = L.DeviceBuffer(per * F, device)
     L.synth_frames_device(buf.ptr, dt, H, W, rank * F, F, total_frames, device=device)
-    impl = {"auto": L.IMPL_AUTO, "simple": L.IMPL_SIMPLE, "tiled": L.IMPL_TILED, "stream": L.IMPL_STREAM}[args.impl]
+    impl = {"auto": L.IMPL_AUTO, "simple": L.IMPL_SIMPLE, "tiled": L.IMPL_TILED}[args.impl]
     st = L.Stack(H, W, in_dtype=dt, out_dtype=np.uint16 if args.dtype == "u16" else np.uint8,
                  device=device, impl=impl, batch_frames=args.batch)
     st.set_first_index(rank * F)

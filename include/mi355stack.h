@@ -73,10 +73,17 @@ enum {
 enum {
     MI_IMPL_AUTO = 0,
     MI_IMPL_SIMPLE = 1, /* one thread per output, global-memory taps: the on-GPU cross-check */
-    MI_IMPL_TILED = 2,  /* LDS-tiled fused level kernels                                     */
-    MI_IMPL_STREAM = 3  /* register-streaming kernel for level interiors (wave-private, DPP
-                           neighbours, packed fp32), LDS-tiled kernel for the border frame    */
+    MI_IMPL_TILED = 2   /* LDS-tiled fused level kernels                                     */
 };
+
+/* arithmetic of the pyramid stencils (mi_stack_params.arith)
+ *   MI_ARITH_EXACT      every 5x5 stencil as the reference's own 25-tap row-major chain (cv2.filter2D order as
+ *                       restated in oracle/): every intermediate bit-identical to the oracle.  The drop-in default.
+ *   MI_ARITH_SEPARABLE  the same stencils as two 5-tap passes with the float32 generating kernel (polyphase for
+ *                       the expand): ~half the arithmetic, coefficients within the float32 forward-error bound
+ *                       of a float64 evaluation, per-pixel arg-max may flip at near ties (tolerance in
+ *                       tests/test_sep_tolerance.py).  float_type must be MI_F32. */
+enum { MI_ARITH_EXACT = 0, MI_ARITH_SEPARABLE = 1 };
 
 typedef struct mi_stack mi_stack_t;
 
@@ -87,12 +94,13 @@ typedef struct mi_stack_params {
     int32_t min_size;      /* pyramid.py:115,165  default 32                                  */
     int32_t kernel_size;   /* pyramid.py:116,18   base-level window only; default 5           */
     double gen_kernel;     /* pyramid.py:117,19   default 0.4                                 */
-    int32_t float_type;    /* MI_F32 (MI_F64 -> MI_ERR_UNSUPPORTED in this round)             */
+    int32_t float_type;    /* MI_F32 / MI_F64 (base_stack_algo.py:14-22; MI_F64 runs one frame at a time) */
     int32_t use_fma;       /* 1: fma chain (OpenCV AVX2 path) 0: mul+add (SSE baseline path)  */
     int32_t device;        /* HIP device ordinal                                              */
     int32_t impl;          /* MI_IMPL_*                                                       */
     int32_t batch_frames;  /* frames consumed per fused launch (tiled impl); 0 = default      */
-    int32_t reserved[5];
+    int32_t arith;         /* MI_ARITH_*; 0 = exact (default)                                  */
+    int32_t reserved[4];
 } mi_stack_params_t;
 
 /* ---- library ---- */

@@ -11,7 +11,8 @@ import numpy as np
 from .errors import DeviceError, InvalidOptionError
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libmi355stack.so")
+# MI355STACK_LIB: another build of the same library (tools/study_build.sh puts its -DMI_STUDY variant there)
+LIB_PATH = os.environ.get("MI355STACK_LIB") or os.path.join(_HERE, "csrc", "libmi355stack.so")
 
 # enums of mi355stack.h
 MI_OK, MI_ERR_INVALID, MI_ERR_NO_DEVICE, MI_ERR_HIP, MI_ERR_STATE, MI_ERR_NOMEM, \
@@ -19,8 +20,11 @@ MI_OK, MI_ERR_INVALID, MI_ERR_NO_DEVICE, MI_ERR_HIP, MI_ERR_STATE, MI_ERR_NOMEM,
 MI_U8, MI_U16, MI_F32, MI_F64 = range(4)
 (TAP_GAUSS, TAP_FUSED_LAP, TAP_ENERGY, TAP_INDEX, TAP_FUSED_BASE, TAP_BASE_IDX_E,
  TAP_BASE_IDX_D, TAP_COLLAPSED, TAP_BASE_ENT, TAP_BASE_DEV) = range(10)
-IMPL_AUTO, IMPL_SIMPLE, IMPL_TILED, IMPL_STREAM = range(4)
+IMPL_AUTO, IMPL_SIMPLE, IMPL_TILED = range(3)
 PROF_LEVEL, PROF_BASE, PROF_COLLAPSE, PROF_LEVEL0 = range(4)
+ARITH_EXACT, ARITH_SEPARABLE = 0, 1
+ARITH_CODE = {"exact": ARITH_EXACT, "separable": ARITH_SEPARABLE, ARITH_EXACT: ARITH_EXACT,
+              ARITH_SEPARABLE: ARITH_SEPARABLE}
 
 DTYPE_CODE = {np.dtype(np.uint8): MI_U8, np.dtype(np.uint16): MI_U16,
               np.dtype(np.float32): MI_F32}
@@ -32,7 +36,7 @@ class StackParams(C.Structure):
                 ("out_dtype", C.c_int32), ("min_size", C.c_int32), ("kernel_size", C.c_int32),
                 ("gen_kernel", C.c_double), ("float_type", C.c_int32), ("use_fma", C.c_int32),
                 ("device", C.c_int32), ("impl", C.c_int32), ("batch_frames", C.c_int32),
-                ("reserved", C.c_int32 * 5)]
+                ("arith", C.c_int32), ("reserved", C.c_int32 * 4)]
 
 
 class DepthMapParams(C.Structure):
@@ -224,7 +228,7 @@ class Stack:
 
     def __init__(self, height, width, in_dtype=np.uint8, out_dtype=None, min_size=32,
                  kernel_size=5, gen_kernel=0.4, use_fma=True, device=0, impl=IMPL_AUTO,
-                 batch_frames=0, float_type=MI_F32):
+                 batch_frames=0, float_type=MI_F32, arith=ARITH_EXACT):
         lib = load()
         require_device()
         p = StackParams()
@@ -237,6 +241,10 @@ class Stack:
         p.min_size, p.kernel_size, p.gen_kernel = int(min_size), int(kernel_size), float(gen_kernel)
         p.float_type, p.use_fma, p.device = float_type, int(bool(use_fma)), int(device)
         p.impl, p.batch_frames = int(impl), int(batch_frames)
+        if arith not in ARITH_CODE:
+            raise InvalidOptionError("arith", arith, "valid values are 'exact' and 'separable'")
+        p.arith = ARITH_CODE[arith]
+        self.arith = p.arith
         self.params = p
         self.in_dtype, self.out_dtype = in_dtype, out_dtype
         self.float_type = int(float_type)

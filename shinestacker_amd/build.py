@@ -9,7 +9,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
-LIB = os.path.join(CSRC, "libmi355stack.so")
+LIB = os.environ.get("MI355STACK_LIB") or os.path.join(CSRC, "libmi355stack.so")
 SOURCES = ["capi.hip"]
 
 

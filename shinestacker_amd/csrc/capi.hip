@@ -12,7 +12,7 @@
 #include "common.hpp"
 #include "kernels_simple.hpp"
 #include "kernels_tiled.hpp"
-#include "kernels_stream.hpp"
+#include "kernels_sep.hpp"
 #include "kernels_align.hpp"
 #include "kernels_ecc.hpp"
 #include "kernels_balance.hpp"
@@ -61,6 +61,8 @@ struct mi_stack {
     int L = 0;                // number of Laplacian levels; base is level L
     std::vector<int> lh, lw;  // level shapes, 0..L
     K25 K{};
+    float k1d[3] = {0.f, 0.f, 0.f};   // MI_ARITH_SEPARABLE: float32 of the 1-D generating kernel (k0, k1, k2)
+    bool sep = false;         // p.arith == MI_ARITH_SEPARABLE
     K25d Kd{};                // float-64 mode: the float64 generating kernel (np.outer, pyramid.py:21)
     bool f64 = false;         // float_type == MI_F64: float buffers below hold doubles (allocated twice as large)
     int pad = 2;
@@ -92,9 +94,6 @@ struct mi_stack {
     bool have_clipped = true;              // `clipped` holds the collapsed image (else the tap rebuilds it)
     void* out_dev = nullptr;
 
-    int stream_levels = 0;    // levels 0..stream_levels-1 run their interior on the streaming kernel
-    int stream_seg = 64;      // rows per wave segment of the streaming kernel
-    int stream_min_waves = 1024;  // levels with fewer strip x segment waves stay on the tiled kernel
     int n_pushed = 0;
     int first_index = 0;
     bool finished = false;
@@ -189,6 +188,28 @@ int process_frame_simple(mi_stack* s, const TIn* frame) {
     const dim3 blk(64, 4);
     const int idx = s->first_index + s->n_pushed;
     const int first = s->n_pushed == 0;
+    if (s->sep) {   // MI_ARITH_SEPARABLE: the same sequence with the two-pass kernels (kernels_sep.hpp)
+        ProfScope ps(s, MI_PROF_LEVEL, algorithmic_bytes_per_frame(s));
+        const float k0 = s->k1d[0], k1 = s->k1d[1], k2 = s->k1d[2];
+        hipLaunchKernelGGL((reduce_sep_simple<TIn>), grid2d(s->lw[1], s->lh[1], blk), blk, 0, s->stream, frame, s->lh[0],
+                           s->lw[0], s->G[1], s->lh[1], s->lw[1], k0, k1, k2);
+        for (int l = 1; l < s->L; ++l)
+            hipLaunchKernelGGL((reduce_sep_simple<float>), grid2d(s->lw[l + 1], s->lh[l + 1], blk), blk, 0, s->stream,
+                               (const float*)s->G[l], s->lh[l], s->lw[l], s->G[l + 1], s->lh[l + 1], s->lw[l + 1], k0, k1, k2);
+        for (int l = 0; l < s->L; ++l) {
+            dim3 g = grid2d(s->lw[l], s->lh[l], blk);
+            if (l == 0)
+                hipLaunchKernelGGL((lapq_sep_simple<TIn>), g, blk, 0, s->stream, frame, s->lh[0], s->lw[0], (const float*)s->G[1],
+                                   s->lh[1], s->lw[1], s->lap_tmp, s->q_tmp, k0, k1, k2);
+            else
+                hipLaunchKernelGGL((lapq_sep_simple<float>), g, blk, 0, s->stream, (const float*)s->G[l], s->lh[l], s->lw[l],
+                                   (const float*)s->G[l + 1], s->lh[l + 1], s->lw[l + 1], s->lap_tmp, s->q_tmp, k0, k1, k2);
+            hipLaunchKernelGGL(select_sep_simple, g, blk, 0, s->stream, (const float*)s->q_tmp, (const float*)s->lap_tmp,
+                               s->lh[l], s->lw[l], idx, first, s->bestE[l], s->bestLap[l], s->bestIdx[l], k0, k1, k2);
+        }
+        MI_HIP(hipGetLastError());
+        return MI_OK;
+    }
     {
         ProfScope ps(s, MI_PROF_LEVEL, algorithmic_bytes_per_frame(s));
         // Gaussian pyramid
@@ -422,6 +443,26 @@ int finish_impl(mi_stack* s) {
     const float* up = s->fusedBase;
     float* bufs[2] = {s->colA, s->colB};
     const dim3 blk(64, 4);
+    if (s->sep && L >= 1) {   // MI_ARITH_SEPARABLE: two-pass expand (kernels_sep.hpp), same structure
+        const float k0 = s->k1d[0], k1 = s->k1d[1], k2 = s->k1d[2];
+        for (int l = L - 1; l >= 1; --l) {
+            float* out = bufs[l & 1];
+            hipLaunchKernelGGL((collapse_sep<float>), grid2d(s->lw[l], s->lh[l], blk), blk, 0, s->stream, up, s->lh[l + 1],
+                               s->lw[l + 1], (const float*)s->bestLap[l], s->lh[l], s->lw[l], s->maxv, out, k0, k1, k2);
+            up = out;
+        }
+        s->collapse_src = up;
+        s->have_clipped = false;
+        const dim3 g0 = grid2d(s->lw[0], s->lh[0], blk);
+        if (s->p.out_dtype == MI_U8)
+            hipLaunchKernelGGL((collapse_sep<uint8_t>), g0, blk, 0, s->stream, up, s->lh[1], s->lw[1],
+                               (const float*)s->bestLap[0], s->lh[0], s->lw[0], s->maxv, (uint8_t*)s->out_dev, k0, k1, k2);
+        else
+            hipLaunchKernelGGL((collapse_sep<uint16_t>), g0, blk, 0, s->stream, up, s->lh[1], s->lw[1],
+                               (const float*)s->bestLap[0], s->lh[0], s->lw[0], s->maxv, (uint16_t*)s->out_dev, k0, k1, k2);
+        MI_HIP(hipGetLastError());
+        return MI_OK;
+    }
     for (int l = L - 1; l >= 1; --l) {
         float* out = bufs[l & 1];
         hipLaunchKernelGGL((collapse_simple<FMA>), grid2d(s->lw[l], s->lh[l], blk), blk, 0,
@@ -666,7 +707,7 @@ int aligner_solve(mi_aligner* al, hipStream_t st, int n, int max_iters, double e
         const int step = np >= (size_t)4000000 ? 2 : 1;   // 1M+ samples are plenty for 4 parameters
         // ~24 samples per thread (the 28 double sums cost a thread ~500 instructions to reduce, as much as 5 samples),
         // at most ECC_MAX_BLOCKS blocks (4 per CU)
-        static const size_t per_blk = getenv("MI_ECC_PER_BLOCK") ? (size_t)atoi(getenv("MI_ECC_PER_BLOCK")) : 6144;   // study knob
+        static const size_t per_blk = (size_t)study_env("MI_ECC_PER_BLOCK", 6144);   // study knob
         const size_t work = (np / ((size_t)step * step) + per_blk - 1) / per_blk;
         const unsigned nblk = (unsigned)(work < 1 ? 1 : (work > (size_t)ECC_MAX_BLOCKS ? ECC_MAX_BLOCKS : work));
         for (auto& f : fr) {
@@ -847,7 +888,10 @@ int mi_stack_create(mi_stack_t** out, const mi_stack_params_t* params) {
     if (p.min_size < 1) return fail(MI_ERR_INVALID, "min_size must be >= 1");
     if (p.kernel_size < 1 || p.kernel_size > 12)
         return fail(MI_ERR_INVALID, "kernel_size must be in [1, 12] (base window <= 11x11)");
-    if (p.impl < MI_IMPL_AUTO || p.impl > MI_IMPL_STREAM) return fail(MI_ERR_INVALID, "bad impl %d", p.impl);
+    if (p.impl < MI_IMPL_AUTO || p.impl > MI_IMPL_TILED) return fail(MI_ERR_INVALID, "bad impl %d", p.impl);
+    if (p.arith != MI_ARITH_EXACT && p.arith != MI_ARITH_SEPARABLE) return fail(MI_ERR_INVALID, "bad arith %d", p.arith);
+    if (p.arith == MI_ARITH_SEPARABLE && p.float_type != MI_F32)
+        return fail(MI_ERR_INVALID, "MI_ARITH_SEPARABLE needs float_type MI_F32");
     int ndev = 0;
     int rc = mi_device_count(&ndev);
     if (rc) return rc;
@@ -858,13 +902,6 @@ int mi_stack_create(mi_stack_t** out, const mi_stack_params_t* params) {
     mi_stack* s = new mi_stack();
     s->p = p;
     if (s->p.impl == MI_IMPL_AUTO) s->p.impl = tiled_available() ? MI_IMPL_TILED : MI_IMPL_SIMPLE;
-    if (s->p.impl == MI_IMPL_STREAM) {
-        s->p.impl = MI_IMPL_TILED;   // same batch pipeline, border frame and state layout
-        s->stream_levels = 1 << 20;
-    }
-    if (const char* e = getenv("MI_STREAM_LEVELS")) s->stream_levels = atoi(e);
-    if (const char* e = getenv("MI_STREAM_MIN_WAVES")) s->stream_min_waves = atoi(e);
-    if (const char* e = getenv("MI_STREAM_SEG")) s->stream_seg = atoi(e) > 1 ? atoi(e) & ~1 : 64;
     // levels = int(log2(min(h,w)/min_size)), pyramid.py:165; stop when a side < 4, :129-130
     {
         double r = (double)(p.height < p.width ? p.height : p.width) / (double)p.min_size;
@@ -895,6 +932,8 @@ int mi_stack_create(mi_stack_t** out, const mi_stack_params_t* params) {
                 s->K.k[i * 5 + j] = (float)(k[i] * k[j]);
                 s->Kd.k[i * 5 + j] = k[i] * k[j];
             }
+        for (int i = 0; i < 3; ++i) s->k1d[i] = (float)k[i];
+        s->sep = p.arith == MI_ARITH_SEPARABLE;
     }
     s->pad = (p.kernel_size - 1) / 2;
     s->nlevels_hist = p.out_dtype == MI_U8 ? 256 : 65536;
@@ -1146,7 +1185,11 @@ int mi_stack_get_level(mi_stack_t* s, int level, int what, void* host_out, size_
             if (!s->finished) return fail(MI_ERR_STATE, "collapsed image is available after finish");
             if (!s->f64 && !s->have_clipped) {   // finish fused the finest collapse step with the cast: redo it unfused
                 const dim3 blk(64, 4);
-                if (s->p.use_fma)
+                if (s->sep)
+                    hipLaunchKernelGGL((collapse_sep<float>), grid2d(s->lw[0], s->lh[0], blk), blk, 0, s->stream, s->collapse_src,
+                                       s->lh[1], s->lw[1], (const float*)s->bestLap[0], s->lh[0], s->lw[0], s->maxv, s->colA,
+                                       s->k1d[0], s->k1d[1], s->k1d[2]);
+                else if (s->p.use_fma)
                     hipLaunchKernelGGL((collapse_simple<true>), grid2d(s->lw[0], s->lh[0], blk), blk, 0, s->stream,
                                        s->collapse_src, s->lh[1], s->lw[1], s->bestLap[0], s->lh[0], s->lw[0], s->colA, s->K);
                 else

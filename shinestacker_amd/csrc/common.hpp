@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string>
 
 #include "../../include/mi355stack.h"
@@ -96,5 +97,18 @@ __device__ __forceinline__ uint32_t lowbias32(uint32_t x) {
 }
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// Timing-study knobs (phase ablation, tile / batch variants) exist only in -DMI_STUDY builds (tools/study_build.sh
+// -> libmi355stack_study.so); the release library reads no environment variable on its compute paths.
+#ifdef MI_STUDY
+inline int study_env(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+#define MI_ABL(bits) ((a.ablate & (bits)) != 0)
+#else
+inline int study_env(const char*, int dflt) { return dflt; }
+#define MI_ABL(bits) (false)
+#endif
 
 }  // namespace mi

@@ -1,0 +1,563 @@
+// kernels_sep.hpp -- MI_ARITH_SEPARABLE: the LDS-staged 5-tap separable / polyphase Burt-Adelson form of the
+// fused level kernel (gfx950).  Same job as kernels_tiled.hpp's level_fused (one launch = one pyramid level of
+// a batch of frames, running first-max state in registers for the whole batch), different arithmetic: every 5x5
+// stencil of the reference (algorithms/pyramid.py:24-46, cv2.filter2D with the outer-product kernel) is evaluated
+// as two 1-D passes with the float32 generating kernel [k0 k1 k2 k1 k0] in its symmetric form
+//
+//     s5(a, b, c, d, e) = fma(k0, a + e, fma(k1, b + d, k2 * c))
+//
+//   reduce   V = s5 down the rows at even rows, G_{l+1} = s5 along the rows at even columns   (pyramid.py:27-32)
+//   expand   X = along the rows:  even column  fma(2k0, N[j-1] + N[j+1], 2k2 * N[j]),  odd  2k1 * (N[j] + N[j+1])
+//            then the same down the rows (the zero-stuffed grid's zero taps skipped)           (pyramid.py:34-46)
+//   lap      G_l - expand(G_{l+1}),  Q = gray(lap)^2                                           (pyramid.py:133-138, :49)
+//   energy   HB = s5 along the rows of Q, E = s5 down the rows of HB                           (pyramid.py:50)
+//
+// This is NOT bit-identical to the exact-order mode (kernels_tiled.hpp, the drop-in default): coefficients agree
+// with a float64 evaluation within the forward-error bound of a 25-term float32 dot product, and the per-pixel
+// arg-max can flip at near ties.  oracle/pyramid_oracle.c restates this arithmetic operation by operation
+// (bit-exact parity target of this file); tests/test_sep_tolerance.py holds the tolerance against float64.
+//
+// Workgroup = 512 threads, tile 28 x 56 pixels of level l; per frame, four barrier phases:
+//   P0 stage   G_l patch (tile + 6 halo = 40 x 68 px) registers -> LDS (prefetched one frame ahead)
+//   P1 v-red   V (18 x 68 px): lane = one float4 column group, 7 ds_read_b128 -> 2 rows, packed fp32
+//   P2 h-red   G_{l+1} patch (18 x 32): lane = one pixel, 32 lanes per row; the tile centre goes to global
+//              memory from registers; the row neighbours come in by DPP wave shifts and the lane writes
+//              the horizontally expanded X (18 rows x 64 columns) -- G_{l+1} itself never sits in LDS
+//   P3 lapq    lane = one 2x2 quad of the 32 x 64 (tile + 2 halo, + 2 dummy columns) region: vertical expand from
+//              3 X rows, Laplacian against the staged G_l, Q; the row blur of Q by DPP wave shifts -> HB in LDS
+//   P4 select  lane's own quad: column blur of HB (6 ds_read_b64, packed), strict '>' against the running max
+// The lane of P3 and P4 is the same, so a quad's Laplacian stays in registers.
+#pragma once
+#include "common.hpp"
+#include "kernels_tiled.hpp"
+
+namespace mi {
+
+template <int TH_, int NT_>
+struct SepGeom {
+    static constexpr int TH = TH_, TW = 56, NT = NT_;
+    static constexpr int GH = TH + 12, GW = TW + 12;          // G_l patch, pixels
+    static constexpr int GD = GW * 3, GS = GD;                // dense rows: chunk id * 4 is the LDS offset
+    static constexpr int NCH = GH * (GD / 4);                 // 16-byte chunks of the patch
+    static constexpr int NPRE = (NCH + NT - 1) / NT;          // chunks (loads) per thread
+    static constexpr int NH = TH / 2 + 4, NW = TW / 2 + 4;    // G_{l+1} patch: 18 x 32
+    static constexpr int VS = GD;
+    static constexpr int XW = 2 * NW, XS = XW * 3;            // expanded columns x0-4 .. x0+TW+4
+    static constexpr int QY = TH / 2 + 2, QL = NW;            // quad rows x lanes per quad row
+    static constexpr int HBH = TH + 4, HBS = XW;              // HB rows y0-2 .. y0+TH+1, columns as X
+    static constexpr int LDS_FLOATS = GH * GS + NH * VS + NH * XS;
+    static_assert(GD % 4 == 0 && NW == 32, "tile width is fixed by the 32-lane quad rows");
+    static_assert(QY * QL == NT, "one quad per lane");
+    static_assert(HBH * HBS <= NH * VS, "HB aliases V");
+    static_assert((NH / 2) * (GD / 4) <= NT && NH % 2 == 0 && NT % 64 == 0, "phase items");
+};
+
+__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v2f s5(v2f a, v2f b, v2f c, v2f d, v2f e, float k0, float k1, float k2) {
+    const v2f t0 = a + e, t1 = b + d;
+    v2f m = c * k2;
+    m = pk_fma((v2f)k1, t1, m);
+    return pk_fma((v2f)k0, t0, m);
+}
+__device__ __forceinline__ float s5(float a, float b, float c, float d, float e, float k0, float k1, float k2) {
+    const float t0 = a + e, t1 = b + d;
+    return __builtin_fmaf(k0, t0, __builtin_fmaf(k1, t1, k2 * c));
+}
+// expand, one dimension: even position from (left, centre, right), odd position from (centre, right)
+__device__ __forceinline__ float ex_even(float l, float c, float r, float ce, float cc) {
+    return __builtin_fmaf(ce, l + r, cc * c);
+}
+__device__ __forceinline__ float ex_odd(float c, float r, float co) { return co * (c + r); }
+__device__ __forceinline__ v2f ex_even(v2f l, v2f c, v2f r, float ce, float cc) { return pk_fma((v2f)ce, l + r, c * cc); }
+__device__ __forceinline__ v2f ex_odd(v2f c, v2f r, float co) { return (c + r) * co; }
+
+// 8-byte LDS load that stays a ds_read_b64 (2 LDS cycles per wave): the machine load/store optimiser otherwise pairs
+// neighbouring ones into ds_read2_b64, which moves the same 16 bytes per lane in 8 cycles
+__device__ __forceinline__ v2f lds_load2s(const float* p) {
+    typedef const volatile v2f __attribute__((address_space(3))) * lds_ptr;   // volatile accesses are never paired
+    return *(lds_ptr)(uint32_t)(uintptr_t)p;                                 // generic LDS address: low 32 bits = offset
+}
+
+// value of lane-1 / lane+1 across the wave; lanes without a source get 0
+__device__ __forceinline__ float dpp_wave_prev(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float dpp_wave_next(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
+}
+
+// 4 consecutive input elements as floats; raw form kept in registers across the frame loop for 8/16-bit input
+template <typename TIn> struct PreChunk;
+template <> struct PreChunk<float> {
+    v4f v;
+    __device__ __forceinline__ void load(const char* p) { __builtin_memcpy(&v, p, 16); }
+    __device__ __forceinline__ void set(float a, float b, float c, float d) { v = v4f{a, b, c, d}; }
+    __device__ __forceinline__ v4f get() const { return v; }
+};
+template <> struct PreChunk<uint8_t> {
+    uint32_t v;
+    __device__ __forceinline__ void load(const char* p) { __builtin_memcpy(&v, p, 4); }
+    __device__ __forceinline__ void set(float a, float b, float c, float d) {
+        v = (uint32_t)a | ((uint32_t)b << 8) | ((uint32_t)c << 16) | ((uint32_t)d << 24);
+    }
+    __device__ __forceinline__ v4f get() const {
+        return v4f{(float)(v & 0xffu), (float)((v >> 8) & 0xffu), (float)((v >> 16) & 0xffu), (float)(v >> 24)};
+    }
+};
+template <> struct PreChunk<uint16_t> {
+    uint32_t v0, v1;
+    __device__ __forceinline__ void load(const char* p) {
+        uint64_t t;
+        __builtin_memcpy(&t, p, 8);
+        v0 = (uint32_t)t;
+        v1 = (uint32_t)(t >> 32);
+    }
+    __device__ __forceinline__ void set(float a, float b, float c, float d) {
+        v0 = (uint32_t)a | ((uint32_t)b << 16);
+        v1 = (uint32_t)c | ((uint32_t)d << 16);
+    }
+    __device__ __forceinline__ v4f get() const {
+        return v4f{(float)(v0 & 0xffffu), (float)(v0 >> 16), (float)(v1 & 0xffffu), (float)(v1 >> 16)};
+    }
+};
+
+template <typename TIn, bool INTERIOR, int TH, int NT>
+__device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
+    using G = SepGeom<TH, NT>;
+    constexpr int TW = G::TW;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sG = smem;
+    float* sV = sG + G::GH * G::GS;
+    float* sX = sV + G::NH * G::VS;
+    float* sHB = sV;   // V is dead once P2 has read it
+    const int tid = threadIdx.x;
+    const int h = a.h, w = a.w, hn = a.hn, wn = a.wn;
+
+    // ---- which tile?  (interior: 8x8-tile super-blocks, one per XCD at a time -- see kernels_tiled.hpp)
+    int y0, x0;
+    if constexpr (INTERIOR) {
+        const int nty = (a.iy1 - a.iy0) / TH, ntx = (a.ix1 - a.ix0) / TW;
+        const int sb_x = (ntx + SB - 1) / SB;
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int S = (slot >> 6) * 8 + xcd, within = slot & 63;
+        const int sby = S / sb_x, sbx = S - sby * sb_x;
+        const int tyi = sby * SB + (within >> 3), txi = sbx * SB + (within & 7);
+        if (tyi >= nty || txi >= ntx) return;
+        y0 = a.iy0 + tyi * TH;
+        x0 = a.ix0 + txi * TW;
+    } else {
+        // every tile of the TH x TW grid that is not inside the interior rectangle: rows above and below it,
+        // then the side columns of the rows it spans
+        const int tiles_x = (w + TW - 1) / TW, tiles_y = (h + TH - 1) / TH;
+        const int ty_lo = a.iy0 / TH, ty_hi = a.iy1 / TH, tx_lo = a.ix0 / TW, tx_hi = a.ix1 / TW;
+        const int nyi = ty_hi - ty_lo, nxi = tx_hi - tx_lo;
+        int t = blockIdx.x, tyi, txi;
+        const int top = ty_lo * tiles_x, bot = (tiles_y - ty_hi) * tiles_x;
+        if (nyi <= 0 || nxi <= 0 || t < top) {
+            tyi = t / tiles_x;
+            txi = t - tyi * tiles_x;
+        } else if (t < top + bot) {
+            t -= top;
+            tyi = ty_hi + t / tiles_x;
+            txi = t - (t / tiles_x) * tiles_x;
+        } else {
+            t -= top + bot;
+            const int side = tiles_x - nxi;
+            tyi = ty_lo + t / side;
+            const int k = t - (t / side) * side;
+            txi = k < tx_lo ? k : tx_hi + (k - tx_lo);
+        }
+        if (tyi >= tiles_y || txi >= tiles_x) return;
+        y0 = tyi * TH;
+        x0 = txi * TW;
+    }
+
+    const float k0 = a.k1d[0], k1 = a.k1d[1], k2 = a.k1d[2];
+    const float ce = 2.0f * k0, cc = 2.0f * k2, co = 2.0f * k1;   // expand taps (the reference's 4 * K, per dimension)
+
+    // ---- the lane's quad: rows y0-2+2qy+{0,1}, columns x0-4+2ql+{0,1}; owned = inside the tile
+    const int qy = tid >> 5, ql = tid & 31;
+    const bool own_tile = qy >= 1 && qy < G::QY - 1 && ql >= 2 && ql < G::QL - 2;
+    const int oy = y0 - 2 + 2 * qy, ox = x0 - 4 + 2 * ql;
+    float bE[4], bL[4][3];
+    int bI[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int y = oy + (p >> 1), x = ox + (p & 1);
+        const bool valid = own_tile && (INTERIOR || (y < h && x < w));
+        if (!a.first && valid) {
+            const size_t px = (size_t)y * w + x;
+            bE[p] = a.best_e[px];
+            bI[p] = a.best_idx[px];
+            bL[p][0] = a.best_lap[px * 3 + 0];
+            bL[p][1] = a.best_lap[px * 3 + 1];
+            bL[p][2] = a.best_lap[px * 3 + 2];
+        } else {
+            bE[p] = -1.0f;   // every energy is >= 0: the first frame always wins
+            bI[p] = -1;
+            bL[p][0] = bL[p][1] = bL[p][2] = 0.f;
+        }
+    }
+
+    // ---- staging: chunk id = tid + n * NT covers patch row id / 51, floats 4 * (id % 51) .. +3
+    constexpr int CPR = G::GD / 4;   // chunks per patch row
+    PreChunk<TIn> pre[G::NPRE];
+    uint32_t goff[G::NPRE];          // interior: byte offset of the chunk inside a frame
+#pragma unroll
+    for (int n = 0; n < G::NPRE; ++n) {
+        const int id = tid + n * NT, row = id / CPR, col = id - row * CPR;
+        goff[n] = (uint32_t)(((y0 - 6 + row) * w + (x0 - 6)) * 3 + 4 * col) * (uint32_t)sizeof(TIn);
+    }
+    auto prefetch = [&](int b) {
+        const char* frb = (const char*)a.src + (size_t)b * a.src_stride;
+#pragma unroll
+        for (int n = 0; n < G::NPRE; ++n) {
+            const int id = tid + n * NT;
+            if ((n + 1) * NT > G::NCH && id >= G::NCH) continue;
+            if constexpr (INTERIOR) {
+                pre[n].load(frb + goff[n]);
+            } else {
+                const TIn* fr = (const TIn*)frb;
+                const int row = id / CPR, col = id - row * CPR;
+                const int gy = map_clamp(y0 - 6 + row, h);
+                const int c_lo = (4 * col) / 3, c_hi = (4 * col + 3) / 3;
+                if (x0 - 6 + c_lo >= 0 && x0 - 6 + c_hi < w) {
+                    pre[n].load((const char*)(fr + ((size_t)gy * w + (x0 - 6)) * 3 + 4 * col));
+                } else {
+                    float e[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int f = 4 * col + k, pc = f / 3, c = f - pc * 3;
+                        e[k] = to_f32(fr[((size_t)gy * w + map_clamp(x0 - 6 + pc, w)) * 3 + c]);
+                    }
+                    pre[n].set(e[0], e[1], e[2], e[3]);
+                }
+            }
+        }
+    };
+    prefetch(0);
+
+    for (int b = 0; b < a.nframes; ++b) {
+        int lt = tid;
+        asm volatile("" : "+v"(lt));   // per-frame addresses are rebuilt from this, not hoisted out of the loop
+        // ---------------- P0: stage
+#pragma unroll
+        for (int n = 0; n < G::NPRE; ++n) {
+            if ((n + 1) * NT > G::NCH && lt + n * NT >= G::NCH) continue;
+            *reinterpret_cast<v4f*>(sG + 4 * (lt + n * NT)) = pre[n].get();
+        }
+        __syncthreads();
+        if (b + 1 < a.nframes && !MI_ABL(16)) prefetch(b + 1);
+
+        // ---------------- P1: vertical reduce, 2 V rows x one float4 column group per lane
+        if (lt < (G::NH / 2) * CPR && !MI_ABL(1)) {
+            const int rp = lt / CPR, g = lt - rp * CPR;
+            v4f o0, o1;
+            if constexpr (INTERIOR) {
+                const float* p = sG + mul24(4 * rp, G::GS) + 4 * g;
+                v4f r[7];
+#pragma unroll
+                for (int t = 0; t < 7; ++t) r[t] = lds_load4(p + t * G::GS);
+                const v2f a0 = s5(r[0].xy, r[1].xy, r[2].xy, r[3].xy, r[4].xy, k0, k1, k2);
+                const v2f a1 = s5(r[0].zw, r[1].zw, r[2].zw, r[3].zw, r[4].zw, k0, k1, k2);
+                const v2f b0 = s5(r[2].xy, r[3].xy, r[4].xy, r[5].xy, r[6].xy, k0, k1, k2);
+                const v2f b1 = s5(r[2].zw, r[3].zw, r[4].zw, r[5].zw, r[6].zw, k0, k1, k2);
+                o0 = v4f{a0.x, a0.y, a1.x, a1.y};
+                o1 = v4f{b0.x, b0.y, b1.x, b1.y};
+            } else {
+                // a cell outside G_{l+1} is computed at its mirror position (REFLECT101 acts on the zero-stuffed
+                // grid: V[-1] = G[1], V[n] = G[n-1]); the staged patch already holds reflected rows
+                v4f o[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int im = map_expand_src(y0 / 2 - 2 + 2 * rp + u, hn);
+                    const int r0 = 2 * im - 2 - (y0 - 6);
+                    v4f r[5];
+#pragma unroll
+                    for (int t = 0; t < 5; ++t) r[t] = lds_load4(sG + mul24(clampi(r0 + t, 0, G::GH - 1), G::GS) + 4 * g);
+                    const v2f a0 = s5(r[0].xy, r[1].xy, r[2].xy, r[3].xy, r[4].xy, k0, k1, k2);
+                    const v2f a1 = s5(r[0].zw, r[1].zw, r[2].zw, r[3].zw, r[4].zw, k0, k1, k2);
+                    o[u] = v4f{a0.x, a0.y, a1.x, a1.y};
+                }
+                o0 = o[0];
+                o1 = o[1];
+            }
+            float* d = sV + mul24(2 * rp, G::VS) + 4 * g;
+            *reinterpret_cast<v4f*>(d) = o0;
+            *reinterpret_cast<v4f*>(d + G::VS) = o1;
+        }
+        __syncthreads();
+
+        // ---------------- P2: horizontal reduce (one G_{l+1} pixel per lane, 32 lanes per patch row), G_{l+1} store,
+        // horizontal expand -> X.  18 rows x 32 = 576 items: the last two rows are a second round on wave 0.
+#pragma unroll
+        for (int rnd = 0; rnd < (G::NH * 32 + NT - 1) / NT; ++rnd) {
+            const int it = lt + rnd * NT;
+            if (it >= G::NH * 32 || MI_ABL(2)) break;   // uniform per wave: NT and the item count are multiples of 64
+            const int r = it >> 5, jp = it & 31;
+            float n[3];
+            if constexpr (INTERIOR) {
+                const float* p = sV + mul24(r, G::VS) + 6 * jp;   // patch pixels 2j' .. 2j'+4: 15 floats, 8-byte aligned
+                float v[16];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const v2f q = lds_load2s(p + 2 * t);
+                    v[2 * t] = q.x; v[2 * t + 1] = q.y;
+                }
+#pragma unroll
+                for (int c = 0; c < 3; ++c) n[c] = s5(v[c], v[3 + c], v[6 + c], v[9 + c], v[12 + c], k0, k1, k2);
+            } else {
+                const int jm = map_expand_src(x0 / 2 - 2 + jp, wn);
+                const int c0 = 2 * jm - 2 - (x0 - 6);
+                const float* vr = sV + mul24(r, G::VS);
+                float t5[5][3];
+#pragma unroll
+                for (int t = 0; t < 5; ++t) {
+                    const float* q = vr + 3 * clampi(c0 + t, 0, G::GW - 1);
+                    t5[t][0] = q[0]; t5[t][1] = q[1]; t5[t][2] = q[2];
+                }
+#pragma unroll
+                for (int c = 0; c < 3; ++c) n[c] = s5(t5[0][c], t5[1][c], t5[2][c], t5[3][c], t5[4][c], k0, k1, k2);
+            }
+            // tile centre of G_{l+1} -> global (input of the next level)
+            {
+                const int i = y0 / 2 - 2 + r, j = x0 / 2 - 2 + jp;
+                bool st = r >= 2 && r < G::NH - 2 && jp >= 2 && jp < G::NW - 2 && !MI_ABL(32);
+                if constexpr (!INTERIOR) st = st && i < hn && j < wn;
+                if (st) {
+                    float* gp = a.gnext + (size_t)b * a.gnext_stride + ((size_t)i * wn + j) * 3;
+                    gp[0] = n[0]; gp[1] = n[1]; gp[2] = n[2];
+                }
+            }
+            // expanded columns 2j', 2j'+1 of row r: the even one from (left, centre, right), the odd one from (centre, right)
+            float xe[3], xo[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float lft = dpp_wave_prev(n[c]), rgt = dpp_wave_next(n[c]);
+                xe[c] = ex_even(lft, n[c], rgt, ce, cc);
+                xo[c] = ex_odd(n[c], rgt, co);
+            }
+            float* xp = sX + mul24(r, G::XS) + 6 * jp;
+            lds_store2(xp, xe[0], xe[1]);
+            lds_store2(xp + 2, xe[2], xo[0]);
+            lds_store2(xp + 4, xo[1], xo[2]);
+        }
+        __syncthreads();
+
+        // ---------------- P3: vertical expand, Laplacian, Q, row blur of Q -> HB
+        float lap[4][3];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) lap[p][0] = lap[p][1] = lap[p][2] = 0.f;
+        if (!MI_ABL(4)) {
+            const int qy3 = lt >> 5, ql3 = lt & 31;
+            if constexpr (INTERIOR) {
+                const float* xr = sX + mul24(qy3, G::XS) + 6 * ql3;           // X rows qy, qy+1, qy+2
+                v2f xa[3], xb[3], xc[3];
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    xa[t] = lds_load2s(xr + 2 * t);
+                    xb[t] = lds_load2s(xr + G::XS + 2 * t);
+                    xc[t] = lds_load2s(xr + 2 * G::XS + 2 * t);
+                }
+                const float* gr = sG + mul24(2 * qy3 + 4, G::GS) + 6 * ql3 + 6;   // patch rows 2qy+4, +5; columns 2ql+2, +3
+                v2f ge[3], go[3];
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    ge[t] = lds_load2s(gr + 2 * t);
+                    go[t] = lds_load2s(gr + G::GS + 2 * t);
+                }
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    const v2f ev = ex_even(xa[t], xb[t], xc[t], ce, cc), od = ex_odd(xb[t], xc[t], co);
+                    const v2f le = ge[t] - ev, lo = go[t] - od;
+                    // floats 2t, 2t+1 of the 6 = (pixel (2t)/3, channel (2t)%3), ...
+                    lap[(2 * t) / 3][(2 * t) % 3] = le.x;
+                    lap[(2 * t + 1) / 3][(2 * t + 1) % 3] = le.y;
+                    lap[2 + (2 * t) / 3][(2 * t) % 3] = lo.x;
+                    lap[2 + (2 * t + 1) / 3][(2 * t + 1) % 3] = lo.y;
+                }
+            } else {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    // the pixel at its mirror position (REFLECT101 of Q); parity is preserved by the mirror
+                    const int ym = map_clamp(y0 - 2 + 2 * qy3 + (p >> 1), h), xm = map_clamp(x0 - 4 + 2 * ql3 + (p & 1), w);
+                    const int ri = clampi((ym >> 1) - (y0 / 2 - 2), 1, G::NH - 2);   // X row of G_{l+1} row ym / 2
+                    const int ec = clampi(xm - (x0 - 4), 0, G::XW - 1);             // X column
+                    const float* xq = sX + mul24(ri, G::XS) + 3 * ec;
+                    const float* gq = sG + mul24(clampi(ym - (y0 - 6), 0, G::GH - 1), G::GS) + 3 * clampi(xm - (x0 - 6), 0, G::GW - 1);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const float e = (p >> 1) == 0 ? ex_even(xq[c - G::XS], xq[c], xq[c + G::XS], ce, cc)
+                                                      : ex_odd(xq[c], xq[c + G::XS], co);
+                        lap[p][c] = gq[c] - e;
+                    }
+                }
+            }
+            float q[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const float gr = gray_of<true>(lap[p][0], lap[p][1], lap[p][2]);
+                q[p] = gr * gr;
+            }
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                const float q0 = q[2 * rr], q1 = q[2 * rr + 1];
+                const float l0 = dpp_wave_prev(q0), l1 = dpp_wave_prev(q1);
+                const float r0 = dpp_wave_next(q0), r1 = dpp_wave_next(q1);
+                const float hb0 = s5(l0, l1, q0, q1, r0, k0, k1, k2);
+                const float hb1 = s5(l1, q0, q1, r0, r1, k0, k1, k2);
+                lds_store2(sHB + mul24(2 * qy3 + rr, G::HBS) + 2 * ql3, hb0, hb1);
+            }
+        }
+        __syncthreads();
+
+        // ---------------- P4: column blur of HB for the own quad + running first-max
+        if (own_tile && !MI_ABL(8)) {
+            const int qy4 = lt >> 5, ql4 = lt & 31;
+            const float* hp = sHB + mul24(2 * qy4 - 2, G::HBS) + 2 * ql4;
+            v2f hb[6];
+#pragma unroll
+            for (int t = 0; t < 6; ++t) hb[t] = lds_load2s(hp + t * G::HBS);
+            const v2f e0 = s5(hb[0], hb[1], hb[2], hb[3], hb[4], k0, k1, k2);
+            const v2f e1 = s5(hb[1], hb[2], hb[3], hb[4], hb[5], k0, k1, k2);
+            const float e[4] = {e0.x, e0.y, e1.x, e1.y};
+            const int fidx = a.frame_idx0 + b;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const bool win = e[p] > bE[p];
+                bE[p] = win ? e[p] : bE[p];
+                bI[p] = win ? fidx : bI[p];
+                bL[p][0] = win ? lap[p][0] : bL[p][0];
+                bL[p][1] = win ? lap[p][1] : bL[p][1];
+                bL[p][2] = win ? lap[p][2] : bL[p][2];
+            }
+        }
+        // no barrier here: sG is rewritten after P3's reads (barrier above), V/HB after the next frame's first
+        // barrier, X after its second
+    }
+
+    // ---- write the running state back (winner's lap with -0 -> +0, as the reference's np.where sum gives)
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int y = oy + (p >> 1), x = ox + (p & 1);
+        if (own_tile && (INTERIOR || (y < h && x < w))) {
+            const size_t px = (size_t)y * w + x;
+            a.best_e[px] = bE[p];
+            a.best_idx[px] = bI[p];
+            a.best_lap[px * 3 + 0] = bL[p][0] + 0.0f;
+            a.best_lap[px * 3 + 1] = bL[p][1] + 0.0f;
+            a.best_lap[px * 3 + 2] = bL[p][2] + 0.0f;
+        }
+    }
+}
+
+// The kernels proper; the coarser levels get their own name so that profiles (rocprofv3 --stats aggregates by
+// kernel name) keep the level-0 launches apart.
+template <typename TIn, bool INTERIOR, int TH, int NT>
+__global__ __launch_bounds__(NT) void level_sep(LevelArgs a) {
+    level_sep_body<TIn, INTERIOR, TH, NT>(a);
+}
+template <typename TIn, bool INTERIOR, int TH, int NT>
+__global__ __launch_bounds__(NT) void level_sep_coarse(LevelArgs a) {
+    level_sep_body<TIn, INTERIOR, TH, NT>(a);
+}
+
+// ================================================================================================
+// One-thread-per-output kernels of the same arithmetic: the on-GPU cross-check (MI_IMPL_SIMPLE) and the
+// once-per-stack collapse.
+
+// V(i, x) of a source row pair: s5 down the rows 2i-2 .. 2i+2 (REFLECT101), one channel
+template <typename TIn>
+__device__ __forceinline__ float sep_v(const TIn* __restrict__ g, int h, int w, int i, int x, int c, float k0, float k1,
+                                       float k2) {
+    float v[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t) v[t] = to_f32(g[((size_t)r101(2 * i - 2 + t, h) * w + x) * 3 + c]);
+    return s5(v[0], v[1], v[2], v[3], v[4], k0, k1, k2);
+}
+
+template <typename TIn>
+__global__ void reduce_sep_simple(const TIn* __restrict__ g, int h, int w, float* __restrict__ out, int ho, int wo,
+                                  float k0, float k1, float k2) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y * blockDim.y + threadIdx.y;
+    if (i >= ho || j >= wo) return;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float v[5];
+#pragma unroll
+        for (int t = 0; t < 5; ++t) v[t] = sep_v(g, h, w, i, r101(2 * j - 2 + t, w), c, k0, k1, k2);
+        out[((size_t)i * wo + j) * 3 + c] = s5(v[0], v[1], v[2], v[3], v[4], k0, k1, k2);
+    }
+}
+
+// expand_layer(src)[y, x, c] for an hs x ws x 3 source, (y, x) inside the 2hs x 2ws grid
+__device__ __forceinline__ float expand_sep_at(const float* __restrict__ src, int hs, int ws, int y, int x, int c, float ce,
+                                               float cc, float co) {
+    const int i = y >> 1, j = x >> 1;
+    auto N = [&](int r, int q) { return src[((size_t)map_expand_src(r, hs) * ws + map_expand_src(q, ws)) * 3 + c]; };
+    auto X = [&](int r) { return (x & 1) ? ex_odd(N(r, j), N(r, j + 1), co) : ex_even(N(r, j - 1), N(r, j), N(r, j + 1), ce, cc); };
+    return (y & 1) ? ex_odd(X(i), X(i + 1), co) : ex_even(X(i - 1), X(i), X(i + 1), ce, cc);
+}
+
+template <typename TIn>
+__global__ void lapq_sep_simple(const TIn* __restrict__ g, int h, int w, const float* __restrict__ gn, int hs, int ws,
+                                float* __restrict__ lap, float* __restrict__ q, float k0, float k1, float k2) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (y >= h || x >= w) return;
+    const float ce = 2.0f * k0, cc = 2.0f * k2, co = 2.0f * k1;
+    const size_t p = (size_t)y * w + x;
+    float l[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        l[c] = to_f32(g[p * 3 + c]) - expand_sep_at(gn, hs, ws, y, x, c, ce, cc, co);
+        lap[p * 3 + c] = l[c];
+    }
+    const float gr = gray_of<true>(l[0], l[1], l[2]);
+    q[p] = gr * gr;
+}
+
+__global__ void select_sep_simple(const float* __restrict__ q, const float* __restrict__ lap, int h, int w, int frame_idx,
+                                  int first, float* __restrict__ best_e, float* __restrict__ best_lap,
+                                  int32_t* __restrict__ best_idx, float k0, float k1, float k2) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (y >= h || x >= w) return;
+    float hb[5];
+#pragma unroll
+    for (int ty = 0; ty < 5; ++ty) {
+        const float* row = q + (size_t)r101(y + ty - 2, h) * w;
+        hb[ty] = s5(row[r101(x - 2, w)], row[r101(x - 1, w)], row[x], row[r101(x + 1, w)], row[r101(x + 2, w)], k0, k1, k2);
+    }
+    const float s = s5(hb[0], hb[1], hb[2], hb[3], hb[4], k0, k1, k2);
+    const size_t p = (size_t)y * w + x;
+    if (first || s > best_e[p]) {
+        best_e[p] = s;
+        best_idx[p] = frame_idx;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float lv = lap[p * 3 + c];
+            best_lap[p * 3 + c] = (lv == 0.0f) ? 0.0f : lv;
+        }
+    }
+}
+
+// collapse step (pyramid.py:57-64): out = expand(up) + lap; TOut != float: the finest step, fused with
+// clip(abs()) and the truncating cast (pyramid.py:64, :179)
+template <typename TOut>
+__global__ void collapse_sep(const float* __restrict__ up, int hs, int ws, const float* __restrict__ lap, int h, int w,
+                             float maxv, TOut* __restrict__ out, float k0, float k1, float k2) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (y >= h || x >= w) return;
+    const float ce = 2.0f * k0, cc = 2.0f * k2, co = 2.0f * k1;
+    const size_t p = ((size_t)y * w + x) * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float v = expand_sep_at(up, hs, ws, y, x, c, ce, cc, co) + lap[p + c];
+        if constexpr (sizeof(TOut) != 4) {
+            v = fabsf(v);
+            v = v > maxv ? maxv : v;
+        }
+        out[p + c] = (TOut)v;
+    }
+}
+
+}  // namespace mi

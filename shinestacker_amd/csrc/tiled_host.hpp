@@ -177,19 +177,8 @@ int launch_level(mi_stack* s, int l, int set, const void* src, size_t src_stride
     a.hn = s->lh[l + 1];
     a.wn = s->lw[l + 1];
     // interior rectangle: whole 6-pixel-haloed patches inside the image, aligned to both tilings
-    // (streaming interior: 8 pixels away from every edge, aligned to the border tiling only)
-    bool stream = l < s->stream_levels;
-    if (stream) {   // enough waves to fill the chip?  (each wave walks the batch's frames in turn)
-        const int iw = (a.w - 8) / BW * BW - cdiv(8, BW) * BW, ih = (a.h - 8) / BH * BH - cdiv(8, BH) * BH;
-        stream = iw > 0 && ih > 0 && cdiv(iw, ST_UW) * cdiv(ih, s->stream_seg) >= s->stream_min_waves;
-    }
     constexpr int AY = ilcm(TH, BH), AX = ilcm(TW, BW);
-    if (stream) {
-        a.iy0 = cdiv(8, BH) * BH;
-        a.ix0 = cdiv(8, BW) * BW;
-        a.iy1 = (a.h - 8) / BH * BH;
-        a.ix1 = (a.w - 8) / BW * BW;
-    } else if (TH % BH == 0 && TW % BW == 0) {
+    if (TH % BH == 0 && TW % BW == 0) {
         // origin on the border tiling, whole interior tiles from there
         a.iy0 = cdiv(6, BH) * BH;
         a.ix0 = cdiv(6, BW) * BW;
@@ -210,10 +199,7 @@ int launch_level(mi_stack* s, int l, int set, const void* src, size_t src_stride
     a.frame_idx0 = s->first_index + s->n_pushed;
     for (int i = 0; i < 3; ++i)
         for (int j = i; j < 3; ++j) a.K.c[i == 0 ? j : (i == 1 ? 2 + j : 5)] = s->K.k[i * 5 + j];
-    {
-        const char* ab = getenv("MI_ABLATE");  // timing studies only; results are wrong when set
-        a.ablate = ab ? atoi(ab) : 0;
-    }
+    a.ablate = study_env("MI_ABLATE", 0);   // -DMI_STUDY builds only (results are wrong when set)
 #ifdef MI_PHASE_CLOCK
     static unsigned long long* dbg_dev = nullptr;
     if (l == 0) {
@@ -254,27 +240,70 @@ int launch_level(mi_stack* s, int l, int set, const void* src, size_t src_stride
         const int tbx = cdiv(a.w, BW), tby = cdiv(a.h, BH);
         const int nborder = tbx * tby - ((a.iy1 - a.iy0) / BH) * ((a.ix1 - a.ix0) / BW);
         ProfScope ps(s, MI_PROF_LEVEL, bytes * (1.0 - frac_in), st_bd);
-        if (nborder > 0 && !(a.ablate & 256)) hipLaunchKernelGGL(kbd, dim3(nborder), dim3(BNT), ldsB, st_bd, a);
+        if (nborder > 0 && !MI_ABL(256)) hipLaunchKernelGGL(kbd, dim3(nborder), dim3(BNT), ldsB, st_bd, a);
     }
-    if (a.ablate & 512) {
-    } else if (stream && a.iy1 > a.iy0) {
-        StreamGeom sg;
-        sg.seg = s->stream_seg;
-        sg.nstrips = cdiv(a.ix1 - a.ix0, ST_UW);
-        sg.nsegs = cdiv(a.iy1 - a.iy0, sg.seg);
-        // vector loads/stores need rows that start 16 bytes (f32) / 4 bytes (u8, u16) aligned
-        const size_t esz = l == 0 ? dtype_size(s->p.in_dtype) : 4;
-        const bool vec = (a.w % 4) == 0 && ((uintptr_t)src % 16) == 0 && (src_stride % 16) == 0 &&
-                         ((a.w * 3 * esz) % (esz == 4 ? 16 : 4)) == 0;
-        // prefetch depth in steps: 2 where the raw rows are small (8/16-bit), 1 for f32 (register budget)
-        constexpr int PF = sizeof(TIn) <= 2 ? 2 : 1;
-        ProfScope ps(s, l == 0 ? MI_PROF_LEVEL0 : MI_PROF_LEVEL, bytes * frac_in, st_in);
-        if (vec) hipLaunchKernelGGL((level_stream<TIn, FMA, true, PF>), dim3(sg.nstrips * sg.nsegs), dim3(64), 0, st_in, a, sg);
-        else hipLaunchKernelGGL((level_stream<TIn, FMA, false, PF>), dim3(sg.nstrips * sg.nsegs), dim3(64), 0, st_in, a, sg);
+    if MI_ABL(512) {
     } else if (nyi > 0) {
         const int nsb = cdiv(nxi, SB) * cdiv(nyi, SB);
         ProfScope ps(s, l == 0 ? MI_PROF_LEVEL0 : MI_PROF_LEVEL, bytes * frac_in, st_in);
         hipLaunchKernelGGL(kin, dim3(cdiv(nsb, 8) * 8 * SB * SB), dim3(NT), ldsA, st_in, a);
+    }
+    return MI_OK;
+}
+
+// MI_ARITH_SEPARABLE: interior and border tiles of level l on the separable kernel (kernels_sep.hpp); one tile
+// grid (28 x 56, origin at the image corner) for both, the interior rectangle = the whole tiles whose 6-pixel
+// halo stays inside the image.
+template <typename TIn, bool L0_NAME>
+int launch_level_sep(mi_stack* s, int l, int set, const void* src, size_t src_stride, int nb, hipStream_t st_in,
+                     hipStream_t st_bd) {
+    constexpr int TH = 28, NT = 512;
+    using SG = SepGeom<TH, NT>;
+    constexpr int TW = SG::TW;
+    TiledState* t = tstate(s);
+    LevelArgs a{};
+    a.src = src;
+    a.src_stride = src_stride;
+    a.gnext = t->Gb[set][l + 1];
+    a.gnext_stride = t->gstride[l + 1];
+    a.nframes = nb;
+    a.h = s->lh[l];
+    a.w = s->lw[l];
+    a.hn = s->lh[l + 1];
+    a.wn = s->lw[l + 1];
+    a.iy0 = cdiv(6, TH) * TH;
+    a.ix0 = cdiv(6, TW) * TW;
+    a.iy1 = (a.h - 6) / TH * TH;
+    a.ix1 = (a.w - 6) / TW * TW;
+    if (a.iy1 <= a.iy0 || a.ix1 <= a.ix0) a.iy0 = a.iy1 = a.ix0 = a.ix1 = 0;
+    const int nyi = (a.iy1 - a.iy0) / TH, nxi = (a.ix1 - a.ix0) / TW;
+    a.best_e = s->bestE[l];
+    a.best_lap = s->bestLap[l];
+    a.best_idx = s->bestIdx[l];
+    a.first = s->n_pushed == 0;
+    a.frame_idx0 = s->first_index + s->n_pushed;
+    for (int i = 0; i < 3; ++i) a.k1d[i] = s->k1d[i];
+    a.ablate = study_env("MI_ABLATE", 0);   // -DMI_STUDY builds only (results are wrong when set)
+    const size_t lds = (size_t)SG::LDS_FLOATS * sizeof(float);
+    auto kin = L0_NAME ? level_sep<TIn, true, TH, NT> : level_sep_coarse<TIn, true, TH, NT>;
+    auto kbd = level_sep<TIn, false, TH, NT>;
+    static thread_local bool attr_set = false;
+    if (!attr_set) {
+        int rc;
+        if ((rc = set_lds_once(kin, lds)) || (rc = set_lds_once(kbd, lds))) return rc;
+        attr_set = true;
+    }
+    const double bytes = ((double)(l == 0 ? dtype_size(s->p.in_dtype) : 4) * 3.0 * a.h * a.w + 24.0 * a.hn * a.wn) * nb;
+    const double frac_in = (double)(a.iy1 - a.iy0) * (a.ix1 - a.ix0) / ((double)a.h * a.w);
+    {
+        const int nborder = cdiv(a.w, TW) * cdiv(a.h, TH) - nyi * nxi;
+        ProfScope ps(s, MI_PROF_LEVEL, bytes * (1.0 - frac_in), st_bd);
+        if (nborder > 0 && !MI_ABL(256)) hipLaunchKernelGGL(kbd, dim3(nborder), dim3(NT), lds, st_bd, a);
+    }
+    if (nyi > 0) {
+        const int nsb = cdiv(nxi, SB) * cdiv(nyi, SB);
+        ProfScope ps(s, l == 0 ? MI_PROF_LEVEL0 : MI_PROF_LEVEL, bytes * frac_in, st_in);
+        hipLaunchKernelGGL(kin, dim3(cdiv(nsb, 8) * 8 * SB * SB), dim3(NT), lds, st_in, a);
     }
     return MI_OK;
 }
@@ -293,9 +322,11 @@ int run_batch(mi_stack* s, const void* frames, size_t stride, int nb) {
     // before the level-0 interior kernel by the stream itself; the border kernel runs on st1 and needs the event
     MI_HIP(hipEventRecord(t->evInput, st0));
     MI_HIP(hipStreamWaitEvent(st1, t->evInput, 0));
-    if ((rc = launch_level<TIn, FMA, MI_TILE0_H, MI_TILE0_W, MI_TILE0_NT, MI_TILE_PAD != 0, MI_TILE_H, MI_TILE_W, MI_TILE_NT>(
-             s, 0, set, frames, stride, nb, st0, st1)))
-        return rc;
+    if (s->sep) rc = launch_level_sep<TIn, true>(s, 0, set, frames, stride, nb, st0, st1);
+    else
+        rc = launch_level<TIn, FMA, MI_TILE0_H, MI_TILE0_W, MI_TILE0_NT, MI_TILE_PAD != 0, MI_TILE_H, MI_TILE_W, MI_TILE_NT>(
+            s, 0, set, frames, stride, nb, st0, st1);
+    if (rc) return rc;
     MI_HIP(hipEventRecord(t->evL0i[set], st0));
     MI_HIP(hipEventRecord(t->evL0b[set], st1));
     MI_HIP(hipStreamWaitEvent(st2, t->evL0i[set], 0));
@@ -303,12 +334,15 @@ int run_batch(mi_stack* s, const void* frames, size_t stride, int nb) {
     MI_HIP(hipStreamWaitEvent(st1, t->evL0i[set], 0));
     // coarser levels: interior tiles on st2, border tiles on st1 (disjoint tiles of one level run
     // side by side); both streams join after every level because level l+1 reads all of G_{l+1}
-    for (int l = 1; l < L; ++l) {
+    static const int only_l0 = study_env("MI_ONLY_L0", 0);   // -DMI_STUDY: level 0 alone on the GPU (results are wrong)
+    for (int l = 1; l < L && !only_l0; ++l) {
         // coarser levels that still have thousands of tiles (4 MP and more: level 1 of a 24 MP frame) run on
         // level 0's tile configuration -- less halo per tile: +2 % on the 256 x 24 MP job; MI_WIDE_LEVELS overrides
-        static const int wide_levels = getenv("MI_WIDE_LEVELS") ? atoi(getenv("MI_WIDE_LEVELS")) : -1;
+        static const int wide_levels = study_env("MI_WIDE_LEVELS", -1);
         const bool wide = wide_levels >= 0 ? l <= wide_levels : (size_t)s->lh[l] * s->lw[l] >= ((size_t)4 << 20);
-        if (wide)
+        if (s->sep)
+            rc = launch_level_sep<float, false>(s, l, set, t->Gb[set][l], t->gstride[l] * sizeof(float), nb, st2, st1);
+        else if (wide)
             rc = launch_level<float, FMA, MI_TILE0_H, MI_TILE0_W, MI_TILE0_NT, MI_TILE_PAD != 0, MI_TILE_H, MI_TILE_W, MI_TILE_NT, true>(
                 s, l, set, t->Gb[set][l], t->gstride[l] * sizeof(float), nb, st2, st1);
         else
@@ -323,7 +357,7 @@ int run_batch(mi_stack* s, const void* frames, size_t stride, int nb) {
         MI_HIP(hipStreamWaitEvent(st1, ei, 0));
     }
     MI_HIP(hipGetLastError());
-    {   // base level of the whole batch
+    if (!only_l0) {   // base level of the whole batch
         ProfScope ps(s, MI_PROF_BASE, 0.0, st2);
         const int hb = s->lh[L], wb = s->lw[L], npix = hb * wb;
         MI_HIP(hipMemsetAsync(t->cnt[set], 0, sizeof(uint32_t) * s->nlevels_hist * nb, st2));
@@ -373,7 +407,7 @@ int tiled_push(mi_stack* s, const void* dev_frames, int n, size_t stride) {
         // levels, which is latency-bound and scales with the batch length.
         const int left = n - f0;
         int nb = left > t->bcap ? t->bcap : left;
-        static const int taper = getenv("MI_TAPER") ? atoi(getenv("MI_TAPER")) : 1;   // 0 / 2: timing studies
+        static const int taper = study_env("MI_TAPER", 1);   // 0 / 2: timing studies (-DMI_STUDY)
         if (taper == 1 && left <= t->bcap && left >= 16 && n > t->bcap) nb = (left / 2 + 3) & ~3;
         if (taper == 2 && left == t->bcap && n > t->bcap) nb = t->bcap / 2;
         const void* fr = (const char*)dev_frames + (size_t)f0 * stride;

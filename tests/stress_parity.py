@@ -34,7 +34,7 @@ def main():
         for f in frames:
             so.push_frame(f)
         want = so.finish()
-        for impl in (L.IMPL_TILED, L.IMPL_STREAM):
+        for impl in (L.IMPL_TILED,):
             st = L.Stack(h, w, in_dtype=dt, impl=impl, batch_frames=batch, **kw)
             for f in frames:
                 st.push_frame(f)

@@ -118,7 +118,7 @@ def test_device_frames_with_odd_alignment_and_stride(L, oracle, h, w, off, pad, 
     buf = L.DeviceBuffer(off + stride * len(frames) + 64)
     for i, f in enumerate(frames):
         buf.upload(f.astype(src_dt), off + i * stride)
-    for impl in (L.IMPL_TILED, L.IMPL_STREAM, L.IMPL_SIMPLE):
+    for impl in (L.IMPL_TILED, L.IMPL_SIMPLE):
         st = L.Stack(h, w, in_dtype=src_dt, out_dtype=dt, impl=impl, batch_frames=3)
         st.push_frames_device(buf.ptr + off, len(frames), stride)
         assert np.array_equal(st.finish(), want), (impl, off, pad)
