@@ -33,7 +33,7 @@ _SO = os.path.join(_HERE, "_build", "liboracle.so")
 
 def build(force=False):
     """Compile liboracle.so with gcc (oracle/Makefile)."""
-    srcs = [os.path.join(_HERE, f) for f in ("pyramid_oracle.c", "align_oracle.c")]
+    srcs = [os.path.join(_HERE, f) for f in ("pyramid_oracle.c", "separable_oracle.c", "align_oracle.c")]
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(map(os.path.getmtime, srcs)):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _SO
@@ -102,6 +102,11 @@ def lib():
         L.orc_synth_frame_u8.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32]
         L.orc_to_f32_u8.argtypes = [_u8p, C.c_size_t, _f32p]
         L.orc_to_f32_u16.argtypes = [_u16p, C.c_size_t, _f32p]
+        L.orc_sep_reduce_f32.argtypes = [_f32p, C.c_int, C.c_int, _f32p, _f32p]
+        L.orc_sep_expand_f32.argtypes = [_f32p, C.c_int, C.c_int, _f32p, C.c_int, C.c_int, _f32p]
+        L.orc_sep_level_select_f32.argtypes = [_f32p, C.c_int, C.c_int, _f32p, C.c_int, C.c_int, _f32p, C.c_int,
+                                               C.c_int, _f32p, _f32p, _i32p, _f32p]
+        L.orc_sep_collapse_level_f32.argtypes = [_f32p, C.c_int, C.c_int, _f32p, _f32p, C.c_int, C.c_int, _f32p]
         L.orc_warp_affine.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                       _f64p, C.c_int, _f64p]
         L.orc_border_blur_composite.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
@@ -129,6 +134,11 @@ def gen_kernel_2d(a=0.4):
 def k25_f32(a=0.4):
     """float32 taps as OpenCV uses them for a CV_32F image [from memory]."""
     return np.ascontiguousarray(gen_kernel_2d(a).astype(np.float32).ravel())
+
+
+def k3_f32(a=0.4):
+    """MI_ARITH_SEPARABLE: float32 of the 1-D generating kernel (k0, k1, k2), separable_oracle.c."""
+    return np.ascontiguousarray(gen_kernel_1d(a)[:3].astype(np.float32))
 
 
 def num_levels(h, w, min_size=32):
@@ -325,7 +335,12 @@ class StreamingOracle:
     apart from the per-frame base images (tiny)."""
 
     def __init__(self, h, w, dtype=np.uint8, min_size=32, kernel_size=5, gen_kernel=0.4,
-                 use_fma=True, levels=None, keep_gauss=True):
+                 use_fma=True, levels=None, keep_gauss=True, arith="exact"):
+        assert arith in ("exact", "separable")
+        # "separable": the MI_ARITH_SEPARABLE arithmetic (separable_oracle.c) for the pyramid stencils; the base
+        # level rule and the final cast are the same in both modes
+        self.sep = arith == "separable"
+        self.k3 = k3_f32(gen_kernel)
         self.keep_gauss = keep_gauss
         self.h, self.w, self.dtype = h, w, np.dtype(dtype)
         self.levels = num_levels(h, w, min_size) if levels is None else levels
@@ -346,7 +361,7 @@ class StreamingOracle:
         self.bases = []
         # every per-frame buffer is allocated and touched once, so a timed push measures
         # arithmetic, not first-touch page faults
-        self._scratch = np.zeros(h * w * 4, np.float32)
+        self._scratch = np.zeros(h * w * 4 + ((h + 1) // 2) * ((w + 1) // 2), np.float32)
         self._g = [np.zeros(s + (3,), np.float32) for s in self.shapes]
         for a in self.best_e + self.best_lap + self.best_idx:
             a.fill(0)
@@ -362,7 +377,10 @@ class StreamingOracle:
             g[0][...] = src
         for lv in range(self.levels):
             h, w = self.shapes[lv]
-            lib().orc_reduce_f32(g[lv], h, w, 3, self.k, g[lv + 1], self.fma)
+            if self.sep:
+                lib().orc_sep_reduce_f32(g[lv], h, w, self.k3, g[lv + 1])
+            else:
+                lib().orc_reduce_f32(g[lv], h, w, 3, self.k, g[lv + 1], self.fma)
         return g
 
     def push_frame(self, frame):
@@ -372,9 +390,13 @@ class StreamingOracle:
         for lv in range(self.levels):
             h, w = self.shapes[lv]
             hs, ws = self.shapes[lv + 1]
-            lib().orc_level_select_f32(g[lv], h, w, g[lv + 1], hs, ws, self.k, self.n, first,
-                                       self.best_e[lv], self.best_lap[lv], self.best_idx[lv],
-                                       self._scratch, self.fma)
+            if self.sep:
+                lib().orc_sep_level_select_f32(g[lv], h, w, g[lv + 1], hs, ws, self.k3, self.n, first,
+                                               self.best_e[lv], self.best_lap[lv], self.best_idx[lv], self._scratch)
+            else:
+                lib().orc_level_select_f32(g[lv], h, w, g[lv + 1], hs, ws, self.k, self.n, first,
+                                           self.best_e[lv], self.best_lap[lv], self.best_idx[lv],
+                                           self._scratch, self.fma)
         hb, wb = self.shapes[self.levels]
         ent = np.empty((hb, wb), np.float32)
         dev = np.empty((hb, wb), np.float32)
@@ -399,8 +421,11 @@ class StreamingOracle:
             h, w = self.shapes[lv]
             hs, ws = self.shapes[lv + 1]
             out = np.empty((h, w, 3), np.float32)
-            lib().orc_collapse_level_f32(img, hs, ws, self.k, self.best_lap[lv], h, w, out,
-                                         self.fma)
+            if self.sep:
+                lib().orc_sep_collapse_level_f32(img, hs, ws, self.k3, self.best_lap[lv], h, w, out)
+            else:
+                lib().orc_collapse_level_f32(img, hs, ws, self.k, self.best_lap[lv], h, w, out,
+                                             self.fma)
             img = out
         return img
 

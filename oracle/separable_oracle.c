@@ -1,0 +1,153 @@
+/*
+ * oracle/separable_oracle.c -- CPU restatement of MI_ARITH_SEPARABLE (shinestacker_amd/csrc/kernels_sep.hpp),
+ * operation by operation.  TEST INFRASTRUCTURE ONLY (see pyramid_oracle.c).
+ *
+ * The separable mode evaluates the reference's 5x5 stencils (algorithms/pyramid.py:24-46: cv2.filter2D with
+ * np.outer(k, k)) as two 5-tap passes with the float32 generating kernel k = [k0 k1 k2 k1 k0]:
+ *
+ *     s5(a, b, c, d, e) = fma(k0, a + e, fma(k1, b + d, k2 * c))
+ *
+ *   reduce   (pyramid.py:27-32)  V = s5 down the rows at even rows (REFLECT101), G' = s5 along the rows of V
+ *            at even columns
+ *   expand   (pyramid.py:34-46)  on the zero-stuffed grid only every second tap is non-zero: with ce = 2 k0,
+ *            cc = 2 k2, co = 2 k1 (the reference's factor 4, split over the two dimensions)
+ *                even position 2j   : fma(ce, N[j-1] + N[j+1], cc * N[j])
+ *                odd  position 2j+1 : co * (N[j] + N[j+1])
+ *            along the rows first, then down the rows; REFLECT101 acts on the stuffed grid: N[-1] = N[1],
+ *            N[n] = N[n-1]
+ *   lap      (pyramid.py:133-138) G - expand(G')                     [3 channels; the fused payload]
+ *   energy   (pyramid.py:49-50)  gray is linear, so gray(lap) = gray(G) - expand(gray(G')):
+ *            Q = (gray(G) - expand(gray(G')))^2, HB = s5 along the rows of Q, E = s5 down the rows of HB
+ *   select   (pyramid.py:51-54)  running first maximum, strict '>', winner's lap with -0 -> +0
+ *
+ * This is NOT the exact-order arithmetic of pyramid_oracle.c (which is what the goldens of the reference's own
+ * run pin): it agrees with it within float32 rounding; tests/test_sep_tolerance.py states and checks the bound
+ * against a float64 evaluation.  The GPU's separable mode must equal THIS file bit for bit.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_API __attribute__((visibility("default")))
+
+static inline int r101(int i, int n) {
+    if (n == 1) return 0;
+    while (i < 0 || i >= n) {
+        if (i < 0) i = -i;
+        if (i >= n) i = 2 * n - 2 - i;
+    }
+    return i;
+}
+/* index map of the expand source: REFLECT101 on the zero-stuffed grid */
+static inline int mes(int i, int n) {
+    int r = i < 0 ? -i : (i >= n ? 2 * n - 1 - i : i);
+    return r < 0 ? 0 : (r >= n ? n - 1 : r);
+}
+static inline float s5(float a, float b, float c, float d, float e, const float* k) {
+    const float t0 = a + e, t1 = b + d;
+    return __builtin_fmaf(k[0], t0, __builtin_fmaf(k[1], t1, k[2] * c));
+}
+static inline float ex_even(float l, float c, float r, float ce, float cc) { return __builtin_fmaf(ce, l + r, cc * c); }
+static inline float ex_odd(float c, float r, float co) { return co * (c + r); }
+static inline float gray_of(float b, float g, float r) {
+    return __builtin_fmaf(r, 0.299f, __builtin_fmaf(g, 0.587f, b * 0.114f));
+}
+
+/* reduce_layer: g is h x w x 3, out is ceil(h/2) x ceil(w/2) x 3; k3 = float32(k0, k1, k2) */
+ORC_API void orc_sep_reduce_f32(const float* g, int h, int w, const float* k3, float* out) {
+    const int ho = (h + 1) / 2, wo = (w + 1) / 2;
+#pragma omp parallel
+    {
+        float* V = (float*)malloc((size_t)w * 3 * sizeof(float));
+#pragma omp for schedule(static)
+        for (int i = 0; i < ho; ++i) {
+            const float* row[5];
+            for (int t = 0; t < 5; ++t) row[t] = g + (size_t)r101(2 * i - 2 + t, h) * w * 3;
+            for (int f = 0; f < w * 3; ++f) V[f] = s5(row[0][f], row[1][f], row[2][f], row[3][f], row[4][f], k3);
+            for (int j = 0; j < wo; ++j) {
+                int x[5];
+                for (int t = 0; t < 5; ++t) x[t] = r101(2 * j - 2 + t, w);
+                for (int c = 0; c < 3; ++c)
+                    out[((size_t)i * wo + j) * 3 + c] =
+                        s5(V[x[0] * 3 + c], V[x[1] * 3 + c], V[x[2] * 3 + c], V[x[3] * 3 + c], V[x[4] * 3 + c], k3);
+            }
+        }
+        free(V);
+    }
+}
+
+/* expand_layer(src)[y, x] of a single-channel plane `n` (hs x ws, element stride `st`) */
+static inline float expand_at(const float* n, int hs, int ws, int st, int y, int x, float ce, float cc, float co) {
+    const int i = y >> 1, j = x >> 1;
+    float X[3];
+    const int r0 = (y & 1) ? i : i - 1, nr = (y & 1) ? 2 : 3;
+    for (int r = 0; r < nr; ++r) {
+        const float* row = n + (size_t)mes(r0 + r, hs) * ws * st;
+        X[r] = (x & 1) ? ex_odd(row[(size_t)mes(j, ws) * st], row[(size_t)mes(j + 1, ws) * st], co)
+                       : ex_even(row[(size_t)mes(j - 1, ws) * st], row[(size_t)mes(j, ws) * st],
+                                 row[(size_t)mes(j + 1, ws) * st], ce, cc);
+    }
+    return (y & 1) ? ex_odd(X[0], X[1], co) : ex_even(X[0], X[1], X[2], ce, cc);
+}
+
+ORC_API void orc_sep_expand_f32(const float* src, int hs, int ws, const float* k3, int h, int w, float* out) {
+    const float ce = 2.0f * k3[0], cc = 2.0f * k3[2], co = 2.0f * k3[1];
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x)
+            for (int c = 0; c < 3; ++c)
+                out[((size_t)y * w + x) * 3 + c] = expand_at(src + c, hs, ws, 3, y, x, ce, cc, co);
+}
+
+/* Laplacian + energy + running first-max for one frame of one level.
+ * scratch: h*w*4 + hs*ws floats (lap, q, gray of gn).  Also returns nothing else: energy is recomputed per frame. */
+ORC_API void orc_sep_level_select_f32(const float* g, int h, int w, const float* gn, int hs, int ws, const float* k3,
+                                      int frame_idx, int first, float* best_e, float* best_lap, int32_t* best_idx,
+                                      float* scratch) {
+    const float ce = 2.0f * k3[0], cc = 2.0f * k3[2], co = 2.0f * k3[1];
+    float* lap = scratch;
+    float* q = scratch + (size_t)h * w * 3;
+    float* gg = q + (size_t)h * w;
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < (size_t)hs * ws; ++i) gg[i] = gray_of(gn[3 * i], gn[3 * i + 1], gn[3 * i + 2]);
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            const size_t p = (size_t)y * w + x;
+            for (int c = 0; c < 3; ++c) lap[p * 3 + c] = g[p * 3 + c] - expand_at(gn + c, hs, ws, 3, y, x, ce, cc, co);
+            const float l = gray_of(g[p * 3], g[p * 3 + 1], g[p * 3 + 2]) - expand_at(gg, hs, ws, 1, y, x, ce, cc, co);
+            q[p] = l * l;
+        }
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < h; ++y) {
+        const float* row[5];
+        for (int t = 0; t < 5; ++t) row[t] = q + (size_t)r101(y - 2 + t, h) * w;
+        for (int x = 0; x < w; ++x) {
+            int xx[5];
+            for (int t = 0; t < 5; ++t) xx[t] = r101(x - 2 + t, w);
+            float hb[5];
+            for (int t = 0; t < 5; ++t) hb[t] = s5(row[t][xx[0]], row[t][xx[1]], row[t][xx[2]], row[t][xx[3]], row[t][xx[4]], k3);
+            const float e = s5(hb[0], hb[1], hb[2], hb[3], hb[4], k3);
+            const size_t p = (size_t)y * w + x;
+            if (first || e > best_e[p]) {
+                best_e[p] = e;
+                best_idx[p] = frame_idx;
+                for (int c = 0; c < 3; ++c) best_lap[p * 3 + c] = lap[p * 3 + c] + 0.0f; /* -0 -> +0 */
+            }
+        }
+    }
+}
+
+/* collapse step: out = expand(up)[:h, :w] + lap */
+ORC_API void orc_sep_collapse_level_f32(const float* up, int hs, int ws, const float* k3, const float* lap, int h, int w,
+                                        float* out) {
+    const float ce = 2.0f * k3[0], cc = 2.0f * k3[2], co = 2.0f * k3[1];
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x)
+            for (int c = 0; c < 3; ++c) {
+                const size_t p = ((size_t)y * w + x) * 3 + c;
+                out[p] = expand_at(up + c, hs, ws, 3, y, x, ce, cc, co) + lap[p];
+            }
+}

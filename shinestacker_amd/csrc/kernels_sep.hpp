@@ -9,8 +9,11 @@
 //   reduce   V = s5 down the rows at even rows, G_{l+1} = s5 along the rows at even columns   (pyramid.py:27-32)
 //   expand   X = along the rows:  even column  fma(2k0, N[j-1] + N[j+1], 2k2 * N[j]),  odd  2k1 * (N[j] + N[j+1])
 //            then the same down the rows (the zero-stuffed grid's zero taps skipped)           (pyramid.py:34-46)
-//   lap      G_l - expand(G_{l+1}),  Q = gray(lap)^2                                           (pyramid.py:133-138, :49)
-//   energy   HB = s5 along the rows of Q, E = s5 down the rows of HB                           (pyramid.py:50)
+//   lap      G_l - expand(G_{l+1})                                                             (pyramid.py:133-138)
+//   energy   gray is linear, so gray(lap) = gray(G_l) - expand(gray(G_{l+1})): the energy path runs on ONE channel:
+//            Q = (gray(G_l) - expand(gray(G_{l+1})))^2, HB = s5 along the rows of Q, E = s5 down the rows of HB
+//            (pyramid.py:49-50); the three-channel Laplacian is only needed for the winning frame of a pixel
+//            and is filled in once per batch (sep_payload)
 //
 // This is NOT bit-identical to the exact-order mode (kernels_tiled.hpp, the drop-in default): coefficients agree
 // with a float64 evaluation within the forward-error bound of a 25-term float32 dot product, and the per-pixel
@@ -20,18 +23,27 @@
 // Workgroup = 512 threads, tile 28 x 56 pixels of level l; per frame, four barrier phases:
 //   P0 stage   G_l patch (tile + 6 halo = 40 x 68 px) registers -> LDS (prefetched one frame ahead)
 //   P1 v-red   V (18 x 68 px): lane = one float4 column group, 7 ds_read_b128 -> 2 rows, packed fp32
-//   P2 h-red   G_{l+1} patch (18 x 32): lane = one pixel, 32 lanes per row; the tile centre goes to global
-//              memory from registers; the row neighbours come in by DPP wave shifts and the lane writes
-//              the horizontally expanded X (18 rows x 64 columns) -- G_{l+1} itself never sits in LDS
+//   P2 h-red   G_{l+1} patch (18 x 32): lane = one pixel, 32 lanes per row; the tile centre goes to global memory
+//              from registers; gray of the pixel, its row neighbours by DPP wave shifts, and the lane writes the
+//              horizontally expanded gray X (18 rows x 64 columns) -- G_{l+1} itself never sits in LDS
 //   P3 lapq    lane = one 2x2 quad of the 32 x 64 (tile + 2 halo, + 2 dummy columns) region: vertical expand from
-//              3 X rows, Laplacian against the staged G_l, Q; the row blur of Q by DPP wave shifts -> HB in LDS
+//              3 X rows, gray of the staged G_l, Q; the row blur of Q by DPP wave shifts -> HB in LDS
 //   P4 select  lane's own quad: column blur of HB (6 ds_read_b64, packed), strict '>' against the running max
-// The lane of P3 and P4 is the same, so a quad's Laplacian stays in registers.
+// Running state per pixel in registers: (max energy, its frame).
 #pragma once
 #include "common.hpp"
 #include "kernels_tiled.hpp"
 
 namespace mi {
+
+// tile height (compile-time; tools build variants with -DMI_SEP_TH=..): 28 -> 512 threads, 3 workgroups per CU
+#ifndef MI_SEP_TH
+#define MI_SEP_TH 28
+#endif
+// non-temporal G_{l+1} stores (written once, read by the next level's launch much later)
+#ifndef MI_SEP_NT_STORE
+#define MI_SEP_NT_STORE 1
+#endif
 
 template <int TH_, int NT_>
 struct SepGeom {
@@ -42,7 +54,7 @@ struct SepGeom {
     static constexpr int NPRE = (NCH + NT - 1) / NT;          // chunks (loads) per thread
     static constexpr int NH = TH / 2 + 4, NW = TW / 2 + 4;    // G_{l+1} patch: 18 x 32
     static constexpr int VS = GD;
-    static constexpr int XW = 2 * NW, XS = XW * 3;            // expanded columns x0-4 .. x0+TW+4
+    static constexpr int XW = 2 * NW, XS = XW;                // expanded GRAY columns x0-4 .. x0+TW+4, one float each
     static constexpr int QY = TH / 2 + 2, QL = NW;            // quad rows x lanes per quad row
     static constexpr int HBH = TH + 4, HBS = XW;              // HB rows y0-2 .. y0+TH+1, columns as X
     static constexpr int LDS_FLOATS = GH * GS + NH * VS + NH * XS;
@@ -175,11 +187,12 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
     const float k0 = a.k1d[0], k1 = a.k1d[1], k2 = a.k1d[2];
     const float ce = 2.0f * k0, cc = 2.0f * k2, co = 2.0f * k1;   // expand taps (the reference's 4 * K, per dimension)
 
-    // ---- the lane's quad: rows y0-2+2qy+{0,1}, columns x0-4+2ql+{0,1}; owned = inside the tile
+    // ---- the lane's quad: rows y0-2+2qy+{0,1}, columns x0-4+2ql+{0,1}; owned = inside the tile.  Running state of
+    // the quad = (max energy, its frame); the winner's Laplacian is filled in after the batch (sep_payload).
     const int qy = tid >> 5, ql = tid & 31;
     const bool own_tile = qy >= 1 && qy < G::QY - 1 && ql >= 2 && ql < G::QL - 2;
     const int oy = y0 - 2 + 2 * qy, ox = x0 - 4 + 2 * ql;
-    float bE[4], bL[4][3];
+    float bE[4];
     int bI[4];
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
@@ -189,13 +202,9 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
             const size_t px = (size_t)y * w + x;
             bE[p] = a.best_e[px];
             bI[p] = a.best_idx[px];
-            bL[p][0] = a.best_lap[px * 3 + 0];
-            bL[p][1] = a.best_lap[px * 3 + 1];
-            bL[p][2] = a.best_lap[px * 3 + 2];
         } else {
             bE[p] = -1.0f;   // every energy is >= 0: the first frame always wins
             bI[p] = -1;
-            bL[p][0] = bL[p][1] = bL[p][2] = 0.f;
         }
     }
 
@@ -252,22 +261,20 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
         // ---------------- P1: vertical reduce, 2 V rows x one float4 column group per lane
         if (lt < (G::NH / 2) * CPR && !MI_ABL(1)) {
             const int rp = lt / CPR, g = lt - rp * CPR;
-            v4f o0, o1;
+            v2f a0, a1, b0, b1;   // (row 2rp | 2rp+1) x (floats 4g, 4g+1 | 4g+2, 4g+3)
             if constexpr (INTERIOR) {
                 const float* p = sG + mul24(4 * rp, G::GS) + 4 * g;
                 v4f r[7];
 #pragma unroll
                 for (int t = 0; t < 7; ++t) r[t] = lds_load4(p + t * G::GS);
-                const v2f a0 = s5(r[0].xy, r[1].xy, r[2].xy, r[3].xy, r[4].xy, k0, k1, k2);
-                const v2f a1 = s5(r[0].zw, r[1].zw, r[2].zw, r[3].zw, r[4].zw, k0, k1, k2);
-                const v2f b0 = s5(r[2].xy, r[3].xy, r[4].xy, r[5].xy, r[6].xy, k0, k1, k2);
-                const v2f b1 = s5(r[2].zw, r[3].zw, r[4].zw, r[5].zw, r[6].zw, k0, k1, k2);
-                o0 = v4f{a0.x, a0.y, a1.x, a1.y};
-                o1 = v4f{b0.x, b0.y, b1.x, b1.y};
+                a0 = s5(r[0].xy, r[1].xy, r[2].xy, r[3].xy, r[4].xy, k0, k1, k2);
+                a1 = s5(r[0].zw, r[1].zw, r[2].zw, r[3].zw, r[4].zw, k0, k1, k2);
+                b0 = s5(r[2].xy, r[3].xy, r[4].xy, r[5].xy, r[6].xy, k0, k1, k2);
+                b1 = s5(r[2].zw, r[3].zw, r[4].zw, r[5].zw, r[6].zw, k0, k1, k2);
             } else {
                 // a cell outside G_{l+1} is computed at its mirror position (REFLECT101 acts on the zero-stuffed
                 // grid: V[-1] = G[1], V[n] = G[n-1]); the staged patch already holds reflected rows
-                v4f o[2];
+                v2f o[2][2];
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     const int im = map_expand_src(y0 / 2 - 2 + 2 * rp + u, hn);
@@ -275,21 +282,19 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
                     v4f r[5];
 #pragma unroll
                     for (int t = 0; t < 5; ++t) r[t] = lds_load4(sG + mul24(clampi(r0 + t, 0, G::GH - 1), G::GS) + 4 * g);
-                    const v2f a0 = s5(r[0].xy, r[1].xy, r[2].xy, r[3].xy, r[4].xy, k0, k1, k2);
-                    const v2f a1 = s5(r[0].zw, r[1].zw, r[2].zw, r[3].zw, r[4].zw, k0, k1, k2);
-                    o[u] = v4f{a0.x, a0.y, a1.x, a1.y};
+                    o[u][0] = s5(r[0].xy, r[1].xy, r[2].xy, r[3].xy, r[4].xy, k0, k1, k2);
+                    o[u][1] = s5(r[0].zw, r[1].zw, r[2].zw, r[3].zw, r[4].zw, k0, k1, k2);
                 }
-                o0 = o[0];
-                o1 = o[1];
+                a0 = o[0][0]; a1 = o[0][1]; b0 = o[1][0]; b1 = o[1][1];
             }
             float* d = sV + mul24(2 * rp, G::VS) + 4 * g;
-            *reinterpret_cast<v4f*>(d) = o0;
-            *reinterpret_cast<v4f*>(d + G::VS) = o1;
+            lds_store4(d, a0.x, a0.y, a1.x, a1.y);
+            lds_store4(d + G::VS, b0.x, b0.y, b1.x, b1.y);
         }
         __syncthreads();
 
-        // ---------------- P2: horizontal reduce (one G_{l+1} pixel per lane, 32 lanes per patch row), G_{l+1} store,
-        // horizontal expand -> X.  18 rows x 32 = 576 items: the last two rows are a second round on wave 0.
+        // ---------------- P2: horizontal reduce (one G_{l+1} pixel per lane, 32 lanes per patch row), G_{l+1} store, gray,
+        // horizontal expand of the gray -> X.  18 rows x 32 = 576 items: the last two rows are a second round on wave 0.
 #pragma unroll
         for (int rnd = 0; rnd < (G::NH * 32 + NT - 1) / NT; ++rnd) {
             const int it = lt + rnd * NT;
@@ -326,56 +331,42 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
                 if constexpr (!INTERIOR) st = st && i < hn && j < wn;
                 if (st) {
                     float* gp = a.gnext + (size_t)b * a.gnext_stride + ((size_t)i * wn + j) * 3;
-                    gp[0] = n[0]; gp[1] = n[1]; gp[2] = n[2];
+                    if (MI_SEP_NT_STORE) {
+                        __builtin_nontemporal_store(n[0], gp);
+                        __builtin_nontemporal_store(n[1], gp + 1);
+                        __builtin_nontemporal_store(n[2], gp + 2);
+                    } else {
+                        gp[0] = n[0]; gp[1] = n[1]; gp[2] = n[2];
+                    }
                 }
             }
-            // expanded columns 2j', 2j'+1 of row r: the even one from (left, centre, right), the odd one from (centre, right)
-            float xe[3], xo[3];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const float lft = dpp_wave_prev(n[c]), rgt = dpp_wave_next(n[c]);
-                xe[c] = ex_even(lft, n[c], rgt, ce, cc);
-                xo[c] = ex_odd(n[c], rgt, co);
-            }
-            float* xp = sX + mul24(r, G::XS) + 6 * jp;
-            lds_store2(xp, xe[0], xe[1]);
-            lds_store2(xp + 2, xe[2], xo[0]);
-            lds_store2(xp + 4, xo[1], xo[2]);
+            // gray of the pixel, its neighbours along the row by DPP, expanded columns 2j' (even) and 2j'+1 (odd)
+            const float g = gray_of<true>(n[0], n[1], n[2]);
+            const float gl = dpp_wave_prev(g), gr = dpp_wave_next(g);
+            lds_store2(sX + mul24(r, G::XS) + 2 * jp, ex_even(gl, g, gr, ce, cc), ex_odd(g, gr, co));
         }
         __syncthreads();
 
-        // ---------------- P3: vertical expand, Laplacian, Q, row blur of Q -> HB
-        float lap[4][3];
-#pragma unroll
-        for (int p = 0; p < 4; ++p) lap[p][0] = lap[p][1] = lap[p][2] = 0.f;
+        // ---------------- P3: vertical expand of the gray, gray Laplacian, Q, row blur of Q -> HB
         if (!MI_ABL(4)) {
             const int qy3 = lt >> 5, ql3 = lt & 31;
+            float q[4];
             if constexpr (INTERIOR) {
-                const float* xr = sX + mul24(qy3, G::XS) + 6 * ql3;           // X rows qy, qy+1, qy+2
-                v2f xa[3], xb[3], xc[3];
-#pragma unroll
-                for (int t = 0; t < 3; ++t) {
-                    xa[t] = lds_load2s(xr + 2 * t);
-                    xb[t] = lds_load2s(xr + G::XS + 2 * t);
-                    xc[t] = lds_load2s(xr + 2 * G::XS + 2 * t);
-                }
-                const float* gr = sG + mul24(2 * qy3 + 4, G::GS) + 6 * ql3 + 6;   // patch rows 2qy+4, +5; columns 2ql+2, +3
+                const float* xr = sX + mul24(qy3, G::XS) + 2 * ql3;           // X rows qy, qy+1, qy+2
+                const v2f xa = lds_load2s(xr), xb = lds_load2s(xr + G::XS), xc = lds_load2s(xr + 2 * G::XS);
+                const float* gp = sG + mul24(2 * qy3 + 4, G::GS) + 6 * ql3 + 6;   // patch rows 2qy+4, +5; columns 2ql+2, +3
                 v2f ge[3], go[3];
 #pragma unroll
                 for (int t = 0; t < 3; ++t) {
-                    ge[t] = lds_load2s(gr + 2 * t);
-                    go[t] = lds_load2s(gr + G::GS + 2 * t);
+                    ge[t] = lds_load2s(gp + 2 * t);
+                    go[t] = lds_load2s(gp + G::GS + 2 * t);
                 }
-#pragma unroll
-                for (int t = 0; t < 3; ++t) {
-                    const v2f ev = ex_even(xa[t], xb[t], xc[t], ce, cc), od = ex_odd(xb[t], xc[t], co);
-                    const v2f le = ge[t] - ev, lo = go[t] - od;
-                    // floats 2t, 2t+1 of the 6 = (pixel (2t)/3, channel (2t)%3), ...
-                    lap[(2 * t) / 3][(2 * t) % 3] = le.x;
-                    lap[(2 * t + 1) / 3][(2 * t + 1) % 3] = le.y;
-                    lap[2 + (2 * t) / 3][(2 * t) % 3] = lo.x;
-                    lap[2 + (2 * t + 1) / 3][(2 * t + 1) % 3] = lo.y;
-                }
+                const v2f ev = ex_even(xa, xb, xc, ce, cc), od = ex_odd(xb, xc, co);
+                const v2f gge = {gray_of<true>(ge[0].x, ge[0].y, ge[1].x), gray_of<true>(ge[1].y, ge[2].x, ge[2].y)};
+                const v2f ggo = {gray_of<true>(go[0].x, go[0].y, go[1].x), gray_of<true>(go[1].y, go[2].x, go[2].y)};
+                const v2f le = gge - ev, lo = ggo - od;
+                const v2f qe = le * le, qo = lo * lo;
+                q[0] = qe.x; q[1] = qe.y; q[2] = qo.x; q[3] = qo.y;
             } else {
 #pragma unroll
                 for (int p = 0; p < 4; ++p) {
@@ -383,21 +374,12 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
                     const int ym = map_clamp(y0 - 2 + 2 * qy3 + (p >> 1), h), xm = map_clamp(x0 - 4 + 2 * ql3 + (p & 1), w);
                     const int ri = clampi((ym >> 1) - (y0 / 2 - 2), 1, G::NH - 2);   // X row of G_{l+1} row ym / 2
                     const int ec = clampi(xm - (x0 - 4), 0, G::XW - 1);             // X column
-                    const float* xq = sX + mul24(ri, G::XS) + 3 * ec;
+                    const float* xq = sX + mul24(ri, G::XS) + ec;
                     const float* gq = sG + mul24(clampi(ym - (y0 - 6), 0, G::GH - 1), G::GS) + 3 * clampi(xm - (x0 - 6), 0, G::GW - 1);
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        const float e = (p >> 1) == 0 ? ex_even(xq[c - G::XS], xq[c], xq[c + G::XS], ce, cc)
-                                                      : ex_odd(xq[c], xq[c + G::XS], co);
-                        lap[p][c] = gq[c] - e;
-                    }
+                    const float e = (p >> 1) == 0 ? ex_even(xq[-G::XS], xq[0], xq[G::XS], ce, cc) : ex_odd(xq[0], xq[G::XS], co);
+                    const float l = gray_of<true>(gq[0], gq[1], gq[2]) - e;
+                    q[p] = l * l;
                 }
-            }
-            float q[4];
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const float gr = gray_of<true>(lap[p][0], lap[p][1], lap[p][2]);
-                q[p] = gr * gr;
             }
 #pragma unroll
             for (int rr = 0; rr < 2; ++rr) {
@@ -427,16 +409,13 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
                 const bool win = e[p] > bE[p];
                 bE[p] = win ? e[p] : bE[p];
                 bI[p] = win ? fidx : bI[p];
-                bL[p][0] = win ? lap[p][0] : bL[p][0];
-                bL[p][1] = win ? lap[p][1] : bL[p][1];
-                bL[p][2] = win ? lap[p][2] : bL[p][2];
             }
         }
         // no barrier here: sG is rewritten after P3's reads (barrier above), V/HB after the next frame's first
         // barrier, X after its second
     }
 
-    // ---- write the running state back (winner's lap with -0 -> +0, as the reference's np.where sum gives)
+    // ---- write the running maxima back
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const int y = oy + (p >> 1), x = ox + (p & 1);
@@ -444,9 +423,6 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
             const size_t px = (size_t)y * w + x;
             a.best_e[px] = bE[p];
             a.best_idx[px] = bI[p];
-            a.best_lap[px * 3 + 0] = bL[p][0] + 0.0f;
-            a.best_lap[px * 3 + 1] = bL[p][1] + 0.0f;
-            a.best_lap[px * 3 + 2] = bL[p][2] + 0.0f;
         }
     }
 }
@@ -460,6 +436,55 @@ __global__ __launch_bounds__(NT) void level_sep(LevelArgs a) {
 template <typename TIn, bool INTERIOR, int TH, int NT>
 __global__ __launch_bounds__(NT) void level_sep_coarse(LevelArgs a) {
     level_sep_body<TIn, INTERIOR, TH, NT>(a);
+}
+
+// ================================================================================================
+// Winner's Laplacian of the frames of one batch (the level kernel keeps only the running maximum and its frame):
+// one lane per 2x2 quad of level l; a pixel whose arg-max is a frame of this batch gets
+// lap = G_l - expand(G_{l+1}) of that frame, with -0 -> +0 as the reference's np.where sum gives (pyramid.py:52-54).
+template <typename TIn>
+__global__ void sep_payload(const void* __restrict__ src, size_t src_stride, const float* __restrict__ gnext,
+                            size_t gnext_stride, int nframes, int h, int w, int hn, int wn,
+                            const int32_t* __restrict__ best_idx, int frame_idx0, float* __restrict__ best_lap, float k0,
+                            float k1, float k2) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y * blockDim.y + threadIdx.y;
+    if (2 * i >= h || 2 * j >= w) return;
+    const float ce = 2.0f * k0, cc = 2.0f * k2, co = 2.0f * k1;
+    int fr[4];
+    bool any = false;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int y = 2 * i + (p >> 1), x = 2 * j + (p & 1);
+        fr[p] = -1;
+        if (y < h && x < w) {
+            const int f = best_idx[(size_t)y * w + x] - frame_idx0;
+            if (f >= 0 && f < nframes) { fr[p] = f; any = true; }
+        }
+    }
+    if (!any) return;
+    const int ri[3] = {map_expand_src(i - 1, hn), i, map_expand_src(i + 1, hn)};
+    const int cj[3] = {map_expand_src(j - 1, wn), j, map_expand_src(j + 1, wn)};
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        if (fr[p] < 0) continue;
+        // frames of a quad mostly agree; the expand source is re-read per pixel only when they differ (cached)
+        const float* gn = gnext + (size_t)fr[p] * gnext_stride;
+        const TIn* g = (const TIn*)((const char*)src + (size_t)fr[p] * src_stride);
+        const int y = 2 * i + (p >> 1), x = 2 * j + (p & 1);
+        const size_t px = (size_t)y * w + x;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float xr[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const float* row = gn + (size_t)ri[r] * wn * 3 + c;
+                xr[r] = (p & 1) ? ex_odd(row[cj[1] * 3], row[cj[2] * 3], co)
+                                : ex_even(row[cj[0] * 3], row[cj[1] * 3], row[cj[2] * 3], ce, cc);
+            }
+            const float e = (p >> 1) ? ex_odd(xr[1], xr[2], co) : ex_even(xr[0], xr[1], xr[2], ce, cc);
+            best_lap[px * 3 + c] = (to_f32(g[px * 3 + c]) - e) + 0.0f;
+        }
+    }
 }
 
 // ================================================================================================
@@ -490,15 +515,17 @@ __global__ void reduce_sep_simple(const TIn* __restrict__ g, int h, int w, float
     }
 }
 
-// expand_layer(src)[y, x, c] for an hs x ws x 3 source, (y, x) inside the 2hs x 2ws grid
-__device__ __forceinline__ float expand_sep_at(const float* __restrict__ src, int hs, int ws, int y, int x, int c, float ce,
-                                               float cc, float co) {
+// expand_layer(N)[y, x] for an hs x ws source given as N(row, col) (indices already inside the source), (y, x)
+// inside the 2hs x 2ws grid: along the rows first, then down the rows
+template <typename F>
+__device__ __forceinline__ float expand_sep_of(F N, int hs, int ws, int y, int x, float ce, float cc, float co) {
     const int i = y >> 1, j = x >> 1;
-    auto N = [&](int r, int q) { return src[((size_t)map_expand_src(r, hs) * ws + map_expand_src(q, ws)) * 3 + c]; };
-    auto X = [&](int r) { return (x & 1) ? ex_odd(N(r, j), N(r, j + 1), co) : ex_even(N(r, j - 1), N(r, j), N(r, j + 1), ce, cc); };
+    auto M = [&](int r, int q) { return N(map_expand_src(r, hs), map_expand_src(q, ws)); };
+    auto X = [&](int r) { return (x & 1) ? ex_odd(M(r, j), M(r, j + 1), co) : ex_even(M(r, j - 1), M(r, j), M(r, j + 1), ce, cc); };
     return (y & 1) ? ex_odd(X(i), X(i + 1), co) : ex_even(X(i - 1), X(i), X(i + 1), ce, cc);
 }
 
+// Laplacian (the payload) and Q = (gray(G_l) - expand(gray(G_{l+1})))^2 (the energy path)
 template <typename TIn>
 __global__ void lapq_sep_simple(const TIn* __restrict__ g, int h, int w, const float* __restrict__ gn, int hs, int ws,
                                 float* __restrict__ lap, float* __restrict__ q, float k0, float k1, float k2) {
@@ -506,14 +533,18 @@ __global__ void lapq_sep_simple(const TIn* __restrict__ g, int h, int w, const f
     if (y >= h || x >= w) return;
     const float ce = 2.0f * k0, cc = 2.0f * k2, co = 2.0f * k1;
     const size_t p = (size_t)y * w + x;
-    float l[3];
+    float gl[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        l[c] = to_f32(g[p * 3 + c]) - expand_sep_at(gn, hs, ws, y, x, c, ce, cc, co);
-        lap[p * 3 + c] = l[c];
+        gl[c] = to_f32(g[p * 3 + c]);
+        lap[p * 3 + c] = gl[c] - expand_sep_of([&](int r, int k) { return gn[((size_t)r * ws + k) * 3 + c]; }, hs, ws, y, x, ce, cc, co);
     }
-    const float gr = gray_of<true>(l[0], l[1], l[2]);
-    q[p] = gr * gr;
+    const float eg = expand_sep_of([&](int r, int k) {
+        const float* s = gn + ((size_t)r * ws + k) * 3;
+        return gray_of<true>(s[0], s[1], s[2]);
+    }, hs, ws, y, x, ce, cc, co);
+    const float l = gray_of<true>(gl[0], gl[1], gl[2]) - eg;
+    q[p] = l * l;
 }
 
 __global__ void select_sep_simple(const float* __restrict__ q, const float* __restrict__ lap, int h, int w, int frame_idx,
@@ -533,10 +564,7 @@ __global__ void select_sep_simple(const float* __restrict__ q, const float* __re
         best_e[p] = s;
         best_idx[p] = frame_idx;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float lv = lap[p * 3 + c];
-            best_lap[p * 3 + c] = (lv == 0.0f) ? 0.0f : lv;
-        }
+        for (int c = 0; c < 3; ++c) best_lap[p * 3 + c] = lap[p * 3 + c] + 0.0f;
     }
 }
 
@@ -551,7 +579,7 @@ __global__ void collapse_sep(const float* __restrict__ up, int hs, int ws, const
     const size_t p = ((size_t)y * w + x) * 3;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        float v = expand_sep_at(up, hs, ws, y, x, c, ce, cc, co) + lap[p + c];
+        float v = expand_sep_of([&](int r, int k) { return up[((size_t)r * ws + k) * 3 + c]; }, hs, ws, y, x, ce, cc, co) + lap[p + c];
         if constexpr (sizeof(TOut) != 4) {
             v = fabsf(v);
             v = v > maxv ? maxv : v;

@@ -257,7 +257,7 @@ int launch_level(mi_stack* s, int l, int set, const void* src, size_t src_stride
 template <typename TIn, bool L0_NAME>
 int launch_level_sep(mi_stack* s, int l, int set, const void* src, size_t src_stride, int nb, hipStream_t st_in,
                      hipStream_t st_bd) {
-    constexpr int TH = 28, NT = 512;
+    constexpr int TH = MI_SEP_TH, NT = (TH / 2 + 2) * 32;
     using SG = SepGeom<TH, NT>;
     constexpr int TW = SG::TW;
     TiledState* t = tstate(s);
@@ -308,6 +308,20 @@ int launch_level_sep(mi_stack* s, int l, int set, const void* src, size_t src_st
     return MI_OK;
 }
 
+// MI_ARITH_SEPARABLE: the winners' Laplacians of level l for the frames of this batch (the level kernel keeps only
+// the running maximum and its frame index); reads the batch's G_l (level 0: the frames) and G_{l+1}.
+template <typename TIn>
+int launch_payload_sep(mi_stack* s, int l, int set, const void* src, size_t src_stride, int nb, hipStream_t st) {
+    TiledState* t = tstate(s);
+    const dim3 blk(32, 8);
+    const dim3 grd(cdiv(cdiv(s->lw[l], 2), blk.x), cdiv(cdiv(s->lh[l], 2), blk.y));
+    ProfScope ps(s, MI_PROF_LEVEL, 0.0, st);
+    hipLaunchKernelGGL((sep_payload<TIn>), grd, blk, 0, st, src, src_stride, (const float*)t->Gb[set][l + 1], t->gstride[l + 1],
+                       nb, s->lh[l], s->lw[l], s->lh[l + 1], s->lw[l + 1], (const int32_t*)s->bestIdx[l],
+                       s->first_index + s->n_pushed, s->bestLap[l], s->k1d[0], s->k1d[1], s->k1d[2]);
+    return MI_OK;
+}
+
 template <typename TIn, bool FMA>
 int run_batch(mi_stack* s, const void* frames, size_t stride, int nb) {
     TiledState* t = tstate(s);
@@ -332,6 +346,7 @@ int run_batch(mi_stack* s, const void* frames, size_t stride, int nb) {
     MI_HIP(hipStreamWaitEvent(st2, t->evL0i[set], 0));
     MI_HIP(hipStreamWaitEvent(st2, t->evL0b[set], 0));
     MI_HIP(hipStreamWaitEvent(st1, t->evL0i[set], 0));
+    if (s->sep && (rc = launch_payload_sep<TIn>(s, 0, set, frames, stride, nb, st2))) return rc;
     // coarser levels: interior tiles on st2, border tiles on st1 (disjoint tiles of one level run
     // side by side); both streams join after every level because level l+1 reads all of G_{l+1}
     static const int only_l0 = study_env("MI_ONLY_L0", 0);   // -DMI_STUDY: level 0 alone on the GPU (results are wrong)
@@ -355,6 +370,7 @@ int run_batch(mi_stack* s, const void* frames, size_t stride, int nb) {
         MI_HIP(hipEventRecord(eb, st1));
         MI_HIP(hipStreamWaitEvent(st2, eb, 0));
         MI_HIP(hipStreamWaitEvent(st1, ei, 0));
+        if (s->sep && (rc = launch_payload_sep<float>(s, l, set, t->Gb[set][l], t->gstride[l] * sizeof(float), nb, st2))) return rc;
     }
     MI_HIP(hipGetLastError());
     if (!only_l0) {   // base level of the whole batch

@@ -1,0 +1,106 @@
+"""GPU: MI_ARITH_SEPARABLE (csrc/kernels_sep.hpp) through the C ABI against its CPU restatement
+(oracle/separable_oracle.c), bit for bit: every tap of both implementations (LDS-tiled and one-thread-per-output),
+interior and border tiles, odd sizes at every level, ties, u8 / u16 / f32 input, host and device pushes, batch
+boundaries.  The tolerance of this arithmetic against float64 is tests/test_sep_tolerance.py (CPU)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def L(hiplib):
+    hiplib.require_device()
+    return hiplib
+
+
+def run_oracle(oracle, frames, **kw):
+    h, w = frames[0].shape[:2]
+    dt = frames[0].dtype if frames[0].dtype != np.float32 else np.uint8
+    so = oracle.StreamingOracle(h, w, dt, arith="separable", **kw)
+    gs = [so.push_frame(f) for f in frames]
+    return so, gs
+
+
+def compare(L, st, so, last_gauss=None):
+    for lv in range(st.levels):
+        assert np.array_equal(st.tap(L.TAP_ENERGY, lv), so.best_e[lv]), f"energy {lv}"
+        assert np.array_equal(st.tap(L.TAP_INDEX, lv), so.best_idx[lv]), f"index {lv}"
+        assert np.array_equal(st.tap(L.TAP_FUSED_LAP, lv), so.best_lap[lv]), f"lap {lv}"
+    if last_gauss is not None:
+        for lv in range(1, st.levels + 1):
+            assert np.array_equal(st.tap(L.TAP_GAUSS, lv), last_gauss[lv]), f"gauss {lv}"
+    want = so.finish()
+    got = st.finish()
+    assert np.array_equal(st.tap(L.TAP_COLLAPSED), np.clip(np.abs(so.collapse()), 0, 255 if got.dtype == np.uint8 else 65535))
+    assert got.dtype == want.dtype and np.array_equal(got, want)
+
+
+CASES = [
+    # (h, w, n, dtype, min_size, gen_kernel, batch)
+    (133, 201, 4, np.uint8, 8, 0.4, 0),       # odd sizes at every level, all tiles are border tiles
+    (300, 452, 5, np.uint8, 32, 0.4, 2),      # interior + border tiles, batches of 2 (state reloaded between launches)
+    (257, 130, 3, np.uint16, 16, 0.35, 0),
+    (96, 64, 3, np.float32, 8, 0.4, 0),
+    (500, 750, 6, np.float32, 32, 0.5, 4),
+    (97, 1031, 3, np.uint8, 8, 0.3, 0),       # one tile row, many tile columns
+    (640, 90, 3, np.uint16, 8, 0.4, 0),       # many tile rows, two tile columns
+]
+
+
+@pytest.mark.parametrize("impl", [1, 2])
+@pytest.mark.parametrize("h,w,n,dt,min_size,a,batch", CASES)
+def test_separable_equals_oracle(L, oracle, impl, h, w, n, dt, min_size, a, batch):
+    rng = np.random.default_rng(h * 7 + w)
+    hi = 65536 if dt == np.uint16 else 256
+    frames = [rng.integers(0, hi, (h, w, 3)).astype(dt) for _ in range(n)]
+    if n > 2:
+        frames[2] = frames[0].copy()     # exact ties: the first maximum must win
+    so, gs = run_oracle(oracle, frames, min_size=min_size, gen_kernel=a)
+    st = L.Stack(h, w, in_dtype=dt, out_dtype=np.uint16 if dt == np.uint16 else np.uint8, impl=impl, arith="separable",
+                 min_size=min_size, gen_kernel=a, batch_frames=batch)
+    assert st.levels == so.levels
+    for f in frames:
+        st.push_frame(f)
+    compare(L, st, so, gs[-1])
+    st.close()
+
+
+def test_separable_device_push_many_frames(L, oracle):
+    """34 frames resident in HBM: one full batch of 32 plus a tail, tiled kernel, synthetic generator."""
+    h, w, n = 420, 620, 34
+    frames = [oracle.synth_frame_numpy(h, w, f, n) for f in range(n)]
+    so, _ = run_oracle(oracle, frames)
+    buf = L.DeviceBuffer(h * w * 3 * n)
+    for i, f in enumerate(frames):
+        buf.upload(f, i * h * w * 3)
+    st = L.Stack(h, w, in_dtype=np.uint8, arith="separable")
+    st.push_frames_device(buf.ptr, n)
+    compare(L, st, so)
+    # the handle is reusable: a second, shorter stack after reset
+    st.reset()
+    st.push_frames_device(buf.ptr, 3)
+    so2, _ = run_oracle(oracle, frames[:3])
+    compare(L, st, so2)
+    st.close()
+    buf.free()
+
+
+def test_separable_close_to_exact_mode(L, oracle):
+    """Same stack in both arithmetic modes: fused images differ by at most 1 count, on few pixels."""
+    h, w, n = 300, 452, 5
+    frames = [oracle.synth_frame_numpy(h, w, f, n) for f in range(n)]
+    outs = []
+    for arith in ("exact", "separable"):
+        st = L.Stack(h, w, in_dtype=np.uint8, arith=arith)
+        for f in frames:
+            st.push_frame(f)
+        outs.append(st.finish().astype(np.int32))
+        st.close()
+    d = np.abs(outs[0] - outs[1])
+    assert d.max() <= 1 and (d != 0).mean() < 1e-3
+
+
+def test_separable_rejects_float64(L):
+    with pytest.raises(ValueError):
+        L.Stack(64, 64, arith="separable", float_type=L.MI_F64)
