@@ -7,8 +7,16 @@ A "step" is one whole focus-stack job over a device-resident synthetic stack:
 push all frames (pyramid build + per-level selection), base fusion, cross-GPU
 combine (N>1), collapse, abs/clip/truncating cast -- result left in HBM.
 Workload at N=1: BASELINE.json configs[1] -- 256 x 24 MP (4000x6000x3) fp32
-frames, 6 Laplacian levels + 63x94 base.  N>1: weak scaling, every rank holds
-its own 256-frame shard of a 256*N-frame stack (contiguous global indices).
+frames, 6 Laplacian levels + 63x94 base.
+  --scaling weak   (default) every rank holds its own 256-frame shard of a 256*N-frame stack;
+  --scaling strong BASELINE.json configs[2]: the SAME 256 frames, 256/N per rank (contiguous global indices).
+  --arith separable (default) north_star's LDS-staged 5-tap separable / polyphase form (MI_ARITH_SEPARABLE,
+                    tolerance-tested against float64, bit-exact against oracle/separable_oracle.c);
+  --arith exact     the reference-order 25-tap form, bit-identical to the oracle of the reference's own run.
+At N=1 the other mode is measured too (a few steps) and reported under "other_mode".
+After the timed region the last step's result is verified (outside the timing): level-0 arg-max against the
+generator's known band structure, and the level-0 state of a 128x128 corner against the CPU oracle fed the same
+frames cropped -> "verified".
 
 One JSON line on rank 0 (see DESIGN.md "Measurement" for every field).
 """
@@ -24,6 +32,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+CORNER, CORNER_OK = 128, 120   # crop fed to the oracle / part of it that does not feel the crop's own borders
 
 
 def parse():
@@ -31,36 +40,55 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--frames", type=int, default=256, help="frames per GPU")
+    ap.add_argument("--frames", type=int, default=256,
+                    help="frames per GPU (weak scaling) / frames of the whole stack (strong scaling)")
     ap.add_argument("--height", type=int, default=4000)
     ap.add_argument("--width", type=int, default=6000)
     ap.add_argument("--dtype", default="f32", choices=["u8", "u16", "f32"])
     ap.add_argument("--impl", default="auto", choices=["auto", "simple", "tiled"])
+    ap.add_argument("--arith", default="separable", choices=["separable", "exact"])
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--batch", type=int, default=0, help="frames per fused launch (0 = library default)")
     ap.add_argument("--source", default="device", choices=["device", "host"],
                     help="host: frames are pushed from host memory one by one (PCIe-inclusive rate; "
                          "never the headline value)")
+    ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--no-other-mode", action="store_true", help="do not also measure the other arithmetic mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=64,
                     help="frames of the CPU-baseline sample (about 10 s of CPU work at 24 MP on 16 cores)")
+    ap.add_argument("--cpu-refshaped", type=int, default=0,
+                    help="also time the reference-SHAPED restatement (all pyramids resident, full-size 25-tap "
+                         "filters) on this many frames (SURVEY 8(d) leg (i): 8; ~5 s per 24 MP frame; off by default)")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic.json"),
                     help="per-launch HBM bytes from the PMC passes (tools/pmc_traffic.py)")
     return ap.parse_args()
 
 
-def cpu_baseline(args):
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for ln in fh:
+                if ln.startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(args, total_frames):
     """The oracle's streaming C port, timed on this host's cores on a bounded sample of
     the same workload (same generator, same geometry, fewer frames)."""
     from oracle import oracle as orc
     orc.build()
-    n = min(args.cpu_frames, args.frames)
+    n = min(args.cpu_frames, total_frames)
     H, W = args.height, args.width
 
     def frame(f):   # generated one at a time, outside the timed sections
-        fr = orc.synth_frame_u8(H, W, f, args.frames)
+        fr = orc.synth_frame_u8(H, W, f, total_frames)
         return fr.astype(np.uint16) * 257 if args.dtype == "u16" else fr
     first = frame(0)
-    so = orc.StreamingOracle(H, W, first.dtype, keep_gauss=False)
+    so = orc.StreamingOracle(H, W, first.dtype, keep_gauss=False, arith=args.arith)
     dt = 0.0
     for f in range(n):
         fr = first if f == 0 else frame(f)
@@ -70,11 +98,55 @@ def cpu_baseline(args):
     t0 = time.perf_counter()
     so.finish()
     dt += time.perf_counter() - t0
-    frames = [first]
-    return {"value": n * H * W / dt / 1e6, "unit": "Mpixels/s", "cores": orc.lib().orc_num_threads(),
-            "kind": "port",
-            "sample": f"{n} of {args.frames} frames of {W}x{H} (same generator, values as "
-                      f"{frames[0].dtype}), oracle.StreamingOracle push+finish, {dt:.1f} s"}
+    out = {"value": n * H * W / dt / 1e6, "unit": "Mpixels/s", "cores": orc.lib().orc_num_threads(),
+           "kind": "port", "cpu_model": cpu_model(), "os_cpu_count": os.cpu_count(),
+           "sample": f"{n} of {total_frames} frames of {W}x{H} (same generator, values as {first.dtype}; the GPU leg "
+                     f"holds the same values as {args.dtype}), oracle.StreamingOracle(arith={args.arith}) push+finish, "
+                     f"OpenMP on {orc.lib().orc_num_threads()} threads, {dt:.1f} s"}
+    if args.cpu_refshaped > 0:
+        # SURVEY 8(d) leg (i): the reference's own structure (per-channel full-size 25-tap filters, zero-stuffed
+        # expand, every frame's pyramid resident, argmax over the frame axis) on a reduced stack
+        m = args.cpu_refshaped
+        frames = [first] + [frame(f) for f in range(1, m)]
+        t0 = time.perf_counter()
+        orc.RefShaped().stack(frames)
+        dr = time.perf_counter() - t0
+        out["reference_shaped"] = {"value": m * H * W / dr / 1e6, "unit": "Mpixels/s", "frames": m,
+                                   "seconds": dr, "note": "oracle.RefShaped (NumPy control flow of pyramid.py, "
+                                   "filter primitives in C/OpenMP); linear in the frame count"}
+    return out
+
+
+def verify(L, st, args, total_frames, world):
+    """Checks on the state the LAST timed step left behind (rank 0; outside the timed region)."""
+    from oracle import oracle as orc
+    orc.build()
+    H, W = args.height, args.width
+    res = {}
+    ok = True
+    if world == 1:
+        idx = st.tap(L.TAP_INDEX, 0)
+        band = (np.arange(H, dtype=np.int64) * total_frames // H)[:, None]
+        res["band_match"] = float((idx == band).mean())
+        ok &= res["band_match"] > 0.9
+    c = min(CORNER, H, W)
+    good = c - (CORNER - CORNER_OK)
+    so = orc.StreamingOracle(c, c, np.uint16 if args.dtype == "u16" else np.uint8, levels=1, arith=args.arith)
+    for f in range(total_frames):
+        crop = orc.synth_crop_u8(H, W, f, total_frames, 0, 0, c, c)
+        so.push_frame(crop.astype(np.uint16) * 257 if args.dtype == "u16" else crop)
+    lap = st.tap(L.TAP_FUSED_LAP, 0)
+    eq = bool(np.array_equal(lap[:good, :good], so.best_lap[0][:good, :good]))
+    if world == 1:
+        eq &= bool(np.array_equal(st.tap(L.TAP_ENERGY, 0)[:good, :good], so.best_e[0][:good, :good]))
+        eq &= bool(np.array_equal(idx[:good, :good], so.best_idx[0][:good, :good]))
+    res["corner_equal"] = eq
+    res["corner"] = (f"level-0 fused Laplacian{' / energy / arg-max' if world == 1 else ''} of the top-left "
+                     f"{good}x{good} pixels == oracle.StreamingOracle(arith={args.arith}) fed the {total_frames} "
+                     f"generator frames cropped to {c}x{c}")
+    ok &= eq
+    res["ok"] = bool(ok)
+    return res
 
 
 def main():
@@ -91,6 +163,7 @@ def main():
     # the host driver only supports dmabuf IPC: without this RCCL's buffer sharing across processes fails
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     force_dist = os.environ.get("MI_BENCH_FORCE_COMBINE") == "1"  # exercise the combine at world 1
+    backend = os.environ.get("MI_BENCH_BACKEND", "nccl")
     if world > 1 or force_dist:
         # torch ships its own HIP runtime: it must be loaded BEFORE libmi355stack.so pulls in
         # /opt/rocm's, otherwise the process holds two runtimes and torch sees no GPU
@@ -107,110 +180,155 @@ def main():
         torch.cuda.set_device(local_rank)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
+        dist.init_process_group(backend, rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
     device = local_rank
 
     dt = {"u8": np.uint8, "u16": np.uint16, "f32": np.float32}[args.dtype]
-    H, W, F = args.height, args.width, args.frames
+    H, W = args.height, args.width
+    if args.scaling == "strong":
+        if args.frames % world:
+            raise SystemExit(f"--scaling strong: {args.frames} frames do not split over {world} ranks")
+        F, total_frames = args.frames // world, args.frames
+    else:
+        F, total_frames = args.frames, args.frames * world
     per = H * W * 3 * np.dtype(dt).itemsize
-    total_frames = F * world
     buf = L.DeviceBuffer(per * F, device)
     L.synth_frames_device(buf.ptr, dt, H, W, rank * F, F, total_frames, device=device)
     impl = {"auto": L.IMPL_AUTO, "simple": L.IMPL_SIMPLE, "tiled": L.IMPL_TILED}[args.impl]
-    st = L.Stack(H, W, in_dtype=dt, out_dtype=np.uint16 if args.dtype == "u16" else np.uint8,
-                 device=device, impl=impl, batch_frames=args.batch)
-    st.set_first_index(rank * F)
-    combiner = None
-    if world > 1 or force_dist:
-        from shinestacker_amd import multigpu
-        combiner = multigpu.Combiner(st, dist.group.WORLD)
-
-    def barrier():
-        if world > 1 or force_dist:
-            import torch
-            dist.barrier()
-            torch.cuda.synchronize()
-        st.sync()
+    out_dt = np.uint16 if args.dtype == "u16" else np.uint8
 
     host_frames = None
     if args.source == "host":
         nh = min(F, 8)  # a few distinct host frames, cycled
         host_frames = [buf.download((H, W, 3), dt, offset=i * per) for i in range(nh)]
 
-    def step():
-        st.reset()
+    def barrier(st):
+        if world > 1 or force_dist:
+            import torch
+            dist.barrier()
+            torch.cuda.synchronize()
+        st.sync()
+
+    def measure(arith, steps, warmup):
+        st = L.Stack(H, W, in_dtype=dt, out_dtype=out_dt, device=device, impl=impl, batch_frames=args.batch, arith=arith)
         st.set_first_index(rank * F)
-        if host_frames is not None:
-            for i in range(F):
-                st.push_frame(host_frames[i % len(host_frames)])
-        else:
-            st.push_frames_device(buf.ptr, F)
-        if combiner is not None:
-            # arg-max-with-payload exchange over xGMI; the fused image needs the winners' payloads only, so the
-            # winner indices are not exchanged and the winners' energies stay on the chunk owners
-            combiner.combine(with_index=False, root_energy=False)
-            if rank == 0:
+        combiner = None
+        if world > 1 or force_dist:
+            from shinestacker_amd import multigpu
+            combiner = multigpu.Combiner(st, dist.group.WORLD)
+        phase = {"compute": 0.0, "combine": 0.0, "collapse": 0.0}
+
+        def step(timed=False):
+            st.reset()
+            st.set_first_index(rank * F)
+            t0 = time.perf_counter()
+            if host_frames is not None:
+                for i in range(F):
+                    st.push_frame(host_frames[i % len(host_frames)])
+            else:
+                st.push_frames_device(buf.ptr, F)
+            if combiner is not None:
+                # the exchange needs this rank's state complete: that wait is the compute time of the step
+                st.sync()
+                t1 = time.perf_counter()
+                combiner.combine(with_index=False, root_energy=False)
+                t2 = time.perf_counter()
+                if rank == 0:
+                    st.finish_device()
+                    st.sync()
+                t3 = time.perf_counter()
+                if timed:
+                    phase["compute"] += t1 - t0
+                    phase["combine"] += t2 - t1
+                    phase["collapse"] += t3 - t2
+            else:
                 st.finish_device()
-        else:
-            st.finish_device()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    st.profile(True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt_s = time.perf_counter() - t0
-    if world > 1 or force_dist:
-        import torch
-        t = torch.tensor([dt_s], device=f"cuda:{local_rank}", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt_s = float(t.item())
+        for _ in range(warmup):
+            step()
+        barrier(st)
+        st.profile(True)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step(timed=True)
+        barrier(st)
+        dt_s = time.perf_counter() - t0
+        if world > 1 or force_dist:
+            import torch
+            t = torch.tensor([dt_s], device=f"cuda:{local_rank}", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt_s = float(t.item())
+        prof = {k: st.profile_get(v) for k, v in (("level0", L.PROF_LEVEL0), ("levels", L.PROF_LEVEL),
+                                                  ("base", L.PROF_BASE), ("collapse", L.PROF_COLLAPSE))}
+        return st, dt_s, prof, phase
 
-    prof = {k: st.profile_get(v) for k, v in (("level0", L.PROF_LEVEL0), ("levels", L.PROF_LEVEL),
-                                              ("base", L.PROF_BASE), ("collapse", L.PROF_COLLAPSE))}
+    st, dt_s, prof, phase = measure(args.arith, args.steps, args.warmup)
     tiled = prof["level0"][1] > 0
     ms_level, n_level, bytes_level = prof["level0"] if tiled else prof["levels"]
     # read level 0 once + 36 B per pixel of every coarser Gaussian level
     job_bytes_per_frame = float(np.dtype(dt).itemsize * 3 * H * W +
                                 36 * sum(h * w for (h, w) in st.shapes[1:]))
+
+    def roofline(ms_level, n_level, bytes_level):
+        return (bytes_level / n_level) / (ms_level / n_level * 1e-3) / 1e9 if n_level else 0.0
+
     if rank == 0:
         ms_per_step = dt_s / args.steps * 1e3
         value = total_frames * H * W * args.steps / dt_s / 1e6
-        achieved = (bytes_level / n_level) / (ms_level / n_level * 1e-3) / 1e9 if n_level else 0.0
+        achieved = roofline(ms_level, n_level, bytes_level)
         traffic = None
         try:
             with open(args.traffic_json) as fh:
-                traffic = json.load(fh).get("hbm_bytes_per_launch")
-        except OSError:
+                tj = json.load(fh)
+            traffic = tj.get(args.arith, tj).get("hbm_bytes_per_launch")
+        except (OSError, AttributeError, ValueError):
             pass
+        kernel = {"separable": "level_sep<level 0> (stage + separable reduce + gray Laplacian + separable energy + "
+                               "select, one launch per frame batch)",
+                  "exact": "level_fused<level 0> (stage+reduce+laplacian+energy+select, one launch per frame batch)"}
+        breakdown = {k: v[0] / args.steps for k, v in prof.items()}
+        if world > 1 or force_dist:
+            breakdown.update({f"{k}_ms_host": v / args.steps * 1e3 for k, v in phase.items()})
         line = {
             "metric": "Mpixels/s fused (pyramid build+select+collapse)",
             "value": value, "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": args.scaling, "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{total_frames}x{W}x{H}x3 {args.dtype} frames resident in "
                                    f"HBM, {st.levels}-level Laplacian pyramid fusion "
-                                   f"(BASELINE.json configs[1])",
-                       "frames_per_gpu": F, "source": args.source, "impl": args.impl if args.impl != "auto" else ["auto", "simple", "tiled"][st.params.impl],
+                                   f"(BASELINE.json configs[{1 if world == 1 or args.scaling == 'weak' else 2}])",
+                       "frames_per_gpu": F, "source": args.source, "arith": args.arith,
+                       "impl": args.impl if args.impl != "auto" else ["auto", "simple", "tiled"][st.params.impl],
                        "device": L.device_name(device),
-                       "parallelism": f"frames sharded over {world} GPU(s)"},
+                       "parallelism": f"{total_frames} frames in contiguous blocks of {F} over {world} GPU(s)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": ("level_fused<level 0> (stage+reduce+laplacian+energy+select, "
-                                    "one launch per frame batch)") if tiled else
-                                   "simple impl: all level kernels of one frame",
+                         "kernel": kernel[args.arith] if tiled else "simple impl: all level kernels of one frame",
                          "algorithmic_bytes_per_launch": bytes_level / max(n_level, 1),
                          "avg_launch_ms": ms_level / max(n_level, 1), "launches": n_level},
-            "breakdown_ms_per_step": {k: v[0] / args.steps for k, v in prof.items()},
+            "breakdown_ms_per_step": breakdown,
             "job_roofline_frac": (job_bytes_per_frame * total_frames * args.steps / dt_s)
                                  / (HBM_PEAK_GBS * 1e9 * world),
         }
+        if not args.no_verify:
+            v = verify(L, st, args, total_frames, world)
+            line["verified"] = v.pop("ok")
+            line["verify"] = v
+    st.close()
+    if world == 1 and not force_dist and not args.no_other_mode and args.source == "device":
+        other = "exact" if args.arith == "separable" else "separable"
+        k2 = max(1, min(3, args.steps))
+        st2, dt2, prof2, _ = measure(other, k2, 1)
+        ms2, n2, b2 = prof2["level0"] if prof2["level0"][1] > 0 else prof2["levels"]
+        line["other_mode"] = {"arith": other, "value": total_frames * H * W * k2 / dt2 / 1e6, "unit": "Mpixels/s",
+                              "steps": k2, "ms_per_step": dt2 / k2 * 1e3,
+                              "roofline_frac": roofline(ms2, n2, b2) / HBM_PEAK_GBS,
+                              "job_roofline_frac": (job_bytes_per_frame * total_frames * k2 / dt2) / (HBM_PEAK_GBS * 1e9)}
+        st2.close()
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args)
+            line["cpu_baseline"] = cpu_baseline(args, total_frames)
         if world > 1 or force_dist:
             # RCCL prints its version banner through C stdio when NCCL_DEBUG is set (it is, on the GPU boxes): push
             # that out first, so that the JSON line is the last line of rank 0's stdout

@@ -100,6 +100,8 @@ def lib():
                                           _f32p, _i32p, _i32p]
         L.orc_base_fuse_f32.argtypes = [_f32p, C.c_size_t, _i32p, _i32p, _f32p]
         L.orc_synth_frame_u8.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32]
+        L.orc_synth_crop_u8.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_int, C.c_int,
+                                        C.c_int, C.c_int]
         L.orc_to_f32_u8.argtypes = [_u8p, C.c_size_t, _f32p]
         L.orc_to_f32_u16.argtypes = [_u16p, C.c_size_t, _f32p]
         L.orc_sep_reduce_f32.argtypes = [_f32p, C.c_int, C.c_int, _f32p, _f32p]
@@ -443,6 +445,13 @@ def synth_frame_u8(h, w, f, n, seed=20250824):
     """SURVEY.md 8(d) config-2 generator (C version)."""
     out = np.empty((h, w, 3), np.uint8)
     lib().orc_synth_frame_u8(out, h, w, f, n, seed)
+    return out
+
+
+def synth_crop_u8(H, W, f, n, y0, x0, h, w, seed=20250824):
+    """rows [y0, y0+h) x columns [x0, x0+w) of frame f of the H x W config-2 generator."""
+    out = np.empty((h, w, 3), np.uint8)
+    lib().orc_synth_crop_u8(out, H, W, f, n, seed, y0, x0, h, w)
     return out
 
 

@@ -419,6 +419,28 @@ static inline uint32_t lowbias32(uint32_t x) {
     x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
     return x;
 }
+/* rows [y0, y0+h) x columns [x0, x0+w) of frame f of the H x W generator (checks on a corner of a full-size frame) */
+ORC_API void orc_synth_crop_u8(uint8_t* out, int H, int W, int f, int N, uint32_t seed, int y0, int x0, int h, int w) {
+    (void)W;
+#pragma omp parallel for schedule(static)
+    for (int yy = 0; yy < h; ++yy)
+        for (int xx = 0; xx < w; ++xx)
+            for (int c = 0; c < 3; ++c) {
+                const int y = y0 + yy, x = x0 + xx;
+                uint32_t hsh = lowbias32(seed ^ ((uint32_t)f * 0x9E3779B1U) ^ ((uint32_t)y * 0x85EBCA77U) ^
+                                         ((uint32_t)x * 0xC2B2AE3DU) ^ (uint32_t)c);
+                int noise = (int)(hsh >> 24) - 128;
+                int band = (int)(((int64_t)y * N) / H);
+                int d = band - f; if (d < 0) d = -d;
+                int amp = 64 >> (d < 6 ? d : 6);
+                int base = ((3 * x + 5 * y + 17 * c) & 127) + 64;
+                int v = base + ((noise * amp) >> 7);
+                if (v < 0) v = 0;
+                if (v > 255) v = 255;
+                out[((size_t)yy * w + xx) * 3 + c] = (uint8_t)v;
+            }
+}
+
 ORC_API void orc_synth_frame_u8(uint8_t* out, int H, int W, int f, int N, uint32_t seed) {
 #pragma omp parallel for schedule(static)
     for (int y = 0; y < H; ++y)
