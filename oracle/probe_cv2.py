@@ -1,0 +1,82 @@
+"""oracle/probe_cv2.py -- pin the cv2 primitives the day OpenCV is importable.   python -m oracle.probe_cv2
+
+TEST INFRASTRUCTURE.  The oracle restates filter2D, cvtColor(BGR2GRAY) on float32 and on integers, warpAffine,
+GaussianBlur and resize(INTER_AREA) from OpenCV's published algorithms [from memory] because OpenCV is neither
+vendored in the reference (pyproject.toml:26, unpinned) nor installed in the build image: "parity unpinned".
+When `import cv2` works, this script runs the REAL primitives on the golden inputs of tests/golden/, reports for
+each one whether the restatement matches bit for bit (filter2D: which of use_fma in {1, 0}, or neither), and writes
+the real outputs to tests/golden/cv2_<primitive>.npz so that the fact survives in the repository.  Without cv2 it
+says so and exits 0 (nothing to pin)."""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def main():
+    try:
+        import cv2
+    except Exception as e:  # noqa: BLE001
+        print(f"probe_cv2: OpenCV is not importable here ({type(e).__name__}: {e}); the cv2 primitives stay "
+              "'parity unpinned' (oracle/pyramid_oracle.c header).  Nothing written.")
+        return 0
+    sys.path.insert(0, ROOT)
+    from oracle import oracle as orc
+    orc.build()
+    report = {"cv2_version": cv2.__version__, "build": cv2.getBuildInformation().split("\n")[0:1]}
+    with np.load(os.path.join(GOLDEN, "g1_u8.npz")) as z:
+        frames = z["frames"]
+    img = frames[0].astype(np.float32)
+    k2d = orc.gen_kernel_2d(0.4)
+
+    # ---- filter2D (pyramid.py:24-25): float32 image, float64 kernel, REFLECT101
+    real = np.stack([cv2.filter2D(np.ascontiguousarray(img[:, :, c]), -1, k2d, borderType=cv2.BORDER_REFLECT101)
+                     for c in range(3)], axis=-1)
+    match = [fma for fma in (1, 0)
+             if all(np.array_equal(orc.filter2D(np.ascontiguousarray(img[:, :, c]), k2d, use_fma=bool(fma)), real[:, :, c])
+                    for c in range(3))]
+    report["filter2D"] = {"matches_use_fma": match, "max_abs_diff_fma": float(max(
+        np.abs(orc.filter2D(np.ascontiguousarray(img[:, :, c]), k2d, True) - real[:, :, c]).max() for c in range(3)))}
+    np.savez_compressed(os.path.join(GOLDEN, "cv2_filter2D.npz"), src=img, kernel=k2d, dst=real)
+
+    # ---- cvtColor BGR2GRAY, float32 (pyramid.py:49) and uint8 (utils.py:37-43)
+    lap = (img - real)
+    real_g = cv2.cvtColor(lap, cv2.COLOR_BGR2GRAY)
+    report["cvtColor_f32"] = {"matches_use_fma": [f for f in (1, 0) if np.array_equal(orc.bgr2gray_f32(lap, bool(f)), real_g)]}
+    real_g8 = cv2.cvtColor(frames[0], cv2.COLOR_BGR2GRAY)
+    report["cvtColor_u8"] = {"matches": bool(np.array_equal(orc.bgr2gray_int(frames[0]), real_g8))}
+    np.savez_compressed(os.path.join(GOLDEN, "cv2_cvtColor.npz"), src_f32=lap, dst_f32=real_g, src_u8=frames[0], dst_u8=real_g8)
+
+    # ---- warpAffine + mask + GaussianBlur composite (align.py:238-251)
+    h, w = frames[0].shape[:2]
+    M = np.array([[0.9998, -0.0123, 3.37], [0.0123, 0.9998, -2.21]], np.float32)
+    real_w = cv2.warpAffine(frames[0], M, (w, h), borderMode=cv2.BORDER_REPLICATE)
+    mask = cv2.warpAffine(np.ones_like(frames[0]), M, (w, h), borderMode=cv2.BORDER_CONSTANT, borderValue=0)
+    blurred = cv2.GaussianBlur(real_w, (21, 21), sigmaX=50)
+    comp = real_w.copy()
+    comp[cv2.cvtColor(mask, cv2.COLOR_BGR2GRAY) == 0] = blurred[cv2.cvtColor(mask, cv2.COLOR_BGR2GRAY) == 0]
+    report["warpAffine"] = {"matches": bool(np.array_equal(orc.warp_affine(frames[0], M, border_mode=1), real_w))}
+    report["warp+blur_composite"] = {"matches": bool(np.array_equal(orc.warp_affine(frames[0], M), comp))}
+    np.savez_compressed(os.path.join(GOLDEN, "cv2_warp.npz"), src=frames[0], M=M, warp=real_w, mask=mask, composite=comp)
+
+    # ---- resize INTER_AREA (utils.py:79-86)
+    res = {}
+    for s in (2, 4, 8):
+        real_r = cv2.resize(frames[0], (0, 0), fx=1 / s, fy=1 / s, interpolation=cv2.INTER_AREA)
+        mine = orc.resize_area_int(frames[0], s)
+        res[str(s)] = bool(mine.shape == real_r.shape and np.array_equal(mine, real_r))
+        np.savez_compressed(os.path.join(GOLDEN, f"cv2_resize_area_{s}.npz"), src=frames[0], dst=real_r)
+    report["resize_INTER_AREA"] = res
+
+    print(json.dumps(report, indent=1))
+    with open(os.path.join(GOLDEN, "cv2_probe_report.json"), "w") as fh:
+        json.dump(report, fh, indent=1)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -183,7 +183,8 @@ class AlignFrames(SubAction):
 
     def begin(self, process):
         self.process = process
-        self.n_matches = np.zeros(process.counts)
+        # indexed by the GLOBAL frame index: a sharded process counts only its own block (process.counts)
+        self.n_matches = np.zeros(len(process.filenames))
 
     def run_frame(self, idx, ref_idx, img_0):
         if idx == self.process.ref_idx:

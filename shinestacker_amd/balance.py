@@ -247,7 +247,8 @@ class BalanceFrames(SubAction):
         self.correction.process = process
         img = read_img(self.process.input_full_path + "/" + self.process.filenames[process.ref_idx])
         self.shape = img.shape
-        self.correction.begin(img, self.process.counts, process.ref_idx)
+        # per-frame tables are indexed by the GLOBAL frame index (a sharded process counts only its own block)
+        self.correction.begin(img, len(self.process.filenames), process.ref_idx)
 
     def end(self):
         self.process.print_message(' ' * 60)

@@ -3,12 +3,15 @@
 Same contract as the reference's read_img / write_img: extension dispatch, jpg ->
 8-bit, tif/tiff/png -> stored depth, arrays are H x W x 3 **BGR** like cv2.imread.
 Codecs are not a GPU target: OpenCV is used when it is
-installed, otherwise Pillow (8-bit) plus a small baseline-TIFF codec for 16-bit
-RGB (uncompressed strips -- what the reference writes with
-IMWRITE_TIFF_COMPRESSION=1).
+installed, otherwise Pillow (8-bit) plus two small codecs for the 16-bit depths
+Pillow cannot hold as RGB: baseline TIFF (uncompressed strips -- what the
+reference writes with IMWRITE_TIFF_COMPRESSION=1) and 16-bit PNG (zlib; all five
+scan-line filters on read).  A 16-bit image never loses depth silently: JPEG,
+which cannot hold it, raises.
 """
 import os
 import struct
+import zlib
 
 import numpy as np
 
@@ -92,6 +95,97 @@ def _tiff_write_rgb(path, rgb):
         fh.write(struct.pack("<HHH", bits, bits, bits))
 
 
+_PNG_SIG = b"\x89PNG\r\n\x1a\n"
+
+
+def _png_chunks(data):
+    pos = 8
+    while pos + 8 <= len(data):
+        n, typ = struct.unpack(">I4s", data[pos:pos + 8])
+        yield typ, data[pos + 8:pos + 8 + n]
+        pos += 12 + n
+
+
+def _png_unfilter(raw, h, w, bpp):
+    """Undo the PNG scan-line filters (0 None, 1 Sub, 2 Up, 3 Average, 4 Paeth) of h rows of w pixels of bpp bytes.
+    Pixel (r, x) depends on its left, upper and upper-left neighbours only, so every anti-diagonal is one vector step."""
+    rows = np.frombuffer(raw, np.uint8, count=h * (1 + w * bpp)).reshape(h, 1 + w * bpp)
+    ft = rows[:, 0].astype(np.int64)
+    px = rows[:, 1:].reshape(h, w, bpp).copy()
+    if not ft.any():
+        return px
+    if np.all((ft == 0) | (ft == 2)):            # what this module writes: cumulative sums down the columns
+        return _png_up_only(px, ft)
+    out = np.zeros((h + 1, w + 1, bpp), np.int64)   # one row / column of zeros in front
+    out[1:, 1:] = px
+    rr_all = np.arange(h)
+    for d in range(h + w - 1):
+        r = rr_all[max(0, d - w + 1):min(h, d + 1)]
+        x = d - r
+        a, b, c = out[r + 1, x], out[r, x + 1], out[r, x]     # left, up, upper-left (already reconstructed)
+        f = ft[r][:, None]
+        pa, pb, pc = np.abs(b - c), np.abs(a - c), np.abs(a + b - 2 * c)
+        paeth = np.where((pa <= pb) & (pa <= pc), a, np.where(pb <= pc, b, c))
+        pred = np.select([f == 1, f == 2, f == 3, f == 4], [a, b, (a + b) >> 1, paeth], 0)
+        out[r + 1, x + 1] = (out[r + 1, x + 1] + pred) & 0xff
+    return out[1:, 1:].astype(np.uint8)
+
+
+def _png_up_only(px, ft):
+    """rows filtered with None (0) or Up (2) only: a row is itself or itself plus the reconstructed row above"""
+    out = px.copy()
+    for r in range(1, out.shape[0]):
+        if ft[r] == 2:
+            out[r] += out[r - 1]
+    return out
+
+
+def _png_read16(path):
+    """16-bit PNG (gray, RGB, with or without alpha, non-interlaced) -> H x W x 3 RGB uint16, or None when the file
+    is not one (8-bit and palette files go through Pillow)."""
+    with open(path, "rb") as fh:
+        data = fh.read()
+    if data[:8] != _PNG_SIG:
+        return None
+    ihdr, idat = None, []
+    for typ, body in _png_chunks(data):
+        if typ == b"IHDR":
+            ihdr = struct.unpack(">IIBBBBB", body)
+        elif typ == b"IDAT":
+            idat.append(body)
+    if ihdr is None or ihdr[2] != 16:
+        return None
+    w, h, _bits, ctype, _comp, _filt, interlace = ihdr
+    nch = {0: 1, 2: 3, 4: 2, 6: 4}.get(ctype)
+    if nch is None or interlace:
+        raise RuntimeError(f"{path}: 16-bit PNG of colour type {ctype} / interlace {interlace} needs OpenCV")
+    px = _png_unfilter(zlib.decompress(b"".join(idat)), h, w, 2 * nch)
+    a = px.reshape(h, w, nch, 2).astype(np.uint16)
+    a = (a[..., 0] << 8) | a[..., 1]
+    if nch <= 2:
+        return np.repeat(a[:, :, :1], 3, 2)      # gray (+ alpha dropped, as cv2.imread's 3-channel form does not apply:
+    return np.ascontiguousarray(a[:, :, :3])     # IMREAD_UNCHANGED keeps alpha; the stack path takes 3 channels)
+
+
+def _png_write16(path, rgb):
+    """16-bit RGB PNG: big-endian samples, Up filter, zlib level 1 (cv2.imwrite's default speed setting)."""
+    h, w, _ = rgb.shape
+    be = np.ascontiguousarray(rgb).astype(">u2").view(np.uint8).reshape(h, w * 6)
+    filt = be.copy()
+    filt[1:] -= be[:-1]
+    rows = np.empty((h, 1 + w * 6), np.uint8)
+    rows[:, 0] = 2
+    rows[0, 0] = 0
+    rows[:, 1:] = filt
+    rows[0, 1:] = be[0]
+
+    def chunk(typ, body):
+        return struct.pack(">I", len(body)) + typ + body + struct.pack(">I", zlib.crc32(typ + body) & 0xffffffff)
+    with open(path, "wb") as fh:
+        fh.write(_PNG_SIG + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 16, 2, 0, 0, 0)) +
+                 chunk(b"IDAT", zlib.compress(rows.tobytes(), 1)) + chunk(b"IEND", b""))
+
+
 def read_img(file_path):
     """H x W x 3 BGR uint8/uint16 array, or None for an unsupported extension.
     RuntimeError when the file does not exist (utils.py:12-13)."""
@@ -105,6 +199,10 @@ def read_img(file_path):
             _cv2.imread(file_path, _cv2.IMREAD_UNCHANGED)
     if ext in ("tiff", "tif"):
         rgb = _tiff_read_rgb16(file_path)
+        if rgb is not None:
+            return np.ascontiguousarray(rgb[:, :, ::-1])
+    if ext == "png":
+        rgb = _png_read16(file_path)
         if rgb is not None:
             return np.ascontiguousarray(rgb[:, :, ::-1])
     from PIL import Image
@@ -136,9 +234,13 @@ def write_img(file_path, img):
     if ext in ("tiff", "tif"):
         _tiff_write_rgb(file_path, rgb)
         return
-    from PIL import Image
     if rgb.dtype == np.uint16:
-        rgb = (rgb >> 8).astype(np.uint8)  # Pillow has no 16-bit RGB; TIFF keeps full depth
+        if ext == "png":
+            _png_write16(file_path, rgb)
+            return
+        # JPEG holds 8 bits per sample: writing would drop depth silently
+        raise ValueError(f"cannot write a 16-bit image to '{file_path}': use .tif or .png")
+    from PIL import Image
     if ext in ("jpeg", "jpg"):
         Image.fromarray(rgb).save(file_path, quality=100, subsampling=0)
     elif ext == "png":

@@ -173,3 +173,35 @@ def test_project_align_balance_stack_on_files(hiplib, oracle, tmp_path):
     for a in results[0][0]:
         so.push_frame(a)
     assert np.array_equal(results[0][1], so.finish())
+
+
+def test_project_align_balance_sharded_over_ranks(hiplib, oracle, tmp_path):
+    """The same CombinedActions[AlignFrames, BalanceFrames] with the frames split over two ranks (shard=(rank, 2),
+    SURVEY 8(e)): the per-frame tables of the sub-actions are indexed by the GLOBAL frame index, so rank 1 (frames 3, 4
+    of 5) must not run off arrays sized by its own block; the files equal the unsharded run's."""
+    from shinestacker_amd import AlignFrames, BalanceFrames, CombinedActions, StackJob
+    from shinestacker_amd.align import ecc_estimator
+    from shinestacker_amd.imageio import read_img, write_img
+    from test_gpu_ecc import make_pair, similarity
+    hiplib.require_device()
+    work = str(tmp_path)
+    os.makedirs(os.path.join(work, "in"))
+    h, w = 192, 256
+    for f in range(5):
+        d = f - 2
+        T = similarity(0.1 * d, 1 + 3e-4 * d, 1.1 * d, -0.7 * d, (w - 1) / 2, (h - 1) / 2)
+        ref, mov = make_pair(oracle, T, h=h, w=w, seed=5, noise=2.0)
+        write_img(os.path.join(work, "in", f"f{f}.png"), np.clip((ref if d == 0 else mov) * (1.0 + 0.08 * d), 0, 255).astype(np.uint8))
+
+    def run(out, shard):
+        job = StackJob("job", work, input_path="in")
+        job.add_action(CombinedActions("align", [AlignFrames(estimator=ecc_estimator(), subsample=1), BalanceFrames(subsample=1)],
+                                       output_path=out, shard=shard))
+        job.run()
+    run("whole", None)
+    for rank in (0, 1):
+        run("sharded", (rank, 2))
+    names = sorted(os.listdir(os.path.join(work, "whole")))
+    assert sorted(n for n in os.listdir(os.path.join(work, "sharded")) if not n.startswith(".")) == names and len(names) == 5
+    for n in names:
+        assert np.array_equal(read_img(os.path.join(work, "whole", n)), read_img(os.path.join(work, "sharded", n))), n

@@ -290,3 +290,66 @@ def test_combined_actions_sharded_over_ranks(workdir):
     assert files == sorted(os.listdir(os.path.join(workdir, "input")))
     with pytest.raises(InvalidOptionError):
         CombinedActions("combo", [Recorder()], step_process=True, shard=(0, 2))
+
+
+def test_align_frames_sharded_indexes_by_global_frame(workdir, monkeypatch):
+    """AlignFrames inside a sharded CombinedActions sized its per-frame table by the rank's own block and
+    indexed it with the global frame index (IndexError on every rank > 0).  CPU form: estimator injected, the device
+    apply step replaced by the identity."""
+    from shinestacker_amd import AlignFrames
+    import shinestacker_amd.align as al
+    monkeypatch.setattr(al, "apply_transform", lambda img, m, cfg, device=0: img)
+    est = lambda a, b, fc, mc, ac: (500, np.array([[1.0, 0.0, 0.0], [0.0, 1.0, 0.0]]))
+    os.makedirs(os.path.join(workdir, "al_sh"))
+    n_in = len(os.listdir(os.path.join(workdir, "input")))
+    for rank in range(2):
+        act = AlignFrames(estimator=est, subsample=1)
+        job = StackJob("job", workdir, input_path="input")
+        job.add_action(CombinedActions("combo", [act], output_path="al_sh", shard=(rank, 2)))
+        job.run()
+        assert len(act.n_matches) == n_in
+        blk = range(0, n_in // 2 + n_in % 2) if rank == 0 else range(n_in // 2 + n_in % 2, n_in)
+        assert all(act.n_matches[i] == 500 for i in blk if i != n_in // 2)
+    assert sorted(f for f in os.listdir(os.path.join(workdir, "al_sh")) if not f.startswith(".")) == \
+        sorted(os.listdir(os.path.join(workdir, "input")))
+
+
+def test_png16_roundtrip_and_all_scanline_filters(tmp_path):
+    """without OpenCV a 16-bit PNG lost its depth silently (Pillow has no 16-bit RGB).  The module's own
+    zlib codec keeps it (utils.py:11-30: png is read IMREAD_UNCHANGED); a foreign file using every scan-line filter
+    decodes to the same pixels; JPEG, which cannot hold 16 bits, raises instead of shifting."""
+    import struct
+    import zlib
+    from shinestacker_amd import imageio as io
+    rng = np.random.default_rng(3)
+    a = rng.integers(0, 65536, (23, 31, 3)).astype(np.uint16)
+    p = str(tmp_path / "a.png")
+    io.write_img(p, a)
+    b = io.read_img(p)
+    assert b.dtype == np.uint16 and np.array_equal(a, b)
+    # the same image encoded with filters None/Sub/Up/Average/Paeth in turn (PNG spec 9.2)
+    h, w = a.shape[:2]
+    be = np.ascontiguousarray(a[:, :, ::-1]).astype(">u2").view(np.uint8).reshape(h, w * 6).astype(np.int64)
+    rows, prev, bpp = bytearray(), np.zeros(w * 6, np.int64), 6
+    for r in range(h):
+        f, cur, out = r % 5, be[r], np.zeros(w * 6, np.int64)
+        for i in range(w * 6):
+            A, B, Cc = (cur[i - bpp] if i >= bpp else 0), prev[i], (prev[i - bpp] if i >= bpp else 0)
+            pa, pb, pc = abs(B - Cc), abs(A - Cc), abs(A + B - 2 * Cc)
+            pred = [0, A, B, (A + B) // 2, A if pa <= pb and pa <= pc else (B if pb <= pc else Cc)][f]
+            out[i] = (cur[i] - pred) & 255
+        rows += bytes([f]) + bytes(out.astype(np.uint8))
+        prev = cur
+
+    def chunk(t, body):
+        return struct.pack(">I", len(body)) + t + body + struct.pack(">I", zlib.crc32(t + body) & 0xffffffff)
+    q = str(tmp_path / "foreign.png")
+    with open(q, "wb") as fh:
+        fh.write(io._PNG_SIG + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 16, 2, 0, 0, 0)) +
+                 chunk(b"IDAT", zlib.compress(bytes(rows))) + chunk(b"IEND", b""))
+    assert np.array_equal(io.read_img(q), a)
+    with pytest.raises(ValueError):
+        io.write_img(str(tmp_path / "x.jpg"), a)
+    a8 = (a >> 8).astype(np.uint8)
+    io.write_img(str(tmp_path / "b.png"), a8)
+    assert np.array_equal(io.read_img(str(tmp_path / "b.png")), a8)
