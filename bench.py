@@ -60,6 +60,10 @@ def parse():
     ap.add_argument("--cpu-refshaped", type=int, default=0,
                     help="also time the reference-SHAPED restatement (all pyramids resident, full-size 25-tap "
                          "filters) on this many frames (SURVEY 8(d) leg (i): 8; ~5 s per 24 MP frame; off by default)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU: every rank runs the CPU oracle on its block of a small stack and the ranks combine over "
+                         "gloo with the same protocol (multigpu.combine_winners) -- exercises the launch contract, the "
+                         "weak / strong split, the timing reduction and the JSON fields on a box without GPUs")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic.json"),
                     help="per-launch HBM bytes from the PMC passes (tools/pmc_traffic.py)")
     return ap.parse_args()
@@ -149,6 +153,95 @@ def verify(L, st, args, total_frames, world):
     return res
 
 
+def dry_run(args, rank, world):
+    """The distributed skeleton of main() on CPU (see --dry-run)."""
+    import torch
+    import torch.distributed as dist
+    from oracle import oracle as orc
+    from shinestacker_amd import multigpu
+    orc.build()
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    H, W = min(args.height, 96), min(args.width, 128)
+    total = args.frames if args.scaling == "strong" else args.frames * world
+    if args.scaling == "strong" and total % world:
+        raise SystemExit(f"--scaling strong: {total} frames do not split over {world} ranks")
+    F = total // world
+    frames = [orc.synth_frame_numpy(H, W, f, total) for f in range(rank * F, (rank + 1) * F)]
+    ops = multigpu.TorchWinnerOps()
+    phase = {"compute": 0.0, "combine": 0.0, "collapse": 0.0}
+    out = None
+
+    def step():
+        nonlocal out
+        t0 = time.perf_counter()
+        so = orc.StreamingOracle(H, W, np.uint8, min_size=16, arith=args.arith)
+        for f in frames:
+            so.push_frame(f)
+        first = rank * F
+        hb, wb = so.shapes[so.levels]
+        yy, xx = np.mgrid[0:hb, 0:wb]
+        bases = np.stack(so.bases)
+        state = [(so.best_e[lv], so.best_lap[lv], so.best_idx[lv] + first) for lv in range(so.levels)]
+        state += [(so.b_ent, bases[so.idx_e, yy, xx], so.idx_e + first), (so.b_dev, bases[so.idx_d, yy, xx], so.idx_d + first)]
+        e = torch.cat([torch.from_numpy(np.ascontiguousarray(a, np.float32).ravel()) for a, _, _ in state])
+        lp = torch.cat([torch.from_numpy(np.ascontiguousarray(b, np.float32).ravel()) for _, b, _ in state])
+        ix = torch.cat([torch.from_numpy(np.ascontiguousarray(c, np.int32).ravel()) for _, _, c in state])
+        t1 = time.perf_counter()
+        if world > 1:
+            n0 = state[0][0].size
+            multigpu.combine_winners(e[:n0], lp[:3 * n0], ix[:n0], dist.group.WORLD, ops, with_index=False, root_energy=False)
+            multigpu.combine_winners(e[n0:], lp[3 * n0:], ix[n0:], dist.group.WORLD, ops, with_index=False, root_energy=False)
+        t2 = time.perf_counter()
+        if rank == 0:   # collapse from the combined payloads
+            off = 0
+            for lv in range(so.levels):
+                n = so.best_e[lv].size
+                so.best_lap[lv][...] = lp[3 * off:3 * (off + n)].numpy().reshape(so.best_lap[lv].shape)
+                off += n
+            nb = hb * wb
+            be, bd = lp[3 * off:3 * (off + nb)].numpy(), lp[3 * (off + nb):3 * (off + 2 * nb)].numpy()
+            so.fused_base = lambda: (((0.0 + be) + bd) / 2.0).astype(np.float32).reshape(hb, wb, 3)
+            out = so.finish()
+        phase["compute"] += t1 - t0
+        phase["combine"] += t2 - t1
+        phase["collapse"] += time.perf_counter() - t2
+
+    for _ in range(args.warmup):
+        step()
+    phase = {k: 0.0 for k in phase}
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if world > 1:
+        dist.barrier()
+    dt_s = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt_s], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt_s = float(t.item())
+    if rank == 0:
+        whole = orc.StreamingOracle(H, W, np.uint8, min_size=16, arith=args.arith)
+        for f in range(total):
+            whole.push_frame(orc.synth_frame_numpy(H, W, f, total))
+        line = {"metric": "Mpixels/s fused (pyramid build+select+collapse)", "value": total * H * W * args.steps / dt_s / 1e6,
+                "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": dt_s / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
+                "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+                "config": {"workload": f"DRY RUN on CPU (oracle + gloo): {total}x{W}x{H}x3 u8 frames", "frames_per_gpu": F,
+                           "arith": args.arith, "parallelism": f"{total} frames in contiguous blocks of {F} over {world} rank(s)"},
+                "roofline": None,
+                "breakdown_ms_per_step": {f"{k}_ms_host": v / args.steps * 1e3 for k, v in phase.items()},
+                "verified": bool(np.array_equal(out, whole.finish())), "dry_run": True}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -158,6 +251,8 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N>1 must be launched with torch.distributed.run")
         args.gpus = world
+    if args.dry_run:
+        return dry_run(args, rank, world)
 
     dist = None
     # the host driver only supports dmabuf IPC: without this RCCL's buffer sharing across processes fails
@@ -229,10 +324,11 @@ def main():
             else:
                 st.push_frames_device(buf.ptr, F)
             if combiner is not None:
-                # the exchange needs this rank's state complete: that wait is the compute time of the step
-                st.sync()
+                # the exchange needs this rank's level-0 state complete: that wait is the compute time of the step
+                # (the coarser levels of the last batch overlap the level-0 exchange)
+                st.sync_level(0)
                 t1 = time.perf_counter()
-                combiner.combine(with_index=False, root_energy=False)
+                combiner.combine_winners(with_index=False, root_energy=False)
                 t2 = time.perf_counter()
                 if rank == 0:
                     st.finish_device()

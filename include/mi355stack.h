@@ -141,6 +141,11 @@ MI_API int mi_stack_push_frames_device(mi_stack_t* s, const void* dev_frames, in
 /* wait for everything enqueued so far */
 MI_API int mi_stack_sync(mi_stack_t* s);
 
+/* wait until the selection state of `level` covers every pushed frame.  level 0 (3/4 of the state) is final while the
+ * coarser levels of the last batch are still running: the cross-GPU exchange of level 0 can start behind this call
+ * (multigpu.Combiner does).  Any other level: same as mi_stack_sync. */
+MI_API int mi_stack_sync_level(mi_stack_t* s, int level);
+
 /* base fusion + collapse + abs/clip/truncating cast.  The handle stays valid
  * (taps readable) until reset/destroy.  host_out: H x W x 3 of out_dtype. */
 MI_API int mi_stack_finish(mi_stack_t* s, void* host_out, size_t row_stride_bytes);
@@ -180,6 +185,22 @@ MI_API int mi_stack_profile_get(mi_stack_t* s, int kind, double* total_ms, int64
  * energy / lap / index to out_*.  `stream` is a hipStream_t (NULL = default stream). */
 MI_API int mi_combine_select(int device, void* stream, int n, const void* cand_e, const void* cand_lap,
                       const void* cand_idx, size_t npix, void* out_e, void* out_lap, void* out_idx);
+
+/* "Winners only" form of the same reduce (what multigpu.Combiner uses; <= 16 ranks): the ranks exchange energies only,
+ * mi_combine_winner names the winning rank of every pixel of a chunk (first maximum in rank order), every rank learns the
+ * whole winner map (1 byte per pixel), and each rank sends just the payload rows it WON -- packed in pixel order by
+ * mi_combine_pack -- straight to the collapsing rank, which puts them in place with mi_combine_unpack.
+ * mi_combine_plan: per-block start positions of every rank's rows in its packed buffer (`plan`: device scratch of
+ * mi_combine_plan_bytes) and the row totals per rank on the host (synchronises the stream).
+ * dev_bufs: DEVICE array of n_ranks device pointers, entry r = rank r's packed rows (the entry of `rank` itself unused). */
+MI_API int mi_combine_winner(int device, void* stream, int n_ranks, const void* cand_e, size_t npix, void* win_u8);
+MI_API size_t mi_combine_plan_bytes(size_t npix, int n_ranks);
+MI_API int mi_combine_plan(int device, void* stream, const void* win_u8, size_t npix, int n_ranks, void* plan,
+                           int64_t* totals);
+MI_API int mi_combine_pack(int device, void* stream, const void* win_u8, size_t npix, int n_ranks, int rank,
+                           const void* plan, const void* src, int width, void* out);
+MI_API int mi_combine_unpack(int device, void* stream, const void* win_u8, size_t npix, int n_ranks, int rank,
+                             const void* plan, const void* const* dev_bufs, int width, void* dst);
 
 /* ---- alignment apply step: cv2.warpAffine(img, M, (w,h), borderMode, borderValue) for the
  * ALIGN_RIGID transform of align_images (reference algorithms/align.py:238-251), H x W x 3

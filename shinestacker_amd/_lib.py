@@ -74,6 +74,7 @@ SIGNATURES = {
     "mi_stack_push_frame": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "mi_stack_push_frames_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t]),
     "mi_stack_sync": (C.c_int, [C.c_void_p]),
+    "mi_stack_sync_level": (C.c_int, [C.c_void_p, C.c_int]),
     "mi_stack_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "mi_stack_finish_device": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mi_stack_get_level": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]),
@@ -86,6 +87,14 @@ SIGNATURES = {
                                        C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "mi_combine_select": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mi_combine_winner": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "mi_combine_plan_bytes": (C.c_size_t, [C.c_size_t, C.c_int]),
+    "mi_combine_plan": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p,
+                                  C.POINTER(C.c_int64)]),
+    "mi_combine_pack": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p,
+                                  C.c_void_p, C.c_int, C.c_void_p]),
+    "mi_combine_unpack": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p,
+                                    C.c_void_p, C.c_int, C.c_void_p]),
     "mi_warp_affine": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                  C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double), C.c_int,
                                  C.c_double]),
@@ -313,6 +322,10 @@ class Stack:
 
     def sync(self):
         check(load().mi_stack_sync(self._h))
+
+    def sync_level(self, level):
+        """wait until the state of `level` covers every pushed frame (level 0: before the coarser levels finish)"""
+        check(load().mi_stack_sync_level(self._h, int(level)))
 
     def finish(self):
         out = np.empty((self.height, self.width, 3), self.out_dtype)

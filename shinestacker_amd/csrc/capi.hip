@@ -32,6 +32,7 @@ int tiled_push(mi_stack* s, const void* dev_frames, int n, size_t stride);
 int tiled_push_host(mi_stack* s, const void* host_bgr, size_t row_stride_bytes);
 int tiled_flush(mi_stack* s);
 int tiled_sync_all(mi_stack* s);
+int tiled_sync_level0(mi_stack* s);
 const float* tiled_last_gauss(mi_stack* s, int level);
 int dispatch_push(mi_stack* s, const void* dev_frames, int n, size_t stride);
 }  // namespace mi
@@ -1116,6 +1117,16 @@ int mi_stack_sync(mi_stack_t* s) {
     return MI_OK;
 }
 
+int mi_stack_sync_level(mi_stack_t* s, int level) {
+    int rc = check_handle(s);
+    if (rc) return rc;
+    MI_HIP(hipSetDevice(s->p.device));
+    rc = tiled_flush(s);
+    if (rc) return rc;
+    if (level != 0) return mi_stack_sync(s);
+    return tiled_sync_level0(s);
+}
+
 int mi_stack_finish_device(mi_stack_t* s, void* dev_out) {
     int rc = check_handle(s);
     if (rc) return rc;
@@ -1295,6 +1306,67 @@ int mi_combine_select(int device, void* stream, int n, const void* cand_e, const
                        (hipStream_t)stream, n, (const float*)cand_e, (const float*)cand_lap,
                        (const int32_t*)cand_idx, npix, (float*)out_e, (float*)out_lap,
                        (int32_t*)out_idx);
+    MI_HIP(hipGetLastError());
+    return MI_OK;
+}
+
+int mi_combine_winner(int device, void* stream, int n, const void* cand_e, size_t npix, void* win) {
+    if (n < 1 || n > CB_MAXR || !cand_e || !win) return fail(MI_ERR_INVALID, "bad argument (1 <= ranks <= %d)", CB_MAXR);
+    if (npix == 0) return MI_OK;
+    MI_HIP(hipSetDevice(device));
+    hipLaunchKernelGGL(combine_winner, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n,
+                       (const float*)cand_e, npix, (uint8_t*)win);
+    MI_HIP(hipGetLastError());
+    return MI_OK;
+}
+
+size_t mi_combine_plan_bytes(size_t npix, int n_ranks) {
+    return ((npix + CB_PX - 1) / CB_PX) * (size_t)n_ranks * sizeof(uint32_t) + CB_MAXR * sizeof(unsigned long long);
+}
+
+int mi_combine_plan(int device, void* stream, const void* win, size_t npix, int n_ranks, void* plan, int64_t* totals) {
+    if (n_ranks < 1 || n_ranks > CB_MAXR || !win || !plan || !totals) return fail(MI_ERR_INVALID, "bad argument");
+    MI_HIP(hipSetDevice(device));
+    const size_t nblocks = (npix + CB_PX - 1) / CB_PX;
+    uint32_t* counts = (uint32_t*)plan;
+    unsigned long long* tot = (unsigned long long*)(counts + nblocks * n_ranks);
+    hipStream_t st = (hipStream_t)stream;
+    if (nblocks) {
+        hipLaunchKernelGGL(combine_count, dim3((unsigned)nblocks), dim3(256), 0, st, (const uint8_t*)win, npix, n_ranks, counts);
+        hipLaunchKernelGGL(combine_scan, dim3(1), dim3(1024), 0, st, counts, (int)nblocks, n_ranks, tot);
+        MI_HIP(hipGetLastError());
+        unsigned long long h[CB_MAXR];
+        MI_HIP(hipMemcpyAsync(h, tot, sizeof(unsigned long long) * n_ranks, hipMemcpyDeviceToHost, st));
+        MI_HIP(hipStreamSynchronize(st));
+        for (int r = 0; r < n_ranks; ++r) totals[r] = (int64_t)h[r];
+    } else {
+        for (int r = 0; r < n_ranks; ++r) totals[r] = 0;
+    }
+    return MI_OK;
+}
+
+int mi_combine_pack(int device, void* stream, const void* win, size_t npix, int n_ranks, int rank, const void* plan,
+                    const void* src, int width, void* out) {
+    if (n_ranks < 1 || n_ranks > CB_MAXR || rank < 0 || rank >= n_ranks || !win || !plan || !src || !out || width < 1)
+        return fail(MI_ERR_INVALID, "bad argument");
+    if (npix == 0) return MI_OK;
+    MI_HIP(hipSetDevice(device));
+    hipLaunchKernelGGL((combine_move<true>), dim3((unsigned)((npix + CB_PX - 1) / CB_PX)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint8_t*)win, npix, n_ranks, rank, (const uint32_t*)plan, (const float*)src,
+                       (const float* const*)nullptr, width, (float*)out);
+    MI_HIP(hipGetLastError());
+    return MI_OK;
+}
+
+int mi_combine_unpack(int device, void* stream, const void* win, size_t npix, int n_ranks, int rank, const void* plan,
+                      const void* const* dev_bufs, int width, void* dst) {
+    if (n_ranks < 1 || n_ranks > CB_MAXR || rank < 0 || rank >= n_ranks || !win || !plan || !dev_bufs || !dst || width < 1)
+        return fail(MI_ERR_INVALID, "bad argument");
+    if (npix == 0) return MI_OK;
+    MI_HIP(hipSetDevice(device));
+    hipLaunchKernelGGL((combine_move<false>), dim3((unsigned)((npix + CB_PX - 1) / CB_PX)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint8_t*)win, npix, n_ranks, rank, (const uint32_t*)plan, (const float*)nullptr,
+                       (const float* const*)dev_bufs, width, (float*)dst);
     MI_HIP(hipGetLastError());
     return MI_OK;
 }

@@ -354,6 +354,113 @@ __global__ void combine_select(int n, const float* __restrict__ cand_e,
     if (cand_idx && out_idx) out_idx[p] = cand_idx[(size_t)bi * npix + p];
 }
 
+// ---- "winners only" form of the combine: the ranks exchange energies, agree on the winning rank of every pixel, and
+// each rank sends just the payload rows it won, packed in pixel order, straight to the collapsing rank.
+// Blocks of CB_PX pixels; pos(p) = offsets[block][rank of p] + (pixels of the same rank before p inside the block).
+constexpr int CB_PX = 1024, CB_MAXR = 16;
+
+__global__ void combine_winner(int n, const float* __restrict__ cand_e, size_t npix, uint8_t* __restrict__ win) {
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npix) return;
+    float be = cand_e[p];
+    int bi = 0;
+    for (int r = 1; r < n; ++r) {
+        const float e = cand_e[(size_t)r * npix + p];
+        if (e > be) { be = e; bi = r; }   // strict: the lowest rank (= lowest global frame index) keeps a tie
+    }
+    win[p] = (uint8_t)bi;
+}
+
+// per block and rank: number of pixels that rank won.  One workgroup of 256 threads per block of CB_PX pixels.
+__global__ void combine_count(const uint8_t* __restrict__ win, size_t npix, int n_ranks, uint32_t* __restrict__ counts) {
+    __shared__ uint32_t c[CB_MAXR];
+    if (threadIdx.x < CB_MAXR) c[threadIdx.x] = 0;
+    __syncthreads();
+    const size_t base = (size_t)blockIdx.x * CB_PX;
+    for (int k = threadIdx.x; k < CB_PX; k += blockDim.x) {
+        const size_t p = base + k;
+        const int r = p < npix ? win[p] : -1;
+        for (int s = 0; s < n_ranks; ++s) {
+            const unsigned long long m = __ballot(r == s);
+            if ((threadIdx.x & 63) == 0 && m) atomicAdd(&c[s], (uint32_t)__popcll(m));
+        }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < n_ranks) counts[(size_t)blockIdx.x * n_ranks + threadIdx.x] = c[threadIdx.x];
+}
+
+// exclusive scan of every rank column down the blocks (one workgroup; in place: counts -> offsets), totals per rank
+__global__ void combine_scan(uint32_t* __restrict__ counts, int nblocks, int n_ranks, unsigned long long* __restrict__ totals) {
+    __shared__ unsigned long long part[1024];
+    const int t = threadIdx.x, nt = blockDim.x;
+    const int per = (nblocks + nt - 1) / nt;
+    for (int s = 0; s < n_ranks; ++s) {
+        unsigned long long sum = 0;
+        for (int k = 0; k < per; ++k) {
+            const int b = t * per + k;
+            if (b < nblocks) sum += counts[(size_t)b * n_ranks + s];
+        }
+        part[t] = sum;
+        __syncthreads();
+        if (t == 0) {
+            unsigned long long run = 0;
+            for (int i = 0; i < nt; ++i) { const unsigned long long v = part[i]; part[i] = run; run += v; }
+            totals[s] = run;
+        }
+        __syncthreads();
+        unsigned long long run = part[t];
+        for (int k = 0; k < per; ++k) {
+            const int b = t * per + k;
+            if (b < nblocks) {
+                const uint32_t v = counts[(size_t)b * n_ranks + s];
+                counts[(size_t)b * n_ranks + s] = (uint32_t)run;
+                run += v;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// PACK: out[pos(p)] = src[p] for the pixels `rank` won; !PACK: dst[p] = bufs[rank of p][pos(p)] for every pixel `rank`
+// (the receiver) did NOT win itself.  Rows of `width` floats.  One workgroup of 256 threads per block of CB_PX pixels,
+// pixels visited in order, 256 at a time: the running per-rank position lives in LDS.
+template <bool PACK>
+__global__ void combine_move(const uint8_t* __restrict__ win, size_t npix, int n_ranks, int rank,
+                             const uint32_t* __restrict__ offsets, const float* __restrict__ src,
+                             const float* const* __restrict__ bufs, int width, float* __restrict__ dst) {
+    __shared__ uint32_t run[CB_MAXR];
+    __shared__ uint32_t wave_cnt[4][CB_MAXR];
+    if ((int)threadIdx.x < n_ranks) run[threadIdx.x] = offsets[(size_t)blockIdx.x * n_ranks + threadIdx.x];
+    __syncthreads();
+    const size_t base = (size_t)blockIdx.x * CB_PX;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int k0 = 0; k0 < CB_PX; k0 += 256) {
+        const size_t p = base + k0 + threadIdx.x;
+        const int r = p < npix ? win[p] : -1;
+        uint32_t before = 0;
+        for (int s = 0; s < n_ranks; ++s) {
+            const unsigned long long m = __ballot(r == s);
+            if (r == s) before = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            if (lane == 0) wave_cnt[wv][s] = (uint32_t)__popcll(m);
+        }
+        __syncthreads();
+        if (r >= 0 && (PACK ? r == rank : r != rank)) {
+            uint32_t pos = run[r] + before;
+            for (int v = 0; v < wv; ++v) pos += wave_cnt[v][r];
+            if (PACK) {
+                for (int c = 0; c < width; ++c) dst[(size_t)pos * width + c] = src[p * width + c];
+            } else {
+                const float* b = bufs[r];
+                for (int c = 0; c < width; ++c) dst[p * width + c] = b[(size_t)pos * width + c];
+            }
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < n_ranks) run[threadIdx.x] += wave_cnt[0][threadIdx.x] + wave_cnt[1][threadIdx.x] +
+                                                           wave_cnt[2][threadIdx.x] + wave_cnt[3][threadIdx.x];
+        __syncthreads();
+    }
+}
+
 // ---------------------------------------------------------------- frame -> float32 (stacks without
 // Laplacian levels: the frame itself is the base, pyramid.py:126 img.astype(float_type))
 template <typename TIn>

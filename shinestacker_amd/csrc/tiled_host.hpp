@@ -32,6 +32,7 @@ struct TiledState {
     float* feat[2] = {nullptr, nullptr};    // (entropy, deviation) of every (frame, pixel) of the batch
     hipStream_t st1 = nullptr, st2 = nullptr;
     hipEvent_t evL0i[2] = {nullptr, nullptr}, evL0b[2] = {nullptr, nullptr}, evRest[2] = {nullptr, nullptr};
+    hipEvent_t evL0done[2] = {nullptr, nullptr};   // level-0 state of the batch is final (separable: after its payload pass)
     std::vector<hipEvent_t> evLvl;  // [set][level][interior|border]: per-level joins of st2 and st1
     bool streams_dirty = false;     // work may be in flight on st1/st2
     // host-frame upload: pinned bounce buffers + a copy stream, so push_frame returns after a
@@ -75,6 +76,7 @@ int tiled_create(mi_stack* s) {
         MI_HIP(hipEventCreateWithFlags(&t->evL0i[set], hipEventDisableTiming));
         MI_HIP(hipEventCreateWithFlags(&t->evL0b[set], hipEventDisableTiming));
         MI_HIP(hipEventCreateWithFlags(&t->evRest[set], hipEventDisableTiming));
+        MI_HIP(hipEventCreateWithFlags(&t->evL0done[set], hipEventDisableTiming));
         for (int i = 0; i < 2 * (L + 1); ++i) {
             hipEvent_t e;
             MI_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -111,6 +113,7 @@ void tiled_destroy(mi_stack* s) {
         if (t->evL0i[set]) (void)hipEventDestroy(t->evL0i[set]);
         if (t->evL0b[set]) (void)hipEventDestroy(t->evL0b[set]);
         if (t->evRest[set]) (void)hipEventDestroy(t->evRest[set]);
+        if (t->evL0done[set]) (void)hipEventDestroy(t->evL0done[set]);
     }
     for (auto e : t->evLvl) (void)hipEventDestroy(e);
     for (int i = 0; i < TiledState::NPIN; ++i) {
@@ -347,6 +350,7 @@ int run_batch(mi_stack* s, const void* frames, size_t stride, int nb) {
     MI_HIP(hipStreamWaitEvent(st2, t->evL0b[set], 0));
     MI_HIP(hipStreamWaitEvent(st1, t->evL0i[set], 0));
     if (s->sep && (rc = launch_payload_sep<TIn>(s, 0, set, frames, stride, nb, st2))) return rc;
+    MI_HIP(hipEventRecord(t->evL0done[set], st2));   // st2 waited for both level-0 kernels above
     // coarser levels: interior tiles on st2, border tiles on st1 (disjoint tiles of one level run
     // side by side); both streams join after every level because level l+1 reads all of G_{l+1}
     static const int only_l0 = study_env("MI_ONLY_L0", 0);   // -DMI_STUDY: level 0 alone on the GPU (results are wrong)
@@ -397,6 +401,16 @@ int run_batch(mi_stack* s, const void* frames, size_t stride, int nb) {
     t->last_nb = nb;
     t->last_set = set;
     t->batch_no++;
+    return MI_OK;
+}
+
+// host waits until the level-0 selection state of every pushed frame is final (the coarser levels of the last batch
+// may still be running): the cross-GPU exchange of level 0 -- 3/4 of the state -- can start here
+int tiled_sync_level0(mi_stack* s) {
+    TiledState* t = tstate(s);
+    if (!t || s->p.impl != MI_IMPL_TILED || t->batch_no == 0) return tiled_sync_all(s);
+    // batches run in order on every stream, so the last batch's event covers the earlier ones
+    MI_HIP(hipEventSynchronize(t->evL0done[t->last_set]));
     return MI_OK;
 }
 

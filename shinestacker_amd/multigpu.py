@@ -137,6 +137,89 @@ def combine_all(states, group, select_fn, width=3, with_index=True, root_energy=
             off += m
 
 
+def first_max_rank(cand_e):
+    """torch form of mi_combine_winner (CPU tests / reference semantics): winning rank per pixel, strict '>' in rank order"""
+    world, m = cand_e.shape
+    best = torch.zeros(m, dtype=torch.uint8, device=cand_e.device)
+    be = cand_e[0].clone()
+    for r in range(1, world):
+        win = cand_e[r] > be
+        be = torch.where(win, cand_e[r], be)
+        best = torch.where(win, torch.full_like(best, r), best)
+    return best
+
+
+class TorchWinnerOps:
+    """The four local steps of `combine_winners` in plain torch (CPU tensors under gloo in tests/; on the GPU the
+    Combiner uses the library's kernels: boolean-mask indexing of 32 Mpixel states costs milliseconds per call)."""
+
+    def winner(self, cand_e):
+        return first_max_rank(cand_e)
+
+    def plan(self, win, world):
+        return None, [int((win == r).sum()) for r in range(world)]
+
+    def pack(self, win, plan, world, rank, arr, width, count):
+        return arr.view(-1, width)[win == rank].reshape(-1).contiguous()
+
+    def unpack(self, win, plan, world, rank, bufs, arr, width):
+        rows = arr.view(-1, width)
+        for r, b in enumerate(bufs):
+            if r != rank and b is not None and b.numel():
+                rows[win == r] = b.view(-1, width)
+
+
+def combine_winners(e_all, l_all, i_all, group, ops, width=3, with_index=True, root_energy=True):
+    """Cross-rank first-max of a flat state (e_all (n,), l_all (n*width,), i_all (n,) or None), result on rank 0.
+    Same outcome as `combine_all`, less traffic -- the payload crosses the fabric once, not twice:
+
+      1. all-to-all of the ENERGIES by pixel chunk (4 B/pixel; 7 of 8 chunks travel, one per xGMI link);
+      2. chunk owners name the winning rank of every pixel (first maximum in rank = frame order);
+      3. all-gather of that map (1 B/pixel): every rank now knows which of its own pixels won;
+      4. every rank packs the payload rows it won (pixel order) and sends them straight to rank 0, which unpacks
+         them into place -- 12 B/pixel in total INTO rank 0, spread over its 7 links, instead of 12 B/pixel all-to-all
+         plus 12 B/pixel to rank 0.  Optionally the winners' energies / indices travel the same way.
+    """
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    n = e_all.numel()
+    if world == 1 or n == 0:
+        return
+    bounds = chunk_bounds(n, world)
+    sizes = [b - a for a, b in bounds]
+    per = -(-n // world)
+    mine = sizes[rank]
+    cand = torch.empty(world * mine, dtype=e_all.dtype, device=e_all.device)
+    dist.all_to_all_single(cand, e_all, output_split_sizes=[mine] * world, input_split_sizes=sizes, group=group)
+    win_chunk = ops.winner(cand.view(world, mine))
+    padded = torch.zeros(per, dtype=torch.uint8, device=e_all.device)
+    padded[:mine] = win_chunk
+    gathered = torch.empty(world * per, dtype=torch.uint8, device=e_all.device)
+    dist.all_gather_into_tensor(gathered, padded, group=group)
+    win = gathered[:n]          # chunk r starts at r * per: the padded layout IS the pixel order
+    plan, totals = ops.plan(win, world)
+    arrays = [(l_all, width)]
+    if root_energy:
+        arrays.append((e_all, 1))
+    if with_index and i_all is not None:
+        arrays.append((i_all.view(torch.float32), 1))   # moved bit for bit
+    root = dist.get_global_rank(group, 0)
+    if rank != 0:
+        packed = [ops.pack(win, plan, world, rank, arr, w, totals[rank]) for arr, w in arrays]
+        if totals[rank]:
+            for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, b, root, group) for b in packed]):
+                req.wait()
+    else:
+        for arr, w in arrays:
+            bufs = [None] + [torch.empty(totals[r] * w, dtype=arr.dtype, device=arr.device) for r in range(1, world)]
+            ops_ = [dist.P2POp(dist.irecv, bufs[r], dist.get_global_rank(group, r), group)
+                    for r in range(1, world) if totals[r]]
+            if ops_:
+                for req in dist.batch_isend_irecv(ops_):
+                    req.wait()
+            ops.unpack(win, plan, world, 0, bufs, arr, w)
+
+
 class _DevArray:
     """`__cuda_array_interface__` view of library-owned device memory (no copy)."""
 
@@ -157,6 +240,7 @@ class Combiner:
         self.stack = stack
         self.group = group if group is not None else dist.group.WORLD
         self.device = stack.device
+        self._slabs = None
 
     def _select_hip(self, cand_e, cand_l, cand_i):
         world, m = cand_e.shape
@@ -169,6 +253,58 @@ class Combiner:
             cand_i.data_ptr() if cand_i is not None else None, m, out_e.data_ptr(), out_l.data_ptr(),
             out_i.data_ptr() if out_i is not None else None))
         return out_e, out_l, out_i
+
+    # ---- the library's kernels behind the TorchWinnerOps protocol
+    def winner(self, cand_e):
+        world, m = cand_e.shape
+        out = torch.empty(m, dtype=torch.uint8, device=cand_e.device)
+        stream = torch.cuda.current_stream(cand_e.device).cuda_stream
+        _lib.check(_lib.load().mi_combine_winner(self.device, C.c_void_p(stream), world, cand_e.data_ptr(), m, out.data_ptr()))
+        return out
+
+    def plan(self, win, world):
+        lib = _lib.load()
+        n = win.numel()
+        plan = torch.empty(lib.mi_combine_plan_bytes(n, world), dtype=torch.uint8, device=win.device)
+        totals = (C.c_int64 * world)()
+        stream = torch.cuda.current_stream(win.device).cuda_stream
+        _lib.check(lib.mi_combine_plan(self.device, C.c_void_p(stream), win.data_ptr(), n, world, plan.data_ptr(), totals))
+        return plan, [int(t) for t in totals]
+
+    def pack(self, win, plan, world, rank, arr, width, count):
+        out = torch.empty(count * width, dtype=arr.dtype, device=arr.device)
+        if count == 0:
+            return out
+        stream = torch.cuda.current_stream(arr.device).cuda_stream
+        _lib.check(_lib.load().mi_combine_pack(self.device, C.c_void_p(stream), win.data_ptr(), win.numel(), world, rank,
+                                               plan.data_ptr(), arr.data_ptr(), width, out.data_ptr()))
+        return out
+
+    def unpack(self, win, plan, world, rank, bufs, arr, width):
+        ptrs = torch.tensor([b.data_ptr() if b is not None and b.numel() else 0 for b in bufs], dtype=torch.int64,
+                            device=arr.device)
+        stream = torch.cuda.current_stream(arr.device).cuda_stream
+        _lib.check(_lib.load().mi_combine_unpack(self.device, C.c_void_p(stream), win.data_ptr(), win.numel(), world, rank,
+                                                 plan.data_ptr(), ptrs.data_ptr(), width, arr.data_ptr()))
+        torch.cuda.current_stream(arr.device).synchronize()   # `ptrs` and the receive buffers go out of scope
+
+    def combine_winners(self, with_index=False, root_energy=False):
+        """The winners-only protocol (`combine_winners`) in two phases: level 0 -- 3/4 of the state, final as soon as
+        the last batch's level-0 kernels are through -- is exchanged while that batch's coarser levels still run on
+        the stacker's side streams; the rest follows after the full synchronisation."""
+        st = self.stack
+        if self._slabs is None:
+            e_ptr, l_ptr, i_ptr, n = st.state_ptrs(-1)     # (synchronises; once per handle: the slabs do not move)
+            n0 = -(-(st.shapes[0][0] * st.shapes[0][1]) // 64) * 64 if st.levels > 0 else 0
+            self._slabs = (wrap_device(e_ptr, n, torch.float32, self.device), wrap_device(l_ptr, n * 3, torch.float32, self.device),
+                           wrap_device(i_ptr, n, torch.int32, self.device), n0)
+        e, l, i, n0 = self._slabs
+        st.sync_level(0)
+        if n0:
+            combine_winners(e[:n0], l[:3 * n0], i[:n0], self.group, self, with_index=with_index, root_energy=root_energy)
+        st.sync()
+        combine_winners(e[n0:], l[3 * n0:], i[n0:], self.group, self, with_index=with_index, root_energy=root_energy)
+        torch.cuda.current_stream(torch.device("cuda", self.device)).synchronize()
 
     def combine(self, with_index=True, root_energy=True):
         """Call on every rank after its frames were pushed; rank 0 may then finish().

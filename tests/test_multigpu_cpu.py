@@ -104,6 +104,23 @@ def _worker(rank, world, port, ret):
             for a, c, orig in zip(per_level, pay, tensors()):
                 assert torch.equal(c[1], a[1]) and torch.equal(c[0], orig[0]) and torch.equal(c[2], orig[2])
             ret["state"] = [(te.numpy(), tl.numpy(), ti.numpy()) for te, tl, ti in flat]
+        # the winners-only protocol (energies -> winner map -> packed rows straight to rank 0): same state on rank 0,
+        # with everything / with the payload alone; in two phases like Combiner.combine_winners (level 0 first)
+        ops = multigpu.TorchWinnerOps()
+        for kw in ({}, {"with_index": False, "root_energy": False}):
+            t = tensors()
+            e_all, l_all, i_all = (torch.cat([a for a, _, _ in t]), torch.cat([b for _, b, _ in t]), torch.cat([c for _, _, c in t]))
+            n0 = t[0][0].numel()
+            multigpu.combine_winners(e_all[:n0], l_all[:3 * n0], i_all[:n0], dist.group.WORLD, ops, **kw)
+            multigpu.combine_winners(e_all[n0:], l_all[3 * n0:], i_all[n0:], dist.group.WORLD, ops, **kw)
+            if rank == 0:
+                assert torch.equal(l_all, torch.cat([b for _, b, _ in flat]))
+                if not kw:
+                    assert torch.equal(e_all, torch.cat([a for a, _, _ in flat]))
+                    assert torch.equal(i_all, torch.cat([c for _, _, c in flat]))
+                else:
+                    o = tensors()
+                    assert torch.equal(e_all, torch.cat([a for a, _, _ in o])) and torch.equal(i_all, torch.cat([c for _, _, c in o]))
     finally:
         dist.destroy_process_group()
 
@@ -144,3 +161,27 @@ def test_chunk_bounds_cover_everything():
             b = chunk_bounds(n, w)
             assert b[0][0] == 0 and b[-1][1] == n
             assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("scaling", ["strong", "weak"])
+def test_bench_dry_run_under_torch_distributed_run(scaling):
+    """bench.py's distributed skeleton the way the driver starts it (python -m torch.distributed.run, one process per
+    rank), on CPU: --dry-run replaces the HIP path by the oracle and RCCL by gloo; the strong split (BASELINE configs[2]:
+    the SAME stack, frames / N per rank), the winners-only combine and the JSON contract are the real ones."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--frames", "6", "--scaling", scaling, "--dry-run"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=280, cwd=root)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and lines, r.stdout[-1500:] + r.stderr[-3000:]
+    d = json.loads(lines[-1])
+    assert d["n_gpus"] == 2 and d["scaling"] == scaling and d["verified"] is True and d["steps"] == 2
+    assert d["config"]["frames_per_gpu"] == (3 if scaling == "strong" else 6)
+    assert {"compute_ms_host", "combine_ms_host", "collapse_ms_host"} <= set(d["breakdown_ms_per_step"])
+    for k in ("metric", "value", "unit", "ms_per_step", "higher_is_better", "vs_baseline", "dtype", "data"):
+        assert k in d
