@@ -6,6 +6,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <map>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -526,22 +528,78 @@ int round_sat(double v, int hi) {
     return r < 0 ? 0 : (r > hi ? hi : (int)r);
 }
 
+// Scratch of the border blur's tile list (kernels_align.hpp): [count, pad to 64 B][bitmap: one bit per 32 x 64 tile]
+// [list: one entry per tile].  One buffer per (device, stream) -- calls on one stream are ordered by the stream, calls on
+// different streams must not share it -- grown on demand, kept for the life of the process.
+struct WarpScratch {
+    void* ptr = nullptr;
+    size_t bytes = 0;
+};
+int warp_scratch(int device, hipStream_t st, size_t ntiles, uint32_t** cnt, uint32_t** bitmap, uint32_t** list, size_t* clear_bytes) {
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, WarpScratch> cache;
+    const size_t bm_bytes = (((ntiles + 31) / 32) * 4 + 63) & ~(size_t)63;
+    const size_t need = 64 + bm_bytes + ntiles * 4;
+    std::lock_guard<std::mutex> lk(mu);
+    WarpScratch& w = cache[{device, st}];
+    if (w.bytes < need) {
+        if (w.ptr) {
+            MI_HIP(hipStreamSynchronize(st));
+            (void)hipFree(w.ptr);
+            w.ptr = nullptr;
+            w.bytes = 0;
+        }
+        MI_HIP(hipMalloc(&w.ptr, need));
+        w.bytes = need;
+    }
+    *cnt = (uint32_t*)w.ptr;
+    *bitmap = (uint32_t*)((char*)w.ptr + 64);
+    *list = (uint32_t*)((char*)w.ptr + 64 + bm_bytes);
+    *clear_bytes = 64 + bm_bytes;
+    return MI_OK;
+}
+
 template <typename T>
-int warp_launch(hipStream_t st, const void* src, void* side, void* out, uint8_t* valid, int h, int w,
+int warp_launch(int device, hipStream_t st, const void* src, void* side, void* out, uint8_t* valid, int h, int w,
                 const AffineArgs& a, bool blur, const GaussArgs& g) {
-    // four pixels per thread; whole-dword stores when every row starts 4-byte aligned
+    // LDS-staged tiles of 256 x 32 (16) destination pixels, four pixels x 8 (4) rows per thread; whole-dword stores
+    // when every row starts 4-byte aligned
     const bool vec = (w % 4) == 0 && ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(valid)) & 3) == 0;
-    const dim3 blk(64, 4), grid(cdiv(cdiv(w, 4), 64), cdiv(h, 4));
-    if (vec) hipLaunchKernelGGL((warp_affine_kernel<T, true>), grid, blk, 0, st, (const T*)src, (T*)out, valid, a);
-    else hipLaunchKernelGGL((warp_affine_kernel<T, false>), grid, blk, 0, st, (const T*)src, (T*)out, valid, a);
+    const dim3 grid(cdiv(w, WT_W), cdiv(h, WarpTile<T>::TH));
+    const size_t lds = (size_t)WT_LDS_DWORDS * 4;
+    auto kv = warp_affine_tiled<T, true>;
+    auto ks = warp_affine_tiled<T, false>;
+    auto kb = border_blur_tiles<T>;
+    const int r = g.ksize / 2;
+    const size_t lds_blur = ((size_t)(BT_H + 2 * r) * (BT_W + 2 * r) * (sizeof(T) == 1 ? 1 : 2) + 3 * (size_t)(BT_H + 2 * r) * BT_W) * 4;
+    static thread_local bool attr_set = false;
+    if (!attr_set) {
+        MI_HIP(hipFuncSetAttribute((const void*)kv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        MI_HIP(hipFuncSetAttribute((const void*)ks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        // largest blur kernel (31 taps): 62 x 94 raw pixels + 3 x 62 x 64 floats
+        MI_HIP(hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)(((size_t)62 * 94 * 2 + 3 * 62 * 64) * 4)));
+        attr_set = true;
+    }
+    if (vec) hipLaunchKernelGGL(kv, grid, dim3(256), lds, st, (const T*)src, (T*)out, valid, a);
+    else hipLaunchKernelGGL(ks, grid, dim3(256), lds, st, (const T*)src, (T*)out, valid, a);
     if (blur) {
-        // the warped image goes straight to `out`; the few pixels outside the source frame are blurred
-        // from it into `side` and copied back (two sparse passes over the mask)
-        const size_t n = (size_t)h * w;
-        hipLaunchKernelGGL((border_blur_collect<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
-                           (const T*)out, valid, (T*)side, h, w, g);
-        hipLaunchKernelGGL((border_blur_scatter<T>), dim3((unsigned)((n / 16 + 256) / 256)), dim3(256), 0, st,
-                           (T*)out, valid, (const T*)side, h, w);
+        // the warped image goes straight to `out`; the few pixels outside the source frame are blurred from it into
+        // `side` and copied back, tile by tile over the tiles that hold a masked pixel
+        const int tiles_x = cdiv(w, BT_W), tiles_y = cdiv(h, BT_H);
+        uint32_t *cnt = nullptr, *bitmap = nullptr, *list = nullptr;
+        size_t clear = 0;
+        int rc = warp_scratch(device, st, (size_t)tiles_x * tiles_y, &cnt, &bitmap, &list, &clear);
+        if (rc) return rc;
+        MI_HIP(hipMemsetAsync(cnt, 0, clear, st));
+        const size_t npx = (size_t)h * w;
+        hipLaunchKernelGGL(mask_scan_tiles, dim3((unsigned)std::min<size_t>(2048, (npx / 16 + 256) / 256)), dim3(256), 0, st,
+                           (const uint8_t*)valid, h, w, tiles_x, bitmap);
+        hipLaunchKernelGGL(tile_bitmap_to_list, dim3(1), dim3(1024), 0, st, (const uint32_t*)bitmap, (tiles_x * tiles_y + 31) / 32, cnt, list);
+        hipLaunchKernelGGL(kb, dim3(1024), dim3(256), lds_blur, st, (const T*)out, (const uint8_t*)valid, (T*)side, h, w, tiles_x, g,
+                           (const uint32_t*)cnt, (const uint32_t*)list);
+        hipLaunchKernelGGL((border_blur_scatter<T>), dim3(1024), dim3(256), 0, st, (T*)out, (const uint8_t*)valid, (const T*)side,
+                           h, w, tiles_x, (const uint32_t*)cnt, (const uint32_t*)list);
     }
     MI_HIP(hipGetLastError());
     return MI_OK;
@@ -1405,8 +1463,8 @@ int mi_warp_affine_device(int device, void* stream, const void* dev_src, void* d
     }
     void* warp = dev_tmp;
     if (dtype == MI_U8)
-        return warp_launch<uint8_t>((hipStream_t)stream, dev_src, warp, dev_dst, (uint8_t*)dev_mask, height, width, a, blur, g);
-    return warp_launch<uint16_t>((hipStream_t)stream, dev_src, warp, dev_dst, (uint8_t*)dev_mask, height, width, a, blur, g);
+        return warp_launch<uint8_t>(device, (hipStream_t)stream, dev_src, warp, dev_dst, (uint8_t*)dev_mask, height, width, a, blur, g);
+    return warp_launch<uint16_t>(device, (hipStream_t)stream, dev_src, warp, dev_dst, (uint8_t*)dev_mask, height, width, a, blur, g);
 }
 
 int mi_warp_affine(int device, const void* host_src, void* host_dst, void* host_mask, int height, int width,

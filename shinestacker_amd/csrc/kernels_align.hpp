@@ -5,6 +5,7 @@
 // OpenCV semantics restated from memory and the parity status).
 #pragma once
 #include "common.hpp"
+#include "kernels_tiled.hpp"   // v4f, mul24
 
 namespace mi {
 
@@ -147,64 +148,201 @@ __device__ __forceinline__ void warp_pixel_inside(const T* __restrict__ src, con
     }
 }
 
-// Four consecutive destination pixels per thread: 12 (uint8) / 24 (uint16) contiguous output bytes
-// and the 4 mask bytes leave as whole dwords when the row start allows it (VEC: w % 4 == 0 and
-// 4-byte aligned images).
+// ---- The warp kernel.  A per-pixel gather spends its time in the texture-address unit (four unaligned 4-byte
+// gathers per pixel: 99 us per 24 MP frame) and in double-precision coordinate arithmetic (OpenCV rounds
+// iM[0]*x*1024 and iM[3]*x*1024 in double per COLUMN -- its adelta / bdelta tables -- and the row terms per ROW).
+// Here a workgroup owns a TH x 256 tile of the destination: the tile's source bounding box (exact: the rounded
+// terms are monotone, so the extremes sit at the tile's corners) is staged into LDS with coalesced dword loads,
+// every thread keeps the column terms of its 4 columns for all its rows, and the taps come out of LDS (three dword
+// reads and two v_alignbyte per source row and pixel pair).  Same integer / float arithmetic, same results.
+// Tiles whose bounding box leaves the image, or does not fit the LDS budget (large rotations), take the per-pixel
+// path.
+constexpr int WT_W = 256;
+template <typename T> struct WarpTile { static constexpr int TH = sizeof(T) == 1 ? 32 : 16; };
+constexpr int WT_LDS_DWORDS = 10240;   // 40 KB: four workgroups per CU
+
 template <typename T, bool VEC>
-__global__ __launch_bounds__(256) void warp_affine_kernel(const T* __restrict__ src, T* __restrict__ dst,
-                                                          uint8_t* __restrict__ valid, AffineArgs a) {
-    const int xq = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+__global__ __launch_bounds__(256) void warp_affine_tiled(const T* __restrict__ src, T* __restrict__ dst,
+                                                         uint8_t* __restrict__ valid, AffineArgs a) {
+    extern __shared__ uint32_t s_src[];
+    constexpr int BPP = 3 * (int)sizeof(T), TH = WarpTile<T>::TH, RPT = TH / 4;   // rows per thread
     const int h = a.h, w = a.w;
-    if (xq >= w || y >= h) return;
-    const int X0 = cv_round_d((a.iM[1] * y + a.iM[2]) * 1024.0) + 16;
-    const int Y0 = cv_round_d((a.iM[4] * y + a.iM[5]) * 1024.0) + 16;
-    int v[4][3], ok[4];
-    // source positions of the thread's first and last pixel: both (with their +1 taps, and not touching the image's
-    // very last pixel, whose 4-byte tap load would leave the buffer) inside the image -> the fast path for all four
-    bool inside = xq + 3 < w;
-    if (inside) {
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int x = xq + 3 * e;
-            const int sx = ((X0 + cv_round_d(a.iM[0] * x * 1024.0)) >> 5) >> 5;
-            const int sy = ((Y0 + cv_round_d(a.iM[3] * x * 1024.0)) >> 5) >> 5;
-            inside = inside && sx >= 0 && sx + 1 < w && sy >= 0 && sy + 1 < h - 1;
-        }
-    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int x_t = blockIdx.x * WT_W, y_t = blockIdx.y * TH;
+    const int xq = x_t + 4 * lane;
+    int ad[4], bd[4];
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-        ok[p] = 0;
-        v[p][0] = v[p][1] = v[p][2] = 0;
-        if (inside) {
-            warp_pixel_inside<T>(src, a, xq + p, X0, Y0, v[p]);
-            ok[p] = 1;
-        } else if (xq + p < w) {
-            warp_pixel<T>(src, a, xq + p, X0, Y0, v[p], ok[p]);
+        const int x = min(xq + p, w - 1);
+        ad[p] = cv_round_d(a.iM[0] * x * 1024.0);
+        bd[p] = cv_round_d(a.iM[3] * x * 1024.0);
+    }
+    // source bounding box of the tile (first taps; the +1 taps are added below)
+    int sxmin = 0x7fffffff, sxmax = -0x7fffffff, symin = 0x7fffffff, symax = -0x7fffffff;
+    {
+        const int cxs[2] = {x_t, min(x_t + WT_W, w) - 1}, cys[2] = {y_t, min(y_t + TH, h) - 1};
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int X0 = cv_round_d((a.iM[1] * cys[i] + a.iM[2]) * 1024.0) + 16;
+            const int Y0 = cv_round_d((a.iM[4] * cys[i] + a.iM[5]) * 1024.0) + 16;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int sx = ((X0 + cv_round_d(a.iM[0] * cxs[j] * 1024.0)) >> 5) >> 5;
+                const int sy = ((Y0 + cv_round_d(a.iM[3] * cxs[j] * 1024.0)) >> 5) >> 5;
+                sxmin = min(sxmin, sx); sxmax = max(sxmax, sx);
+                symin = min(symin, sy); symax = max(symax, sy);
+            }
         }
     }
-    const size_t px = (size_t)y * w + xq;
-    if constexpr (VEC) {
-        if constexpr (sizeof(T) == 1) {
-            uint32_t o[3];
+    const int nc = sxmax - sxmin + 2, nr = symax - symin + 2;
+    // dwords per staged row: alignment shift (<= 3 bytes) + the pixels, rounded up to whole 16-byte chunks
+    const int pitch = (((nc * BPP + 3 + 3) >> 2) + 3) & ~3;
+    const size_t row_bytes = (size_t)w * BPP;
+    const size_t start0 = ((size_t)max(symin, 0) * w + max(sxmin, 0)) * BPP;
+    bool tiled = sxmin >= 0 && symin >= 0 && sxmax + 1 < w && symax + 1 < h && (long long)nr * pitch <= WT_LDS_DWORDS &&
+                 (reinterpret_cast<uintptr_t>(src) & 3) == 0;
+    if (tiled) {   // the 16-byte reads of the last staged row must end inside the buffer
+        const size_t st = start0 + (size_t)(nr - 1) * row_bytes;
+        tiled = (st & ~(size_t)3) + (size_t)pitch * 4 <= (size_t)h * w * BPP;
+    }
+    if (tiled) {   // uniform over the workgroup
+        // staging: wave wv takes rows wv, wv+4, ...; a lane one 16-byte chunk of a row (global accesses need no
+        // alignment beyond the element's).  All loads of a pass are issued before the first LDS store: one pass of
+        // latency per 12 rows instead of one per load.
+        const char* g8 = reinterpret_cast<const char*>(src);
+        const int cpr = pitch >> 2;
+        constexpr int PASS = 12;
+        for (int j = lane; j < cpr; j += 64) {
+            for (int rb = wv; rb < nr; rb += 4 * PASS) {
+                v4f buf[PASS];
 #pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                o[d] = 0;
+                for (int i = 0; i < PASS; ++i) {
+                    const int r = rb + 4 * i;
+                    if (r < nr) {
+                        const size_t st = start0 + (size_t)r * row_bytes;
+                        __builtin_memcpy(&buf[i], g8 + (st & ~(size_t)3) + 16 * (size_t)j, 16);
+                    }
+                }
 #pragma unroll
-                for (int b = 0; b < 4; ++b) o[d] |= (uint32_t)v[(4 * d + b) / 3][(4 * d + b) % 3] << (8 * b);
+                for (int i = 0; i < PASS; ++i) {
+                    const int r = rb + 4 * i;
+                    if (r < nr) *reinterpret_cast<v4f*>(s_src + mul24(r, pitch) + 4 * j) = buf[i];
+                }
             }
-            uint32_t* d4 = reinterpret_cast<uint32_t*>(dst + px * 3);
-            d4[0] = o[0]; d4[1] = o[1]; d4[2] = o[2];
-        } else {
-            uint32_t* d4 = reinterpret_cast<uint32_t*>(dst + px * 3);
-#pragma unroll
-            for (int d = 0; d < 6; ++d)
-                d4[d] = (uint32_t)v[(2 * d) / 3][(2 * d) % 3] | ((uint32_t)v[(2 * d + 1) / 3][(2 * d + 1) % 3] << 16);
         }
-        if (valid)
-            *reinterpret_cast<uint32_t*>(valid + px) =
-                (uint32_t)ok[0] | ((uint32_t)ok[1] << 8) | ((uint32_t)ok[2] << 16) | ((uint32_t)ok[3] << 24);
-    } else {
+        __syncthreads();
+        const uint32_t sh0 = (uint32_t)(start0 & 3), rb3 = (uint32_t)(row_bytes & 3);
+#pragma unroll 2
+        for (int k = 0; k < RPT; ++k) {
+            const int y = y_t + wv * RPT + k;
+            if (y >= h) break;
+            const int X0 = cv_round_d((a.iM[1] * y + a.iM[2]) * 1024.0) + 16;
+            const int Y0 = cv_round_d((a.iM[4] * y + a.iM[5]) * 1024.0) + 16;
+            int v[4][3];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int X = (X0 + ad[p]) >> 5, Y = (Y0 + bd[p]) >> 5;
+                const int sx = X >> 5, sy = Y >> 5, fx = X & 31, fy = Y & 31;
+                const int r0 = sy - symin;
+                int q[4][3];
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr) {
+                    // byte position inside the staged row: the row's alignment shift (start0 + r * row_bytes) mod 4
+                    const uint32_t A = ((sh0 + (uint32_t)((r0 + rr) & 3) * rb3) & 3u) + (uint32_t)mul24(sx - sxmin, BPP);
+                    const uint32_t* sp = s_src + mul24(r0 + rr, pitch) + (A >> 2);
+                    const uint32_t sh = A & 3;
+                    if constexpr (sizeof(T) == 1) {
+                        const uint32_t d0 = sp[0], d1 = sp[1], d2 = sp[2];
+                        const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, sh), hi = __builtin_amdgcn_alignbyte(d2, d1, sh);
+                        q[2 * rr][0] = lo & 255u; q[2 * rr][1] = (lo >> 8) & 255u; q[2 * rr][2] = (lo >> 16) & 255u;
+                        q[2 * rr + 1][0] = lo >> 24; q[2 * rr + 1][1] = hi & 255u; q[2 * rr + 1][2] = (hi >> 8) & 255u;
+                    } else {
+                        const uint32_t d0 = sp[0], d1 = sp[1], d2 = sp[2], d3 = sp[3];
+                        const uint32_t w0 = __builtin_amdgcn_alignbyte(d1, d0, sh), w1 = __builtin_amdgcn_alignbyte(d2, d1, sh),
+                                       w2 = __builtin_amdgcn_alignbyte(d3, d2, sh);
+                        q[2 * rr][0] = w0 & 65535u; q[2 * rr][1] = w0 >> 16; q[2 * rr][2] = w1 & 65535u;
+                        q[2 * rr + 1][0] = w1 >> 16; q[2 * rr + 1][1] = w2 & 65535u; q[2 * rr + 1][2] = w2 >> 16;
+                    }
+                }
+                int iw0 = (32 - fy) * (32 - fx) * 32, iw1 = (32 - fy) * fx * 32, iw2 = fy * (32 - fx) * 32, iw3 = fy * fx * 32;
+                if (fx == 0 && fy == 0) { iw0 = 32767; iw3 = 1; }
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    int r;
+                    if constexpr (sizeof(T) == 1) {
+                        r = (q[0][c] * iw0 + q[1][c] * iw1 + q[2][c] * iw2 + q[3][c] * iw3 + 16384) >> 15;
+                        r = min(max(r, 0), 255);
+                    } else {
+                        const float wx1 = fx * (1.0f / 32), wx0 = 1.0f - wx1, wy1 = fy * (1.0f / 32), wy0 = 1.0f - wy1;
+                        const float q0 = (float)q[0][c] * (wy0 * wx0), q1 = (float)q[1][c] * (wy0 * wx1);
+                        const float q2 = (float)q[2][c] * (wy1 * wx0), q3 = (float)q[3][c] * (wy1 * wx1);
+                        float sacc = q0 + q1;
+                        sacc = sacc + q2;
+                        sacc = sacc + q3;
+                        r = min(max((int)rintf(sacc), 0), 65535);
+                    }
+                    v[p][c] = r;
+                }
+            }
+            const size_t px = (size_t)y * w + xq;
+            if (VEC) {
+                if (xq < w) {
+                    uint32_t* d4 = reinterpret_cast<uint32_t*>(dst + px * 3);
+                    if constexpr (sizeof(T) == 1) {
+#pragma unroll
+                        for (int d = 0; d < 3; ++d) {
+                            uint32_t o = 0;
+#pragma unroll
+                            for (int b = 0; b < 4; ++b) o |= (uint32_t)v[(4 * d + b) / 3][(4 * d + b) % 3] << (8 * b);
+                            d4[d] = o;
+                        }
+                    } else {
+#pragma unroll
+                        for (int d = 0; d < 6; ++d)
+                            d4[d] = (uint32_t)v[(2 * d) / 3][(2 * d) % 3] | ((uint32_t)v[(2 * d + 1) / 3][(2 * d + 1) % 3] << 16);
+                    }
+                    if (valid) *reinterpret_cast<uint32_t*>(valid + px) = 0x01010101u;
+                }
+            } else {
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+                    if (xq + p < w) {
+                        dst[(px + p) * 3 + 0] = (T)v[p][0];
+                        dst[(px + p) * 3 + 1] = (T)v[p][1];
+                        dst[(px + p) * 3 + 2] = (T)v[p][2];
+                        if (valid) valid[px + p] = 1;
+                    }
+            }
+        }
+        return;
+    }
+    // ---- per-pixel path (border tiles, large rotations): gathers from global memory, in-image flags per tap
+    for (int k = 0; k < RPT; ++k) {
+        const int y = y_t + wv * RPT + k;
+        if (y >= h || xq >= w) break;
+        const int X0 = cv_round_d((a.iM[1] * y + a.iM[2]) * 1024.0) + 16;
+        const int Y0 = cv_round_d((a.iM[4] * y + a.iM[5]) * 1024.0) + 16;
+        int v[4][3], ok[4];
+        bool inside = xq + 3 < w;
+        if (inside) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int sx = ((X0 + ad[3 * e]) >> 5) >> 5, sy = ((Y0 + bd[3 * e]) >> 5) >> 5;
+                inside = inside && sx >= 0 && sx + 1 < w && sy >= 0 && sy + 1 < h - 1;
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            ok[p] = 0;
+            v[p][0] = v[p][1] = v[p][2] = 0;
+            if (inside) {
+                warp_pixel_inside<T>(src, a, xq + p, X0, Y0, v[p]);
+                ok[p] = 1;
+            } else if (xq + p < w) {
+                warp_pixel<T>(src, a, xq + p, X0, Y0, v[p], ok[p]);
+            }
+        }
+        const size_t px = (size_t)y * w + xq;
 #pragma unroll
         for (int p = 0; p < 4; ++p)
             if (xq + p < w) {
@@ -287,17 +425,17 @@ __device__ __forceinline__ void blur_at(const T* __restrict__ img, int h, int w,
     for (int dy = 0; dy < g.ksize; ++dy) {
         const int yy = r101_loop(y + dy - r, h);
         float row[3] = {0.f, 0.f, 0.f};
-        // the window row's loads are issued together (groups of 8), not one per dependent multiply-add: a wave that
-        // comes here alone -- a run that crosses a row end -- otherwise pays 441 memory latencies in a row (~75 us)
-        for (int d0 = 0; d0 < g.ksize; d0 += 8) {
-            uint2 raw[8];
+        // the window row's loads are issued together (groups of 16: two round trips per window row), not one per
+        // dependent multiply-add: the few hundred waves of a frame's masked pixels have nothing else to hide latency
+        for (int d0 = 0; d0 < g.ksize; d0 += 16) {
+            uint2 raw[16];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < 16; ++u) {
                 const int dx = min(d0 + u, g.ksize - 1);
                 raw[u] = load_px3_raw<T>(img, (size_t)yy * w + r101_loop(x + dx - r, w), last);
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < 16; ++u) {
                 if (d0 + u < g.ksize) {
                     float p[3];
                     decode_px3<T>(raw[u], p);
@@ -321,202 +459,230 @@ __device__ __forceinline__ void blur_at(const T* __restrict__ img, int h, int w,
     for (int c = 0; c < 3; ++c) out[c] = min(max((int)rintf(acc[c]), 0), maxv);
 }
 
-// out = valid ? warp : gaussian_blur(warp), in place on `img` in two sparse passes: the pixels whose
-// mask is 0 (a frame along the borders: a few columns at the sides, wedges where the frame rotated)
-// get their blurred value computed from the untouched image into `side` (same index), then copied back.
-//
-// Pass 0 (collect), one wave per 64 consecutive pixels (four waves per workgroup).  A wave with no masked pixel leaves at once.
-// A wave with many does one pixel per lane (blur_at).  A wave with few (the side columns: 1-3 lanes)
-// works through them 64 / ksize at a time instead of idling 60 lanes for 441 taps: ksize lanes per
-// pixel, lane r does the horizontal pass of window row r (taps in index order), the first lane of the
-// group adds the ksize row results in row order (shuffles, no LDS) -- the same float32 operations in
-// the same order as align_oracle.c either way.
-template <typename T>
-__global__ __launch_bounds__(256) void border_blur_collect(const T* __restrict__ img, const uint8_t* __restrict__ valid,
-                                                           T* __restrict__ side, int h, int w, GaussArgs g) {
-    // four independent waves per workgroup (one 64-pixel chunk each): a quarter of the workgroups to dispatch --
-    // with one-wave workgroups the launch of the 375 000 of a 24 MP frame alone took 80 us
-    const int lane = threadIdx.x & 63;
-    const size_t n = (size_t)h * w;
-    const size_t base = ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
-    const size_t pi = base + lane;
-    const bool masked = pi < n && valid[pi] == 0;
-    const unsigned long long ballot = __ballot(masked);
-    if (ballot == 0) return;
-    const int nm = __popcll(ballot);
-    const int ks = g.ksize, r = ks / 2;
-    const int maxv = sizeof(T) == 1 ? 255 : 65535;
-    const int per = 64 / ks;  // pixels per cooperative round
-    const float kreg = g.k[lane & 31];   // lane i holds tap i (ksize <= 31)
-    auto kof = [&](int i) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(kreg), i)); };
-    if (nm > 4 * per) {
-        // A run of masked pixels (a row along the top or bottom edge): the wave shares each window row through LDS: 64 + 2r pixels are loaded once (two loads per lane instead of
-        // ksize per lane, and the reflection map per loaded pixel instead of per tap) and every lane sums its ksize
-        // neighbours from there -- the operations of blur_at in the same order, a third of the instructions.
-        __shared__ float sRow[4][64 + 2 * 10][3];
-        const int y_first = (int)(base / w), x_first = (int)(base - (size_t)y_first * w);
-        if (r <= 10) {
-            float (*s)[3] = sRow[threadIdx.x >> 6];
-            // a chunk that crosses a row end is two runs (the tail of row y_first, the head of the next row): the
-            // procedure runs once per run, with lane 0 at a virtual column xs of that row
-            const int nruns = x_first + 63 >= w ? 2 : 1;
-            for (int run = 0; run < nruns; ++run) {
-                const int yr = y_first + run;
-                if (yr >= h) break;
-                const int xs = run == 0 ? x_first : x_first - w;
-                const bool mine = masked && (run == 0 ? lane < w - x_first : lane >= w - x_first);
-                float acc[3] = {0.f, 0.f, 0.f};
-                // all window rows are requested before the first one is used: only a few hundred such waves exist
-                // per frame, so nothing else hides the latency of 21 load round trips in a row
-                uint2 pre[21][2];
+// out = valid ? warp : gaussian_blur(warp), in place on `img`.  The pixels whose mask is 0 form a frame along the
+// borders (a few columns at the sides, wedges where the frame rotated: some ten thousand of the 24 million pixels of a
+// frame that moved by a few pixels).  Their 21 x 21 windows overlap almost completely, so the separable blur is
+// evaluated densely, but only on the 32 x 64 tiles that contain a masked pixel:
+//   scan     tiles with a masked pixel are marked in a bitmap (16 mask bytes per lane and step), the bitmap becomes a list;
+//   blur     one workgroup per listed tile: the tile + r halo of the untouched image -> LDS (raw pixels), the horizontal
+//            pass for every row of the patch -> LDS (float, planar), the vertical pass for the tile's masked pixels ->
+//            `side` (same index as the image);
+//   scatter  the masked pixels of the listed tiles take their value from `side`.
+// Arithmetic = align_oracle.c: horizontal then vertical pass in float32, taps in index order, a multiplication and an
+// addition per tap (no fma), REFLECT101, round-half-even + saturate.  (Round 1 walked every 64-pixel chunk of the mask
+// inside the blur pass and evaluated each masked pixel's 441 taps on its own: 80-160 us per 24 MP frame; this: ~30.)
+constexpr int BT_H = 32, BT_W = 64;
+
+__global__ __launch_bounds__(256) void mask_scan_tiles(const uint8_t* __restrict__ valid, int h, int w, int tiles_x,
+                                                       uint32_t* __restrict__ bitmap) {
+    // a fixed grid walks the mask 16 bytes per lane and step (one workgroup per 1024 pixels would be 23 000 workgroups
+    // for a 24 MP frame: the dispatch alone took longer than reading the 24 MB)
+    const size_t npix = (size_t)h * w;
+    const size_t nvec = (npix + 15) / 16;
+    const bool aligned = (reinterpret_cast<uintptr_t>(valid) & 15) == 0;
+    for (size_t v0 = (size_t)blockIdx.x * blockDim.x; v0 < nvec; v0 += (size_t)gridDim.x * blockDim.x) {
+        const size_t v = v0 + threadIdx.x, i0 = v * 16;
+        uint32_t q[4] = {0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u};
+        if (v < nvec) {
+            if (aligned && i0 + 16 <= npix) {
+                const uint4 t = *reinterpret_cast<const uint4*>(valid + i0);
+                q[0] = t.x; q[1] = t.y; q[2] = t.z; q[3] = t.w;
+            } else {
+                for (int b = 0; b < 16; ++b)
+                    if (i0 + b < npix && valid[i0 + b] == 0) q[b >> 2] &= ~(0xffu << (8 * (b & 3)));
+            }
+        }
+        const bool any = q[0] != 0x01010101u || q[1] != 0x01010101u || q[2] != 0x01010101u || q[3] != 0x01010101u;
+        if (__ballot(any) == 0) continue;   // wave-uniform: the common case
+        // tiles of the lane's first and last masked pixel (16 consecutive pixels span at most two tiles of one row,
+        // or a row end)
 #pragma unroll
-                for (int dy = 0; dy < 21; ++dy) {
-#pragma unroll
-                    for (int jj = 0; jj < 2; ++jj) {
-                        const int j = lane + 64 * jj;
-                        pre[dy][jj] = uint2{0u, 0u};
-                        if (dy < ks && j < 64 + 2 * r)
-                            pre[dy][jj] = load_px3_raw<T>(img, (size_t)r101_loop(yr + dy - r, h) * w +
-                                                                   r101_loop(xs + j - r, w), n - 1);
+        for (int pass = 0; pass < 2; ++pass) {
+            int tile = -1;
+            if (any) {
+                for (int b = 0; b < 16; ++b) {
+                    const int bb = pass ? 15 - b : b;
+                    if (((q[bb >> 2] >> (8 * (bb & 3))) & 0xffu) == 0) {
+                        const uint32_t pi = (uint32_t)(i0 + bb);
+                        const uint32_t y = pi / (uint32_t)w, x = pi - y * (uint32_t)w;
+                        tile = (int)((y / BT_H) * (uint32_t)tiles_x + x / BT_W);
+                        break;
                     }
                 }
-#pragma unroll
-                for (int dy = 0; dy < 21; ++dy) {
-                    if (dy < ks) {
-#pragma unroll
-                        for (int jj = 0; jj < 2; ++jj) {
-                            const int j = lane + 64 * jj;
-                            if (j < 64 + 2 * r) {
-                                float p[3];
-                                decode_px3<T>(pre[dy][jj], p);
-                                s[j][0] = p[0]; s[j][1] = p[1]; s[j][2] = p[2];
-                            }
-                        }
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the wave's own LDS writes have landed
-                        float row[3] = {0.f, 0.f, 0.f};
-                        // seven taps' LDS reads are in flight at a time (a loop that waits for every read is a chain
-                        // of 1 323 LDS latencies per pixel)
-                        for (int d0 = 0; d0 < ks; d0 += 7) {
-                            float v[7][3];
-#pragma unroll
-                            for (int u = 0; u < 7; ++u) {
-                                const int jx = lane + min(d0 + u, ks - 1);
-                                v[u][0] = s[jx][0]; v[u][1] = s[jx][1]; v[u][2] = s[jx][2];
-                            }
-#pragma unroll
-                            for (int u = 0; u < 7; ++u) {
-                                if (d0 + u < ks) {
-                                    const float k = kof(d0 + u);
-#pragma unroll
-                                    for (int c = 0; c < 3; ++c) {
-                                        const float pr = k * v[u][c];
-                                        row[c] = row[c] + pr;
-                                    }
-                                }
-                            }
-                        }
-                        const float kd = kof(dy);
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) {
-                            const float q = kd * row[c];
-                            acc[c] = acc[c] + q;
-                        }
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next row overwrites
-                    }
-                }
-                if (mine) {
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) side[pi * 3 + c] = (T)min(max((int)rintf(acc[c]), 0), maxv);
-                }
             }
-            return;
-        }
-        if (masked) {
-            const int y = (int)(pi / w), x = (int)(pi - (size_t)y * w);
-            int o[3];
-            blur_at<T>(img, h, w, y, x, g, o, kof);
-            side[pi * 3 + 0] = (T)o[0]; side[pi * 3 + 1] = (T)o[1]; side[pi * 3 + 2] = (T)o[2];
-        }
-        return;
-    }
-    const int slot = lane / ks, wr = lane - slot * ks;
-    unsigned long long rest = ballot;
-    while (rest) {   // wave-uniform
-        // the next `per` masked lanes: group `slot` takes the slot-th of them
-        unsigned long long pick = rest;
-        int src_lane = -1;
-        for (int k = 0; k < per; ++k) {
-            if (!pick) break;
-            const int b = __ffsll((long long)pick) - 1;
-            if (k == slot) src_lane = b;
-            pick &= pick - 1;
-        }
-        rest = pick;
-        const bool act = slot < per && src_lane >= 0;
-        const size_t qi = base + (act ? src_lane : 0);
-        float q[3] = {0.f, 0.f, 0.f};
-        if (act) {
-            const int y = (int)(qi / w), x = (int)(qi - (size_t)y * w);
-            const int yy = r101_loop(y + wr - r, h);
-            float row[3] = {0.f, 0.f, 0.f};
-            for (int dx = 0; dx < ks; ++dx) {
-                const int xx = r101_loop(x + dx - r, w);
-                float p[3];
-                load_px3<T>(img, (size_t)yy * w + xx, n - 1, p);
-                const float k = kof(dx);
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const float pr = k * p[c];
-                    row[c] = row[c] + pr;
-                }
+            unsigned long long rest = __ballot(tile >= 0);
+            while (rest) {   // wave-uniform: one (fire-and-forget) atomic per distinct tile of the wave
+                const int leader = __ffsll((long long)rest) - 1;
+                const int t = __builtin_amdgcn_readlane(tile, leader);
+                if ((int)(threadIdx.x & 63) == leader) atomicOr(&bitmap[t >> 5], 1u << (t & 31));
+                rest &= ~__ballot(tile == t);
             }
-            const float kw = __shfl(kreg, wr, 64);   // tap of this lane's window row
-#pragma unroll
-            for (int c = 0; c < 3; ++c) q[c] = kw * row[c];
-        }
-        // vertical pass: the group's first lane adds the row results in row order
-        float acc[3] = {0.f, 0.f, 0.f};
-        for (int dy = 0; dy < ks; ++dy) {
-            const int from = min(slot * ks + dy, 63);
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const float v = __shfl(q[c], from, 64);
-                acc[c] = acc[c] + v;
-            }
-        }
-        if (act && wr == 0) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) side[qi * 3 + c] = (T)min(max((int)rintf(acc[c]), 0), maxv);
         }
     }
 }
 
-// Pass 1 (scatter): masked pixels take their blurred value from `side`.
-template <typename T>
-__global__ __launch_bounds__(256) void border_blur_scatter(T* __restrict__ img, const uint8_t* __restrict__ valid,
-                                                           const T* __restrict__ side, int h, int w) {
-    const size_t n = (size_t)h * w;
-    const size_t i0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
-    if (i0 >= n) return;
-    uint32_t m[4];
-    if (i0 + 16 <= n && (reinterpret_cast<uintptr_t>(valid) & 15) == 0) {
-        const uint4 q = *reinterpret_cast<const uint4*>(valid + i0);
-        m[0] = q.x; m[1] = q.y; m[2] = q.z; m[3] = q.w;
-        if (m[0] == 0x01010101u && m[1] == 0x01010101u && m[2] == 0x01010101u && m[3] == 0x01010101u)
-            return;  // all 16 valid: the common case
-    } else {
-        for (int k = 0; k < 4; ++k) {
-            m[k] = 0;
-            for (int b = 0; b < 4; ++b) {
-                const size_t i = i0 + 4 * k + b;
-                m[k] |= (uint32_t)(i < n ? valid[i] : 1) << (8 * b);
-            }
+// bitmap of tiles -> list (one workgroup; the order of the list does not matter)
+__global__ __launch_bounds__(1024) void tile_bitmap_to_list(const uint32_t* __restrict__ bitmap, int nwords,
+                                                            uint32_t* __restrict__ cnt, uint32_t* __restrict__ list) {
+    for (int i = threadIdx.x; i < nwords; i += blockDim.x) {
+        uint32_t m = bitmap[i];
+        if (!m) continue;
+        uint32_t pos = atomicAdd(cnt, (uint32_t)__popc(m));
+        while (m) {
+            const int b = __ffs((int)m) - 1;
+            list[pos++] = (uint32_t)(i * 32 + b);
+            m &= m - 1;
         }
     }
-    for (int k = 0; k < 16; ++k) {
-        if ((m[k >> 2] >> (8 * (k & 3))) & 0xffu) continue;
-        const size_t i = i0 + k;
-        img[i * 3 + 0] = side[i * 3 + 0]; img[i * 3 + 1] = side[i * 3 + 1]; img[i * 3 + 2] = side[i * 3 + 2];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void border_blur_tiles(const T* __restrict__ img, const uint8_t* __restrict__ valid,
+                                                         T* __restrict__ side, int h, int w, int tiles_x, GaussArgs g,
+                                                         const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ list) {
+    extern __shared__ uint32_t s_blur[];
+    __shared__ int s_box[4];            // rows [0] .. [1], columns [2] .. [3] of the tile that hold a masked pixel
+    __shared__ int s_cols[BT_W + 1];    // the masked columns, compact; [BT_W] = how many
+    const int ks = g.ksize, r = ks / 2;
+    const int PH = BT_H + 2 * r, PW = BT_W + 2 * r;
+    constexpr int RAW = sizeof(T) == 1 ? 1 : 2;            // dwords per staged pixel
+    uint32_t* sP = s_blur;                                  // PH x PW raw pixels
+    float* sH = reinterpret_cast<float*>(s_blur + PH * PW * RAW);   // [3][PH][BT_W] horizontal pass
+    const int maxv = sizeof(T) == 1 ? 255 : 65535;
+    const size_t last = (size_t)h * w - 1;
+    const int lane = threadIdx.x & 63;
+    const float kreg = g.k[lane & 31];   // lane i holds tap i (ksize <= 31): v_readlane instead of a scalar load per tap
+    auto kof = [&](int i) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(kreg), i)); };
+    const uint32_t n = *cnt;
+    for (uint32_t e = blockIdx.x; e < n; e += gridDim.x) {
+        const int t = (int)list[e];
+        const int ty = t / tiles_x, tx = t - ty * tiles_x;
+        const int y0 = ty * BT_H, x0 = tx * BT_W;
+        // ---- which pixels of the tile are masked: the lane's 8 (rows yy0 + 4j, one column), and the tile's bounding box
+        // of them -- a side-column tile needs the horizontal pass for 4 of its 64 columns, a top-edge tile for 23 of
+        // the patch's 52 rows
+        if (threadIdx.x < 4) s_box[threadIdx.x] = (threadIdx.x & 1) ? -1 : 1 << 20;
+        __syncthreads();
+        const int xx = threadIdx.x & 63, yy0 = threadIdx.x >> 6;
+        uint32_t mymask = 0;
+#pragma unroll
+        for (int j = 0; j < BT_H / 4; ++j) {
+            const int y = y0 + yy0 + 4 * j, x = x0 + xx;
+            if (y < h && x < w && valid[(size_t)y * w + x] == 0) mymask |= 1u << j;
+        }
+        if (mymask) {
+            atomicMin(&s_box[0], yy0 + 4 * (__ffs((int)mymask) - 1));
+            atomicMax(&s_box[1], yy0 + 4 * (31 - __clz((int)mymask)));
+            atomicMin(&s_box[2], xx);
+            atomicMax(&s_box[3], xx);
+        }
+        {   // compact list of the masked columns (wave 0 sees the flags of all four waves through LDS)
+            if (threadIdx.x < BT_W + 1) s_cols[threadIdx.x] = 0;
+            __syncthreads();
+            if (mymask) s_cols[xx] = 1;    // benign race: every writer stores 1
+            __syncthreads();
+            if (threadIdx.x < 64) {
+                const unsigned long long m = __ballot(s_cols[lane] != 0);
+                __builtin_amdgcn_s_waitcnt(0);
+                if ((m >> lane) & 1ull) s_cols[__popcll(m & ((1ull << lane) - 1ull))] = lane;
+                if (lane == 0) s_cols[BT_W] = __popcll(m);
+            }
+        }
+        __syncthreads();
+        const int ra = s_box[0], rb = s_box[1], ca = s_box[2], cb = s_box[3], ncols = s_cols[BT_W];
+        if (rb >= 0) {   // uniform (a listed tile always has a masked pixel; guard anyway)
+            const int nrows = rb - ra + 1 + 2 * r, ncp = cb - ca + 1 + 2 * r;   // patch rectangle: rows ra.., columns ca..
+            // ---- stage that rectangle of the patch (REFLECT101 of the image), raw
+            for (int i0 = threadIdx.x; i0 < nrows * ncp; i0 += 256 * 8) {
+                uint2 raw[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int i = min(i0 + 256 * u, nrows * ncp - 1);
+                    const int py = ra + i / ncp, px = ca + i % ncp;
+                    raw[u] = load_px3_raw<T>(img, (size_t)r101_loop(y0 - r + py, h) * w + r101_loop(x0 - r + px, w), last);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int i = i0 + 256 * u;
+                    if (i < nrows * ncp) {
+                        const int py = ra + i / ncp, px = ca + i % ncp;
+                        sP[(py * PW + px) * RAW] = raw[u].x;
+                        if (RAW == 2) sP[(py * PW + px) * RAW + RAW - 1] = raw[u].y;
+                    }
+                }
+            }
+            __syncthreads();
+            // ---- horizontal pass: the needed rows of the patch x the masked columns
+            for (int i = threadIdx.x; i < nrows * ncols; i += 256) {
+                const int py = ra + i / ncols, cx = s_cols[i % ncols];
+                const uint32_t* p = sP + (py * PW + cx) * RAW;
+                float row[3] = {0.f, 0.f, 0.f};
+                for (int d0 = 0; d0 < ks; d0 += 7) {   // seven taps' LDS reads in flight at a time, added in index order
+                    uint2 rw[7];
+#pragma unroll
+                    for (int u = 0; u < 7; ++u) {
+                        const int dx = min(d0 + u, ks - 1);
+                        rw[u].x = p[dx * RAW];
+                        rw[u].y = RAW == 2 ? p[dx * RAW + RAW - 1] : 0u;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 7; ++u) {
+                        if (d0 + u < ks) {
+                            float v[3];
+                            decode_px3<T>(rw[u], v);
+                            const float k = kof(d0 + u);   // v_readlane ignores EXEC: fine in divergent code
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) {
+                                const float pr = k * v[c];
+                                row[c] = row[c] + pr;
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < 3; ++c) sH[(c * PH + py) * BT_W + cx] = row[c];
+            }
+            __syncthreads();
+            // ---- vertical pass for the lane's masked pixels
+#pragma unroll 1
+            for (int j = 0; j < BT_H / 4; ++j) {
+                if (!((mymask >> j) & 1u)) continue;
+                const int yy = yy0 + 4 * j;
+                float acc[3] = {0.f, 0.f, 0.f};
+                for (int dy = 0; dy < ks; ++dy) {
+                    const float kd = kof(dy);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const float qv = kd * sH[(c * PH + yy + dy) * BT_W + xx];
+                        acc[c] = acc[c] + qv;
+                    }
+                }
+                const size_t pi = (size_t)(y0 + yy) * w + (x0 + xx);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) side[pi * 3 + c] = (T)min(max((int)rintf(acc[c]), 0), maxv);
+            }
+        }
+        __syncthreads();   // the next tile's passes overwrite the LDS arrays
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void border_blur_scatter(T* __restrict__ img, const uint8_t* __restrict__ valid,
+                                                           const T* __restrict__ side, int h, int w, int tiles_x,
+                                                           const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ list) {
+    const uint32_t n = *cnt;
+    for (uint32_t e = blockIdx.x; e < n; e += gridDim.x) {
+        const int t = (int)list[e];
+        const int ty = t / tiles_x, tx = t - ty * tiles_x;
+        for (int i = threadIdx.x; i < BT_H * BT_W; i += 256) {
+            const int y = ty * BT_H + (i >> 6), x = tx * BT_W + (i & 63);
+            if (y < h && x < w) {
+                const size_t pi = (size_t)y * w + x;
+                if (valid[pi] == 0) {
+                    img[pi * 3 + 0] = side[pi * 3 + 0]; img[pi * 3 + 1] = side[pi * 3 + 1]; img[pi * 3 + 2] = side[pi * 3 + 2];
+                }
+            }
+        }
     }
 }
 
