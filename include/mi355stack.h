@@ -217,6 +217,16 @@ MI_API int mi_warp_affine_device(int device, void* stream, const void* dev_src, 
                           void* dev_mask, int height, int width, int dtype, const double* M,
                           int border_mode, const double* border_value, int blur_ksize, double blur_sigma);
 
+/* The same for the ALIGN_HOMOGRAPHY transform: cv2.warpPerspective(img, M, (w, h), borderMode, borderValue) of image and
+ * all-ones mask (reference algorithms/align.py:231-237) + the same blurred-border composite.  M: the 3x3 src->dst matrix
+ * as OpenCV takes it (row-major, 9 doubles). */
+MI_API int mi_warp_perspective(int device, const void* host_src, void* host_dst, void* host_mask, int height, int width,
+                        int dtype, const double* M, int border_mode, const double* border_value, int blur_ksize,
+                        double blur_sigma);
+MI_API int mi_warp_perspective_device(int device, void* stream, const void* dev_src, void* dev_dst, void* dev_tmp,
+                               void* dev_mask, int height, int width, int dtype, const double* M, int border_mode,
+                               const double* border_value, int blur_ksize, double blur_sigma);
+
 /* ---- GPU transform estimator (new capability; north_star's "ECC warp-affine alignment loop"):
  * Enhanced-Correlation-Coefficient maximisation of a 4-DoF similarity -- the motion model of the
  * reference's default ALIGN_RIGID estimate (cv2.estimateAffinePartial2D, algorithms/align.py:141-148)

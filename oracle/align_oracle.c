@@ -68,16 +68,75 @@ static inline void wtab_i(int fx, int fy, int* iw) {
     if (fx == 0 && fy == 0) { iw[0] = 32767; iw[3] = 1; } /* short saturation + OpenCV's fix-up */
 }
 
-/* dtype: 0 = u8, 1 = u16.  mode: 0 = constant(border[c]), 1 = replicate.
- * valid (may be NULL): h*w bytes, the warped all-ones mask. */
-ORC_API void orc_warp_affine(const void* src_, void* dst_, uint8_t* valid, int h, int w, int dtype,
-                             const double* M, int mode, const double* border) {
-    double iM[6];
-    orc_invert_affine(M, iM);
+/* one destination pixel from the source position (X, Y) in 1/32 pixel: the remap core shared by warpAffine and
+ * warpPerspective.  dtype: 0 = u8, 1 = u16.  mode: 0 = constant(border[c]), 1 = replicate. */
+static void sample_px(const void* src_, void* dst_, uint8_t* valid, int h, int w, int dtype, int mode, const double* border,
+                      int y, int x, int X, int Y) {
     const uint8_t* s8 = (const uint8_t*)src_;
     const uint16_t* s16 = (const uint16_t*)src_;
     uint8_t* d8 = (uint8_t*)dst_;
     uint16_t* d16 = (uint16_t*)dst_;
+    int sx = X >> 5, sy = Y >> 5, fx = X & 31, fy = Y & 31;
+    int in00 = sx >= 0 && sx < w && sy >= 0 && sy < h;
+    int in01 = sx + 1 >= 0 && sx + 1 < w && sy >= 0 && sy < h;
+    int in10 = sx >= 0 && sx < w && sy + 1 >= 0 && sy + 1 < h;
+    int in11 = sx + 1 >= 0 && sx + 1 < w && sy + 1 >= 0 && sy + 1 < h;
+    int iw[4];
+    wtab_i(fx, fy, iw);
+    if (valid) {
+        int s = (in00 ? iw[0] : 0) + (in01 ? iw[1] : 0) + (in10 ? iw[2] : 0) + (in11 ? iw[3] : 0);
+        valid[(size_t)y * w + x] = (uint8_t)(((s + 16384) >> 15) != 0);
+    }
+    int all_out = !(in00 || in01 || in10 || in11);
+    int x0 = clampi(sx, 0, w - 1), x1 = clampi(sx + 1, 0, w - 1);
+    int y0 = clampi(sy, 0, h - 1), y1 = clampi(sy + 1, 0, h - 1);
+    for (int c = 0; c < 3; ++c) {
+        size_t o = ((size_t)y * w + x) * 3 + c;
+        double bv = border[c];
+        if (dtype == 0) {
+            int cb = clampi(cv_round(bv), 0, 255);
+            int v00, v01, v10, v11;
+            if (mode == 1) {
+                v00 = s8[((size_t)y0 * w + x0) * 3 + c]; v01 = s8[((size_t)y0 * w + x1) * 3 + c];
+                v10 = s8[((size_t)y1 * w + x0) * 3 + c]; v11 = s8[((size_t)y1 * w + x1) * 3 + c];
+            } else {
+                v00 = in00 ? s8[((size_t)sy * w + sx) * 3 + c] : cb;
+                v01 = in01 ? s8[((size_t)sy * w + sx + 1) * 3 + c] : cb;
+                v10 = in10 ? s8[((size_t)(sy + 1) * w + sx) * 3 + c] : cb;
+                v11 = in11 ? s8[((size_t)(sy + 1) * w + sx + 1) * 3 + c] : cb;
+            }
+            int r = (mode == 0 && all_out) ? cb
+                    : clampi((v00 * iw[0] + v01 * iw[1] + v10 * iw[2] + v11 * iw[3] + 16384) >> 15, 0, 255);
+            d8[o] = (uint8_t)r;
+        } else {
+            int cb = clampi(cv_round(bv), 0, 65535);
+            float v00, v01, v10, v11;
+            if (mode == 1) {
+                v00 = s16[((size_t)y0 * w + x0) * 3 + c]; v01 = s16[((size_t)y0 * w + x1) * 3 + c];
+                v10 = s16[((size_t)y1 * w + x0) * 3 + c]; v11 = s16[((size_t)y1 * w + x1) * 3 + c];
+            } else {
+                v00 = in00 ? s16[((size_t)sy * w + sx) * 3 + c] : (float)cb;
+                v01 = in01 ? s16[((size_t)sy * w + sx + 1) * 3 + c] : (float)cb;
+                v10 = in10 ? s16[((size_t)(sy + 1) * w + sx) * 3 + c] : (float)cb;
+                v11 = in11 ? s16[((size_t)(sy + 1) * w + sx + 1) * 3 + c] : (float)cb;
+            }
+            float wx1 = fx * (1.0f / 32), wx0 = 1.0f - wx1, wy1 = fy * (1.0f / 32), wy0 = 1.0f - wy1;
+            volatile float p0 = v00 * (wy0 * wx0), p1 = v01 * (wy0 * wx1);
+            volatile float p2 = v10 * (wy1 * wx0), p3 = v11 * (wy1 * wx1);
+            volatile float s = p0 + p1;
+            s = s + p2;
+            s = s + p3;
+            int r = (mode == 0 && all_out) ? cb : clampi((int)lrintf(s), 0, 65535);
+            d16[o] = (uint16_t)r;
+        }
+    }
+}
+
+/* cv2.warpAffine.  valid (may be NULL): h*w bytes, the warped all-ones mask. */
+ORC_API void orc_warp_affine(const void* src_, void* dst_, uint8_t* valid, int h, int w, int dtype,
+                             const double* M, int mode, const double* border) {
+    double iM[6];
+    orc_invert_affine(M, iM);
 #pragma omp parallel for schedule(static)
     for (int y = 0; y < h; ++y) {
         int X0 = cv_round((iM[1] * y + iM[2]) * 1024.0) + 16;
@@ -85,62 +144,43 @@ ORC_API void orc_warp_affine(const void* src_, void* dst_, uint8_t* valid, int h
         for (int x = 0; x < w; ++x) {
             int X = (X0 + cv_round(iM[0] * x * 1024.0)) >> 5;
             int Y = (Y0 + cv_round(iM[3] * x * 1024.0)) >> 5;
-            int sx = X >> 5, sy = Y >> 5, fx = X & 31, fy = Y & 31;
-            int in00 = sx >= 0 && sx < w && sy >= 0 && sy < h;
-            int in01 = sx + 1 >= 0 && sx + 1 < w && sy >= 0 && sy < h;
-            int in10 = sx >= 0 && sx < w && sy + 1 >= 0 && sy + 1 < h;
-            int in11 = sx + 1 >= 0 && sx + 1 < w && sy + 1 >= 0 && sy + 1 < h;
-            int iw[4];
-            wtab_i(fx, fy, iw);
-            if (valid) {
-                int s = (in00 ? iw[0] : 0) + (in01 ? iw[1] : 0) + (in10 ? iw[2] : 0) + (in11 ? iw[3] : 0);
-                valid[(size_t)y * w + x] = (uint8_t)(((s + 16384) >> 15) != 0);
-            }
-            int all_out = !(in00 || in01 || in10 || in11);
-            int x0 = clampi(sx, 0, w - 1), x1 = clampi(sx + 1, 0, w - 1);
-            int y0 = clampi(sy, 0, h - 1), y1 = clampi(sy + 1, 0, h - 1);
-            for (int c = 0; c < 3; ++c) {
-                size_t o = ((size_t)y * w + x) * 3 + c;
-                double bv = border[c];
-                if (dtype == 0) {
-                    int cb = clampi(cv_round(bv), 0, 255);
-                    int v00, v01, v10, v11;
-                    if (mode == 1) {
-                        v00 = s8[((size_t)y0 * w + x0) * 3 + c]; v01 = s8[((size_t)y0 * w + x1) * 3 + c];
-                        v10 = s8[((size_t)y1 * w + x0) * 3 + c]; v11 = s8[((size_t)y1 * w + x1) * 3 + c];
-                    } else {
-                        v00 = in00 ? s8[((size_t)sy * w + sx) * 3 + c] : cb;
-                        v01 = in01 ? s8[((size_t)sy * w + sx + 1) * 3 + c] : cb;
-                        v10 = in10 ? s8[((size_t)(sy + 1) * w + sx) * 3 + c] : cb;
-                        v11 = in11 ? s8[((size_t)(sy + 1) * w + sx + 1) * 3 + c] : cb;
-                    }
-                    int r = (mode == 0 && all_out) ? cb
-                            : clampi((v00 * iw[0] + v01 * iw[1] + v10 * iw[2] + v11 * iw[3] + 16384) >> 15, 0, 255);
-                    d8[o] = (uint8_t)r;
-                } else {
-                    int cb = clampi(cv_round(bv), 0, 65535);
-                    float v00, v01, v10, v11;
-                    if (mode == 1) {
-                        v00 = s16[((size_t)y0 * w + x0) * 3 + c]; v01 = s16[((size_t)y0 * w + x1) * 3 + c];
-                        v10 = s16[((size_t)y1 * w + x0) * 3 + c]; v11 = s16[((size_t)y1 * w + x1) * 3 + c];
-                    } else {
-                        v00 = in00 ? s16[((size_t)sy * w + sx) * 3 + c] : (float)cb;
-                        v01 = in01 ? s16[((size_t)sy * w + sx + 1) * 3 + c] : (float)cb;
-                        v10 = in10 ? s16[((size_t)(sy + 1) * w + sx) * 3 + c] : (float)cb;
-                        v11 = in11 ? s16[((size_t)(sy + 1) * w + sx + 1) * 3 + c] : (float)cb;
-                    }
-                    float wx1 = fx * (1.0f / 32), wx0 = 1.0f - wx1, wy1 = fy * (1.0f / 32), wy0 = 1.0f - wy1;
-                    volatile float p0 = v00 * (wy0 * wx0), p1 = v01 * (wy0 * wx1);
-                    volatile float p2 = v10 * (wy1 * wx0), p3 = v11 * (wy1 * wx1);
-                    volatile float s = p0 + p1;
-                    s = s + p2;
-                    s = s + p3;
-                    int r = (mode == 0 && all_out) ? cb : clampi((int)lrintf(s), 0, 65535);
-                    d16[o] = (uint16_t)r;
-                }
-            }
+            sample_px(src_, dst_, valid, h, w, dtype, mode, border, y, x, X, Y);
         }
     }
+}
+
+/* cv2.warpPerspective (align.py:231-237) [from memory of imgwarp.cpp's WarpPerspectiveInvoker]: M (3x3, src->dst) is
+ * inverted (cv::invert of a 3x3 double matrix: cofactors times 1 / det); the image is walked in blocks of
+ * bw0 = min(1024 / min(16, h), w) columns, and for the block starting at column bx:
+ *     X0 = M0*bx + M1*y + M2,  Y0 = M3*bx + M4*y + M5,  W0 = M6*bx + M7*y + M8
+ *     W = W0 + M6*x1;  W = W ? 32 / W : 0;  X = cvRound(clamp((X0 + M0*x1) * W)),  Y likewise      (x1 = x - bx)
+ * in double (no fused multiply-add: the translation unit is built with -ffp-contract=off); then the same remap core. */
+ORC_API void orc_invert_3x3(const double* m, double* o) {
+    double d = m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
+    d = d != 0.0 ? 1.0 / d : 0.0;
+    o[0] = (m[4] * m[8] - m[5] * m[7]) * d; o[1] = (m[2] * m[7] - m[1] * m[8]) * d; o[2] = (m[1] * m[5] - m[2] * m[4]) * d;
+    o[3] = (m[5] * m[6] - m[3] * m[8]) * d; o[4] = (m[0] * m[8] - m[2] * m[6]) * d; o[5] = (m[2] * m[3] - m[0] * m[5]) * d;
+    o[6] = (m[3] * m[7] - m[4] * m[6]) * d; o[7] = (m[1] * m[6] - m[0] * m[7]) * d; o[8] = (m[0] * m[4] - m[1] * m[3]) * d;
+}
+
+ORC_API void orc_warp_perspective(const void* src_, void* dst_, uint8_t* valid, int h, int w, int dtype,
+                                  const double* M9, int mode, const double* border) {
+    double M[9];
+    orc_invert_3x3(M9, M);
+    const int bh0 = h < 16 ? h : 16;
+    const int bw0 = 1024 / bh0 < w ? 1024 / bh0 : w;
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < h; ++y)
+        for (int bx = 0; bx < w; bx += bw0) {
+            const double X0 = M[0] * bx + M[1] * y + M[2], Y0 = M[3] * bx + M[4] * y + M[5], W0 = M[6] * bx + M[7] * y + M[8];
+            for (int x1 = 0; x1 < bw0 && bx + x1 < w; ++x1) {
+                double W = W0 + M[6] * x1;
+                W = W != 0.0 ? 32.0 / W : 0.0;
+                const double fX = fmax(-2147483648.0, fmin(2147483647.0, (X0 + M[0] * x1) * W));
+                const double fY = fmax(-2147483648.0, fmin(2147483647.0, (Y0 + M[3] * x1) * W));
+                sample_px(src_, dst_, valid, h, w, dtype, mode, border, y, bx + x1, cv_round(fX), cv_round(fY));
+            }
+        }
 }
 
 ORC_API void orc_gauss_kernel_f32(int ksize, double sigma, float* k) {

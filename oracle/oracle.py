@@ -111,6 +111,8 @@ def lib():
         L.orc_sep_collapse_level_f32.argtypes = [_f32p, C.c_int, C.c_int, _f32p, _f32p, C.c_int, C.c_int, _f32p]
         L.orc_warp_affine.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                       _f64p, C.c_int, _f64p]
+        L.orc_warp_perspective.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                           _f64p, C.c_int, _f64p]
         L.orc_border_blur_composite.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                                 C.c_int, C.c_int, C.c_double]
         L.orc_gauss_kernel_f32.argtypes = [C.c_int, C.c_double, _f32p]
@@ -497,6 +499,26 @@ def warp_affine(img, M, border_mode=BORDER_REPLICATE_BLUR, border_value=(0, 0, 0
     valid = np.empty((h, w), np.uint8)
     mode = 0 if border_mode == BORDER_CONSTANT else 1
     lib().orc_warp_affine(img.ctypes.data, warp.ctypes.data, valid.ctypes.data, h, w, dt, M, mode, bv)
+    out = warp
+    if border_mode == BORDER_REPLICATE_BLUR:
+        out = np.empty_like(img)
+        lib().orc_border_blur_composite(warp.ctypes.data, valid.ctypes.data, out.ctypes.data, h, w, dt,
+                                        blur_ksize, float(blur_sigma))
+    return (out, valid) if want_mask else out
+
+
+def warp_perspective(img, M, border_mode=BORDER_REPLICATE_BLUR, border_value=(0, 0, 0, 0),
+                     blur_ksize=21, blur_sigma=50.0, want_mask=False):
+    """warpPerspective (+ mask + border blur for BORDER_REPLICATE_BLUR), M: 3x3 src->dst (align.py:231-237)."""
+    img = np.ascontiguousarray(img)
+    h, w = img.shape[:2]
+    dt = 0 if img.dtype == np.uint8 else 1
+    M = np.ascontiguousarray(np.asarray(M, dtype=np.float64).reshape(9))
+    bv = np.ascontiguousarray(np.asarray(list(border_value) + [0, 0, 0, 0], dtype=np.float64)[:4])
+    warp = np.empty_like(img)
+    valid = np.empty((h, w), np.uint8)
+    mode = 0 if border_mode == BORDER_CONSTANT else 1
+    lib().orc_warp_perspective(img.ctypes.data, warp.ctypes.data, valid.ctypes.data, h, w, dt, M, mode, bv)
     out = warp
     if border_mode == BORDER_REPLICATE_BLUR:
         out = np.empty_like(img)

@@ -101,6 +101,11 @@ SIGNATURES = {
     "mi_warp_affine_device": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double),
                                         C.c_int, C.POINTER(C.c_double), C.c_int, C.c_double]),
+    "mi_warp_perspective": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                      C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double), C.c_int, C.c_double]),
+    "mi_warp_perspective_device": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double),
+                                             C.c_int, C.POINTER(C.c_double), C.c_int, C.c_double]),
     "mi_ecc_similarity": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                     C.c_int, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                     C.POINTER(C.c_int)]),
@@ -472,6 +477,24 @@ def warp_affine(img, M, border_mode=BORDER_REPLICATE_BLUR, border_value=(0, 0, 0
     check(load().mi_warp_affine(device, a.ctypes.data, out.ctypes.data,
                                 mask.ctypes.data if want_mask else None, h, w, DTYPE_CODE[a.dtype], m,
                                 int(border_mode), bv, int(blur_ksize), float(blur_sigma)))
+    return (out, mask) if want_mask else out
+
+
+def warp_perspective(img, M, border_mode=BORDER_REPLICATE_BLUR, border_value=(0, 0, 0, 0), blur_ksize=21,
+                     blur_sigma=50.0, want_mask=False, device=0):
+    """cv2.warpPerspective + warped mask + blurred-border composite on the GPU (mi_warp_perspective); M: 3x3."""
+    require_device()
+    a = np.ascontiguousarray(img)
+    if a.ndim != 3 or a.shape[2] != 3 or a.dtype not in (np.uint8, np.uint16):
+        raise ValueError("warp_perspective expects an H x W x 3 uint8/uint16 image")
+    h, w = a.shape[:2]
+    m = (C.c_double * 9)(*np.asarray(M, dtype=np.float64).reshape(9))
+    bv = (C.c_double * 4)(*(list(border_value) + [0, 0, 0, 0])[:4])
+    out = np.empty_like(a)
+    mask = np.empty((h, w), np.uint8) if want_mask else None
+    check(load().mi_warp_perspective(device, a.ctypes.data, out.ctypes.data,
+                                     mask.ctypes.data if want_mask else None, h, w, DTYPE_CODE[a.dtype], m,
+                                     int(border_mode), bv, int(blur_ksize), float(blur_sigma)))
     return (out, mask) if want_mask else out
 
 

@@ -5,15 +5,14 @@ configuration dictionaries and defaults, same return value `(n_good_matches, M, 
 same errors), with the work split the way SURVEY.md 8(a) A1-A7 prescribes:
 
 * **estimate** (A1-A4: sub-sample, feature detection, matching, RANSAC) is irregular CPU work
-  that the reference delegates entirely to OpenCV; it stays on the host behind a small
-  `estimator` callable.  The default estimator is the reference's recipe on `cv2` when OpenCV is
-  importable and raises a clear error otherwise -- no estimator is bundled, none is faked.
-* **apply** (A5-A6: `cv2.warpAffine`, the warped all-ones mask, the blurred-border composite,
-  align.py:238-251) runs on the MI355X through `mi_warp_affine` (C ABI), bit-identical to
-  `oracle/align_oracle.c`.
-
-Only the default `ALIGN_RIGID` transform has a GPU apply path; `ALIGN_HOMOGRAPHY` raises
-`InvalidOptionError`.
+  that the reference delegates entirely to OpenCV; it sits behind a small `estimator` callable.
+  The default (`estimator="auto"`) is the reference's own recipe on `cv2` when OpenCV is importable
+  (`opencv_estimator`: every detector / descriptor / matcher / transform option of align.py:48-151),
+  and the GPU ECC estimator (`ecc_estimator`, mi_ecc_similarity) otherwise -- so `AlignFrames()` works
+  out of the box on a box without OpenCV, as the reference's does with it.
+* **apply** (A5-A6: `cv2.warpAffine` / `cv2.warpPerspective`, the warped all-ones mask, the
+  blurred-border composite, align.py:231-251) runs on the MI355X through `mi_warp_affine` /
+  `mi_warp_perspective` (C ABI), bit-identical to `oracle/align_oracle.c`.
 """
 import logging
 
@@ -52,37 +51,105 @@ def img_subsample(img, subsample, fast=True):
     return ((s + area // 2) // area).astype(img.dtype).reshape(h // subsample, w // subsample, *img.shape[2:])
 
 
+def validate_align_config(detector, descriptor, match_method):
+    """align.py:71-87: the detector x descriptor x matcher combinations the reference refuses, with its messages."""
+    c = constants
+    if descriptor == c.DESCRIPTOR_SIFT and match_method == c.MATCHING_NORM_HAMMING:
+        raise ValueError("Descriptor SIFT requires matching method KNN")
+    if detector == c.DETECTOR_ORB and descriptor == c.DESCRIPTOR_AKAZE and match_method == c.MATCHING_NORM_HAMMING:
+        raise ValueError("Detector ORB and descriptor AKAZE require matching method KNN")
+    if detector == c.DETECTOR_BRISK and descriptor == c.DESCRIPTOR_AKAZE:
+        raise ValueError("Detector BRISK is incompatible with descriptor AKAZE")
+    if detector == c.DETECTOR_SURF and descriptor == c.DESCRIPTOR_AKAZE:
+        raise ValueError("Detector SURF is incompatible with descriptor AKAZE")
+    if detector == c.DETECTOR_SIFT and descriptor != c.DESCRIPTOR_SIFT:
+        raise ValueError("Detector SIFT requires descriptor SIFT")
+    if detector in c.NOKNN_METHODS['detectors'] and descriptor in c.NOKNN_METHODS['descriptors'] and \
+            match_method != c.MATCHING_NORM_HAMMING:
+        raise ValueError(f"Detector {detector} and descriptor {descriptor} require matching method Hamming distance")
+
+
 def opencv_estimator(img_0_sub, img_1_sub, feature_config, matching_config, alignment_config):
-    """The reference's estimator (align.py:90-151, :186-199) on OpenCV: returns
-    (n_good_matches, M or None).  M maps img_0 (moving) onto img_1 (reference)."""
+    """The reference's estimator (align.py:48-151, :186-199) on OpenCV: returns (n_good_matches, M or None); M maps
+    img_0 (moving) onto img_1 (reference): 2x3 for ALIGN_RIGID, 3x3 for ALIGN_HOMOGRAPHY."""
+    detector_name, descriptor_name = feature_config['detector'], feature_config['descriptor']
+    match_method = matching_config['match_method']
+    validate_align_config(detector_name, descriptor_name, match_method)
     try:
         import cv2
     except ImportError as e:  # pragma: no cover - OpenCV is not part of this image
         raise RuntimeError(
-            "align_images: the transform estimator needs OpenCV (cv2), which is not installed; "
+            "opencv_estimator needs OpenCV (cv2), which is not installed; use estimator='auto' / ecc_estimator(), or "
             "pass estimator=callable(img_0_sub, img_1_sub, feature_cfg, matching_cfg, alignment_cfg) "
             "-> (n_good_matches, M)") from e
-    def gray8(im):  # pragma: no cover
+    c = constants  # pragma: no cover
+
+    def gray8(im):  # pragma: no cover  (utils.py:37-43 img_bw_8bit)
         im = (im >> 8).astype('uint8') if im.dtype == np.uint16 else im
         return cv2.cvtColor(im, cv2.COLOR_BGR2GRAY) if im.ndim == 3 else im
-    det = cv2.SIFT_create()  # pragma: no cover
-    kp0, d0 = det.detectAndCompute(gray8(img_0_sub), None)  # pragma: no cover
-    kp1, d1 = det.detectAndCompute(gray8(img_1_sub), None)  # pragma: no cover
-    flann = cv2.FlannBasedMatcher({'algorithm': matching_config['flann_idx_kdtree'],  # pragma: no cover
-                                   'trees': matching_config['flann_trees']},
-                                  {'checks': matching_config['flann_checks']})
-    good = [m for m, n in flann.knnMatch(d0, d1, k=2)  # pragma: no cover
-            if m.distance < matching_config['threshold'] * n.distance]
-    min_matches = 3  # pragma: no cover
-    if len(good) < min_matches:  # pragma: no cover
+    det_map = {c.DETECTOR_SIFT: cv2.SIFT_create, c.DETECTOR_ORB: cv2.ORB_create,  # pragma: no cover
+               c.DETECTOR_SURF: cv2.FastFeatureDetector_create, c.DETECTOR_AKAZE: cv2.AKAZE_create,
+               c.DETECTOR_BRISK: cv2.BRISK_create}
+    des_map = {c.DESCRIPTOR_SIFT: cv2.SIFT_create, c.DESCRIPTOR_ORB: cv2.ORB_create,  # pragma: no cover
+               c.DESCRIPTOR_AKAZE: cv2.AKAZE_create, c.DESCRIPTOR_BRISK: cv2.BRISK_create}
+    g0, g1 = gray8(img_0_sub), gray8(img_1_sub)  # pragma: no cover
+    det = det_map[detector_name]()  # pragma: no cover
+    if detector_name == descriptor_name and detector_name in (c.DETECTOR_SIFT, c.DETECTOR_AKAZE, c.DETECTOR_BRISK):  # pragma: no cover
+        kp0, d0 = det.detectAndCompute(g0, None)
+        kp1, d1 = det.detectAndCompute(g1, None)
+    else:  # pragma: no cover
+        des = des_map[descriptor_name]()
+        kp0, d0 = des.compute(g0, det.detect(g0, None))
+        kp1, d1 = des.compute(g1, det.detect(g1, None))
+    if match_method == c.MATCHING_KNN:  # pragma: no cover
+        flann = cv2.FlannBasedMatcher({'algorithm': matching_config['flann_idx_kdtree'], 'trees': matching_config['flann_trees']},
+                                      {'checks': matching_config['flann_checks']})
+        good = [m for m, n in flann.knnMatch(d0, d1, k=2) if m.distance < matching_config['threshold'] * n.distance]
+    elif match_method == c.MATCHING_NORM_HAMMING:  # pragma: no cover
+        good = sorted(cv2.BFMatcher(cv2.NORM_HAMMING, crossCheck=True).match(d0, d1), key=lambda x: x.distance)
+    else:  # pragma: no cover
+        raise InvalidOptionError('match_method', match_method, f". Valid options are: {c.MATCHING_KNN}, {c.MATCHING_NORM_HAMMING}")
+    transform = alignment_config['transform']  # pragma: no cover
+    if len(good) < (4 if transform == c.ALIGN_HOMOGRAPHY else 3):  # pragma: no cover
         return len(good), None
+    method = {'RANSAC': cv2.RANSAC, 'LMEDS': cv2.LMEDS}.get(alignment_config['align_method'])  # pragma: no cover
+    if method is None:  # pragma: no cover
+        raise InvalidOptionError('align_method', alignment_config['align_method'], f". Valid options are: {c.ALIGN_RANSAC}, {c.ALIGN_LMEDS}")
     src = np.float32([kp0[m.queryIdx].pt for m in good]).reshape(-1, 1, 2)  # pragma: no cover
     dst = np.float32([kp1[m.trainIdx].pt for m in good]).reshape(-1, 1, 2)  # pragma: no cover
-    m, _ = cv2.estimateAffinePartial2D(  # pragma: no cover
-        src, dst, method=cv2.RANSAC, ransacReprojThreshold=alignment_config['rans_threshold'],
-        confidence=alignment_config['align_confidence'] / 100.0,
-        refineIters=alignment_config['refine_iters'])
+    if transform == c.ALIGN_HOMOGRAPHY:  # pragma: no cover
+        m, _ = cv2.findHomography(src, dst, method=method, ransacReprojThreshold=alignment_config['rans_threshold'],
+                                  maxIters=alignment_config['max_iters'])
+    else:  # pragma: no cover
+        m, _ = cv2.estimateAffinePartial2D(src, dst, method=method, ransacReprojThreshold=alignment_config['rans_threshold'],
+                                           confidence=alignment_config['align_confidence'] / 100.0,
+                                           refineIters=alignment_config['refine_iters'])
     return len(good), m  # pragma: no cover
+
+
+def have_opencv():
+    try:
+        import cv2  # noqa: F401
+        return True
+    except Exception:  # noqa: BLE001
+        return False
+
+
+def auto_estimator(device=0):
+    """`estimator="auto"`: the reference's own recipe when OpenCV is importable, the GPU ECC estimator otherwise."""
+    return opencv_estimator if have_opencv() else ecc_estimator(device=device)
+
+
+def resolve_estimator(estimator, device=0):
+    if estimator is None or estimator == "auto":
+        return auto_estimator(device)
+    if estimator == "opencv":
+        return opencv_estimator
+    if estimator == "ecc":
+        return ecc_estimator(device=device)
+    if callable(estimator):
+        return estimator
+    raise InvalidOptionError("estimator", estimator, ". Valid options are: 'auto', 'opencv', 'ecc' or a callable")
 
 
 def ecc_estimator(min_correlation=0.5, max_iters=60, device=0):
@@ -90,17 +157,42 @@ def ecc_estimator(min_correlation=0.5, max_iters=60, device=0):
     a 4-DoF similarity, coarse to fine.  It needs no feature matches; to satisfy the protocol it
     reports 1000 "good matches" when the final correlation coefficient reaches `min_correlation`
     and 0 otherwise (which makes align_images / AlignFrames raise AlignmentError as usual)."""
-    def estimate(img_0_sub, img_1_sub, _feature_config, _matching_config, _alignment_config):
+    def estimate(img_0_sub, img_1_sub, _feature_config, _matching_config, alignment_config):
         m, cc, _iters = _lib.ecc_similarity(img_1_sub, img_0_sub, max_iters=max_iters, device=device)
-        return (1000, m) if cc >= min_correlation else (0, None)
+        if cc < min_correlation:
+            return 0, None
+        if (alignment_config or {}).get('transform') == constants.ALIGN_HOMOGRAPHY:
+            m = np.vstack([m, [0.0, 0.0, 1.0]])   # the similarity, in the shape the homography apply takes
+        return 1000, m
     return estimate
 
 
 def apply_transform(img, m, alignment_config, device=0):
-    """align.py:238-251 on the GPU: warp + mask + blurred-border composite."""
+    """align.py:231-251 on the GPU: warp (affine for a 2x3, perspective for a 3x3 matrix) + mask + blurred-border
+    composite."""
     mode = _BORDER_CODE[alignment_config['border_mode']]
-    return _lib.warp_affine(img, m, border_mode=mode, border_value=alignment_config['border_value'],
-                            blur_ksize=21, blur_sigma=alignment_config['border_blur'], device=device)
+    fn = _lib.warp_perspective if np.asarray(m).shape == (3, 3) else _lib.warp_affine
+    return fn(img, m, border_mode=mode, border_value=alignment_config['border_value'],
+              blur_ksize=21, blur_sigma=alignment_config['border_blur'], device=device)
+
+
+def rescale_transform(m, transform, subsample, shape, shape_sub):
+    """align.py:212-227: a transform found on images sub-sampled by `subsample`, for the full-size images.
+    ALIGN_RIGID: translation times the factor, stored as float32 like the reference does.  ALIGN_HOMOGRAPHY: conjugation
+    with the corner-to-corner scalings cv2.getPerspectiveTransform returns for the two image rectangles, i.e.
+    diag(w / w_sub, h / h_sub, 1) and its inverse."""
+    m = np.asarray(m)
+    if transform == constants.ALIGN_HOMOGRAPHY:
+        (h, w), (hs, ws) = shape[:2], shape_sub[:2]
+        up = np.diag([w / ws, h / hs, 1.0])
+        down = np.diag([ws / w, hs / h, 1.0])
+        return up @ m @ down
+    if transform == constants.ALIGN_RIGID:
+        full = np.empty((2, 3), dtype=np.float32)
+        full[:2, :2] = m[:2, :2]
+        full[:, 2] = m[:, 2] * subsample
+        return full
+    raise InvalidOptionError("transform", transform)
 
 
 def align_images(img_1, img_0, feature_config=None, matching_config=None, alignment_config=None,
@@ -113,16 +205,16 @@ def align_images(img_1, img_0, feature_config=None, matching_config=None, alignm
     if alignment_config['border_mode'] not in _BORDER_CODE:
         raise InvalidOptionError("border_mode", alignment_config['border_mode'])
     transform = alignment_config['transform']
-    if transform == constants.ALIGN_HOMOGRAPHY:
-        raise InvalidOptionError("transform", transform,
-                                 "the MI355X apply path implements ALIGN_RIGID only")
-    if transform != constants.ALIGN_RIGID:
+    if transform not in (constants.ALIGN_RIGID, constants.ALIGN_HOMOGRAPHY):
         raise InvalidOptionError("transform", transform)
-    min_matches = 3
+    min_matches = 4 if transform == constants.ALIGN_HOMOGRAPHY else 3
+    # the reference refuses these combinations inside detect_and_compute (align.py:71-87, :97): same errors here,
+    # whichever estimator runs
+    validate_align_config(feature_config['detector'], feature_config['descriptor'], matching_config['match_method'])
     validate_image(img_0, *get_img_metadata(img_1))
     if callbacks and 'message' in callbacks:
         callbacks['message']()
-    estimator = estimator or opencv_estimator
+    estimator = resolve_estimator(estimator)
     subsample = alignment_config['subsample']
     fast = alignment_config['fast_subsampling']
     while True:
@@ -143,13 +235,10 @@ def align_images(img_1, img_0, feature_config=None, matching_config=None, alignm
     img_warp = None
     if n_good_matches >= min_matches and m is not None:
         m = np.asarray(m)
+        if transform == constants.ALIGN_HOMOGRAPHY and m.shape == (2, 3):
+            m = np.vstack([m, [0.0, 0.0, 1.0]])
         if subsample > 1:
-            # translation found on the sub-sampled pair, applied at full resolution; the
-            # reference stores the rescaled matrix as float32 (align.py:217-223)
-            full = np.empty((2, 3), dtype=np.float32)
-            full[:2, :2] = m[:2, :2]
-            full[:, 2] = m[:, 2] * subsample
-            m = full
+            m = rescale_transform(m, transform, subsample, img_0.shape, img_0_sub.shape)
         if callbacks and 'align_message' in callbacks:
             callbacks['align_message']()
         blur = alignment_config['border_mode'] == constants.BORDER_REPLICATE_BLUR

@@ -559,50 +559,64 @@ int warp_scratch(int device, hipStream_t st, size_t ntiles, uint32_t** cnt, uint
     return MI_OK;
 }
 
+// the blurred-border composite behind a warp (align.py:245-251): passes over the tiles that hold a masked pixel
 template <typename T>
-int warp_launch(int device, hipStream_t st, const void* src, void* side, void* out, uint8_t* valid, int h, int w,
-                const AffineArgs& a, bool blur, const GaussArgs& g) {
-    // LDS-staged tiles of 256 x 32 (16) destination pixels, four pixels x 8 (4) rows per thread; whole-dword stores
-    // when every row starts 4-byte aligned
-    const bool vec = (w % 4) == 0 && ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(valid)) & 3) == 0;
-    const dim3 grid(cdiv(w, WT_W), cdiv(h, WarpTile<T>::TH));
-    const size_t lds = (size_t)WT_LDS_DWORDS * 4;
-    auto kv = warp_affine_tiled<T, true>;
-    auto ks = warp_affine_tiled<T, false>;
+int blur_launch(int device, hipStream_t st, void* side, void* out, uint8_t* valid, int h, int w, const GaussArgs& g) {
     auto kb = border_blur_tiles<T>;
     const int r = g.ksize / 2;
     const size_t lds_blur = ((size_t)(BT_H + 2 * r) * (BT_W + 2 * r) * (sizeof(T) == 1 ? 1 : 2) + 3 * (size_t)(BT_H + 2 * r) * BT_W) * 4;
     static thread_local bool attr_set = false;
     if (!attr_set) {
-        MI_HIP(hipFuncSetAttribute((const void*)kv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        MI_HIP(hipFuncSetAttribute((const void*)ks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         // largest blur kernel (31 taps): 62 x 94 raw pixels + 3 x 62 x 64 floats
         MI_HIP(hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)(((size_t)62 * 94 * 2 + 3 * 62 * 64) * 4)));
         attr_set = true;
     }
-    if (vec) hipLaunchKernelGGL(kv, grid, dim3(256), lds, st, (const T*)src, (T*)out, valid, a);
-    else hipLaunchKernelGGL(ks, grid, dim3(256), lds, st, (const T*)src, (T*)out, valid, a);
-    if (blur) {
-        // the warped image goes straight to `out`; the few pixels outside the source frame are blurred from it into
-        // `side` and copied back, tile by tile over the tiles that hold a masked pixel
-        const int tiles_x = cdiv(w, BT_W), tiles_y = cdiv(h, BT_H);
-        uint32_t *cnt = nullptr, *bitmap = nullptr, *list = nullptr;
-        size_t clear = 0;
-        int rc = warp_scratch(device, st, (size_t)tiles_x * tiles_y, &cnt, &bitmap, &list, &clear);
-        if (rc) return rc;
-        MI_HIP(hipMemsetAsync(cnt, 0, clear, st));
-        const size_t npx = (size_t)h * w;
-        hipLaunchKernelGGL(mask_scan_tiles, dim3((unsigned)std::min<size_t>(2048, (npx / 16 + 256) / 256)), dim3(256), 0, st,
-                           (const uint8_t*)valid, h, w, tiles_x, bitmap);
-        hipLaunchKernelGGL(tile_bitmap_to_list, dim3(1), dim3(1024), 0, st, (const uint32_t*)bitmap, (tiles_x * tiles_y + 31) / 32, cnt, list);
-        hipLaunchKernelGGL(kb, dim3(1024), dim3(256), lds_blur, st, (const T*)out, (const uint8_t*)valid, (T*)side, h, w, tiles_x, g,
-                           (const uint32_t*)cnt, (const uint32_t*)list);
-        hipLaunchKernelGGL((border_blur_scatter<T>), dim3(1024), dim3(256), 0, st, (T*)out, (const uint8_t*)valid, (const T*)side,
-                           h, w, tiles_x, (const uint32_t*)cnt, (const uint32_t*)list);
-    }
+    const int tiles_x = cdiv(w, BT_W), tiles_y = cdiv(h, BT_H);
+    uint32_t *cnt = nullptr, *bitmap = nullptr, *list = nullptr;
+    size_t clear = 0;
+    int rc = warp_scratch(device, st, (size_t)tiles_x * tiles_y, &cnt, &bitmap, &list, &clear);
+    if (rc) return rc;
+    MI_HIP(hipMemsetAsync(cnt, 0, clear, st));
+    const size_t npx = (size_t)h * w;
+    hipLaunchKernelGGL(mask_scan_tiles, dim3((unsigned)std::min<size_t>(2048, (npx / 16 + 256) / 256)), dim3(256), 0, st,
+                       (const uint8_t*)valid, h, w, tiles_x, bitmap);
+    hipLaunchKernelGGL(tile_bitmap_to_list, dim3(1), dim3(1024), 0, st, (const uint32_t*)bitmap, (tiles_x * tiles_y + 31) / 32, cnt, list);
+    hipLaunchKernelGGL(kb, dim3(1024), dim3(256), lds_blur, st, (const T*)out, (const uint8_t*)valid, (T*)side, h, w, tiles_x, g,
+                       (const uint32_t*)cnt, (const uint32_t*)list);
+    hipLaunchKernelGGL((border_blur_scatter<T>), dim3(1024), dim3(256), 0, st, (T*)out, (const uint8_t*)valid, (const T*)side,
+                       h, w, tiles_x, (const uint32_t*)cnt, (const uint32_t*)list);
     MI_HIP(hipGetLastError());
     return MI_OK;
+}
+
+template <typename T>
+int warp_launch(int device, hipStream_t st, const void* src, void* side, void* out, uint8_t* valid, int h, int w,
+                const AffineArgs& a, bool blur, const GaussArgs& g, const PerspArgs* persp) {
+    if (persp) {
+        const dim3 blk(64, 4), grid(cdiv(w, 64), cdiv(h, 4));
+        hipLaunchKernelGGL((warp_perspective_kernel<T>), grid, blk, 0, st, (const T*)src, (T*)out, valid, a, *persp);
+    } else {
+        // LDS-staged tiles of 256 x 32 (16) destination pixels, four pixels x 8 (4) rows per thread; whole-dword stores
+        // when every row starts 4-byte aligned
+        const bool vec = (w % 4) == 0 && ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(valid)) & 3) == 0;
+        const dim3 grid(cdiv(w, WT_W), cdiv(h, WarpTile<T>::TH));
+        const size_t lds = (size_t)WT_LDS_DWORDS * 4;
+        auto kv = warp_affine_tiled<T, true>;
+        auto ks = warp_affine_tiled<T, false>;
+        static thread_local bool attr_set = false;
+        if (!attr_set) {
+            MI_HIP(hipFuncSetAttribute((const void*)kv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            MI_HIP(hipFuncSetAttribute((const void*)ks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_set = true;
+        }
+        if (vec) hipLaunchKernelGGL(kv, grid, dim3(256), lds, st, (const T*)src, (T*)out, valid, a);
+        else hipLaunchKernelGGL(ks, grid, dim3(256), lds, st, (const T*)src, (T*)out, valid, a);
+    }
+    MI_HIP(hipGetLastError());
+    // the warped image went straight to `out`; the few pixels outside the source frame are blurred from it into `side`
+    // and copied back
+    return blur ? blur_launch<T>(device, st, side, out, valid, h, w, g) : MI_OK;
 }
 
 }  // namespace
@@ -1429,9 +1443,11 @@ int mi_combine_unpack(int device, void* stream, const void* win, size_t npix, in
     return MI_OK;
 }
 
-int mi_warp_affine_device(int device, void* stream, const void* dev_src, void* dev_dst, void* dev_tmp,
-                          void* dev_mask, int height, int width, int dtype, const double* M,
-                          int border_mode, const double* border_value, int blur_ksize, double blur_sigma) {
+namespace {
+// shared body of mi_warp_affine_device (M: 2x3, persp == false) and mi_warp_perspective_device (M: 3x3)
+int warp_device_impl(int device, void* stream, const void* dev_src, void* dev_dst, void* dev_tmp, void* dev_mask, int height,
+                     int width, int dtype, const double* M, bool persp, int border_mode, const double* border_value,
+                     int blur_ksize, double blur_sigma) {
     if (!dev_src || !dev_dst || !M || height < 1 || width < 1) return fail(MI_ERR_INVALID, "bad argument");
     if (dtype != MI_U8 && dtype != MI_U16) return fail(MI_ERR_INVALID, "dtype must be MI_U8 or MI_U16");
     if (border_mode < 0 || border_mode > 2) return fail(MI_ERR_INVALID, "bad border_mode %d", border_mode);
@@ -1441,7 +1457,20 @@ int mi_warp_affine_device(int device, void* stream, const void* dev_src, void* d
         return fail(MI_ERR_INVALID, "blur kernel size must be odd and <= 31, sigma > 0");
     MI_HIP(hipSetDevice(device));
     AffineArgs a{};
-    invert_affine_host(M, a.iM);
+    PerspArgs pa{};
+    if (persp) {
+        // cv::invert of a 3x3 double matrix: cofactors times 1 / det [from memory]; singular -> zeros
+        const double* m = M;
+        double d = m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
+        d = d != 0.0 ? 1.0 / d : 0.0;
+        pa.iM[0] = (m[4] * m[8] - m[5] * m[7]) * d; pa.iM[1] = (m[2] * m[7] - m[1] * m[8]) * d; pa.iM[2] = (m[1] * m[5] - m[2] * m[4]) * d;
+        pa.iM[3] = (m[5] * m[6] - m[3] * m[8]) * d; pa.iM[4] = (m[0] * m[8] - m[2] * m[6]) * d; pa.iM[5] = (m[2] * m[3] - m[0] * m[5]) * d;
+        pa.iM[6] = (m[3] * m[7] - m[4] * m[6]) * d; pa.iM[7] = (m[1] * m[6] - m[0] * m[7]) * d; pa.iM[8] = (m[0] * m[4] - m[1] * m[3]) * d;
+        const int bh0 = height < 16 ? height : 16;
+        pa.bw0 = 1024 / bh0 < width ? 1024 / bh0 : width;
+    } else {
+        invert_affine_host(M, a.iM);
+    }
     a.h = height;
     a.w = width;
     a.mode = border_mode == 0 ? 0 : 1;
@@ -1461,15 +1490,16 @@ int mi_warp_affine_device(int device, void* stream, const void* dev_src, void* d
         sum = 1.0 / sum;
         for (int i = 0; i < blur_ksize; ++i) g.k[i] = (float)(t[i] * sum);
     }
-    void* warp = dev_tmp;
     if (dtype == MI_U8)
-        return warp_launch<uint8_t>(device, (hipStream_t)stream, dev_src, warp, dev_dst, (uint8_t*)dev_mask, height, width, a, blur, g);
-    return warp_launch<uint16_t>(device, (hipStream_t)stream, dev_src, warp, dev_dst, (uint8_t*)dev_mask, height, width, a, blur, g);
+        return warp_launch<uint8_t>(device, (hipStream_t)stream, dev_src, dev_tmp, dev_dst, (uint8_t*)dev_mask, height, width, a,
+                                    blur, g, persp ? &pa : nullptr);
+    return warp_launch<uint16_t>(device, (hipStream_t)stream, dev_src, dev_tmp, dev_dst, (uint8_t*)dev_mask, height, width, a, blur,
+                                 g, persp ? &pa : nullptr);
 }
 
-int mi_warp_affine(int device, const void* host_src, void* host_dst, void* host_mask, int height, int width,
-                   int dtype, const double* M, int border_mode, const double* border_value,
-                   int blur_ksize, double blur_sigma) {
+// host-buffer form of both
+int warp_host_impl(int device, const void* host_src, void* host_dst, void* host_mask, int height, int width, int dtype,
+                   const double* M, bool persp, int border_mode, const double* border_value, int blur_ksize, double blur_sigma) {
     if (!host_src || !host_dst) return fail(MI_ERR_INVALID, "null image");
     if (dtype != MI_U8 && dtype != MI_U16) return fail(MI_ERR_INVALID, "dtype must be MI_U8 or MI_U16");
     if (height < 1 || width < 1) return fail(MI_ERR_INVALID, "bad image size");
@@ -1489,8 +1519,8 @@ int mi_warp_affine(int device, const void* host_src, void* host_dst, void* host_
     TRYH(hipMalloc(&tmp, nb));
     TRYH(hipMalloc(&mask, np));
     TRYH(hipMemcpy(src, host_src, nb, hipMemcpyHostToDevice));
-    rc = mi_warp_affine_device(device, nullptr, src, dst, tmp, mask, height, width, dtype, M, border_mode,
-                               border_value, blur_ksize, blur_sigma);
+    rc = warp_device_impl(device, nullptr, src, dst, tmp, mask, height, width, dtype, M, persp, border_mode, border_value,
+                          blur_ksize, blur_sigma);
     if (rc) { cleanup(); return rc; }
     TRYH(hipDeviceSynchronize());
     TRYH(hipMemcpy(host_dst, dst, nb, hipMemcpyDeviceToHost));
@@ -1498,6 +1528,35 @@ int mi_warp_affine(int device, const void* host_src, void* host_dst, void* host_
 #undef TRYH
     cleanup();
     return MI_OK;
+}
+}  // namespace
+
+int mi_warp_affine_device(int device, void* stream, const void* dev_src, void* dev_dst, void* dev_tmp,
+                          void* dev_mask, int height, int width, int dtype, const double* M,
+                          int border_mode, const double* border_value, int blur_ksize, double blur_sigma) {
+    return warp_device_impl(device, stream, dev_src, dev_dst, dev_tmp, dev_mask, height, width, dtype, M, false, border_mode,
+                            border_value, blur_ksize, blur_sigma);
+}
+
+int mi_warp_perspective_device(int device, void* stream, const void* dev_src, void* dev_dst, void* dev_tmp,
+                               void* dev_mask, int height, int width, int dtype, const double* M,
+                               int border_mode, const double* border_value, int blur_ksize, double blur_sigma) {
+    return warp_device_impl(device, stream, dev_src, dev_dst, dev_tmp, dev_mask, height, width, dtype, M, true, border_mode,
+                            border_value, blur_ksize, blur_sigma);
+}
+
+int mi_warp_perspective(int device, const void* host_src, void* host_dst, void* host_mask, int height, int width,
+                        int dtype, const double* M, int border_mode, const double* border_value,
+                        int blur_ksize, double blur_sigma) {
+    return warp_host_impl(device, host_src, host_dst, host_mask, height, width, dtype, M, true, border_mode, border_value,
+                          blur_ksize, blur_sigma);
+}
+
+int mi_warp_affine(int device, const void* host_src, void* host_dst, void* host_mask, int height, int width,
+                   int dtype, const double* M, int border_mode, const double* border_value,
+                   int blur_ksize, double blur_sigma) {
+    return warp_host_impl(device, host_src, host_dst, host_mask, height, width, dtype, M, false, border_mode, border_value,
+                          blur_ksize, blur_sigma);
 }
 
 int mi_aligner_create(mi_aligner_t* out, int device, int height, int width, int dtype, int subsample,

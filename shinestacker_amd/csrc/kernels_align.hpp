@@ -23,12 +23,11 @@ __device__ __forceinline__ int cv_round_d(double v) {
 }
 
 // one destination pixel: the 3 channel values and the mask bit
+// (X, Y): the source position in 1/32 pixel
 template <typename T>
-__device__ __forceinline__ void warp_pixel(const T* __restrict__ src, const AffineArgs& a, int x, int X0, int Y0,
-                                           int out[3], int& ok) {
+__device__ __forceinline__ void warp_pixel_xy(const T* __restrict__ src, const AffineArgs& a, int X, int Y,
+                                              int out[3], int& ok) {
     const int h = a.h, w = a.w;
-    const int X = (X0 + cv_round_d(a.iM[0] * x * 1024.0)) >> 5;
-    const int Y = (Y0 + cv_round_d(a.iM[3] * x * 1024.0)) >> 5;
     const int sx = X >> 5, sy = Y >> 5, fx = X & 31, fy = Y & 31;
     const bool inx0 = sx >= 0 && sx < w, inx1 = sx + 1 >= 0 && sx + 1 < w;
     const bool iny0 = sy >= 0 && sy < h, iny1 = sy + 1 >= 0 && sy + 1 < h;
@@ -146,6 +145,36 @@ __device__ __forceinline__ void warp_pixel_inside(const T* __restrict__ src, con
         }
         out[c] = r;
     }
+}
+
+// ---- cv2.warpPerspective (ALIGN_HOMOGRAPHY, align.py:231-237): the same interpolation, the source position from the
+// projective map.  OpenCV's WarpPerspectiveInvoker [from memory] walks blocks of bw0 = min(1024 / min(16, h), w) columns:
+//   X0 = M0*bx + M1*y + M2, Y0 = M3*bx + M4*y + M5, W0 = M6*bx + M7*y + M8   (bx = the block's first column)
+//   W = W0 + M6*x1;  W = W ? 32 / W : 0;  X = cvRound(clamp((X0 + M0*x1) * W)),  Y likewise   (x1 = x - bx)
+// all in double, no fused multiply-add (oracle/align_oracle.c restates the same).  One pixel per thread, gathers from
+// global memory: homographies are rare in focus stacking; this path is about having the option, not about speed.
+struct PerspArgs {
+    double iM[9];   // inverted 3x3 (dst -> src)
+    int bw0;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void warp_perspective_kernel(const T* __restrict__ src, T* __restrict__ dst,
+                                                               uint8_t* __restrict__ valid, AffineArgs a, PerspArgs pa) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= a.w || y >= a.h) return;
+    const int bx = (x / pa.bw0) * pa.bw0, x1 = x - bx;
+    const double* M = pa.iM;
+    const double X0 = M[0] * bx + M[1] * y + M[2], Y0 = M[3] * bx + M[4] * y + M[5], W0 = M[6] * bx + M[7] * y + M[8];
+    double W = W0 + M[6] * x1;
+    W = W != 0.0 ? 32.0 / W : 0.0;
+    const double fX = fmax(-2147483648.0, fmin(2147483647.0, (X0 + M[0] * x1) * W));
+    const double fY = fmax(-2147483648.0, fmin(2147483647.0, (Y0 + M[3] * x1) * W));
+    int v[3], ok;
+    warp_pixel_xy<T>(src, a, cv_round_d(fX), cv_round_d(fY), v, ok);
+    const size_t px = (size_t)y * a.w + x;
+    dst[px * 3 + 0] = (T)v[0]; dst[px * 3 + 1] = (T)v[1]; dst[px * 3 + 2] = (T)v[2];
+    if (valid) valid[px] = (uint8_t)ok;
 }
 
 // ---- The warp kernel.  A per-pixel gather spends its time in the texture-address unit (four unaligned 4-byte
@@ -339,7 +368,7 @@ __global__ __launch_bounds__(256) void warp_affine_tiled(const T* __restrict__ s
                 warp_pixel_inside<T>(src, a, xq + p, X0, Y0, v[p]);
                 ok[p] = 1;
             } else if (xq + p < w) {
-                warp_pixel<T>(src, a, xq + p, X0, Y0, v[p], ok[p]);
+                warp_pixel_xy<T>(src, a, (X0 + ad[p]) >> 5, (Y0 + bd[p]) >> 5, v[p], ok[p]);
             }
         }
         const size_t px = (size_t)y * w + xq;

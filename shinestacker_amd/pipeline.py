@@ -15,7 +15,7 @@ import numpy as np
 
 from . import _lib
 from .align import (_BORDER_CODE, _DEFAULT_ALIGNMENT_CONFIG, _DEFAULT_FEATURE_CONFIG,
-                    _DEFAULT_MATCHING_CONFIG, img_subsample, opencv_estimator)
+                    _DEFAULT_MATCHING_CONFIG, img_subsample, rescale_transform, resolve_estimator)
 from .defaults import constants
 from .errors import AlignmentError, InvalidOptionError
 from .imageio import validate_image
@@ -36,10 +36,11 @@ def align_and_stack(frames, ref_idx=-1, estimator=None, alignment_config=None, f
     cfg = {**_DEFAULT_ALIGNMENT_CONFIG, **(alignment_config or {})}
     if cfg['border_mode'] not in _BORDER_CODE:
         raise InvalidOptionError("border_mode", cfg['border_mode'])
-    if cfg['transform'] != constants.ALIGN_RIGID:
-        raise InvalidOptionError("transform", cfg['transform'],
-                                 "the MI355X apply path implements ALIGN_RIGID only")
-    estimator = estimator or opencv_estimator
+    if cfg['transform'] not in (constants.ALIGN_RIGID, constants.ALIGN_HOMOGRAPHY):
+        raise InvalidOptionError("transform", cfg['transform'])
+    homography = cfg['transform'] == constants.ALIGN_HOMOGRAPHY
+    min_matches = 4 if homography else 3
+    estimator = resolve_estimator(estimator, device)
     if ref_idx == -1:
         ref_idx = n // 2
     ref = np.ascontiguousarray(frames[ref_idx])
@@ -82,19 +83,18 @@ def align_and_stack(frames, ref_idx=-1, estimator=None, alignment_config=None, f
                     break
                 sub = 1
             matches.append(ng)
-            if ng < 3 or m is None:
-                raise AlignmentError(i, f"too few matches found: {ng} < 3")
+            if ng < min_matches or m is None:
+                raise AlignmentError(i, f"too few matches found: {ng} < {min_matches}")
             m = np.asarray(m)
+            if homography and m.shape == (2, 3):
+                m = np.vstack([m, [0.0, 0.0, 1.0]])
             if sub > 1:
-                full = np.empty((2, 3), dtype=np.float32)
-                full[:2, :2] = m[:2, :2]
-                full[:, 2] = m[:, 2] * sub
-                m = full
-            mm = (C.c_double * 6)(*np.asarray(m, dtype=np.float64).reshape(6))
+                m = rescale_transform(m, cfg['transform'], sub, fr.shape, a.shape)
+            mm = (C.c_double * m.size)(*np.asarray(m, dtype=np.float64).reshape(-1))
             src.upload(fr)
-            _lib.check(lib.mi_warp_affine_device(device, None, src.ptr, dst, tmp.ptr, mask.ptr, h, w,
-                                                 _lib.DTYPE_CODE[dt], mm, mode, bv, 21,
-                                                 float(cfg['border_blur'])))
+            warp = lib.mi_warp_perspective_device if homography else lib.mi_warp_affine_device
+            _lib.check(warp(device, None, src.ptr, dst, tmp.ptr, mask.ptr, h, w, _lib.DTYPE_CODE[dt], mm, mode, bv, 21,
+                            float(cfg['border_blur'])))
         filled += 1
         if filled == batch_frames:
             flush()
@@ -107,9 +107,58 @@ def align_and_stack(frames, ref_idx=-1, estimator=None, alignment_config=None, f
     return out, matches
 
 
+def _align_chains_device(lib, dev_frames, aligned, n_frames, height, width, dt, ref_idx, cfg, min_correlation, max_iters,
+                         device):
+    """`step_process=True` (stack_framework.py:214-232, the documented default of the reference's jobs): frame ref+1 is
+    aligned to the reference frame, ref+2 to the ALIGNED ref+1, ... and ref-1, ref-2, ... the same way downwards -- two
+    serial chains.  Every step needs the previous step's warped frame, so the batched estimator does not apply; the two
+    chains are independent and run side by side (one host thread and one estimator handle each).  Aligned frames are
+    written to `aligned` at their own index.  Returns (transforms, correlation coefficients)."""
+    import threading
+    fb = height * width * 3 * dt.itemsize
+    mode = _BORDER_CODE[cfg['border_mode']]
+    bv = (C.c_double * 4)(*(list(cfg['border_value']) + [0, 0, 0, 0])[:4])
+    homography = cfg['transform'] == constants.ALIGN_HOMOGRAPHY
+    transforms, ccs, errors = [None] * n_frames, [1.0] * n_frames, []
+    _lib.check(lib.mi_memcpy_d2d(device, aligned + ref_idx * fb, dev_frames + ref_idx * fb, fb))   # align.py:279-280
+
+    def chain(indices):
+        try:
+            aligner = _lib.Aligner(height, width, dt, subsample=max(1, int(cfg['subsample'])), device=device)
+            tmp = _lib.DeviceBuffer(fb, device)
+            mask = _lib.DeviceBuffer(height * width, device)
+            prev = ref_idx
+            for i in indices:
+                aligner.set_reference(aligned + prev * fb)
+                m, cc, _ = aligner.estimate(dev_frames + i * fb, max_iters=max_iters)
+                if not cc >= min_correlation:
+                    raise AlignmentError(i, f"correlation {cc:.3f} < {min_correlation}")
+                transforms[i], ccs[i] = m, float(cc)
+                mm = np.vstack([m, [0.0, 0.0, 1.0]]) if homography else m
+                arr = (C.c_double * mm.size)(*mm.reshape(-1))
+                warp = lib.mi_warp_perspective_device if homography else lib.mi_warp_affine_device
+                _lib.check(warp(device, None, dev_frames + i * fb, aligned + i * fb, tmp.ptr, mask.ptr, height, width,
+                                _lib.DTYPE_CODE[dt], arr, mode, bv, 21, float(cfg['border_blur'])))
+                _lib.check(lib.mi_device_synchronize(device))    # the next step's reference is this warp's output
+                prev = i
+            aligner.close()
+        except Exception as e:  # noqa: BLE001  re-raised on the calling thread
+            errors.append(e)
+
+    threads = [threading.Thread(target=chain, args=(list(range(ref_idx + 1, n_frames)),)),
+               threading.Thread(target=chain, args=(list(range(ref_idx - 1, -1, -1)),))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errors:
+        raise errors[0]
+    return transforms, ccs
+
+
 def align_and_stack_device(dev_frames, n_frames, height, width, dtype, ref_idx=-1, alignment_config=None,
                            min_correlation=0.5, max_iters=60, device=0, batch_frames=16, out_dev=None,
-                           balance=None, ecc_batch=16, **stack_kwargs):
+                           balance=None, ecc_batch=16, step_process=False, **stack_kwargs):
     """BASELINE config 4 with every frame resident in HBM: `dev_frames` is the device address of
     `n_frames` contiguous H x W x 3 frames.  Each frame is registered against frames[ref_idx] by
     the device ECC estimator (mi_aligner_*), warped with the blurred replicate border of
@@ -127,6 +176,10 @@ def align_and_stack_device(dev_frames, n_frames, height, width, dtype, ref_idx=-
     (balance.py; the order of the reference's example projects: align, balance, stack) in place on the
     device -- histogram on the GPU, the 256/65536-entry table on the host, table apply on the GPU.
 
+    `step_process=True`: the reference's chained order (see `_align_chains_device`): every frame is registered against
+    its already-aligned neighbour; the aligned frames are kept in one extra device buffer (n_frames frames) and fused in
+    file order afterwards, so that the stack sees them exactly as the reference's FocusStack reads the aligned files.
+
     Returns (fused image as ndarray, or None when `out_dev` -- a device address for the result --
     is given; list of 2x3 transforms, None at ref_idx; list of correlation coefficients)."""
     _lib.require_device()
@@ -135,14 +188,46 @@ def align_and_stack_device(dev_frames, n_frames, height, width, dtype, ref_idx=-
     cfg = {**_DEFAULT_ALIGNMENT_CONFIG, **(alignment_config or {})}
     if cfg['border_mode'] not in _BORDER_CODE:
         raise InvalidOptionError("border_mode", cfg['border_mode'])
-    if cfg['transform'] != constants.ALIGN_RIGID:
-        raise InvalidOptionError("transform", cfg['transform'],
-                                 "the MI355X apply path implements ALIGN_RIGID only")
+    if cfg['transform'] not in (constants.ALIGN_RIGID, constants.ALIGN_HOMOGRAPHY):
+        raise InvalidOptionError("transform", cfg['transform'])
+    # the device estimator finds a similarity; with ALIGN_HOMOGRAPHY it is applied through the projective warp
+    homography = cfg['transform'] == constants.ALIGN_HOMOGRAPHY
     if ref_idx == -1:
         ref_idx = n_frames // 2
     dt = np.dtype(dtype)
     fb = height * width * 3 * dt.itemsize
     lib = _lib.load()
+    if step_process:
+        aligned = _lib.DeviceBuffer(fb * n_frames, device)
+        transforms, ccs = _align_chains_device(lib, dev_frames, aligned.ptr, n_frames, height, width, dt, ref_idx, cfg,
+                                               min_correlation, max_iters, device)
+        stack = _lib.Stack(height, width, in_dtype=dt, out_dtype=dt, device=device, **stack_kwargs)
+        try:
+            if balance is not None:
+                from .balance import LumiCorrection, RGBCorrection
+                opts = dict(balance)
+                channel = opts.pop('channel', constants.DEFAULT_CHANNEL)
+                if channel not in (constants.BALANCE_LUMI, constants.BALANCE_RGB):
+                    raise InvalidOptionError("channel", channel, "the MI355X path implements LUMI and RGB balancing only")
+                if opts.get('subsample', -1) == -1:
+                    opts['subsample'] = 1 if opts.get('corr_map') == constants.BALANCE_MATCH_HIST \
+                        else constants.DEFAULT_BALANCE_SUBSAMPLE
+                corr = (LumiCorrection if channel == constants.BALANCE_LUMI else RGBCorrection)(device=device, **opts)
+                corr.begin_device(aligned.ptr + ref_idx * fb, height, width, dt, n_frames)
+                for i in range(n_frames):
+                    if i != ref_idx:
+                        corr.apply_correction_device(i, aligned.ptr + i * fb, stack.stream)
+            stack.push_frames_device(aligned.ptr, n_frames, fb)
+            if out_dev is not None:
+                stack.finish_device(out_dev)
+                stack.sync()
+                out = None
+            else:
+                out = stack.finish()
+        finally:
+            stack.close()
+            aligned.free()
+        return out, transforms, ccs
     stack = _lib.Stack(height, width, in_dtype=dt, out_dtype=dt, device=device, batch_frames=batch_frames,
                        **stack_kwargs)
     aligner = _lib.Aligner(height, width, dt, subsample=max(1, int(cfg['subsample'])), device=device)
@@ -204,10 +289,12 @@ def align_and_stack_device(dev_frames, n_frames, height, width, dtype, ref_idx=-
                 m, cc = estimates.pop(i)
                 if not cc >= min_correlation:
                     raise AlignmentError(i, f"correlation {cc:.3f} < {min_correlation}")
-                mm = (C.c_double * 6)(*m.reshape(6))
-                _lib.check(lib.mi_warp_affine_device(device, st, src, dst, tmp.ptr, mask.ptr, height, width,
-                                                     _lib.DTYPE_CODE[dt], mm, mode, bv, 21,
-                                                     float(cfg['border_blur'])))
+                if homography:
+                    m = np.vstack([m, [0.0, 0.0, 1.0]])
+                mm = (C.c_double * m.size)(*m.reshape(-1))
+                warp = lib.mi_warp_perspective_device if homography else lib.mi_warp_affine_device
+                _lib.check(warp(device, st, src, dst, tmp.ptr, mask.ptr, height, width, _lib.DTYPE_CODE[dt], mm, mode, bv, 21,
+                                float(cfg['border_blur'])))
                 if corr is not None:
                     corr.apply_correction_device(i, dst, st)
                 transforms.append(m)

@@ -73,20 +73,77 @@ def test_option_and_shape_errors():
     with pytest.raises(InvalidOptionError):
         align_images(img, img, alignment_config={'border_mode': 'BORDER_WRAP'}, estimator=fake_estimator(5, None))
     with pytest.raises(InvalidOptionError):
-        align_images(img, img, alignment_config={'transform': 'ALIGN_HOMOGRAPHY'}, estimator=fake_estimator(5, None))
+        align_images(img, img, alignment_config={'transform': 'ALIGN_AFFINE'}, estimator=fake_estimator(5, None))
     with pytest.raises(ShapeError):
         align_images(img, np.zeros((16, 17, 3), np.uint8), estimator=fake_estimator(5, None))
 
 
-def test_default_estimator_needs_opencv():
-    try:
-        import cv2  # noqa: F401
-        pytest.skip("OpenCV is installed here")
-    except ImportError:
-        pass
+def test_estimator_selection():
+    """estimator='auto' (the default): the reference's recipe when OpenCV is importable, the GPU ECC estimator
+    otherwise; 'opencv' without OpenCV says so; anything else is an InvalidOptionError."""
+    import shinestacker_amd.align as al
     img = np.zeros((16, 16, 3), np.uint8)
-    with pytest.raises(RuntimeError, match="OpenCV"):
-        align_images(img, img, alignment_config={'subsample': 1})
+    if not al.have_opencv():
+        with pytest.raises(RuntimeError, match="OpenCV"):
+            align_images(img, img, alignment_config={'subsample': 1}, estimator="opencv")
+        assert al.resolve_estimator("auto").__name__ == "estimate"          # the ECC closure
+    else:
+        assert al.resolve_estimator(None) is al.opencv_estimator
+    f = fake_estimator(5, None)
+    assert al.resolve_estimator(f) is f
+    with pytest.raises(InvalidOptionError):
+        al.resolve_estimator("sift-gpu")
+
+
+def test_feature_config_validation_as_reference():
+    """align.py:71-87: the reference refuses these combinations with these messages (tests/test_0032_align_methods.py)."""
+    from shinestacker_amd.align import validate_align_config
+    bad = [("SIFT", "SIFT", "NORM_HAMMING", "Descriptor SIFT requires matching method KNN"),
+           ("ORB", "AKAZE", "NORM_HAMMING", "Detector ORB and descriptor AKAZE require matching method KNN"),
+           ("BRISK", "AKAZE", "KNN", "Detector BRISK is incompatible with descriptor AKAZE"),
+           ("SURF", "AKAZE", "KNN", "Detector SURF is incompatible with descriptor AKAZE"),
+           ("SIFT", "ORB", "KNN", "Detector SIFT requires descriptor SIFT"),
+           ("ORB", "ORB", "KNN", "Detector ORB and descriptor ORB require matching method Hamming distance")]
+    for det, des, mm, msg in bad:
+        with pytest.raises(ValueError, match=msg):
+            validate_align_config(det, des, mm)
+    for det, des, mm in [("SIFT", "SIFT", "KNN"), ("ORB", "ORB", "NORM_HAMMING"), ("AKAZE", "AKAZE", "NORM_HAMMING"),
+                         ("SURF", "ORB", "NORM_HAMMING"), ("ORB", "SIFT", "KNN")]:
+        validate_align_config(det, des, mm)
+    img = np.zeros((16, 16, 3), np.uint8)
+    with pytest.raises(ValueError, match="requires descriptor SIFT"):      # whichever estimator runs
+        align_images(img, img, feature_config={'detector': 'SIFT', 'descriptor': 'ORB'}, estimator=fake_estimator(5, None))
+
+
+def test_homography_transform_path():
+    """ALIGN_HOMOGRAPHY (align.py:212-221, :231-237): four matches needed, the sub-sampled estimate is conjugated with
+    the corner-to-corner scalings, the apply step receives a 3x3 matrix."""
+    from shinestacker_amd.align import rescale_transform
+    img = np.zeros((40, 60, 3), np.uint8)
+    Hs = np.array([[1.01, 0.02, 3.0], [-0.01, 0.99, -2.0], [1e-4, -2e-4, 1.0]])
+    seen = {}
+
+    def apply_fn(im, m, cfg):
+        seen['m'] = np.asarray(m)
+        return im
+    n, m, warp = align_images(img, img, estimator=fake_estimator(200, Hs), apply_fn=apply_fn,
+                              alignment_config={'transform': 'ALIGN_HOMOGRAPHY', 'subsample': 2, 'fast_subsampling': True})
+    assert n == 200 and m.shape == (3, 3) and seen['m'].shape == (3, 3)
+    up, down = np.diag([2.0, 2.0, 1.0]), np.diag([0.5, 0.5, 1.0])
+    assert np.allclose(m, up @ Hs @ down, rtol=0, atol=1e-15)
+    # a point of the sub-sampled image maps consistently: full-res map of 2p == 2 * sub-res map of p
+    p = np.array([7.0, 5.0, 1.0])
+    q_sub = Hs @ p
+    q_full = m @ np.array([14.0, 10.0, 1.0])
+    assert np.allclose(q_full[:2] / q_full[2], 2 * q_sub[:2] / q_sub[2])
+    # three matches are too few for a homography (min_matches = 4), and a similarity is embedded as 3x3
+    n, m, warp = align_images(img, img, estimator=fake_estimator(3, Hs), apply_fn=apply_fn,
+                              alignment_config={'transform': 'ALIGN_HOMOGRAPHY', 'subsample': 1})
+    assert (m, warp) == (None, None)
+    n, m, _ = align_images(img, img, estimator=fake_estimator(9, [[1, 0, 2], [0, 1, 3]]), apply_fn=apply_fn,
+                           alignment_config={'transform': 'ALIGN_HOMOGRAPHY', 'subsample': 1})
+    assert m.shape == (3, 3) and np.array_equal(m[2], [0, 0, 1])
+    assert rescale_transform(np.eye(2, 3), 'ALIGN_RIGID', 4, (8, 8), (2, 2)).dtype == np.float32
 
 
 def test_area_subsample_rounds_half_up():

@@ -205,3 +205,76 @@ def test_project_align_balance_sharded_over_ranks(hiplib, oracle, tmp_path):
     assert sorted(n for n in os.listdir(os.path.join(work, "sharded")) if not n.startswith(".")) == names and len(names) == 5
     for n in names:
         assert np.array_equal(read_img(os.path.join(work, "whole", n)), read_img(os.path.join(work, "sharded", n))), n
+
+
+# ---------------------------------------------------------------- ALIGN_HOMOGRAPHY apply (align.py:231-237)
+HOMOGRAPHIES = {
+    "similarity": [[0.999, -0.012, 2.3], [0.012, 0.999, -1.7], [0, 0, 1]],
+    "mild_perspective": [[1.002, 0.004, -3.1], [-0.003, 0.998, 4.4], [1.5e-5, -2.5e-5, 1.0]],
+    "strong_perspective": [[0.9, 0.1, 12.0], [-0.08, 1.1, -9.0], [6e-4, 3e-4, 1.0]],
+    "scaled": [[2.0, 0.02, -30.0], [0.01, 2.0, -20.0], [1e-5, 0, 2.0]],     # homogeneous scale 2
+}
+
+
+@pytest.mark.parametrize("name", sorted(HOMOGRAPHIES))
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16])
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_warp_perspective_equals_oracle(L, oracle, name, dtype, mode):
+    """mi_warp_perspective (image, mask, blurred border) == oracle/align_oracle.c's restatement of cv2.warpPerspective,
+    odd sizes (the 64-column blocks of the coordinate recurrence end mid-block), all three border modes."""
+    rng = np.random.default_rng(11)
+    hi = 256 if dtype == np.uint8 else 65536
+    img = rng.integers(0, hi, (133, 203, 3)).astype(dtype)
+    M = np.array(HOMOGRAPHIES[name], np.float64)
+    bv = (7, 250, 99, 0)
+    got, gmask = L.warp_perspective(img, M, border_mode=mode, border_value=bv, want_mask=True)
+    want, wmask = oracle.warp_perspective(img, M, border_mode=mode, border_value=bv, want_mask=True)
+    assert np.array_equal(gmask, wmask)
+    assert np.array_equal(got, want)
+
+
+def test_align_images_homography_on_gpu(L, oracle):
+    from shinestacker_amd.align import align_images
+    """align_images with ALIGN_HOMOGRAPHY end to end on the device apply path: an injected 3x3 estimate found at
+    sub-sample 2 is rescaled (align.py:213-221) and applied by mi_warp_perspective == the oracle's warp of the
+    rescaled matrix."""
+    rng = np.random.default_rng(2)
+    ref = rng.integers(0, 256, (120, 160, 3)).astype(np.uint8)
+    Hs = np.array([[1.004, 0.006, 1.2], [-0.005, 0.997, -0.8], [2e-5, -1e-5, 1.0]])
+    n, m, warp = align_images(ref, ref, estimator=lambda a, b, fc, mc, ac: (300, Hs),
+                              alignment_config={'transform': 'ALIGN_HOMOGRAPHY', 'subsample': 2, 'fast_subsampling': True})
+    assert n == 300 and m.shape == (3, 3)
+    assert np.array_equal(warp, oracle.warp_perspective(ref, m))
+
+
+def test_align_frames_default_estimator_runs_out_of_the_box(hiplib, oracle, tmp_path):
+    """The reference's AlignFrames() works with no arguments (align.py:90-151 on OpenCV); here the default estimator is
+    'auto': OpenCV's recipe when cv2 is importable, the GPU ECC estimator otherwise.  stack-from-frames.fsp shaped job
+    (docs/job.md: step_process on, sub-sample 2 with the area mean) on shifted copies of one scene."""
+    from shinestacker_amd import AlignFrames, CombinedActions, StackJob
+    from shinestacker_amd.imageio import read_img, write_img
+    from test_gpu_ecc import make_pair, similarity
+    hiplib.require_device()
+    work = str(tmp_path)
+    os.makedirs(os.path.join(work, "in"))
+    h, w = 256, 384
+    truth = []
+    for f in range(5):
+        d = f - 2
+        T = similarity(0.1 * d, 1 + 3e-4 * d, 0.9 * d, -0.6 * d, (w - 1) / 2, (h - 1) / 2)
+        ref, mov = make_pair(oracle, T, h=h, w=w, seed=8, noise=1.5)
+        write_img(os.path.join(work, "in", f"f{f}.png"), (ref if d == 0 else mov).astype(np.uint8))
+        truth.append(T)
+    af = AlignFrames()                        # no estimator argument
+    job = StackJob("job", work, input_path="in")
+    job.add_action(CombinedActions("align", [af], output_path="aligned", step_process=True))
+    job.run()
+    names = sorted(os.listdir(os.path.join(work, "aligned")))
+    assert len(names) == 5
+    refimg = read_img(os.path.join(work, "in", "f2.png")).astype(np.int16)
+    inner = (slice(24, h - 24), slice(24, w - 24))
+    for n_ in names:
+        a = read_img(os.path.join(work, "aligned", n_)).astype(np.int16)
+        before = np.abs(read_img(os.path.join(work, "in", n_)).astype(np.int16)[inner] - refimg[inner]).mean()
+        after = np.abs(a[inner] - refimg[inner]).mean()
+        assert after <= max(before, 1e-9) + 1e-9 and after < 6.0, (n_, before, after)

@@ -194,3 +194,51 @@ def test_batched_estimate_equals_single_estimates(L, oracle):
     with pytest.raises(Exception):
         al.estimate(ptrs[2])
     al.close()
+
+
+def test_align_and_stack_device_step_process_chains(L, oracle):
+    """step_process=True (the reference's documented default, stack_framework.py:214-232): every frame is registered
+    against its already ALIGNED neighbour, in two chains away from the reference frame.  The resident pipeline must give
+    what the same procedure gives step by step through the single-frame entry points, fused in file order; and the
+    chained transforms still bring every frame onto the reference frame."""
+    from shinestacker_amd.pipeline import align_and_stack_device
+    h, w, n = 384, 512, 7
+    ref_idx = n // 2
+    frames, truth = [], []
+    for f in range(n):
+        d = f - ref_idx
+        T = similarity(0.12 * d, 1 + 4e-4 * d, 1.4 * d, -0.9 * d, (w - 1) / 2, (h - 1) / 2)
+        ref, mov = make_pair(oracle, T, h=h, w=w, seed=13, noise=2.0)
+        frames.append(ref if d == 0 else mov)
+        truth.append(T)
+    fb = frames[0].nbytes
+    buf = L.DeviceBuffer(n * fb)
+    for f, fr in enumerate(frames):
+        buf.upload(fr, f * fb)
+    cfg = {'subsample': 1}
+    fused, tr, ccs = align_and_stack_device(buf.ptr, n, h, w, np.uint8, alignment_config=cfg, step_process=True)
+    assert tr[ref_idx] is None and all(c > 0.9 for c in ccs)
+    # the same chains, one step at a time: estimate against the previous ALIGNED frame, warp, remember
+    aligned = {ref_idx: frames[ref_idx]}
+    for chain in (range(ref_idx + 1, n), range(ref_idx - 1, -1, -1)):
+        prev = ref_idx
+        for i in chain:
+            m, cc, _ = L.ecc_similarity(aligned[prev], frames[i])
+            assert np.allclose(m, tr[i], rtol=0, atol=1e-9), i
+            aligned[i] = L.warp_affine(frames[i], tr[i])
+            prev = i
+    so = oracle.StreamingOracle(h, w, np.uint8, keep_gauss=False)
+    for i in range(n):
+        so.push_frame(aligned[i])
+    assert np.array_equal(fused, so.finish())
+    # accuracy of the chained estimate against the known transforms (tests/test_0031_align_precision.py:62-65 tolerances,
+    # the shift one widened by the chain length: errors of the steps add up)
+    cx, cy = (w - 1) / 2, (h - 1) / 2
+    for i in range(n):
+        if i == ref_idx:
+            continue
+        A = np.array(truth[i])[:, :2]
+        Ai = np.linalg.inv(A)
+        want = np.hstack([Ai, -Ai @ np.array(truth[i])[:, 2:3]])
+        ctr = np.array([cx, cy, 1.0])
+        assert np.abs(tr[i] @ ctr - want @ ctr).max() < 0.2 * abs(i - ref_idx), i
