@@ -250,6 +250,9 @@ MI_API int mi_ecc_similarity(int device, const void* host_ref, const void* host_
 typedef struct mi_aligner* mi_aligner_t;
 MI_API int mi_aligner_create(mi_aligner_t* out, int device, int height, int width, int dtype, int subsample,
                       int max_levels);
+/* sub-sample like the reference's default (fast_subsampling = False: cv2.resize(INTER_AREA), the mean of every s x s
+ * block, utils.py:83) instead of img[::s, ::s]; call before mi_aligner_set_reference */
+MI_API int mi_aligner_set_area_subsampling(mi_aligner_t al, int enable);
 MI_API int mi_aligner_destroy(mi_aligner_t al);
 MI_API int mi_aligner_set_reference(mi_aligner_t al, void* stream, const void* dev_ref);
 MI_API int mi_aligner_estimate(mi_aligner_t al, void* stream, const void* dev_mov, int max_iters, double eps,

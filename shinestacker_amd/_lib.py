@@ -111,6 +111,7 @@ SIGNATURES = {
                                     C.POINTER(C.c_int)]),
     "mi_aligner_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                     C.c_int]),
+    "mi_aligner_set_area_subsampling": (C.c_int, [C.c_void_p, C.c_int]),
     "mi_aligner_destroy": (C.c_int, [C.c_void_p]),
     "mi_aligner_set_reference": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "mi_aligner_estimate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double,
@@ -517,12 +518,14 @@ class Aligner:
     """Device-resident ECC estimator (mi_aligner_t): frames stay in HBM, the pyramids are allocated
     once, `subsample` is the reference's fast sub-sampling factor (align.py default 2)."""
 
-    def __init__(self, height, width, dtype=np.uint8, subsample=1, max_levels=0, device=0):
+    def __init__(self, height, width, dtype=np.uint8, subsample=1, max_levels=0, device=0, fast=True):
         require_device()
         self._h = C.c_void_p()
         self.device = device
         check(load().mi_aligner_create(C.byref(self._h), device, height, width,
                                        DTYPE_CODE[np.dtype(dtype)], int(subsample), int(max_levels)))
+        if not fast and subsample > 1:   # the reference's default: cv2.resize(INTER_AREA) (utils.py:83)
+            check(load().mi_aligner_set_area_subsampling(self._h, 1))
 
     def set_reference(self, dev_ptr, stream=None):
         check(load().mi_aligner_set_reference(self._h, stream, dev_ptr))

@@ -671,6 +671,7 @@ struct EccLevel {
 // scratch for the sums, all allocated once per (shape, dtype, subsample).
 struct mi_aligner {
     int device = 0, height = 0, width = 0, dtype = 0, subsample = 1;
+    int area = 0;      // sub-sample by area mean (cv2.resize INTER_AREA) instead of img[::s, ::s]
     int h = 0, w = 0;  // size of the sub-sampled images the estimate works on
     std::vector<EccLevel> lv;   // tmpl: one image; img: `cap` images (frame f at + f * h * w)
     float* gray = nullptr;
@@ -737,11 +738,11 @@ int aligner_reserve(mi_aligner* al, int n) {
 int aligner_build(mi_aligner* al, hipStream_t st, const void* dev_img, bool is_tmpl, int slot) {
     const dim3 blk(64, 4), g0(cdiv(al->w, 64), cdiv(al->h, 4));
     if (al->dtype == MI_U8)
-        hipLaunchKernelGGL((ecc_gray<uint8_t>), g0, blk, 0, st, (const uint8_t*)dev_img, al->width, al->h, al->w,
-                           al->subsample, al->gray);
+        hipLaunchKernelGGL((ecc_gray<uint8_t>), g0, blk, 0, st, (const uint8_t*)dev_img, al->height, al->width, al->h, al->w,
+                           al->subsample, al->area, al->gray);
     else
-        hipLaunchKernelGGL((ecc_gray<uint16_t>), g0, blk, 0, st, (const uint16_t*)dev_img, al->width, al->h, al->w,
-                           al->subsample, al->gray);
+        hipLaunchKernelGGL((ecc_gray<uint16_t>), g0, blk, 0, st, (const uint16_t*)dev_img, al->height, al->width, al->h, al->w,
+                           al->subsample, al->area, al->gray);
     auto& lv = al->lv;
     auto at = [&](float* base, size_t l) { return base + (size_t)slot * lv[l].h * lv[l].w; };
     for (size_t l = 0; l < lv.size(); ++l) {
@@ -1606,6 +1607,13 @@ int mi_aligner_create(mi_aligner_t* out, int device, int height, int width, int 
         return fail(MI_ERR_NOMEM, "out of device memory");
     }
     *out = al;
+    return MI_OK;
+}
+
+int mi_aligner_set_area_subsampling(mi_aligner_t al, int enable) {
+    if (!al) return fail(MI_ERR_INVALID, "null handle");
+    al->area = enable != 0;
+    al->have_ref = false;   // the reference pyramid was built with the other rule
     return MI_OK;
 }
 

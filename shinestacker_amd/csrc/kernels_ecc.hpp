@@ -16,16 +16,35 @@
 
 namespace mi {
 
-// gray (float) of a BGR image, with the reference's fast sub-sampling img[::s, ::s]
-// (utils.py img_subsample, fast branch) folded in; any fixed positive combination of the channels
-// works for registration.  out is h x w, the source row pitch is src_w pixels.
+// gray (float) of a BGR image with the reference's sub-sampling (utils.py:79-86 img_subsample) folded in: the fast
+// branch img[::s, ::s], or (area != 0) the integer-factor cv2.resize(INTER_AREA) -- the mean of the s x s block per
+// channel, rounded to the image's integer type (half up; blocks that hang over the right / bottom edge average the
+// pixels they have).  Any fixed positive combination of the channels works for registration.  out is h x w, the source
+// is src_h x src_w pixels.
 template <typename T>
-__global__ void ecc_gray(const T* __restrict__ img, int src_w, int h, int w, int s, float* __restrict__ out) {
+__global__ void ecc_gray(const T* __restrict__ img, int src_h, int src_w, int h, int w, int s, int area,
+                         float* __restrict__ out) {
     int x = blockIdx.x * blockDim.x + threadIdx.x;
     int y = blockIdx.y * blockDim.y + threadIdx.y;
     if (x >= w || y >= h) return;
     const T* p = img + ((size_t)y * s * src_w + (size_t)x * s) * 3;
-    out[(size_t)y * w + x] = 0.114f * (float)p[0] + 0.587f * (float)p[1] + 0.299f * (float)p[2];
+    float c[3];
+    if (!area || s == 1) {
+        c[0] = (float)p[0]; c[1] = (float)p[1]; c[2] = (float)p[2];
+    } else {
+        const int ny = min(s, src_h - y * s), nx = min(s, src_w - x * s);
+        uint32_t sum[3] = {0u, 0u, 0u};
+        for (int dy = 0; dy < ny; ++dy) {
+            const T* q = p + (size_t)dy * src_w * 3;
+            for (int dx = 0; dx < nx; ++dx) {
+                sum[0] += q[3 * dx]; sum[1] += q[3 * dx + 1]; sum[2] += q[3 * dx + 2];
+            }
+        }
+        const uint32_t n = (uint32_t)(ny * nx);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) c[k] = (float)((sum[k] + n / 2) / n);
+    }
+    out[(size_t)y * w + x] = 0.114f * c[0] + 0.587f * c[1] + 0.299f * c[2];
 }
 
 // 5x5 binomial blur ([1 4 6 4 1]/16 separable, replicate border) then 2x decimation

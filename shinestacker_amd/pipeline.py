@@ -124,7 +124,8 @@ def _align_chains_device(lib, dev_frames, aligned, n_frames, height, width, dt, 
 
     def chain(indices):
         try:
-            aligner = _lib.Aligner(height, width, dt, subsample=max(1, int(cfg['subsample'])), device=device)
+            aligner = _lib.Aligner(height, width, dt, subsample=max(1, int(cfg['subsample'])), device=device,
+                                   fast=bool(cfg['fast_subsampling']))
             tmp = _lib.DeviceBuffer(fb, device)
             mask = _lib.DeviceBuffer(height * width, device)
             prev = ref_idx
@@ -230,7 +231,8 @@ def align_and_stack_device(dev_frames, n_frames, height, width, dtype, ref_idx=-
         return out, transforms, ccs
     stack = _lib.Stack(height, width, in_dtype=dt, out_dtype=dt, device=device, batch_frames=batch_frames,
                        **stack_kwargs)
-    aligner = _lib.Aligner(height, width, dt, subsample=max(1, int(cfg['subsample'])), device=device)
+    aligner = _lib.Aligner(height, width, dt, subsample=max(1, int(cfg['subsample'])), device=device,
+                                   fast=bool(cfg['fast_subsampling']))
     ecc_batch = max(1, min(int(ecc_batch), _lib.Aligner.MAX_BATCH))
     tmp = _lib.DeviceBuffer(fb, device)
     mask = _lib.DeviceBuffer(height * width, device)

@@ -242,3 +242,34 @@ def test_align_and_stack_device_step_process_chains(L, oracle):
         want = np.hstack([Ai, -Ai @ np.array(truth[i])[:, 2:3]])
         ctr = np.array([cx, cy, 1.0])
         assert np.abs(tr[i] @ ctr - want @ ctr).max() < 0.2 * abs(i - ref_idx), i
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16])
+@pytest.mark.parametrize("s", [2, 4, 8])
+def test_device_area_subsampling_equals_host_resize(L, oracle, dtype, s):
+    """fast_subsampling=False (the reference's default and the setting of its example projects, utils.py:79-86:
+    cv2.resize(INTER_AREA) by an integer factor) folded into the device estimator's first kernel == the host-side
+    img_subsample followed by the estimate on the small images (translation rescaled as align.py:223 does)."""
+    from shinestacker_amd.align import img_subsample
+    h, w = 384, 512
+    T = similarity(0.3, 1.002, 6.0, -4.0, (w - 1) / 2, (h - 1) / 2)
+    ref, mov = make_pair(oracle, T, h=h, w=w, seed=21, noise=2.0)
+    if dtype == np.uint16:
+        ref, mov = ref.astype(np.uint16) * 257, mov.astype(np.uint16) * 257
+    buf = L.DeviceBuffer(2 * ref.nbytes)
+    buf.upload(ref)
+    buf.upload(mov, ref.nbytes)
+    al = L.Aligner(h, w, dtype, subsample=s, fast=False)
+    al.set_reference(buf.ptr)
+    m_dev, cc_dev, _ = al.estimate(buf.ptr + ref.nbytes)
+    al.close()
+    m_host, cc_host, _ = L.ecc_similarity(img_subsample(ref, s, fast=False), img_subsample(mov, s, fast=False))
+    m_host = m_host.copy()
+    m_host[:, 2] *= s
+    assert np.allclose(m_dev, m_host, rtol=0, atol=1e-9) and abs(cc_dev - cc_host) < 1e-12
+    # and it is not the strided sub-sampling
+    al = L.Aligner(h, w, dtype, subsample=s, fast=True)
+    al.set_reference(buf.ptr)
+    m_fast, _, _ = al.estimate(buf.ptr + ref.nbytes)
+    al.close()
+    assert not np.array_equal(m_fast, m_dev)
