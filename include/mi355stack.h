@@ -285,6 +285,15 @@ MI_API int mi_apply_lut(int device, const void* host_src, void* host_dst, int he
 MI_API int mi_apply_lut_device(int device, void* stream, const void* dev_src, void* dev_dst, size_t npixels,
                         int dtype, const void* dev_lut, int nlut);
 
+/* 8-bit BGR <-> HSV / HLS (cv2.cvtColor COLOR_BGR2HSV, _HSV2BGR, _BGR2HLS, _HLS2BGR): the pre- and post-processing of the
+ * HSV / HLS channel modes of BalanceFrames (balance.py:340-363: SVCorrection / LSCorrection balance S and V, or L and S,
+ * and leave the hue alone).  uint8 only, as in OpenCV (MI_ERR_UNSUPPORTED for 16-bit; the reference raises there too).
+ * In place is allowed (dev_dst == dev_src). */
+enum { MI_CVT_BGR2HSV = 0, MI_CVT_HSV2BGR = 1, MI_CVT_BGR2HLS = 2, MI_CVT_HLS2BGR = 3 };
+MI_API int mi_cvt_color(int device, const void* host_src, void* host_dst, int height, int width, int dtype, int code);
+MI_API int mi_cvt_color_device(int device, void* stream, const void* dev_src, void* dev_dst, size_t npixels, int dtype,
+                        int code);
+
 /* ---- DepthMapStack: the second stacker behind the same plug-in boundary ----
  * Replaces the arithmetic of DepthMapStack.focus_stack (reference algorithms/depth_map.py:64-123) for
  * both float types: push = the first file loop (:67-75: read, img_bw, then per frame get_sobel_map :28-34

@@ -285,7 +285,10 @@ def balance_case():
             np.array([0.9, 1.0, 0.8])
         ref = np.clip(base * hi + rng.normal(0, hi / 40, base.shape), 0, hi - 1).astype(dtype)
         mov = np.clip((base ** 1.15) * hi * 0.85 + rng.normal(0, hi / 40, base.shape), 0, hi - 1).astype(dtype)
-        for channel, cls in (("LUMI", bal.LumiCorrection), ("RGB", bal.RGBCorrection)):
+        for channel, cls in (("LUMI", bal.LumiCorrection), ("RGB", bal.RGBCorrection), ("HSV", bal.SVCorrection),
+                             ("HLS", bal.LSCorrection)):
+            if channel in ("HSV", "HLS") and dtype != np.uint8:
+                continue   # cv2.cvtColor has no 16-bit HSV / HLS: the reference raises there
             for cmap in ("LINEAR", "GAMMA", "MATCH_HIST"):
                 for opts in ({"subsample": 1}, {"subsample": 2, "fast_subsampling": True},
                              {"subsample": 4, "fast_subsampling": False, "mask_size": 0.8},
@@ -313,8 +316,16 @@ def balance_case():
                     # the NumPy restatement of the device steps agrees with the reference run
                     o = {"subsample": opts.get("subsample", 1), "fast": opts.get("fast_subsampling", False),
                          "mask_size": opts.get("mask_size", 0)}
-                    assert np.array_equal(orc.balance_hist(mov, channel == "LUMI", **o), hist_mov)
-                    assert np.array_equal(orc.apply_lut(mov, luts), out)
+                    if channel in ("HSV", "HLS"):
+                        to, back = ((orc.CVT_BGR2HSV, orc.CVT_HSV2BGR) if channel == "HSV" else (orc.CVT_BGR2HLS, orc.CVT_HLS2BGR))
+                        pre = orc.cvt_color_u8(mov, to)
+                        arrays[f"{tag}_pre"] = pre
+                        assert np.array_equal(orc.balance_hist(pre, False, **o)[1:], hist_mov)
+                        ident = np.arange(hi).astype(dtype)[None]
+                        assert np.array_equal(orc.cvt_color_u8(orc.apply_lut(pre, np.concatenate([ident, luts])), back), out)
+                    else:
+                        assert np.array_equal(orc.balance_hist(mov, channel == "LUMI", **o), hist_mov)
+                        assert np.array_equal(orc.apply_lut(mov, luts), out)
                     k += 1
         arrays[f"ref_{np.dtype(dtype).name}"] = ref
         arrays[f"mov_{np.dtype(dtype).name}"] = mov

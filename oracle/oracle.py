@@ -575,3 +575,122 @@ def apply_lut(img, luts):
     for c in range(3):
         out[..., c] = luts[0 if luts.shape[0] == 1 else c][img[..., c]]
     return out
+
+
+# --------------------------------------------------------------------------
+# 8-bit BGR <-> HSV / HLS (cv2.cvtColor, reference algorithms/balance.py:340-363) -- NumPy restatement of OpenCV's
+# color_hsv code [from memory; parity unpinned like every other cv2 primitive here].  cv2 supports these conversions
+# for CV_8U and CV_32F only: a 16-bit frame raises in the reference (cv2.error), and in the mirror.
+#   BGR2HSV_b : integer arithmetic with the 12-bit reciprocal tables sdiv / hdiv180; H in [0, 180)
+#   HSV2BGR_b : through float: (h, s/255, v/255) -> sector tables -> round(x * 255)
+#   BGR2HLS_b : through float: x/255 -> h (degrees * 0.5), l, s -> round(h), round(l * 255), round(s * 255)
+#   HLS2BGR_b : through float
+# float32 operations one by one in the order written (no fused multiply-add), round half to even, saturate.
+# --------------------------------------------------------------------------
+_HSV_SHIFT = 12
+_SECTOR = np.array([[1, 3, 0], [1, 0, 2], [3, 0, 1], [0, 2, 1], [0, 1, 3], [2, 1, 0]])
+
+
+def _hsv_tables():
+    i = np.arange(1, 256, dtype=np.float64)
+    sdiv = np.zeros(256, np.int64)
+    hdiv = np.zeros(256, np.int64)
+    sdiv[1:] = np.rint((255 << _HSV_SHIFT) / (1.0 * i)).astype(np.int64)     # saturate_cast<int> = cvRound
+    hdiv[1:] = np.rint((180 << _HSV_SHIFT) / (6.0 * i)).astype(np.int64)
+    return sdiv, hdiv
+
+
+def _sat_u8(x):
+    return np.clip(np.rint(x), 0, 255).astype(np.uint8)
+
+
+def bgr2hsv_u8(img):
+    assert img.dtype == np.uint8
+    sdiv, hdiv = _hsv_tables()
+    b, g, r = (img[..., c].astype(np.int64) for c in range(3))
+    v = np.maximum(np.maximum(b, g), r)
+    vmin = np.minimum(np.minimum(b, g), r)
+    diff = v - vmin
+    s = (diff * sdiv[v] + (1 << (_HSV_SHIFT - 1))) >> _HSV_SHIFT
+    h = np.where(v == r, g - b, np.where(v == g, b - r + 2 * diff, r - g + 4 * diff))
+    h = (h * hdiv[diff] + (1 << (_HSV_SHIFT - 1))) >> _HSV_SHIFT
+    h = h + np.where(h < 0, 180, 0)
+    return np.stack([h, s, v], axis=-1).astype(np.uint8)
+
+
+def _sector_pick(tab, sector):
+    """b, g, r = tab[sector_data[sector]]"""
+    t = np.stack(tab, axis=-1)                                   # (..., 4)
+    idx = _SECTOR[sector]                                        # (..., 3)
+    return [np.take_along_axis(t, idx[..., k:k + 1], axis=-1)[..., 0] for k in range(3)]
+
+
+def hsv2bgr_u8(img):
+    assert img.dtype == np.uint8
+    f = np.float32
+    h = img[..., 0].astype(f)
+    s = img[..., 1].astype(f) * f(1.0 / 255.0)
+    v = img[..., 2].astype(f) * f(1.0 / 255.0)
+    hh = h * f(6.0 / 180.0)
+    sector = np.floor(hh).astype(np.int64)
+    hh = hh - sector.astype(f)
+    bad = (sector < 0) | (sector >= 6)
+    sector = np.where(bad, 0, sector)
+    hh = np.where(bad, f(0), hh)
+    one = f(1.0)
+    tab = [v, v * (one - s), v * (one - s * hh), v * (one - s * (one - hh))]
+    b, g, r = _sector_pick(tab, sector)
+    gray = s == 0
+    out = [np.where(gray, v, c) for c in (b, g, r)]
+    return np.stack([_sat_u8(c * f(255.0)) for c in out], axis=-1)
+
+
+def bgr2hls_u8(img):
+    assert img.dtype == np.uint8
+    f = np.float32
+    b, g, r = (img[..., c].astype(f) * f(1.0 / 255.0) for c in range(3))
+    vmax = np.maximum(np.maximum(r, g), b)
+    vmin = np.minimum(np.minimum(r, g), b)
+    diff = vmax - vmin
+    l = (vmax + vmin) * f(0.5)
+    ok = diff > np.finfo(f).eps
+    with np.errstate(divide="ignore", invalid="ignore"):
+        s = np.where(l < f(0.5), diff / (vmax + vmin), diff / (f(2.0) - vmax - vmin))
+        d60 = f(60.0) / diff
+        h = np.where(vmax == r, (g - b) * d60, np.where(vmax == g, (b - r) * d60 + f(120.0), (r - g) * d60 + f(240.0)))
+    h = np.where(h < 0, h + f(360.0), h)
+    h = np.where(ok, h, f(0)) * f(180.0 / 360.0)
+    s = np.where(ok, s, f(0))
+    return np.stack([_sat_u8(h), _sat_u8(l * f(255.0)), _sat_u8(s * f(255.0))], axis=-1)
+
+
+def hls2bgr_u8(img):
+    assert img.dtype == np.uint8
+    f = np.float32
+    h = img[..., 0].astype(f)
+    l = img[..., 1].astype(f) * f(1.0 / 255.0)
+    s = img[..., 2].astype(f) * f(1.0 / 255.0)
+    one = f(1.0)
+    p2 = np.where(l <= f(0.5), l * (one + s), l + s - l * s)
+    p1 = f(2.0) * l - p2
+    hh = h * f(6.0 / 180.0)
+    sector = np.floor(hh).astype(np.int64)
+    hh = hh - sector.astype(f)
+    bad = (sector < 0) | (sector >= 6)
+    sector = np.where(bad, 0, sector)
+    hh = np.where(bad, f(0), hh)
+    tab = [p2, p1, p1 + (p2 - p1) * (one - hh), p1 + (p2 - p1) * hh]
+    b, g, r = _sector_pick(tab, sector)
+    gray = s == 0
+    out = [np.where(gray, l, c) for c in (b, g, r)]
+    return np.stack([_sat_u8(c * f(255.0)) for c in out], axis=-1)
+
+
+CVT_BGR2HSV, CVT_HSV2BGR, CVT_BGR2HLS, CVT_HLS2BGR = range(4)
+_CVT = {CVT_BGR2HSV: bgr2hsv_u8, CVT_HSV2BGR: hsv2bgr_u8, CVT_BGR2HLS: bgr2hls_u8, CVT_HLS2BGR: hls2bgr_u8}
+
+
+def cvt_color_u8(img, code):
+    if img.dtype != np.uint8:
+        raise ValueError("cv2.cvtColor(BGR <-> HSV / HLS) supports 8-bit (and float32) images only")
+    return _CVT[code](np.ascontiguousarray(img))

@@ -36,6 +36,7 @@ def make_cv2_shim(use_fma=True):
     cv2.BORDER_REPLICATE = 1
     cv2.COLOR_BGR2GRAY = 6
     cv2.COLOR_BGR2RGB = 4
+    cv2.COLOR_BGR2HSV, cv2.COLOR_HSV2BGR, cv2.COLOR_BGR2HLS, cv2.COLOR_HLS2BGR = 40, 54, 52, 60
     cv2.INTER_AREA = 3
     cv2.IMREAD_UNCHANGED = -1
     cv2.IMWRITE_JPEG_QUALITY = 1
@@ -49,6 +50,10 @@ def make_cv2_shim(use_fma=True):
         return orc.filter2D(np.ascontiguousarray(img), kernel, use_fma)
 
     def cvtColor(img, code):
+        hue = {cv2.COLOR_BGR2HSV: orc.CVT_BGR2HSV, cv2.COLOR_HSV2BGR: orc.CVT_HSV2BGR,
+               cv2.COLOR_BGR2HLS: orc.CVT_BGR2HLS, cv2.COLOR_HLS2BGR: orc.CVT_HLS2BGR}
+        if code in hue:
+            return orc.cvt_color_u8(img, hue[code])      # raises for 16-bit input, as cv2 does
         assert code == cv2.COLOR_BGR2GRAY
         if img.dtype in (np.uint8, np.uint16):
             return orc.bgr2gray_int(img)

@@ -124,6 +124,8 @@ SIGNATURES = {
                                C.c_int]),
     "mi_apply_lut_device": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int,
                                       C.c_void_p, C.c_int]),
+    "mi_cvt_color": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "mi_cvt_color_device": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int]),
     "mi_aligner_estimate_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int,
                                             C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                             C.POINTER(C.c_int)]),
@@ -578,6 +580,22 @@ def histogram(img, mode=HIST_BGR, subsample=1, fast=True, mask_size=0.0, device=
     out = np.zeros((3 if mode == HIST_BGR else 1, nbins), np.int64)
     check(load().mi_histogram(device, a.ctypes.data, a.shape[0], a.shape[1], DTYPE_CODE[a.dtype], int(mode),
                               int(subsample), int(bool(fast)), float(mask_size), out.ctypes.data))
+    return out
+
+
+CVT_BGR2HSV, CVT_HSV2BGR, CVT_BGR2HLS, CVT_HLS2BGR = range(4)
+
+
+def cvt_color(img, code, device=0):
+    """cv2.cvtColor(BGR <-> HSV / HLS) of an H x W x 3 uint8 image on the GPU (mi_cvt_color)."""
+    require_device()
+    a = np.ascontiguousarray(img)
+    if a.ndim != 3 or a.shape[2] != 3:
+        raise ValueError("cvt_color expects an H x W x 3 image")
+    if a.dtype not in DTYPE_CODE:
+        raise ValueError(f"unsupported dtype {a.dtype}")
+    out = np.empty_like(a)
+    check(load().mi_cvt_color(device, a.ctypes.data, out.ctypes.data, a.shape[0], a.shape[1], DTYPE_CODE[a.dtype], int(code)))
     return out
 
 

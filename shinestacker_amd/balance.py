@@ -216,6 +216,74 @@ class RGBCorrection(Correction):
     channels = 3
 
 
+class Ch2Correction(Correction):
+    """balance.py:304-338: the frame goes to a hue-based colour space, the two non-hue channels are balanced (one table
+    each, from the histograms of those channels), the hue channel passes through, and the frame comes back to BGR.
+    8-bit frames only, like cv2.cvtColor's HSV / HLS conversions."""
+    hist_mode = _lib.HIST_BGR     # per-channel histograms of the converted image; channel 0 (hue) is dropped
+    channels = 2
+    to_code = from_code = None
+
+    def _need_u8(self, dtype):
+        if np.dtype(dtype) != np.uint8:
+            raise InvalidOptionError("channel", type(self).__name__,
+                                     "HSV / HLS balancing works on 8-bit frames (cv2.cvtColor has no 16-bit form)")
+
+    def preprocess(self, image):
+        self._need_u8(image.dtype)
+        return _lib.cvt_color(image, self.to_code, self.device)
+
+    def postprocess(self, image):
+        return _lib.cvt_color(image, self.from_code, self.device)
+
+    def get_hist(self, image, _idx=None):
+        return Correction.get_hist(self, image, _idx)[1:]
+
+    def begin(self, ref_image, size, ref_idx):
+        Correction.begin(self, self.preprocess(ref_image), size, ref_idx)
+
+    def tables(self, correction):
+        m = self.corr_map
+        ident = np.arange(_pixel_range(self.dtype)).astype(self.dtype)
+        return [ident] + [m.table(correction[c], m.reference[c]) for c in range(2)]
+
+    def apply_correction(self, idx, image):
+        return self.postprocess(Correction.apply_correction(self, idx, self.preprocess(image)))
+
+    # -- frames resident in HBM
+    def begin_device(self, dev_ref, height, width, dtype, size):
+        self._need_u8(dtype)
+        self._cvt = _lib.DeviceBuffer(height * width * 3, self.device)
+        _lib.check(_lib.load().mi_cvt_color_device(self.device, None, dev_ref, self._cvt.ptr, height * width,
+                                                   _lib.MI_U8, self.to_code))
+        Correction.begin_device(self, self._cvt.ptr, height, width, dtype, size)
+
+    def hist_device(self, dev_img, stream=None):
+        self.channels = 3
+        try:
+            return Correction.hist_device(self, dev_img, stream)[1:]
+        finally:
+            self.channels = 2
+
+    def apply_correction_device(self, idx, dev_img, stream=None):
+        lib, n = _lib.load(), self._shape[0] * self._shape[1]
+        _lib.check(lib.mi_cvt_color_device(self.device, stream, dev_img, dev_img, n, _lib.MI_U8, self.to_code))
+        Correction.apply_correction_device(self, idx, dev_img, stream)
+        _lib.check(lib.mi_cvt_color_device(self.device, stream, dev_img, dev_img, n, _lib.MI_U8, self.from_code))
+
+
+class SVCorrection(Ch2Correction):
+    """S and V of HSV (balance.py:340-350)."""
+    to_code, from_code = _lib.CVT_BGR2HSV, _lib.CVT_HSV2BGR
+    labels = ("H", "S", "V")
+
+
+class LSCorrection(Ch2Correction):
+    """L and S of HLS (balance.py:353-363)."""
+    to_code, from_code = _lib.CVT_BGR2HLS, _lib.CVT_HLS2BGR
+    labels = ("H", "L", "S")
+
+
 class BalanceFrames(SubAction):
     """Sub-action of CombinedActions (balance.py:366-416)."""
 
@@ -236,9 +304,10 @@ class BalanceFrames(SubAction):
             self.correction = LumiCorrection(**kwargs)
         elif channel == constants.BALANCE_RGB:
             self.correction = RGBCorrection(**kwargs)
-        elif channel in (constants.BALANCE_HSV, constants.BALANCE_HLS):
-            raise InvalidOptionError("channel", channel,
-                                     "the MI355X path implements LUMI and RGB balancing only")
+        elif channel == constants.BALANCE_HSV:
+            self.correction = SVCorrection(**kwargs)
+        elif channel == constants.BALANCE_HLS:
+            self.correction = LSCorrection(**kwargs)
         else:
             raise InvalidOptionError("channel", channel)
 

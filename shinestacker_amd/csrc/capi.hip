@@ -1767,6 +1767,51 @@ int mi_apply_lut_device(int device, void* stream, const void* dev_src, void* dev
     return MI_OK;
 }
 
+int mi_cvt_color_device(int device, void* stream, const void* dev_src, void* dev_dst, size_t npixels, int dtype, int code) {
+    if (!dev_src || !dev_dst) return fail(MI_ERR_INVALID, "null argument");
+    if (dtype != MI_U8)
+        return fail(MI_ERR_UNSUPPORTED, "BGR <-> HSV / HLS is defined for 8-bit images only (as cv2.cvtColor: CV_8U / CV_32F)");
+    if (code < CVT_BGR2HSV || code > CVT_HLS2BGR) return fail(MI_ERR_INVALID, "bad conversion code %d", code);
+    MI_HIP(hipSetDevice(device));
+    if (npixels == 0) return MI_OK;
+    const dim3 grid((unsigned)std::min<size_t>((npixels + 255) / 256, 256 * 16)), blk(256);
+    hipStream_t st = (hipStream_t)stream;
+    const uint8_t* s = (const uint8_t*)dev_src;
+    uint8_t* d = (uint8_t*)dev_dst;
+    switch (code) {
+        case CVT_BGR2HSV: hipLaunchKernelGGL((cvt_color_u8<CVT_BGR2HSV>), grid, blk, 0, st, s, d, npixels); break;
+        case CVT_HSV2BGR: hipLaunchKernelGGL((cvt_color_u8<CVT_HSV2BGR>), grid, blk, 0, st, s, d, npixels); break;
+        case CVT_BGR2HLS: hipLaunchKernelGGL((cvt_color_u8<CVT_BGR2HLS>), grid, blk, 0, st, s, d, npixels); break;
+        default: hipLaunchKernelGGL((cvt_color_u8<CVT_HLS2BGR>), grid, blk, 0, st, s, d, npixels); break;
+    }
+    MI_HIP(hipGetLastError());
+    return MI_OK;
+}
+
+int mi_cvt_color(int device, const void* host_src, void* host_dst, int height, int width, int dtype, int code) {
+    if (!host_src || !host_dst || height < 1 || width < 1) return fail(MI_ERR_INVALID, "bad argument");
+    if (dtype != MI_U8)
+        return fail(MI_ERR_UNSUPPORTED, "BGR <-> HSV / HLS is defined for 8-bit images only (as cv2.cvtColor: CV_8U / CV_32F)");
+    int ndev = 0;
+    int rc = mi_device_count(&ndev);
+    if (rc) return rc;
+    if (ndev == 0) return fail(MI_ERR_NO_DEVICE, "no HIP device visible");
+    MI_HIP(hipSetDevice(device));
+    const size_t np = (size_t)height * width, nb = np * 3;
+    void* buf = nullptr;
+    MI_HIP(hipMalloc(&buf, nb));
+    hipError_t e = hipMemcpy(buf, host_src, nb, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        rc = mi_cvt_color_device(device, nullptr, buf, buf, np, dtype, code);
+        if (rc) { (void)hipFree(buf); return rc; }
+        e = hipDeviceSynchronize();
+    }
+    if (e == hipSuccess) e = hipMemcpy(host_dst, buf, nb, hipMemcpyDeviceToHost);
+    (void)hipFree(buf);
+    if (e != hipSuccess) return fail(MI_ERR_HIP, "mi_cvt_color: %s", hipGetErrorString(e));
+    return MI_OK;
+}
+
 int mi_apply_lut(int device, const void* host_src, void* host_dst, int height, int width, int dtype,
                  const void* host_lut, int nlut) {
     if (!host_src || !host_dst || !host_lut) return fail(MI_ERR_INVALID, "null argument");

@@ -132,4 +132,91 @@ __global__ __launch_bounds__(256) void lut_apply_u16(const uint16_t* __restrict_
     }
 }
 
+// ---------------------------------------------------------------- 8-bit BGR <-> HSV / HLS
+// cv2.cvtColor(COLOR_BGR2HSV / HSV2BGR / BGR2HLS / HLS2BGR) on uint8 images: the pre- and post-processing of the
+// reference's SVCorrection / LSCorrection (balance.py:340-363; cv2 has no 16-bit form of these conversions, the
+// reference raises there).  OpenCV's color_hsv arithmetic restated [from memory -- parity unpinned]: BGR2HSV in
+// integers with 12-bit reciprocal tables (H in [0, 180)), the other three through float32, one rounding per written
+// operation (the translation unit is built with fp-contract off), round-half-even + saturate at the end.
+// oracle/oracle.py (bgr2hsv_u8 ...) states the same operations in NumPy float32: equal bit for bit.
+enum { CVT_BGR2HSV = 0, CVT_HSV2BGR = 1, CVT_BGR2HLS = 2, CVT_HLS2BGR = 3 };
+
+__device__ __forceinline__ int sat_u8(float v) {
+    const float r = rintf(v);
+    return (int)(r < 0.f ? 0.f : (r > 255.f ? 255.f : r));
+}
+
+__device__ __forceinline__ void sector_pick(const float tab[4], int sector, float& b, float& g, float& r) {
+    // sector_data[6][3] = {1,3,0},{1,0,2},{3,0,1},{0,2,1},{0,1,3},{2,1,0}
+    const int ib = (0x200311 >> (4 * sector)) & 15;
+    const int ig = (0x112003 >> (4 * sector)) & 15;
+    const int ir = (0x031120 >> (4 * sector)) & 15;
+    auto pick = [&](int i) { return i == 0 ? tab[0] : (i == 1 ? tab[1] : (i == 2 ? tab[2] : tab[3])); };
+    b = pick(ib); g = pick(ig); r = pick(ir);
+}
+
+template <int CODE>
+__global__ __launch_bounds__(256) void cvt_color_u8(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, size_t npix) {
+    __shared__ int sdiv[256], hdiv[256];
+    if constexpr (CODE == CVT_BGR2HSV) {
+        const int i = threadIdx.x;   // blockDim.x == 256
+        sdiv[i] = i ? (int)rint((double)(255 << 12) / (1.0 * i)) : 0;
+        hdiv[i] = i ? (int)rint((double)(180 << 12) / (6.0 * i)) : 0;
+        __syncthreads();
+    }
+    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (size_t)gridDim.x * blockDim.x) {
+        const int c0 = src[p * 3], c1 = src[p * 3 + 1], c2 = src[p * 3 + 2];
+        int o0, o1, o2;
+        if constexpr (CODE == CVT_BGR2HSV) {
+            const int b = c0, g = c1, r = c2;
+            const int v = max(max(b, g), r), vmin = min(min(b, g), r), diff = v - vmin;
+            const int s = (diff * sdiv[v] + (1 << 11)) >> 12;
+            int h = v == r ? g - b : (v == g ? b - r + 2 * diff : r - g + 4 * diff);
+            h = (h * hdiv[diff] + (1 << 11)) >> 12;
+            h += h < 0 ? 180 : 0;
+            o0 = h & 255; o1 = s & 255; o2 = v;
+        } else if constexpr (CODE == CVT_HSV2BGR) {
+            const float h0 = (float)c0, s = (float)c1 * (1.0f / 255.0f), v = (float)c2 * (1.0f / 255.0f);
+            float hh = h0 * (6.0f / 180.0f);
+            int sector = (int)floorf(hh);
+            hh = hh - (float)sector;
+            if ((unsigned)sector >= 6u) { sector = 0; hh = 0.f; }
+            const float tab[4] = {v, v * (1.0f - s), v * (1.0f - s * hh), v * (1.0f - s * (1.0f - hh))};
+            float b, g, r;
+            sector_pick(tab, sector, b, g, r);
+            if (s == 0.f) b = g = r = v;
+            o0 = sat_u8(b * 255.0f); o1 = sat_u8(g * 255.0f); o2 = sat_u8(r * 255.0f);
+        } else if constexpr (CODE == CVT_BGR2HLS) {
+            const float b = (float)c0 * (1.0f / 255.0f), g = (float)c1 * (1.0f / 255.0f), r = (float)c2 * (1.0f / 255.0f);
+            const float vmax = fmaxf(fmaxf(r, g), b), vmin = fminf(fminf(r, g), b);
+            const float diff = vmax - vmin, l = (vmax + vmin) * 0.5f;
+            float h = 0.f, s = 0.f;
+            if (diff > 1.1920929e-07f) {
+                s = l < 0.5f ? diff / (vmax + vmin) : diff / (2.0f - vmax - vmin);
+                const float d60 = 60.0f / diff;
+                if (vmax == r) h = (g - b) * d60;
+                else if (vmax == g) h = (b - r) * d60 + 120.0f;
+                else h = (r - g) * d60 + 240.0f;
+                if (h < 0.f) h = h + 360.0f;
+            }
+            h = h * (180.0f / 360.0f);
+            o0 = sat_u8(h); o1 = sat_u8(l * 255.0f); o2 = sat_u8(s * 255.0f);
+        } else {
+            const float h0 = (float)c0, l = (float)c1 * (1.0f / 255.0f), s = (float)c2 * (1.0f / 255.0f);
+            const float p2 = l <= 0.5f ? l * (1.0f + s) : l + s - l * s;
+            const float p1 = 2.0f * l - p2;
+            float hh = h0 * (6.0f / 180.0f);
+            int sector = (int)floorf(hh);
+            hh = hh - (float)sector;
+            if ((unsigned)sector >= 6u) { sector = 0; hh = 0.f; }
+            const float tab[4] = {p2, p1, p1 + (p2 - p1) * (1.0f - hh), p1 + (p2 - p1) * hh};
+            float b, g, r;
+            sector_pick(tab, sector, b, g, r);
+            if (s == 0.f) b = g = r = l;
+            o0 = sat_u8(b * 255.0f); o1 = sat_u8(g * 255.0f); o2 = sat_u8(r * 255.0f);
+        }
+        dst[p * 3] = (uint8_t)o0; dst[p * 3 + 1] = (uint8_t)o1; dst[p * 3 + 2] = (uint8_t)o2;
+    }
+}
+
 }  // namespace mi

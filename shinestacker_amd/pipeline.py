@@ -157,6 +157,22 @@ def _align_chains_device(lib, dev_frames, aligned, n_frames, height, width, dt, 
     return transforms, ccs
 
 
+def _make_correction(balance, device):
+    """The correction object of BalanceFrames for a dict of its options (balance.py:366-388: channel -> class; the
+    sub-sampling default depends on the map)."""
+    from .balance import LSCorrection, LumiCorrection, RGBCorrection, SVCorrection
+    classes = {constants.BALANCE_LUMI: LumiCorrection, constants.BALANCE_RGB: RGBCorrection,
+               constants.BALANCE_HSV: SVCorrection, constants.BALANCE_HLS: LSCorrection}
+    opts = dict(balance)
+    channel = opts.pop('channel', constants.DEFAULT_CHANNEL)
+    if channel not in classes:
+        raise InvalidOptionError("channel", channel)
+    if opts.get('subsample', -1) == -1:
+        opts['subsample'] = 1 if opts.get('corr_map') == constants.BALANCE_MATCH_HIST \
+            else constants.DEFAULT_BALANCE_SUBSAMPLE
+    return classes[channel](device=device, **opts)
+
+
 def align_and_stack_device(dev_frames, n_frames, height, width, dtype, ref_idx=-1, alignment_config=None,
                            min_correlation=0.5, max_iters=60, device=0, batch_frames=16, out_dev=None,
                            balance=None, ecc_batch=16, step_process=False, **stack_kwargs):
@@ -205,15 +221,7 @@ def align_and_stack_device(dev_frames, n_frames, height, width, dtype, ref_idx=-
         stack = _lib.Stack(height, width, in_dtype=dt, out_dtype=dt, device=device, **stack_kwargs)
         try:
             if balance is not None:
-                from .balance import LumiCorrection, RGBCorrection
-                opts = dict(balance)
-                channel = opts.pop('channel', constants.DEFAULT_CHANNEL)
-                if channel not in (constants.BALANCE_LUMI, constants.BALANCE_RGB):
-                    raise InvalidOptionError("channel", channel, "the MI355X path implements LUMI and RGB balancing only")
-                if opts.get('subsample', -1) == -1:
-                    opts['subsample'] = 1 if opts.get('corr_map') == constants.BALANCE_MATCH_HIST \
-                        else constants.DEFAULT_BALANCE_SUBSAMPLE
-                corr = (LumiCorrection if channel == constants.BALANCE_LUMI else RGBCorrection)(device=device, **opts)
+                corr = _make_correction(balance, device)
                 corr.begin_device(aligned.ptr + ref_idx * fb, height, width, dt, n_frames)
                 for i in range(n_frames):
                     if i != ref_idx:
@@ -255,15 +263,7 @@ def align_and_stack_device(dev_frames, n_frames, height, width, dtype, ref_idx=-
 
     corr = None
     if balance is not None:
-        from .balance import LumiCorrection, RGBCorrection
-        opts = dict(balance)
-        channel = opts.pop('channel', constants.DEFAULT_CHANNEL)
-        if channel not in (constants.BALANCE_LUMI, constants.BALANCE_RGB):
-            raise InvalidOptionError("channel", channel, "the MI355X path implements LUMI and RGB balancing only")
-        if opts.get('subsample', -1) == -1:
-            opts['subsample'] = 1 if opts.get('corr_map') == constants.BALANCE_MATCH_HIST \
-                else constants.DEFAULT_BALANCE_SUBSAMPLE
-        corr = (LumiCorrection if channel == constants.BALANCE_LUMI else RGBCorrection)(device=device, **opts)
+        corr = _make_correction(balance, device)
         corr.begin_device(dev_frames + ref_idx * fb, height, width, dt, n_frames)
 
     def flush():

@@ -44,22 +44,35 @@ def test_oracle_device_steps_equal_the_reference(gold, oracle):
         t = m["tag"]
         mov = g["mov_" + m["dtype"]]
         o = m["opts"]
-        h = oracle.balance_hist(mov, m["channel"] == "LUMI", subsample=o.get("subsample", 1),
-                                fast=o.get("fast_subsampling", False), mask_size=o.get("mask_size", 0))
+        kw = dict(subsample=o.get("subsample", 1), fast=o.get("fast_subsampling", False), mask_size=o.get("mask_size", 0))
+        if m["channel"] in ("HSV", "HLS"):
+            # balance.py:340-363: to the hue-based space, balance channels 1 and 2, back to BGR
+            to, back = ((oracle.CVT_BGR2HSV, oracle.CVT_HSV2BGR) if m["channel"] == "HSV"
+                        else (oracle.CVT_BGR2HLS, oracle.CVT_HLS2BGR))
+            pre = oracle.cvt_color_u8(mov, to)
+            assert np.array_equal(pre, g[f"{t}_pre"])
+            assert np.array_equal(oracle.balance_hist(pre, False, **kw)[1:], g[f"{t}_hist_mov"])
+            luts = np.concatenate([np.arange(256, dtype=np.uint8)[None], g[f"{t}_luts"]])
+            assert np.array_equal(oracle.cvt_color_u8(oracle.apply_lut(pre, luts), back), g[f"{t}_out"])
+            continue
+        h = oracle.balance_hist(mov, m["channel"] == "LUMI", **kw)
         assert np.array_equal(h, g[f"{t}_hist_mov"])
         assert np.array_equal(oracle.apply_lut(mov, g[f"{t}_luts"]), g[f"{t}_out"])
 
 
 def test_constructor_options():
-    from shinestacker_amd.balance import BalanceFrames, LumiCorrection, RGBCorrection
+    from shinestacker_amd.balance import BalanceFrames, LSCorrection, LumiCorrection, RGBCorrection, SVCorrection
     from shinestacker_amd.errors import InvalidOptionError
     assert isinstance(BalanceFrames().correction, LumiCorrection)
     b = BalanceFrames(channel="RGB", corr_map="MATCH_HIST", subsample=-1)
     assert isinstance(b.correction, RGBCorrection) and b.correction.subsample == 1   # balance.py:378-380
     assert BalanceFrames(subsample=-1).correction.subsample == 8
-    for ch in ("HSV", "HLS", "XYZ"):
-        with pytest.raises(InvalidOptionError):
-            BalanceFrames(channel=ch)
+    assert isinstance(BalanceFrames(channel="HSV").correction, SVCorrection)     # balance.py:385-388
+    assert isinstance(BalanceFrames(channel="HLS").correction, LSCorrection)
+    with pytest.raises(InvalidOptionError):
+        BalanceFrames(channel="XYZ")
+    with pytest.raises(InvalidOptionError):      # cv2.cvtColor has no 16-bit HSV: the reference raises there as well
+        SVCorrection()._need_u8(np.uint16)
     c = LumiCorrection(corr_map="NOPE")
     with pytest.raises((InvalidOptionError, Exception)):
         c.begin(np.zeros((8, 8, 3), np.uint8), 2, 0)

@@ -19,13 +19,16 @@ def L(hiplib):
 def test_golden_histograms_tables_and_frames(L):
     g = load_golden("balance")
     from shinestacker_amd import balance as b
-    cls = {"LUMI": b.LumiCorrection, "RGB": b.RGBCorrection}
+    cls = {"LUMI": b.LumiCorrection, "RGB": b.RGBCorrection, "HSV": b.SVCorrection, "HLS": b.LSCorrection}
     for m in json.loads(str(g["meta"])):
         t = m["tag"]
         ref, mov = g["ref_" + m["dtype"]], g["mov_" + m["dtype"]]
         corr = cls[m["channel"]](corr_map=m["corr_map"], **m["opts"])
         corr.begin(ref, 2, 0)
-        assert np.array_equal(np.stack(corr.get_hist(mov)), g[f"{t}_hist_mov"]), m
+        pre = corr.preprocess(mov) if m["channel"] in ("HSV", "HLS") else mov
+        if m["channel"] in ("HSV", "HLS"):
+            assert np.array_equal(pre, g[f"{t}_pre"]), m        # the device colour conversion == the recording
+        assert np.array_equal(np.stack(corr.get_hist(pre)), g[f"{t}_hist_mov"]), m
         out = corr.apply_correction(1, mov)
         assert out.dtype == mov.dtype and np.array_equal(out, g[f"{t}_out"]), m
         assert np.array_equal(np.asarray(corr.corrections[1], np.float64).ravel(), np.asarray(g[f"{t}_size"]).ravel())
@@ -44,6 +47,23 @@ def test_histogram_vs_oracle(L, oracle, dtype, shape):
             want = oracle.balance_hist(img, lumi, sub, fast, mask)
             got = L.histogram(img, L.HIST_LUMI if lumi else L.HIST_BGR, sub, fast, mask)
             assert got.dtype == np.int64 and np.array_equal(got, want), (lumi, sub, fast, mask)
+
+
+@pytest.mark.parametrize("code", [0, 1, 2, 3])
+def test_cvt_color_vs_oracle(L, oracle, code):
+    """mi_cvt_color (BGR <-> HSV / HLS, 8-bit) == the oracle's restatement of cv2.cvtColor on every colour of a dense
+    sample of the cube plus random images; 16-bit input is refused like cv2 refuses it."""
+    from shinestacker_amd.errors import InvalidOptionError
+    rng = np.random.default_rng(code)
+    r = np.arange(0, 256, 5, dtype=np.uint8)
+    cube = np.stack(np.meshgrid(r, r, r, indexing="ij"), axis=-1).reshape(52, -1, 3)
+    if code in (1, 3):
+        cube = cube.copy()
+        cube[..., 0] = cube[..., 0] % 180          # hue channel of 8-bit HSV / HLS lives in [0, 180)
+    for img in (cube, rng.integers(0, 180 if code in (1, 3) else 256, (97, 131, 3)).astype(np.uint8)):
+        assert np.array_equal(L.cvt_color(img, code), oracle.cvt_color_u8(img, code)), code
+    with pytest.raises(InvalidOptionError):
+        L.cvt_color(np.zeros((4, 4, 3), np.uint16), code)
 
 
 @pytest.mark.parametrize("dtype", [np.uint8, np.uint16])
@@ -93,10 +113,11 @@ def test_balance_frames_sub_action(L, oracle, tmp_path):
     assert bal.correction.corrections[0, 0] > 1.2 and bal.correction.corrections[2, 0] < 0.95
 
 
-def test_resident_pipeline_with_balance(L, oracle):
+@pytest.mark.parametrize("channel", ["LUMI", "HSV", "HLS"])
+def test_resident_pipeline_with_balance(L, oracle, channel):
     """align -> balance -> stack with every frame in HBM: the device balance equals the host-array
-    sub-action applied to the same aligned frames."""
-    from shinestacker_amd.balance import LumiCorrection
+    sub-action applied to the same aligned frames (HSV / HLS: the colour conversions run in place on the device)."""
+    from shinestacker_amd import balance as b
     from shinestacker_amd.pipeline import align_and_stack_device
     from test_gpu_ecc import make_pair, similarity
     h, w, n = 256, 384, 3
@@ -110,7 +131,7 @@ def test_resident_pipeline_with_balance(L, oracle):
     buf = L.DeviceBuffer(n * frames[0].nbytes)
     for f, fr in enumerate(frames):
         buf.upload(fr, f * fr.nbytes)
-    opts = {"channel": "LUMI", "corr_map": "LINEAR", "subsample": 2, "fast_subsampling": True}
+    opts = {"channel": channel, "corr_map": "LINEAR", "subsample": 2, "fast_subsampling": True}
     cfg = {"subsample": 1}
     fused_bal, tr, _ = align_and_stack_device(buf.ptr, n, h, w, np.uint8, alignment_config=cfg, batch_frames=2,
                                               balance=opts)
@@ -120,7 +141,8 @@ def test_resident_pipeline_with_balance(L, oracle):
     # stack in memory -> identical bytes
     from shinestacker_amd.pyramid import PyramidStack
     aligned = [frames[1] if t is None else L.warp_affine(fr, t) for fr, t in zip(frames, tr)]
-    c = LumiCorrection(corr_map="LINEAR", subsample=2, fast_subsampling=True)
+    cls = {"LUMI": b.LumiCorrection, "HSV": b.SVCorrection, "HLS": b.LSCorrection}[channel]
+    c = cls(corr_map="LINEAR", subsample=2, fast_subsampling=True)
     c.begin(frames[1], n, 1)
     balanced = [a if i == 1 else c.apply_correction(i, a) for i, a in enumerate(aligned)]
     want = PyramidStack().focus_stack_arrays(balanced)
