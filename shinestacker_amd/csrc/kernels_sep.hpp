@@ -150,7 +150,9 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
     if constexpr (INTERIOR) {
         const int nty = (a.iy1 - a.iy0) / TH, ntx = (a.ix1 - a.ix0) / TW;
         const int sb_x = (ntx + SB - 1) / SB;
-        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        // frame chunks (blockIdx.y) rotate the XCD a super-block runs on: a small level has fewer super-blocks than
+        // the GPU has XCDs, and its chunks would otherwise all queue up on the same few
+        const int xcd = (blockIdx.x + 8 - (blockIdx.y & 7)) & 7, slot = blockIdx.x >> 3;
         const int S = (slot >> 6) * 8 + xcd, within = slot & 63;
         const int sby = S / sb_x, sbx = S - sby * sb_x;
         const int tyi = sby * SB + (within >> 3), txi = sbx * SB + (within & 7);
@@ -187,6 +189,15 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
     const float k0 = a.k1d[0], k1 = a.k1d[1], k2 = a.k1d[2];
     const float ce = 2.0f * k0, cc = 2.0f * k2, co = 2.0f * k1;   // expand taps (the reference's 4 * K, per dimension)
 
+    // ---- which frames?  (levels with few tiles split the batch into chunks along blockIdx.y, see LevelArgs)
+    const int ck = blockIdx.y, f_lo = ck * a.chunk_frames;
+    const int nfr = min(a.nframes - f_lo, a.chunk_frames);
+    const bool fresh = ck > 0 || a.first;
+    float* const st_e = ck ? a.part_e + (size_t)(ck - 1) * a.part_stride : a.best_e;
+    int32_t* const st_i = ck ? a.part_idx + (size_t)(ck - 1) * a.part_stride : a.best_idx;
+    const char* const src0 = (const char*)a.src + (size_t)f_lo * a.src_stride;
+    float* const gnext0 = a.gnext + (size_t)f_lo * a.gnext_stride;
+
     // ---- the lane's quad: rows y0-2+2qy+{0,1}, columns x0-4+2ql+{0,1}; owned = inside the tile.  Running state of
     // the quad = (max energy, its frame); the winner's Laplacian is filled in after the batch (sep_payload).
     const int qy = tid >> 5, ql = tid & 31;
@@ -198,10 +209,10 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
     for (int p = 0; p < 4; ++p) {
         const int y = oy + (p >> 1), x = ox + (p & 1);
         const bool valid = own_tile && (INTERIOR || (y < h && x < w));
-        if (!a.first && valid) {
+        if (!fresh && valid) {
             const size_t px = (size_t)y * w + x;
-            bE[p] = a.best_e[px];
-            bI[p] = a.best_idx[px];
+            bE[p] = st_e[px];
+            bI[p] = st_i[px];
         } else {
             bE[p] = -1.0f;   // every energy is >= 0: the first frame always wins
             bI[p] = -1;
@@ -218,7 +229,7 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
         goff[n] = (uint32_t)(((y0 - 6 + row) * w + (x0 - 6)) * 3 + 4 * col) * (uint32_t)sizeof(TIn);
     }
     auto prefetch = [&](int b) {
-        const char* frb = (const char*)a.src + (size_t)b * a.src_stride;
+        const char* frb = src0 + (size_t)b * a.src_stride;
 #pragma unroll
         for (int n = 0; n < G::NPRE; ++n) {
             const int id = tid + n * NT;
@@ -246,7 +257,7 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
     };
     prefetch(0);
 
-    for (int b = 0; b < a.nframes; ++b) {
+    for (int b = 0; b < nfr; ++b) {
         int lt = tid;
         asm volatile("" : "+v"(lt));   // per-frame addresses are rebuilt from this, not hoisted out of the loop
         // ---------------- P0: stage
@@ -256,7 +267,7 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
             *reinterpret_cast<v4f*>(sG + 4 * (lt + n * NT)) = pre[n].get();
         }
         __syncthreads();
-        if (b + 1 < a.nframes && !MI_ABL(16)) prefetch(b + 1);
+        if (b + 1 < nfr && !MI_ABL(16)) prefetch(b + 1);
 
         // ---------------- P1: vertical reduce, 2 V rows x one float4 column group per lane
         if (lt < (G::NH / 2) * CPR && !MI_ABL(1)) {
@@ -330,7 +341,7 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
                 bool st = r >= 2 && r < G::NH - 2 && jp >= 2 && jp < G::NW - 2 && !MI_ABL(32);
                 if constexpr (!INTERIOR) st = st && i < hn && j < wn;
                 if (st) {
-                    float* gp = a.gnext + (size_t)b * a.gnext_stride + ((size_t)i * wn + j) * 3;
+                    float* gp = gnext0 + (size_t)b * a.gnext_stride + ((size_t)i * wn + j) * 3;
                     if (MI_SEP_NT_STORE) {
                         __builtin_nontemporal_store(n[0], gp);
                         __builtin_nontemporal_store(n[1], gp + 1);
@@ -403,7 +414,7 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
             const v2f e0 = s5(hb[0], hb[1], hb[2], hb[3], hb[4], k0, k1, k2);
             const v2f e1 = s5(hb[1], hb[2], hb[3], hb[4], hb[5], k0, k1, k2);
             const float e[4] = {e0.x, e0.y, e1.x, e1.y};
-            const int fidx = a.frame_idx0 + b;
+            const int fidx = a.frame_idx0 + f_lo + b;
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 const bool win = e[p] > bE[p];
@@ -421,8 +432,8 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
         const int y = oy + (p >> 1), x = ox + (p & 1);
         if (own_tile && (INTERIOR || (y < h && x < w))) {
             const size_t px = (size_t)y * w + x;
-            a.best_e[px] = bE[p];
-            a.best_idx[px] = bI[p];
+            st_e[px] = bE[p];
+            st_i[px] = bI[p];
         }
     }
 }
@@ -438,10 +449,31 @@ __global__ __launch_bounds__(NT) void level_sep_coarse(LevelArgs a) {
     level_sep_body<TIn, INTERIOR, TH, NT>(a);
 }
 
+// Fold the chunks' partial (max, arg-max) into the running state, in chunk order with a strict '>': the earliest frame
+// holding the maximum stays the winner, as if the frames had been visited one after the other.
+__global__ void merge_chunks(float* __restrict__ best_e, int32_t* __restrict__ best_idx, const float* __restrict__ part_e,
+                             const int32_t* __restrict__ part_idx, size_t part_stride, int nparts, size_t npx) {
+    const size_t px = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (px >= npx) return;
+    float e = best_e[px];
+    int32_t i = best_idx[px];
+    for (int c = 0; c < nparts; ++c) {
+        const float pe = part_e[(size_t)c * part_stride + px];
+        const int32_t pi = part_idx[(size_t)c * part_stride + px];
+        const bool win = pe > e;
+        e = win ? pe : e;
+        i = win ? pi : i;
+    }
+    best_e[px] = e;
+    best_idx[px] = i;
+}
+
 // ================================================================================================
 // Winner's Laplacian of the frames of one batch (the level kernel keeps only the running maximum and its frame):
 // one lane per 2x2 quad of level l; a pixel whose arg-max is a frame of this batch gets
 // lap = G_l - expand(G_{l+1}) of that frame, with -0 -> +0 as the reference's np.where sum gives (pyramid.py:52-54).
+struct __attribute__((packed, aligned(4))) Px3 { float v[3]; };   // one pixel: a 12-byte load / store
+
 template <typename TIn>
 __global__ void sep_payload(const void* __restrict__ src, size_t src_stride, const float* __restrict__ gnext,
                             size_t gnext_stride, int nframes, int h, int w, int hn, int wn,
@@ -464,25 +496,47 @@ __global__ void sep_payload(const void* __restrict__ src, size_t src_stride, con
     if (!any) return;
     const int ri[3] = {map_expand_src(i - 1, hn), i, map_expand_src(i + 1, hn)};
     const int cj[3] = {map_expand_src(j - 1, wn), j, map_expand_src(j + 1, wn)};
+    // The four pixels of a quad mostly have the same winner: the 3x3 patch of G_{l+1} that expands to the quad is loaded
+    // once per DISTINCT frame (12-byte pixel loads), expanded for the four positions, and stored for the pixels that frame won.
+    unsigned pending = (fr[0] >= 0 ? 1u : 0u) | (fr[1] >= 0 ? 2u : 0u) | (fr[2] >= 0 ? 4u : 0u) | (fr[3] >= 0 ? 8u : 0u);
+    while (pending) {
+        const int f = (pending & 1u) ? fr[0] : (pending & 2u) ? fr[1] : (pending & 4u) ? fr[2] : fr[3];
+        const float* gn = gnext + (size_t)f * gnext_stride;
+        const TIn* g = (const TIn*)((const char*)src + (size_t)f * src_stride);
+        Px3 N[3][3];
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        if (fr[p] < 0) continue;
-        // frames of a quad mostly agree; the expand source is re-read per pixel only when they differ (cached)
-        const float* gn = gnext + (size_t)fr[p] * gnext_stride;
-        const TIn* g = (const TIn*)((const char*)src + (size_t)fr[p] * src_stride);
-        const int y = 2 * i + (p >> 1), x = 2 * j + (p & 1);
-        const size_t px = (size_t)y * w + x;
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) N[r][q] = *(const Px3*)(gn + ((size_t)ri[r] * wn + cj[q]) * 3);
+        float e[4][3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            float xr[3];
+            float xe[3], xo[3];
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
-                const float* row = gn + (size_t)ri[r] * wn * 3 + c;
-                xr[r] = (p & 1) ? ex_odd(row[cj[1] * 3], row[cj[2] * 3], co)
-                                : ex_even(row[cj[0] * 3], row[cj[1] * 3], row[cj[2] * 3], ce, cc);
+                xe[r] = ex_even(N[r][0].v[c], N[r][1].v[c], N[r][2].v[c], ce, cc);
+                xo[r] = ex_odd(N[r][1].v[c], N[r][2].v[c], co);
             }
-            const float e = (p >> 1) ? ex_odd(xr[1], xr[2], co) : ex_even(xr[0], xr[1], xr[2], ce, cc);
-            best_lap[px * 3 + c] = (to_f32(g[px * 3 + c]) - e) + 0.0f;
+            e[0][c] = ex_even(xe[0], xe[1], xe[2], ce, cc);
+            e[1][c] = ex_even(xo[0], xo[1], xo[2], ce, cc);
+            e[2][c] = ex_odd(xe[1], xe[2], co);
+            e[3][c] = ex_odd(xo[1], xo[2], co);
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            if (!((pending >> p) & 1u) || fr[p] != f) continue;
+            pending &= ~(1u << p);
+            const size_t px = (size_t)(2 * i + (p >> 1)) * w + 2 * j + (p & 1);
+            Px3 o;
+            if constexpr (sizeof(TIn) == 4) {
+                const Px3 gv = *(const Px3*)((const float*)g + px * 3);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) o.v[c] = (gv.v[c] - e[p][c]) + 0.0f;
+            } else {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) o.v[c] = (to_f32(g[px * 3 + c]) - e[p][c]) + 0.0f;
+            }
+            *(Px3*)(best_lap + px * 3) = o;
         }
     }
 }

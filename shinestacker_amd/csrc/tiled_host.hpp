@@ -17,8 +17,13 @@
 namespace mi {
 
 struct TiledState {
-    int bcap = 0;                   // frames per fused launch
-    std::vector<float*> Gb[2];      // Gb[set][l], l = 1..L : bcap images of level l
+    int bcap = 0;                   // frames per fused launch of the host-frame ring (and of MI_ARITH_EXACT)
+    int dev_cap = 0;                // MI_ARITH_SEPARABLE, frames resident in HBM: largest batch (0 = not decided yet)
+    int gcap[2] = {0, 0};           // frames the per-batch buffers of a set hold at the moment
+    std::vector<float*> Gb[2];      // Gb[set][l], l = 1..L : gcap[set] images of level l
+    std::vector<float*> partE;      // [l] frame-chunk partial maxima / arg-maxima of level l (launch_level_sep)
+    std::vector<int32_t*> partI;
+    std::vector<size_t> part_cap;   // elements allocated in partE[l] / partI[l]
     std::vector<size_t> gstride;    // floats between frames in Gb[.][l]
     void* ring = nullptr;           // staging ring for host-pushed frames (bcap frames, in_dtype)
     size_t frame_bytes = 0;
@@ -52,6 +57,51 @@ inline TiledState* tstate(const mi_stack* s) { return reinterpret_cast<TiledStat
 
 bool tiled_available() { return true; }
 
+void dev_release(mi_stack* s, void* p) {
+    if (!p) return;
+    for (size_t i = 0; i < s->allocs.size(); ++i)
+        if (s->allocs[i] == p) {
+            s->allocs[i] = s->allocs.back();
+            s->allocs.pop_back();
+            break;
+        }
+    (void)hipFree(p);
+}
+
+int tiled_sync_all(mi_stack* s);
+
+// bytes of per-batch buffers one frame needs in a set (its Gaussian levels 1..L and the base scratch)
+size_t tiled_bytes_per_frame(const mi_stack* s) {
+    const TiledState* t = tstate(s);
+    size_t b = 0;
+    for (int l = 1; l <= s->L; ++l) b += t->gstride[l] * sizeof(float);
+    return b + (size_t)s->lh[s->L] * s->lw[s->L] * 12 + (size_t)s->nlevels_hist * 8;
+}
+
+// make the per-batch buffers of `set` hold `nb` frames (grows only; growing waits for the work in flight)
+int tiled_reserve(mi_stack* s, int set, int nb) {
+    TiledState* t = tstate(s);
+    if (nb <= t->gcap[set]) return MI_OK;
+    int rc;
+    if (t->gcap[set] > 0) {
+        if ((rc = tiled_sync_all(s))) return rc;
+        MI_HIP(hipStreamSynchronize(s->stream));
+        for (int l = 1; l <= s->L; ++l) { dev_release(s, t->Gb[set][l]); t->Gb[set][l] = nullptr; }
+        dev_release(s, t->lev[set]); dev_release(s, t->cnt[set]); dev_release(s, t->logp[set]); dev_release(s, t->feat[set]);
+        t->lev[set] = nullptr; t->cnt[set] = nullptr; t->logp[set] = nullptr; t->feat[set] = nullptr;
+        t->gcap[set] = 0;
+    }
+    for (int l = 1; l <= s->L; ++l)
+        if ((rc = dev_alloc_t(s, &t->Gb[set][l], t->gstride[l] * nb))) return rc;
+    const size_t npb = (size_t)s->lh[s->L] * s->lw[s->L];
+    if ((rc = dev_alloc_t(s, &t->lev[set], npb * nb))) return rc;
+    if ((rc = dev_alloc_t(s, &t->cnt[set], (size_t)s->nlevels_hist * nb))) return rc;
+    if ((rc = dev_alloc_t(s, &t->logp[set], (size_t)s->nlevels_hist * nb))) return rc;
+    if ((rc = dev_alloc_t(s, &t->feat[set], 2 * npb * nb))) return rc;
+    t->gcap[set] = nb;
+    return MI_OK;
+}
+
 int tiled_create(mi_stack* s) {
     auto* t = new TiledState();
     tstate(s) = t;
@@ -67,8 +117,13 @@ int tiled_create(mi_stack* s) {
     // they run beside; otherwise they starve and become the critical path.
     int prio_lo = 0, prio_hi = 0;
     MI_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-    MI_HIP(hipStreamCreateWithPriority(&t->st1, hipStreamNonBlocking, prio_hi));
-    MI_HIP(hipStreamCreateWithPriority(&t->st2, hipStreamNonBlocking, prio_hi));
+    if (study_env("MI_SERIAL", 0)) t->st1 = t->st2 = s->stream;   // -DMI_STUDY: every kernel alone on the GPU
+    else {
+        const int bd = study_env("MI_BD_PRIO", 0), co = study_env("MI_CO_PRIO", 0);   // 0 high, 1 normal, 2 low
+        MI_HIP(hipStreamCreateWithPriority(&t->st1, hipStreamNonBlocking, bd == 0 ? prio_hi : bd == 1 ? 0 : prio_lo));
+        MI_HIP(hipStreamCreateWithPriority(&t->st2, hipStreamNonBlocking, co == 0 ? prio_hi : co == 1 ? 0 : prio_lo));
+        if (study_env("MI_BD_PRIO", 0)) fprintf(stderr, "priority range lo=%d hi=%d\n", prio_lo, prio_hi);
+    }
     t->gstride.assign(L + 1, 0);
     int rc;
     MI_HIP(hipEventCreateWithFlags(&t->evInput, hipEventDisableTiming));
@@ -83,16 +138,13 @@ int tiled_create(mi_stack* s) {
             t->evLvl.push_back(e);
         }
         t->Gb[set].assign(L + 1, nullptr);
-        for (int l = 1; l <= L; ++l) {
-            t->gstride[l] = (size_t)s->lh[l] * s->lw[l] * 3;
-            if ((rc = dev_alloc_t(s, &t->Gb[set][l], t->gstride[l] * t->bcap))) return rc;
-        }
-        const size_t nb = (size_t)s->lh[L] * s->lw[L];
-        if ((rc = dev_alloc_t(s, &t->lev[set], nb * t->bcap))) return rc;
-        if ((rc = dev_alloc_t(s, &t->cnt[set], (size_t)s->nlevels_hist * t->bcap))) return rc;
-        if ((rc = dev_alloc_t(s, &t->logp[set], (size_t)s->nlevels_hist * t->bcap))) return rc;
-        if ((rc = dev_alloc_t(s, &t->feat[set], 2 * nb * t->bcap))) return rc;
+        for (int l = 1; l <= L; ++l) t->gstride[l] = (size_t)s->lh[l] * s->lw[l] * 3;
+        // the ring's batch size up front (an allocation failure belongs to create); resident pushes grow it on demand
+        if ((rc = tiled_reserve(s, set, t->bcap))) return rc;
     }
+    t->partE.assign(L + 1, nullptr);
+    t->partI.assign(L + 1, nullptr);
+    t->part_cap.assign(L + 1, 0);
     return MI_OK;
 }
 
@@ -124,8 +176,8 @@ void tiled_destroy(mi_stack* s) {
     if (t->evRingFree) (void)hipEventDestroy(t->evRingFree);
     if (t->evInput) (void)hipEventDestroy(t->evInput);
     if (t->stc) (void)hipStreamDestroy(t->stc);
-    if (t->st1) (void)hipStreamDestroy(t->st1);
-    if (t->st2) (void)hipStreamDestroy(t->st2);
+    if (t->st1 && t->st1 != s->stream) (void)hipStreamDestroy(t->st1);
+    if (t->st2 && t->st2 != s->stream) (void)hipStreamDestroy(t->st2);
     delete t;
     tstate(s) = nullptr;
 }
@@ -257,9 +309,26 @@ int launch_level(mi_stack* s, int l, int set, const void* src, size_t src_stride
 // MI_ARITH_SEPARABLE: interior and border tiles of level l on the separable kernel (kernels_sep.hpp); one tile
 // grid (28 x 56, origin at the image corner) for both, the interior rectangle = the whole tiles whose 6-pixel
 // halo stays inside the image.
+// How a level with `tiles` workgroups walks the `nb` frames of a batch.  A workgroup visits its frames one after the
+// other, so (a) a level with few tiles is latency-bound unless the batch is cut into chunks that run side by side
+// (blockIdx.y; about four rounds of workgroups for the GPU's 768 slots, chunks of 16 to 32 frames, partial maxima merged
+// afterwards), and (b) over a long walk neighbouring workgroups drift apart in time and stop sharing their halos in L2
+// (measured on 24 MP frames: 256 frames in one launch cost 3.1 ms per 32 frames, launches of 32 frames 2.9 ms, of 16
+// frames 2.7 ms, of 8 frames 2.75 ms), so a level with many tiles runs as consecutive launches of 16 frames.  Returns the frames per chunk / per launch.
+constexpr int SEP_LAUNCH_FRAMES = 16;
+inline int sep_chunk_frames(int nb, int tiles, bool* parallel) {
+    static const int on = study_env("MI_CHUNK", 1);           // -DMI_STUDY: 0 = never in parallel chunks
+    static const int lf = study_env("MI_LAUNCH_FRAMES", SEP_LAUNCH_FRAMES);
+    const int c = 3072 / std::max(tiles, 1);
+    *parallel = on && c > 1 && nb >= 32;
+    if (!*parallel) return std::min(nb, lf);
+    return std::min(lf, std::max(16, cdiv(cdiv(nb, c), 4) * 4));
+}
+
+// `ev_bd`: recorded on st_bd behind the border kernel when the level ran in chunks (the merge on st_in waits for it).
 template <typename TIn, bool L0_NAME>
 int launch_level_sep(mi_stack* s, int l, int set, const void* src, size_t src_stride, int nb, hipStream_t st_in,
-                     hipStream_t st_bd) {
+                     hipStream_t st_bd, hipEvent_t ev_bd) {
     constexpr int TH = MI_SEP_TH, NT = (TH / 2 + 2) * 32;
     using SG = SepGeom<TH, NT>;
     constexpr int TW = SG::TW;
@@ -298,15 +367,58 @@ int launch_level_sep(mi_stack* s, int l, int set, const void* src, size_t src_st
     }
     const double bytes = ((double)(l == 0 ? dtype_size(s->p.in_dtype) : 4) * 3.0 * a.h * a.w + 24.0 * a.hn * a.wn) * nb;
     const double frac_in = (double)(a.iy1 - a.iy0) * (a.ix1 - a.ix0) / ((double)a.h * a.w);
-    {
-        const int nborder = cdiv(a.w, TW) * cdiv(a.h, TH) - nyi * nxi;
-        ProfScope ps(s, MI_PROF_LEVEL, bytes * (1.0 - frac_in), st_bd);
-        if (nborder > 0 && !MI_ABL(256)) hipLaunchKernelGGL(kbd, dim3(nborder), dim3(NT), lds, st_bd, a);
+    const int ntiles = cdiv(a.w, TW) * cdiv(a.h, TH);
+    const size_t npx = (size_t)a.h * a.w;
+    bool parallel = false;
+    const int fc = sep_chunk_frames(nb, ntiles, &parallel);
+    const int nchunks = parallel ? cdiv(nb, fc) : 1;
+    if (nchunks > 1) {
+        const size_t need = npx * (size_t)(nchunks - 1);
+        if (t->part_cap[l] < need) {   // grows only; the buffers may still be in use by the previous batch
+            int rc;
+            if ((rc = tiled_sync_all(s))) return rc;
+            MI_HIP(hipStreamSynchronize(s->stream));
+            dev_release(s, t->partE[l]);
+            dev_release(s, t->partI[l]);
+            t->partE[l] = nullptr;
+            t->partI[l] = nullptr;
+            t->part_cap[l] = 0;
+            if ((rc = dev_alloc_t(s, &t->partE[l], need)) || (rc = dev_alloc_t(s, &t->partI[l], need))) return rc;
+            t->part_cap[l] = need;
+        }
+        a.part_e = t->partE[l];
+        a.part_idx = t->partI[l];
+        a.part_stride = npx;
     }
-    if (nyi > 0) {
-        const int nsb = cdiv(nxi, SB) * cdiv(nyi, SB);
-        ProfScope ps(s, l == 0 ? MI_PROF_LEVEL0 : MI_PROF_LEVEL, bytes * frac_in, st_in);
-        hipLaunchKernelGGL(kin, dim3(cdiv(nsb, 8) * 8 * SB * SB), dim3(NT), lds, st_in, a);
+    // parallel chunks: one launch over all the frames; otherwise consecutive launches of `fc` frames (the interior and the
+    // border launches of a level touch disjoint pixels, so each sequence only has to keep its own order)
+    const int nborder = ntiles - nyi * nxi;
+    const int nsb = cdiv(nxi, SB) * cdiv(nyi, SB);
+    const int first = a.first, idx0 = a.frame_idx0;
+    for (int f0 = 0; f0 < nb; f0 += parallel ? nb : fc) {
+        const int nf = parallel ? nb : std::min(fc, nb - f0);
+        a.src = (const char*)src + (size_t)f0 * src_stride;
+        a.gnext = t->Gb[set][l + 1] + (size_t)f0 * a.gnext_stride;
+        a.nframes = nf;
+        a.chunk_frames = parallel ? fc : nf;
+        a.first = first && f0 == 0;
+        a.frame_idx0 = idx0 + f0;
+        const double by = bytes * nf / nb;
+        {
+            ProfScope ps(s, MI_PROF_LEVEL, by * (1.0 - frac_in), st_bd);
+            if (nborder > 0 && !MI_ABL(256)) hipLaunchKernelGGL(kbd, dim3(nborder, nchunks), dim3(NT), lds, st_bd, a);
+        }
+        if (nyi > 0) {
+            ProfScope ps(s, l == 0 ? MI_PROF_LEVEL0 : MI_PROF_LEVEL, by * frac_in, st_in);
+            hipLaunchKernelGGL(kin, dim3(cdiv(nsb, 8) * 8 * SB * SB, nchunks), dim3(NT), lds, st_in, a);
+        }
+    }
+    if (nchunks > 1) {
+        MI_HIP(hipEventRecord(ev_bd, st_bd));
+        MI_HIP(hipStreamWaitEvent(st_in, ev_bd, 0));
+        ProfScope ps(s, MI_PROF_LEVEL, 0.0, st_in);
+        hipLaunchKernelGGL(merge_chunks, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, st_in, s->bestE[l], s->bestIdx[l],
+                           t->partE[l], t->partI[l], npx, nchunks - 1, npx);
     }
     return MI_OK;
 }
@@ -332,6 +444,7 @@ int run_batch(mi_stack* s, const void* frames, size_t stride, int nb) {
     const int set = (int)(t->batch_no & 1);
     hipStream_t st0 = s->stream, st1 = t->st1, st2 = t->st2;
     int rc;
+    if ((rc = tiled_reserve(s, set, nb))) return rc;
     // Gb[set] is free once st2 finished batch k-2 (no-op for the first two batches)
     MI_HIP(hipStreamWaitEvent(st0, t->evRest[set], 0));
     MI_HIP(hipStreamWaitEvent(st1, t->evRest[set], 0));
@@ -339,7 +452,7 @@ int run_batch(mi_stack* s, const void* frames, size_t stride, int nb) {
     // before the level-0 interior kernel by the stream itself; the border kernel runs on st1 and needs the event
     MI_HIP(hipEventRecord(t->evInput, st0));
     MI_HIP(hipStreamWaitEvent(st1, t->evInput, 0));
-    if (s->sep) rc = launch_level_sep<TIn, true>(s, 0, set, frames, stride, nb, st0, st1);
+    if (s->sep) rc = launch_level_sep<TIn, true>(s, 0, set, frames, stride, nb, st0, st1, t->evL0b[set]);
     else
         rc = launch_level<TIn, FMA, MI_TILE0_H, MI_TILE0_W, MI_TILE0_NT, MI_TILE_PAD != 0, MI_TILE_H, MI_TILE_W, MI_TILE_NT>(
             s, 0, set, frames, stride, nb, st0, st1);
@@ -360,7 +473,8 @@ int run_batch(mi_stack* s, const void* frames, size_t stride, int nb) {
         static const int wide_levels = study_env("MI_WIDE_LEVELS", -1);
         const bool wide = wide_levels >= 0 ? l <= wide_levels : (size_t)s->lh[l] * s->lw[l] >= ((size_t)4 << 20);
         if (s->sep)
-            rc = launch_level_sep<float, false>(s, l, set, t->Gb[set][l], t->gstride[l] * sizeof(float), nb, st2, st1);
+            rc = launch_level_sep<float, false>(s, l, set, t->Gb[set][l], t->gstride[l] * sizeof(float), nb, st2, st1,
+                                                t->evLvl[(set * (L + 1) + l) * 2 + 1]);
         else if (wide)
             rc = launch_level<float, FMA, MI_TILE0_H, MI_TILE0_W, MI_TILE0_NT, MI_TILE_PAD != 0, MI_TILE_H, MI_TILE_W, MI_TILE_NT, true>(
                 s, l, set, t->Gb[set][l], t->gstride[l] * sizeof(float), nb, st2, st1);
@@ -431,6 +545,24 @@ int tiled_push(mi_stack* s, const void* dev_frames, int n, size_t stride) {
     int rc = tiled_flush(s);  // keep global frame order: staged host frames come first
     if (rc) return rc;
     const bool fma = s->p.use_fma != 0;
+    // MI_ARITH_SEPARABLE: the whole push is one batch when its per-batch buffers fit (level after level over all the
+    // frames: every kernel has the GPU to itself, a pixel's winning Laplacian is filled in once, and the small levels run
+    // in frame chunks); longer pushes are cut into equal batches.  MI_ARITH_EXACT keeps batches of `bcap` frames.
+    int sep_nb = 0;
+    if (s->sep && n > 0) {
+        if (t->dev_cap == 0) {
+            if (s->p.batch_frames > 0) t->dev_cap = s->p.batch_frames;
+            else {
+                size_t free_b = 0, total_b = 0;
+                MI_HIP(hipMemGetInfo(&free_b, &total_b));
+                // a quarter of what is free now per set of buffers (two sets when a push needs more than one batch)
+                const size_t fit = free_b / 4 / std::max<size_t>(tiled_bytes_per_frame(s), 1);
+                t->dev_cap = (int)std::min<size_t>(256, std::max<size_t>(t->bcap, fit & ~(size_t)7));
+            }
+        }
+        const int nbat = cdiv(n, t->dev_cap);
+        sep_nb = std::min(t->dev_cap, cdiv(cdiv(n, nbat), 4) * 4);
+    }
     for (int f0 = 0; f0 < n;) {
         // Full batches while more than one batch is left; the last `bcap` frames are tapered
         // (1/2, 1/4, 1/4): what cannot overlap anything is the final batch's chain of coarser
@@ -440,6 +572,7 @@ int tiled_push(mi_stack* s, const void* dev_frames, int n, size_t stride) {
         static const int taper = study_env("MI_TAPER", 1);   // 0 / 2: timing studies (-DMI_STUDY)
         if (taper == 1 && left <= t->bcap && left >= 16 && n > t->bcap) nb = (left / 2 + 3) & ~3;
         if (taper == 2 && left == t->bcap && n > t->bcap) nb = t->bcap / 2;
+        if (sep_nb) nb = std::min(left, sep_nb);
         const void* fr = (const char*)dev_frames + (size_t)f0 * stride;
         switch (s->p.in_dtype) {
             case MI_U8: rc = fma ? run_batch<uint8_t, true>(s, fr, stride, nb) : run_batch<uint8_t, false>(s, fr, stride, nb); break;

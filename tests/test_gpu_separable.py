@@ -86,6 +86,35 @@ def test_separable_device_push_many_frames(L, oracle):
     buf.free()
 
 
+@pytest.mark.parametrize("dt", [np.uint8, np.float32])
+def test_separable_frame_chunks(L, oracle, dt):
+    """Long resident pushes of small frames: every level runs in frame chunks (blockIdx.y) whose partial maxima are merged
+    in chunk order.  Duplicate frames sit in different chunks and in different pushes -- the earliest must stay the
+    winner -- and the second push continues the state the first one left."""
+    h, w, n = 133, 201, 70
+    rng = np.random.default_rng(5)
+    frames = [rng.integers(0, 256, (h, w, 3)).astype(np.uint8) for _ in range(n)]
+    for dup, of in ((17, 3), (29, 3), (44, 30), (58, 3), (69, 44), (52, 51)):
+        frames[dup] = frames[of].copy()
+    so, _ = run_oracle(oracle, frames, min_size=8)
+    fr = [f.astype(dt) for f in frames]
+    fb = h * w * 3 * np.dtype(dt).itemsize
+    buf = L.DeviceBuffer(fb * n)
+    for i, f in enumerate(fr):
+        buf.upload(f, i * fb)
+    st = L.Stack(h, w, in_dtype=dt, out_dtype=np.uint8, arith="separable", min_size=8)
+    st.push_frames_device(buf.ptr, 50)
+    st.push_frames_device(buf.ptr + 50 * fb, 20)
+    compare(L, st, so)
+    st.close()
+    # the same through batches of 48 frames (chunks of 16) and 22
+    st = L.Stack(h, w, in_dtype=dt, out_dtype=np.uint8, arith="separable", min_size=8, batch_frames=48)
+    st.push_frames_device(buf.ptr, n)
+    compare(L, st, so)
+    st.close()
+    buf.free()
+
+
 def test_separable_close_to_exact_mode(L, oracle):
     """Same stack in both arithmetic modes: fused images differ by at most 1 count, on few pixels."""
     h, w, n = 300, 452, 5

@@ -23,7 +23,7 @@ for f in glob.glob(os.path.join(out, "stats", "**", "*kernel_trace.csv"), recurs
             dur[key].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 tot = sum(sum(v) for v in dur.values()) or 1.0
 print(f"{'kernel':72s} {'grid':>10s} {'calls':>6s} {'total_ms':>9s} {'avg_us':>9s} {'min_us':>9s} {'pct':>6s}")
-for key in sorted(dur, key=lambda k: -sum(dur[k]))[:16]:
+for key in sorted(dur, key=lambda k: -sum(dur[k]))[:40]:
     v = dur[key]
     print(f"{key[0]:72s} {key[1]:10d} {len(v):6d} {sum(v)/1e3:9.3f} {sum(v)/len(v):9.1f} {min(v):9.1f} "
           f"{100*sum(v)/tot:6.2f}")

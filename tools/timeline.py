@@ -11,7 +11,7 @@ with open(sys.argv[1]) as fh:
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), n[:46], gs, r.get("Queue_Id", r.get("Stream_Id", "?"))))
 rows.sort()
 # last step: take the last finalize as the end, and the previous finalize as the start marker
-fin = [i for i, r in enumerate(rows) if "finalize" in r[2]]
+fin = [i for i, r in enumerate(rows) if "finalize" in r[2] or "collapse_final" in r[2] or r[2].startswith("collapse_sep<unsigned")]
 lo = fin[-2] + 1 if len(fin) >= 2 else 0
 hi = fin[-1] + 1
 t0 = rows[lo][0]
