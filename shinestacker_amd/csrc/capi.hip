@@ -450,13 +450,13 @@ int finish_impl(mi_stack* s) {
         const float k0 = s->k1d[0], k1 = s->k1d[1], k2 = s->k1d[2];
         for (int l = L - 1; l >= 1; --l) {
             float* out = bufs[l & 1];
-            hipLaunchKernelGGL((collapse_sep<float>), grid2d(s->lw[l], s->lh[l], blk), blk, 0, s->stream, up, s->lh[l + 1],
+            hipLaunchKernelGGL((collapse_sep<float>), grid2d(cdiv(s->lw[l], 2), cdiv(s->lh[l], 2), blk), blk, 0, s->stream, up, s->lh[l + 1],
                                s->lw[l + 1], (const float*)s->bestLap[l], s->lh[l], s->lw[l], s->maxv, out, k0, k1, k2);
             up = out;
         }
         s->collapse_src = up;
         s->have_clipped = false;
-        const dim3 g0 = grid2d(s->lw[0], s->lh[0], blk);
+        const dim3 g0 = grid2d(cdiv(s->lw[0], 2), cdiv(s->lh[0], 2), blk);
         if (s->p.out_dtype == MI_U8)
             hipLaunchKernelGGL((collapse_sep<uint8_t>), g0, blk, 0, s->stream, up, s->lh[1], s->lw[1],
                                (const float*)s->bestLap[0], s->lh[0], s->lw[0], s->maxv, (uint8_t*)s->out_dev, k0, k1, k2);
@@ -1270,7 +1270,7 @@ int mi_stack_get_level(mi_stack_t* s, int level, int what, void* host_out, size_
             if (!s->f64 && !s->have_clipped) {   // finish fused the finest collapse step with the cast: redo it unfused
                 const dim3 blk(64, 4);
                 if (s->sep)
-                    hipLaunchKernelGGL((collapse_sep<float>), grid2d(s->lw[0], s->lh[0], blk), blk, 0, s->stream, s->collapse_src,
+                    hipLaunchKernelGGL((collapse_sep<float>), grid2d(cdiv(s->lw[0], 2), cdiv(s->lh[0], 2), blk), blk, 0, s->stream, s->collapse_src,
                                        s->lh[1], s->lw[1], (const float*)s->bestLap[0], s->lh[0], s->lw[0], s->maxv, s->colA,
                                        s->k1d[0], s->k1d[1], s->k1d[2]);
                 else if (s->p.use_fma)

@@ -64,6 +64,8 @@ struct SepGeom {
     static_assert((NH / 2) * (GD / 4) <= NT && NH % 2 == 0 && NT % 64 == 0, "phase items");
 };
 
+struct __attribute__((packed, aligned(4))) Px3 { float v[3]; };   // one pixel: a 12-byte load / store
+
 __device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ v2f s5(v2f a, v2f b, v2f c, v2f d, v2f e, float k0, float k1, float k2) {
     const v2f t0 = a + e, t1 = b + d;
@@ -472,8 +474,6 @@ __global__ void merge_chunks(float* __restrict__ best_e, int32_t* __restrict__ b
 // Winner's Laplacian of the frames of one batch (the level kernel keeps only the running maximum and its frame):
 // one lane per 2x2 quad of level l; a pixel whose arg-max is a frame of this batch gets
 // lap = G_l - expand(G_{l+1}) of that frame, with -0 -> +0 as the reference's np.where sum gives (pyramid.py:52-54).
-struct __attribute__((packed, aligned(4))) Px3 { float v[3]; };   // one pixel: a 12-byte load / store
-
 template <typename TIn>
 __global__ void sep_payload(const void* __restrict__ src, size_t src_stride, const float* __restrict__ gnext,
                             size_t gnext_stride, int nframes, int h, int w, int hn, int wn,
@@ -623,22 +623,50 @@ __global__ void select_sep_simple(const float* __restrict__ q, const float* __re
 }
 
 // collapse step (pyramid.py:57-64): out = expand(up) + lap; TOut != float: the finest step, fused with
-// clip(abs()) and the truncating cast (pyramid.py:64, :179)
+// clip(abs()) and the truncating cast (pyramid.py:64, :179).  One lane per 2x2 quad of the output (launch over
+// ceil(w/2) x ceil(h/2)): the 3x3 patch of `up` that expands to the quad is loaded once, as 12-byte pixels.
 template <typename TOut>
 __global__ void collapse_sep(const float* __restrict__ up, int hs, int ws, const float* __restrict__ lap, int h, int w,
                              float maxv, TOut* __restrict__ out, float k0, float k1, float k2) {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
-    if (y >= h || x >= w) return;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y * blockDim.y + threadIdx.y;
+    if (2 * i >= h || 2 * j >= w) return;
     const float ce = 2.0f * k0, cc = 2.0f * k2, co = 2.0f * k1;
-    const size_t p = ((size_t)y * w + x) * 3;
+    const int ri[3] = {map_expand_src(i - 1, hs), map_expand_src(i, hs), map_expand_src(i + 1, hs)};
+    const int cj[3] = {map_expand_src(j - 1, ws), map_expand_src(j, ws), map_expand_src(j + 1, ws)};
+    Px3 N[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) N[r][q] = *(const Px3*)(up + ((size_t)ri[r] * ws + cj[q]) * 3);
+    float e[4][3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        float v = expand_sep_of([&](int r, int k) { return up[((size_t)r * ws + k) * 3 + c]; }, hs, ws, y, x, ce, cc, co) + lap[p + c];
-        if constexpr (sizeof(TOut) != 4) {
-            v = fabsf(v);
-            v = v > maxv ? maxv : v;
+        float xe[3], xo[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            xe[r] = ex_even(N[r][0].v[c], N[r][1].v[c], N[r][2].v[c], ce, cc);
+            xo[r] = ex_odd(N[r][1].v[c], N[r][2].v[c], co);
         }
-        out[p + c] = (TOut)v;
+        e[0][c] = ex_even(xe[0], xe[1], xe[2], ce, cc);
+        e[1][c] = ex_even(xo[0], xo[1], xo[2], ce, cc);
+        e[2][c] = ex_odd(xe[1], xe[2], co);
+        e[3][c] = ex_odd(xo[1], xo[2], co);
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int y = 2 * i + (p >> 1), x = 2 * j + (p & 1);
+        if (y >= h || x >= w) continue;
+        const size_t px = ((size_t)y * w + x) * 3;
+        const Px3 lv = *(const Px3*)(lap + px);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float v = e[p][c] + lv.v[c];
+            if constexpr (sizeof(TOut) != 4) {
+                v = fabsf(v);
+                v = v > maxv ? maxv : v;
+            }
+            out[px + c] = (TOut)v;
+        }
     }
 }
 
