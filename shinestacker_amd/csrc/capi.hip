@@ -561,7 +561,8 @@ int warp_scratch(int device, hipStream_t st, size_t ntiles, uint32_t** cnt, uint
 
 // the blurred-border composite behind a warp (align.py:245-251): passes over the tiles that hold a masked pixel
 template <typename T>
-int blur_launch(int device, hipStream_t st, void* side, void* out, uint8_t* valid, int h, int w, const GaussArgs& g) {
+int blur_launch(int device, hipStream_t st, void* side, void* out, uint8_t* valid, int h, int w, const GaussArgs& g,
+                bool tiles_marked) {
     auto kb = border_blur_tiles<T>;
     const int r = g.ksize / 2;
     const size_t lds_blur = ((size_t)(BT_H + 2 * r) * (BT_W + 2 * r) * (sizeof(T) == 1 ? 1 : 2) + 3 * (size_t)(BT_H + 2 * r) * BT_W) * 4;
@@ -577,10 +578,12 @@ int blur_launch(int device, hipStream_t st, void* side, void* out, uint8_t* vali
     size_t clear = 0;
     int rc = warp_scratch(device, st, (size_t)tiles_x * tiles_y, &cnt, &bitmap, &list, &clear);
     if (rc) return rc;
-    MI_HIP(hipMemsetAsync(cnt, 0, clear, st));
     const size_t npx = (size_t)h * w;
-    hipLaunchKernelGGL(mask_scan_tiles, dim3((unsigned)std::min<size_t>(2048, (npx / 16 + 256) / 256)), dim3(256), 0, st,
-                       (const uint8_t*)valid, h, w, tiles_x, bitmap);
+    if (!tiles_marked) {   // the warp kernel did not mark the tiles with masked pixels itself: scan the mask
+        MI_HIP(hipMemsetAsync(cnt, 0, clear, st));
+        hipLaunchKernelGGL(mask_scan_tiles, dim3((unsigned)std::min<size_t>(2048, (npx / 16 + 256) / 256)), dim3(256), 0, st,
+                           (const uint8_t*)valid, h, w, tiles_x, bitmap);
+    }
     hipLaunchKernelGGL(tile_bitmap_to_list, dim3(1), dim3(1024), 0, st, (const uint32_t*)bitmap, (tiles_x * tiles_y + 31) / 32, cnt, list);
     hipLaunchKernelGGL(kb, dim3(1024), dim3(256), lds_blur, st, (const T*)out, (const uint8_t*)valid, (T*)side, h, w, tiles_x, g,
                        (const uint32_t*)cnt, (const uint32_t*)list);
@@ -593,10 +596,21 @@ int blur_launch(int device, hipStream_t st, void* side, void* out, uint8_t* vali
 template <typename T>
 int warp_launch(int device, hipStream_t st, const void* src, void* side, void* out, uint8_t* valid, int h, int w,
                 const AffineArgs& a, bool blur, const GaussArgs& g, const PerspArgs* persp) {
+    bool tiles_marked = false;
     if (persp) {
         const dim3 blk(64, 4), grid(cdiv(w, 64), cdiv(h, 4));
         hipLaunchKernelGGL((warp_perspective_kernel<T>), grid, blk, 0, st, (const T*)src, (T*)out, valid, a, *persp);
     } else {
+        uint32_t* bitmap = nullptr;
+        const int blur_tiles_x = cdiv(w, BT_W);
+        if (blur) {   // the kernel marks the blur tiles that hold masked pixels
+            uint32_t *cnt = nullptr, *list = nullptr;
+            size_t clear = 0;
+            int rc = warp_scratch(device, st, (size_t)blur_tiles_x * cdiv(h, BT_H), &cnt, &bitmap, &list, &clear);
+            if (rc) return rc;
+            MI_HIP(hipMemsetAsync(cnt, 0, clear, st));
+            tiles_marked = true;
+        }
         // LDS-staged tiles of 256 x 32 (16) destination pixels, four pixels x 8 (4) rows per thread; whole-dword stores
         // when every row starts 4-byte aligned
         const bool vec = (w % 4) == 0 && ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(valid)) & 3) == 0;
@@ -610,13 +624,13 @@ int warp_launch(int device, hipStream_t st, const void* src, void* side, void* o
             MI_HIP(hipFuncSetAttribute((const void*)ks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             attr_set = true;
         }
-        if (vec) hipLaunchKernelGGL(kv, grid, dim3(256), lds, st, (const T*)src, (T*)out, valid, a);
-        else hipLaunchKernelGGL(ks, grid, dim3(256), lds, st, (const T*)src, (T*)out, valid, a);
+        if (vec) hipLaunchKernelGGL(kv, grid, dim3(256), lds, st, (const T*)src, (T*)out, valid, a, bitmap, blur_tiles_x);
+        else hipLaunchKernelGGL(ks, grid, dim3(256), lds, st, (const T*)src, (T*)out, valid, a, bitmap, blur_tiles_x);
     }
     MI_HIP(hipGetLastError());
     // the warped image went straight to `out`; the few pixels outside the source frame are blurred from it into `side`
     // and copied back
-    return blur ? blur_launch<T>(device, st, side, out, valid, h, w, g) : MI_OK;
+    return blur ? blur_launch<T>(device, st, side, out, valid, h, w, g, tiles_marked) : MI_OK;
 }
 
 }  // namespace

@@ -107,8 +107,15 @@ class PyramidStack(BaseStackAlgo):
                  kernel_size=constants.DEFAULT_PY_KERNEL_SIZE,
                  gen_kernel=constants.DEFAULT_PY_GEN_KERNEL,
                  float_type=constants.DEFAULT_PY_FLOAT, *, device=0, use_fma=True,
-                 impl=_lib.IMPL_AUTO, batch_frames=0, decode_threads=8):
+                 impl=_lib.IMPL_AUTO, batch_frames=0, decode_threads=8, arith="exact"):
         super().__init__("pyramid", 2, float_type)
+        # arith (keyword-only extension): "exact" = the reference's own evaluation order, bit-identical results (default);
+        # "separable" = MI_ARITH_SEPARABLE, the 5 + 5 tap form within the stated float32 tolerance, ~1.35x the throughput
+        if arith not in _lib.ARITH_CODE:
+            raise InvalidOptionError("arith", arith, details=" valid values are 'exact' and 'separable'")
+        if arith == "separable" and float_type == constants.FLOAT_64:
+            raise InvalidOptionError("arith", arith, details=" the separable arithmetic is float-32 only")
+        self.arith = arith
         self.min_size = min_size
         self.kernel_size = kernel_size
         self.pad_amount = (kernel_size - 1) // 2
@@ -137,7 +144,7 @@ class PyramidStack(BaseStackAlgo):
                                  min_size=self.min_size, kernel_size=self.kernel_size,
                                  gen_kernel=self.gen_kernel_a, use_fma=self.use_fma,
                                  device=self.device, impl=self.impl,
-                                 batch_frames=self.batch_frames,
+                                 batch_frames=self.batch_frames, arith=self.arith,
                                  float_type=_lib.MI_F64 if self.float_type is np.float64 else _lib.MI_F32)
         self._stack_key = key
         return self._stack

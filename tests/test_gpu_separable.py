@@ -130,6 +130,25 @@ def test_separable_close_to_exact_mode(L, oracle):
     assert d.max() <= 1 and (d != 0).mean() < 1e-3
 
 
+def test_pyramid_stack_arith_option(L, oracle):
+    """PyramidStack(arith="separable") -- the keyword the drop-in class adds -- fuses with the separable arithmetic
+    (== its oracle), the default stays the reference's evaluation order, and bad combinations are refused."""
+    from shinestacker_amd.errors import InvalidOptionError
+    from shinestacker_amd.pyramid import PyramidStack
+    h, w, n = 300, 452, 5
+    frames = [oracle.synth_frame_numpy(h, w, f, n) for f in range(n)]
+    so, _ = run_oracle(oracle, frames)
+    assert np.array_equal(PyramidStack(arith="separable").focus_stack_arrays(frames), so.finish())
+    se = oracle.StreamingOracle(h, w, np.uint8)
+    for f in frames:
+        se.push_frame(f)
+    assert np.array_equal(PyramidStack().focus_stack_arrays(frames), se.finish())
+    with pytest.raises(InvalidOptionError):
+        PyramidStack(arith="fast")
+    with pytest.raises(InvalidOptionError):
+        PyramidStack(arith="separable", float_type="float-64")
+
+
 def test_separable_rejects_float64(L):
     with pytest.raises(ValueError):
         L.Stack(64, 64, arith="separable", float_type=L.MI_F64)

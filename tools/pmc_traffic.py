@@ -2,7 +2,10 @@
 """HBM traffic of the dominant kernel from the PMC passes of tools/profile.sh, corrected with the
 calibration factors measured by tools/calib_fetch.hip (gpurun_out/calib/).
 
-    python tools/pmc_traffic.py gpurun_out/prof_<tag> gpurun_out/calib > profiles/traffic.json
+    python tools/pmc_traffic.py gpurun_out/prof_<tag> gpurun_out/calib [kernel-name-substring] > traffic_<arith>.json
+
+The kernel is the one whose name contains the substring (default "level_fused") with the largest grid; the output is
+one entry of profiles/traffic.json ({"separable": {...}, "exact": {...}}, read by bench.py for roofline.traffic).
 """
 import csv
 import glob
@@ -12,6 +15,7 @@ import sys
 from collections import defaultdict
 
 prof, calib = sys.argv[1], sys.argv[2]
+want = sys.argv[3] if len(sys.argv) > 3 else "level_fused"
 BYTES = 4 << 30
 
 
@@ -36,7 +40,7 @@ for k, v in cal.items():
 pm = counters(prof)
 best = None
 for k, v in pm.items():
-    if "level_fused" in k and "FETCH_SIZE" in v:
+    if want in k and "FETCH_SIZE" in v:
         g = max(x[0] for x in v["FETCH_SIZE"])
         if best is None or g > best[1]:
             best = (k, g)
