@@ -40,15 +40,41 @@ _BORDER_CODE = {constants.BORDER_CONSTANT: _lib.BORDER_CONSTANT,
 
 
 def img_subsample(img, subsample, fast=True):
-    """utils.py:79-86.  `fast`: strided view; otherwise the integer-factor area average that
-    cv2.resize(INTER_AREA) computes (mean of the s x s block, rounded half up) [from memory]."""
+    """utils.py:79-86.  `fast`: strided view.  Otherwise cv2.resize(img, (0, 0), fx=1/s, fy=1/s, INTER_AREA): OpenCV itself
+    when it is importable, else its integer-factor area path restated [from memory, parity unpinned]: output size
+    round-half-even(dim / s); whole s x s blocks -> (sum + 2) >> 2 for s == 2, else the float32 product sum * (1 / s^2)
+    rounded half to even; the partial blocks of a last row / column (sizes not divisible by s) -> float32 sum / count
+    over the pixels that exist, rounded half to even."""
     if fast:
         return img[::subsample, ::subsample]
-    h, w = img.shape[0] // subsample * subsample, img.shape[1] // subsample * subsample
-    blk = img[:h, :w].reshape(h // subsample, subsample, w // subsample, subsample, -1).astype(np.uint32)
-    s = blk.sum(axis=(1, 3))
-    area = subsample * subsample
-    return ((s + area // 2) // area).astype(img.dtype).reshape(h // subsample, w // subsample, *img.shape[2:])
+    s = int(subsample)
+    if s == 1:
+        return img
+    if have_opencv():   # pragma: no cover - OpenCV is not part of this image
+        import cv2
+        return cv2.resize(img, (0, 0), fx=1 / s, fy=1 / s, interpolation=cv2.INTER_AREA)
+    h, w = img.shape[:2]
+    dh, dw = int(np.rint(h * (1.0 / s))), int(np.rint(w * (1.0 / s)))
+    ph, pw = dh * s, dw * s
+    pad = np.zeros((ph, pw) + img.shape[2:], np.uint32)
+    cnt = np.zeros((ph, pw), np.uint32)
+    hh, ww = min(h, ph), min(w, pw)
+    pad[:hh, :ww] = img[:hh, :ww]
+    cnt[:hh, :ww] = 1
+    tail = img.shape[2:]
+    sums = pad.reshape(dh, s, dw, s, -1).sum(axis=(1, 3))
+    counts = cnt.reshape(dh, s, dw, s).sum(axis=(1, 3))[..., None]
+    full = counts == s * s
+    if s == 2:
+        whole = (sums + 2) >> 2
+    else:
+        whole = np.rint(sums.astype(np.float32) * np.float32(1.0 / (s * s))).astype(np.int64)
+    part = np.rint(sums.astype(np.float32) / np.maximum(counts, 1).astype(np.float32)).astype(np.int64)
+    out = np.where(full, whole, np.where(counts > 0, part, 0))
+    hi = np.iinfo(img.dtype).max if np.issubdtype(img.dtype, np.integer) else None
+    if hi is not None:
+        out = np.clip(out, 0, hi)
+    return out.astype(img.dtype).reshape((dh, dw) + tail)
 
 
 def validate_align_config(detector, descriptor, match_method):

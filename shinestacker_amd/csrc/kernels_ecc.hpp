@@ -40,9 +40,15 @@ __global__ void ecc_gray(const T* __restrict__ img, int src_h, int src_w, int h,
                 sum[0] += q[3 * dx]; sum[1] += q[3 * dx + 1]; sum[2] += q[3 * dx + 2];
             }
         }
-        const uint32_t n = (uint32_t)(ny * nx);
+        // cv2.resize(INTER_AREA) by an integer factor [from memory, as align.img_subsample restates it]: whole blocks
+        // (sum + 2) >> 2 for s == 2, else the float32 product sum * (1 / s^2) rounded half to even; the partial blocks
+        // of a last row / column float32 sum / count, rounded half to even
+        const int n = ny * nx;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) c[k] = (float)((sum[k] + n / 2) / n);
+        for (int k = 0; k < 3; ++k) {
+            if (n == s * s) c[k] = s == 2 ? (float)((sum[k] + 2u) >> 2) : (float)__float2int_rn((float)sum[k] * (1.0f / (float)(s * s)));
+            else c[k] = (float)__float2int_rn((float)sum[k] / (float)n);
+        }
     }
     out[(size_t)y * w + x] = 0.114f * c[0] + 0.587f * c[1] + 0.299f * c[2];
 }

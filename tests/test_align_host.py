@@ -153,6 +153,24 @@ def test_area_subsample_rounds_half_up():
     assert np.array_equal(img_subsample(a, 2, fast=True), a[::2, ::2])
 
 
+def test_area_subsample_rules_of_cv2_resize():
+    """The integer-factor INTER_AREA path as img_subsample restates it (docstring): s == 2 rounds halves up, other
+    factors round the float32 product half to even, the output size is round-half-even(dim / s) and the partial blocks
+    of sizes that do not divide are means over the pixels that exist."""
+    a = np.zeros((4, 8, 1), np.uint8)
+    a[:, :4] = [[[0], [0], [0], [0]], [[0], [0], [0], [0]], [[0], [0], [0], [0]], [[0], [0], [4], [4]]]   # sum 8 / 16 = 0.5
+    a[:, 4:] = 3
+    a[0, 4] = 11                                                                                           # sum 56 / 16 = 3.5
+    out = img_subsample(a, 4, fast=False)
+    assert out.shape == (1, 2, 1) and out[0, 0, 0] == 0 and out[0, 1, 0] == 4      # 0.5 -> 0, 3.5 -> 4 (half to even)
+    b = np.arange(5 * 7, dtype=np.uint16).reshape(5, 7, 1) * 1000
+    out = img_subsample(b, 2, fast=False)
+    assert out.shape == (2, 4, 1)                                                  # rint(2.5) = 2 rows, rint(3.5) = 4 columns
+    assert out[0, 0, 0] == (0 + 1000 + 7000 + 8000 + 2) // 4
+    assert out[0, 3, 0] == int(np.rint((6000 + 13000) / 2))                        # last column: the two pixels that exist
+    assert img_subsample(b, 1, fast=False) is b
+
+
 def test_align_frames_subaction_protocol(tmp_path, monkeypatch):
     """AlignFrames inside CombinedActions: reference frame untouched, AlignmentError on few matches."""
     import shinestacker_amd.align as al
