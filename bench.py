@@ -381,7 +381,7 @@ def main():
         except (OSError, AttributeError, ValueError):
             pass
         kernel = {"separable": "level_sep<level 0> (stage + separable reduce + gray Laplacian + separable energy + "
-                               "select, one launch per frame batch)",
+                               "select; one launch = 16 frames of the resident push)",
                   "exact": "level_fused<level 0> (stage+reduce+laplacian+energy+select, one launch per frame batch)"}
         breakdown = {k: v[0] / args.steps for k, v in prof.items()}
         if world > 1 or force_dist:
