@@ -442,8 +442,12 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
 
 // The kernels proper; the coarser levels get their own name so that profiles (rocprofv3 --stats aggregates by
 // kernel name) keep the level-0 launches apart.
+// border instantiation: minimum waves per SIMD the compiler has to leave room for (caps its VGPRs; 1 = no cap)
+#ifndef MI_SEP_BD_WAVES
+#define MI_SEP_BD_WAVES 1
+#endif
 template <typename TIn, bool INTERIOR, int TH, int NT>
-__global__ __launch_bounds__(NT) void level_sep(LevelArgs a) {
+__global__ __launch_bounds__(NT, INTERIOR ? 1 : MI_SEP_BD_WAVES) void level_sep(LevelArgs a) {
     level_sep_body<TIn, INTERIOR, TH, NT>(a);
 }
 template <typename TIn, bool INTERIOR, int TH, int NT>

@@ -130,6 +130,34 @@ def test_separable_close_to_exact_mode(L, oracle):
     assert d.max() <= 1 and (d != 0).mean() < 1e-3
 
 
+def test_separable_mixed_pushes_grow_the_batch_buffers(L, oracle):
+    """Host frames (32-frame ring), then resident pushes of growing length on the same handle: the per-batch buffers and
+    the chunk partials are re-allocated on demand, the running state carries over, reset() starts a new stack."""
+    h, w = 210, 340
+    rng = np.random.default_rng(11)
+    frames = [rng.integers(0, 256, (h, w, 3)).astype(np.uint8) for _ in range(3 + 40 + 7 + 66)]
+    frames[50] = frames[2].copy()
+    frames[100] = frames[2].copy()
+    fb = h * w * 3
+    buf = L.DeviceBuffer(fb * len(frames))
+    for i, f in enumerate(frames):
+        buf.upload(f, i * fb)
+    st = L.Stack(h, w, in_dtype=np.uint8, arith="separable", min_size=16)
+    for f in frames[:3]:
+        st.push_frame(f)
+    st.push_frames_device(buf.ptr + 3 * fb, 40)
+    st.push_frames_device(buf.ptr + 43 * fb, 7)
+    st.push_frames_device(buf.ptr + 50 * fb, 66)
+    so, _ = run_oracle(oracle, frames, min_size=16)
+    compare(L, st, so)
+    st.reset()
+    st.push_frames_device(buf.ptr + 20 * fb, 35)
+    so, _ = run_oracle(oracle, frames[20:55], min_size=16)
+    compare(L, st, so)
+    st.close()
+    buf.free()
+
+
 def test_pyramid_stack_arith_option(L, oracle):
     """PyramidStack(arith="separable") -- the keyword the drop-in class adds -- fuses with the separable arithmetic
     (== its oracle), the default stays the reference's evaluation order, and bad combinations are refused."""
