@@ -749,9 +749,19 @@ int aligner_reserve(mi_aligner* al, int n) {
 }
 
 // gray + pyramid (+ gradients) of one image: the template, or moving frame `slot`
-int aligner_build(mi_aligner* al, hipStream_t st, const void* dev_img, bool is_tmpl, int slot) {
+// `upto`: build levels 0 .. upto-1 only (the batch builds the small levels of all its frames with one launch each)
+int aligner_build(mi_aligner* al, hipStream_t st, const void* dev_img, bool is_tmpl, int slot, int upto = 1 << 30) {
     const dim3 blk(64, 4), g0(cdiv(al->w, 64), cdiv(al->h, 4));
-    if (al->dtype == MI_U8)
+    if (al->subsample == 2) {   // the common factor: four outputs per thread from 8-byte loads
+        const dim3 g2(cdiv(cdiv(al->w, 4), 64), cdiv(al->h, 4));
+        if (al->dtype == MI_U8) {
+            if (al->area) hipLaunchKernelGGL((ecc_gray_s2<uint8_t, true>), g2, blk, 0, st, (const uint8_t*)dev_img, al->height, al->width, al->h, al->w, al->gray);
+            else hipLaunchKernelGGL((ecc_gray_s2<uint8_t, false>), g2, blk, 0, st, (const uint8_t*)dev_img, al->height, al->width, al->h, al->w, al->gray);
+        } else {
+            if (al->area) hipLaunchKernelGGL((ecc_gray_s2<uint16_t, true>), g2, blk, 0, st, (const uint16_t*)dev_img, al->height, al->width, al->h, al->w, al->gray);
+            else hipLaunchKernelGGL((ecc_gray_s2<uint16_t, false>), g2, blk, 0, st, (const uint16_t*)dev_img, al->height, al->width, al->h, al->w, al->gray);
+        }
+    } else if (al->dtype == MI_U8)
         hipLaunchKernelGGL((ecc_gray<uint8_t>), g0, blk, 0, st, (const uint8_t*)dev_img, al->height, al->width, al->h, al->w,
                            al->subsample, al->area, al->gray);
     else
@@ -759,12 +769,13 @@ int aligner_build(mi_aligner* al, hipStream_t st, const void* dev_img, bool is_t
                            al->subsample, al->area, al->gray);
     auto& lv = al->lv;
     auto at = [&](float* base, size_t l) { return base + (size_t)slot * lv[l].h * lv[l].w; };
-    for (size_t l = 0; l < lv.size(); ++l) {
+    for (size_t l = 0; l < lv.size() && (int)l < upto; ++l) {
         float* dst = is_tmpl ? lv[l].tmpl : at(lv[l].img, l);
         const float* src = l == 0 ? al->gray : (is_tmpl ? lv[l - 1].tmpl : at(lv[l - 1].img, l - 1));
         const int sh = l == 0 ? al->h : lv[l - 1].h, sw = l == 0 ? al->w : lv[l - 1].w;
-        hipLaunchKernelGGL(ecc_blur_down, dim3(cdiv(lv[l].w, 64), cdiv(lv[l].h, 4)), blk, 0, st, src, sh, sw, dst,
-                           lv[l].h, lv[l].w, l == 0 ? 0 : 1);
+        const dim3 gt(cdiv(lv[l].w, 64), cdiv(lv[l].h, 16));
+        if (l == 0) hipLaunchKernelGGL((ecc_blur_tile<0>), gt, dim3(256), 0, st, src, sh, sw, dst, lv[l].h, lv[l].w);
+        else hipLaunchKernelGGL((ecc_blur_tile<1>), gt, dim3(256), 0, st, src, sh, sw, dst, lv[l].h, lv[l].w);
     }
     MI_HIP(hipGetLastError());
     return MI_OK;
@@ -1660,8 +1671,19 @@ int mi_aligner_estimate_batch(mi_aligner_t al, void* stream, const void* const* 
     hipStream_t st = stream ? (hipStream_t)stream : al->own;
     int rc = aligner_reserve(al, n);
     if (rc) return rc;
+    // gray + the two large levels frame by frame (each gray image is still in L2 when its blur reads it: batching those
+    // was 10 % slower); the small levels (1.5 MP and below at 24 MP / sub-sample 2) are launch-latency-bound, so one
+    // launch per level builds them for the whole batch (blockIdx.z = frame).  Same kernel, same values.
+    const int split = n > 1 ? 2 : 1 << 30;
     for (int k = 0; k < n; ++k)
-        if ((rc = aligner_build(al, st, dev_movs[k], false, k))) return rc;
+        if ((rc = aligner_build(al, st, dev_movs[k], false, k, split))) return rc;
+    for (size_t l = (size_t)split; l < al->lv.size(); ++l) {
+        const auto& a = al->lv[l - 1];
+        const auto& b = al->lv[l];
+        hipLaunchKernelGGL((ecc_blur_tile<1>), dim3(cdiv(b.w, 64), cdiv(b.h, 16), n), dim3(256), 0, st, (const float*)a.img, a.h, a.w,
+                           b.img, b.h, b.w);
+    }
+    MI_HIP(hipGetLastError());
     return aligner_solve(al, st, n, max_iters, eps, M_out, cc_out, iters_out);
 }
 

@@ -71,6 +71,114 @@ __global__ void ecc_blur_down(const float* __restrict__ src, int h, int w, float
     dst[(size_t)y * wo + x] = acc;
 }
 
+// The two kernels above, restructured for bandwidth (same arithmetic in the same order: bit-identical output).
+//
+// ecc_gray_s2: the common sub-sampling factor 2; a thread produces four outputs of one row from 8 consecutive source
+// pixels (24 / 48 bytes, loaded as three / six 8-byte words) of one row (fast) or two rows (area), instead of
+// byte-wide loads per channel and output.  The launch covers ceil(w / 4) x h threads; threads whose 8 source pixels
+// are not all inside the row use the scalar form.
+template <typename T, bool AREA>
+__global__ __launch_bounds__(256) void ecc_gray_s2(const T* __restrict__ img, int src_h, int src_w, int h, int w,
+                                                   float* __restrict__ out) {
+    const int x0 = 4 * (blockIdx.x * blockDim.x + threadIdx.x), y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x0 >= w || y >= h) return;
+    const bool rows_ok = !AREA || 2 * y + 1 < src_h;
+    if (x0 + 3 < w && 2 * x0 + 7 < src_w && rows_ok) {
+        constexpr int NW = 24 * (int)sizeof(T) / 8;   // 8-byte words per row segment
+        uint64_t r0[NW], r1[NW];
+        const T* p0 = img + ((size_t)2 * y * src_w + 2 * x0) * 3;
+#pragma unroll
+        for (int k = 0; k < NW; ++k) __builtin_memcpy(&r0[k], (const char*)p0 + 8 * k, 8);
+        if constexpr (AREA) {
+            const T* p1 = p0 + (size_t)src_w * 3;
+#pragma unroll
+            for (int k = 0; k < NW; ++k) __builtin_memcpy(&r1[k], (const char*)p1 + 8 * k, 8);
+        }
+        auto elem = [&](const uint64_t* r, int e) -> uint32_t {   // element e (0..23) of the row segment
+            constexpr int PER = 8 / (int)sizeof(T);
+            return (uint32_t)(r[e / PER] >> (8 * (int)sizeof(T) * (e % PER))) & (sizeof(T) == 1 ? 0xffu : 0xffffu);
+        };
+        float o[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float c[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                if constexpr (AREA) {
+                    const uint32_t sum = elem(r0, 6 * q + k) + elem(r0, 6 * q + 3 + k) + elem(r1, 6 * q + k) + elem(r1, 6 * q + 3 + k);
+                    c[k] = (float)((sum + 2u) >> 2);
+                } else {
+                    c[k] = (float)elem(r0, 6 * q + k);
+                }
+            }
+            o[q] = 0.114f * c[0] + 0.587f * c[1] + 0.299f * c[2];
+        }
+        float* d = out + (size_t)y * w + x0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) d[q] = o[q];
+        return;
+    }
+    for (int x = x0; x < min(x0 + 4, w); ++x) {   // row / image ends: the scalar form of ecc_gray
+        const T* p = img + ((size_t)y * 2 * src_w + (size_t)x * 2) * 3;
+        float c[3];
+        if (!AREA) {
+            c[0] = (float)p[0]; c[1] = (float)p[1]; c[2] = (float)p[2];
+        } else {
+            const int ny = min(2, src_h - y * 2), nx = min(2, src_w - x * 2);
+            uint32_t sum[3] = {0u, 0u, 0u};
+            for (int dy = 0; dy < ny; ++dy)
+                for (int dx = 0; dx < nx; ++dx)
+                    for (int k = 0; k < 3; ++k) sum[k] += p[((size_t)dy * src_w + dx) * 3 + k];
+            const int n = ny * nx;
+            for (int k = 0; k < 3; ++k)
+                c[k] = n == 4 ? (float)((sum[k] + 2u) >> 2) : (float)__float2int_rn((float)sum[k] / (float)n);
+        }
+        out[(size_t)y * w + x] = 0.114f * c[0] + 0.587f * c[1] + 0.299f * c[2];
+    }
+}
+
+// ecc_blur_tile: ecc_blur_down through LDS -- a workgroup stages the source patch of a 64 x 16 output tile (replicate
+// border), runs the 5-tap row pass into a second LDS image and the 5-tap column pass from there; every source value is
+// read from HBM once instead of up to 25 times through the texture units.
+// blockIdx.z = image of a batch (consecutive images of h x w / ho x wo floats).
+template <int DEC>
+__global__ __launch_bounds__(256) void ecc_blur_tile(const float* __restrict__ src, int h, int w, float* __restrict__ dst,
+                                                     int ho, int wo) {
+    src += (size_t)blockIdx.z * h * w;
+    dst += (size_t)blockIdx.z * ho * wo;
+    constexpr int TW = 64, TH = 16, S = DEC ? 2 : 1;
+    constexpr int IW = S * (TW - 1) + 5, IH = S * (TH - 1) + 5, IS = IW | 1;
+    __shared__ float s_in[IH * IS];
+    __shared__ float s_row[IH * TW];
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH, tid = threadIdx.x;
+    const float k[5] = {1.f / 16, 4.f / 16, 6.f / 16, 4.f / 16, 1.f / 16};
+    for (int i = tid; i < IH * IW; i += 256) {
+        const int r = i / IW, c = i - r * IW;
+        const int yy = min(max(S * y0 - 2 + r, 0), h - 1), xx = min(max(S * x0 - 2 + c, 0), w - 1);
+        s_in[r * IS + c] = src[(size_t)yy * w + xx];
+    }
+    __syncthreads();
+    for (int i = tid; i < IH * TW; i += 256) {
+        const int r = i / TW, x = i - r * TW;
+        const float* p = s_in + r * IS + S * x;
+        float row = 0.f;
+#pragma unroll
+        for (int t = 0; t < 5; ++t) row += k[t] * p[t];
+        s_row[i] = row;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < TH * TW / 256; ++j) {
+        const int i = tid + j * 256, yl = i / TW, x = i - yl * TW;
+        if (y0 + yl >= ho || x0 + x >= wo) continue;
+        const float* p = s_row + (S * yl) * TW + x;
+        float acc = 0.f;
+#pragma unroll
+        for (int t = 0; t < 5; ++t) acc += k[t] * p[t * TW];
+        dst[(size_t)(y0 + yl) * wo + x0 + x] = acc;
+    }
+}
+
 __device__ __forceinline__ float bilerp(const float* __restrict__ im, int w, int x0, int y0, float fx, float fy) {
     const float* p = im + (size_t)y0 * w + x0;
     const float a = p[0] + fx * (p[1] - p[0]);

@@ -319,7 +319,8 @@ constexpr int SEP_LAUNCH_FRAMES = 16;
 inline int sep_chunk_frames(int nb, int tiles, bool* parallel) {
     static const int on = study_env("MI_CHUNK", 1);           // -DMI_STUDY: 0 = never in parallel chunks
     static const int lf = study_env("MI_LAUNCH_FRAMES", SEP_LAUNCH_FRAMES);
-    const int c = 3072 / std::max(tiles, 1);
+    static const int par = study_env("MI_PAR_TILES", 3072);   // -DMI_STUDY: tile count below which chunks run side by side
+    const int c = par / std::max(tiles, 1);
     *parallel = on && c > 1 && nb >= 32;
     if (!*parallel) return std::min(nb, lf);
     return std::min(lf, std::max(16, cdiv(cdiv(nb, c), 4) * 4));
