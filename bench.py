@@ -391,8 +391,9 @@ def main():
             "value": value, "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"{total_frames}x{W}x{H}x3 {args.dtype} frames resident in "
-                                   f"HBM, {st.levels}-level Laplacian pyramid fusion "
+            "config": {"workload": f"{total_frames}x{W}x{H}x3 {args.dtype} frames "
+                                   f"{'resident in HBM' if args.source == 'device' else 'pushed from host memory (PCIe inside the timed region)'}, "
+                                   f"{st.levels}-level Laplacian pyramid fusion "
                                    f"(BASELINE.json configs[{1 if world == 1 or args.scaling == 'weak' else 2}])",
                        "frames_per_gpu": F, "source": args.source, "arith": args.arith,
                        "impl": args.impl if args.impl != "auto" else ["auto", "simple", "tiled"][st.params.impl],
