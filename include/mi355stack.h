@@ -175,7 +175,8 @@ enum {
     MI_PROF_KINDS = 4
 };
 MI_API int mi_stack_profile(mi_stack_t* s, int enable);
-/* sums since the last reset; algorithmic_bytes follows SURVEY.md 8(d) */
+/* sums since the last reset; algorithmic_bytes follows SURVEY.md 8(d).  The consecutive launches of one level pass on
+ * one stream share an event pair (first start .. last end, idle gaps between them included); `launches` counts kernels. */
 MI_API int mi_stack_profile_get(mi_stack_t* s, int kind, double* total_ms, int64_t* launches,
                          double* algorithmic_bytes);
 

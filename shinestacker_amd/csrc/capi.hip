@@ -55,6 +55,7 @@ struct ProfRec {
     int kind;
     hipEvent_t a, b;
     double bytes;
+    int launches = 1;   // kernel launches between the two events (consecutive launches of one level share a pair)
 };
 
 }  // namespace
@@ -166,7 +167,7 @@ int prof_drain(mi_stack* s) {
         float ms = 0.f;
         MI_HIP(hipEventElapsedTime(&ms, r.a, r.b));
         s->prof_ms[r.kind] += ms;
-        s->prof_n[r.kind] += 1;
+        s->prof_n[r.kind] += r.launches;
         s->prof_bytes[r.kind] += r.bytes;
         s->ev_pool.push_back(r.a);
         s->ev_pool.push_back(r.b);

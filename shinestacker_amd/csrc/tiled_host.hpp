@@ -396,7 +396,8 @@ int launch_level_sep(mi_stack* s, int l, int set, const void* src, size_t src_st
     const int nborder = ntiles - nyi * nxi;
     const int nsb = cdiv(nxi, SB) * cdiv(nyi, SB);
     const int first = a.first, idx0 = a.frame_idx0;
-    for (int f0 = 0; f0 < nb; f0 += parallel ? nb : fc) {
+    const int step = parallel ? nb : fc, nlaunch = cdiv(nb, step);
+    auto frames_of = [&](int f0) {
         const int nf = parallel ? nb : std::min(fc, nb - f0);
         a.src = (const char*)src + (size_t)f0 * src_stride;
         a.gnext = t->Gb[set][l + 1] + (size_t)f0 * a.gnext_stride;
@@ -404,13 +405,22 @@ int launch_level_sep(mi_stack* s, int l, int set, const void* src, size_t src_st
         a.chunk_frames = parallel ? fc : nf;
         a.first = first && f0 == 0;
         a.frame_idx0 = idx0 + f0;
-        const double by = bytes * nf / nb;
-        {
-            ProfScope ps(s, MI_PROF_LEVEL, by * (1.0 - frac_in), st_bd);
-            if (nborder > 0 && !MI_ABL(256)) hipLaunchKernelGGL(kbd, dim3(nborder, nchunks), dim3(NT), lds, st_bd, a);
+    };
+    // one timing-event pair around each stream's sequence of launches (an event record between two kernels of a stream
+    // costs a few microseconds of idle GPU: 30 launches per level pass)
+    if (nborder > 0 && !MI_ABL(256)) {
+        ProfScope ps(s, MI_PROF_LEVEL, bytes * (1.0 - frac_in), st_bd);
+        ps.r.launches = nlaunch;
+        for (int f0 = 0; f0 < nb; f0 += step) {
+            frames_of(f0);
+            hipLaunchKernelGGL(kbd, dim3(nborder, nchunks), dim3(NT), lds, st_bd, a);
         }
-        if (nyi > 0) {
-            ProfScope ps(s, l == 0 ? MI_PROF_LEVEL0 : MI_PROF_LEVEL, by * frac_in, st_in);
+    }
+    if (nyi > 0) {
+        ProfScope ps(s, l == 0 ? MI_PROF_LEVEL0 : MI_PROF_LEVEL, bytes * frac_in, st_in);
+        ps.r.launches = nlaunch;
+        for (int f0 = 0; f0 < nb; f0 += step) {
+            frames_of(f0);
             hipLaunchKernelGGL(kin, dim3(cdiv(nsb, 8) * 8 * SB * SB, nchunks), dim3(NT), lds, st_in, a);
         }
     }
