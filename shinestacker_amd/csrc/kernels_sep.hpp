@@ -214,7 +214,7 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
         if (!fresh && valid) {
             const size_t px = (size_t)y * w + x;
             bE[p] = st_e[px];
-            bI[p] = st_i[px];
+            bI[p] = -1;      // the running arg-max is not read: -1 = "no frame of this launch has won (yet)"
         } else {
             bE[p] = -1.0f;   // every energy is >= 0: the first frame always wins
             bI[p] = -1;
@@ -434,8 +434,10 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
         const int y = oy + (p >> 1), x = ox + (p & 1);
         if (own_tile && (INTERIOR || (y < h && x < w))) {
             const size_t px = (size_t)y * w + x;
-            st_e[px] = bE[p];
-            st_i[px] = bI[p];
+            if (bI[p] >= 0) {   // only pixels a frame of this launch won are written back (a fresh state: all of them)
+                st_e[px] = bE[p];
+                st_i[px] = bI[p];
+            }
         }
     }
 }
