@@ -4,7 +4,6 @@
 // Batch pipeline over three HIP streams (all work of one handle):
 //   st0 = s->stream : level-0 interior kernel of batch k      (the big one)
 //   st1             : level-0 border kernel of batch k, then the border kernels of levels 1..L-1
-//   st3             : MI_ARITH_SEPARABLE: the payload pass of every level (beside the next level's kernels)
 //   st2             : interior kernels of levels 1..L-1 (joined with st1 after every level) and
 //                     the base features of batch k
 // Level 0 of batch k+1 runs while st2 still works on batch k, so the latency-bound small
@@ -36,8 +35,7 @@ struct TiledState {
     uint32_t* cnt[2] = {nullptr, nullptr};
     float* logp[2] = {nullptr, nullptr};
     float* feat[2] = {nullptr, nullptr};    // (entropy, deviation) of every (frame, pixel) of the batch
-    hipStream_t st1 = nullptr, st2 = nullptr, st3 = nullptr;   // st3: the separable mode's payload passes
-    hipEvent_t evPay[2] = {nullptr, nullptr};   // the batch's payload passes are done (they read its Gaussians)
+    hipStream_t st1 = nullptr, st2 = nullptr;
     hipEvent_t evL0i[2] = {nullptr, nullptr}, evL0b[2] = {nullptr, nullptr}, evRest[2] = {nullptr, nullptr};
     hipEvent_t evL0done[2] = {nullptr, nullptr};   // level-0 state of the batch is final (separable: after its payload pass)
     std::vector<hipEvent_t> evLvl;  // [set][level][interior|border]: per-level joins of st2 and st1
@@ -119,23 +117,20 @@ int tiled_create(mi_stack* s) {
     // they run beside; otherwise they starve and become the critical path.
     int prio_lo = 0, prio_hi = 0;
     MI_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-    if (study_env("MI_SERIAL", 0)) t->st1 = t->st2 = t->st3 = s->stream;   // -DMI_STUDY: every kernel alone on the GPU
+    if (study_env("MI_SERIAL", 0)) t->st1 = t->st2 = s->stream;   // -DMI_STUDY: every kernel alone on the GPU
     else {
         const int bd = study_env("MI_BD_PRIO", 0), co = study_env("MI_CO_PRIO", 0);   // 0 high, 1 normal, 2 low
         MI_HIP(hipStreamCreateWithPriority(&t->st1, hipStreamNonBlocking, bd == 0 ? prio_hi : bd == 1 ? 0 : prio_lo));
         MI_HIP(hipStreamCreateWithPriority(&t->st2, hipStreamNonBlocking, co == 0 ? prio_hi : co == 1 ? 0 : prio_lo));
-        MI_HIP(hipStreamCreateWithPriority(&t->st3, hipStreamNonBlocking, prio_hi));
         if (study_env("MI_BD_PRIO", 0)) fprintf(stderr, "priority range lo=%d hi=%d\n", prio_lo, prio_hi);
     }
     t->gstride.assign(L + 1, 0);
-    int rc;
     MI_HIP(hipEventCreateWithFlags(&t->evInput, hipEventDisableTiming));
     for (int set = 0; set < 2; ++set) {
         MI_HIP(hipEventCreateWithFlags(&t->evL0i[set], hipEventDisableTiming));
         MI_HIP(hipEventCreateWithFlags(&t->evL0b[set], hipEventDisableTiming));
         MI_HIP(hipEventCreateWithFlags(&t->evRest[set], hipEventDisableTiming));
         MI_HIP(hipEventCreateWithFlags(&t->evL0done[set], hipEventDisableTiming));
-        MI_HIP(hipEventCreateWithFlags(&t->evPay[set], hipEventDisableTiming));
         for (int i = 0; i < 2 * (L + 1); ++i) {
             hipEvent_t e;
             MI_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -143,8 +138,14 @@ int tiled_create(mi_stack* s) {
         }
         t->Gb[set].assign(L + 1, nullptr);
         for (int l = 1; l <= L; ++l) t->gstride[l] = (size_t)s->lh[l] * s->lw[l] * 3;
-        // the ring's batch size up front (an allocation failure belongs to create); resident pushes grow it on demand
-        if ((rc = tiled_reserve(s, set, t->bcap))) return rc;
+        // The per-batch buffers are allocated by the first batch that needs them (tiled_reserve in run_batch): a stack
+        // that arrives as one resident push never uses the second set, and growing a set later (free + allocate behind a
+        // device synchronisation) cost 0.7 s for a 256-frame push.  A caller that names its batch size pushes batch after
+        // batch: both sets up front, so that no allocation synchronises the device in the middle of its pipeline.
+        if (s->p.batch_frames > 0) {
+            int rc = tiled_reserve(s, set, t->bcap);
+            if (rc) return rc;
+        }
     }
     t->partE.assign(L + 1, nullptr);
     t->partI.assign(L + 1, nullptr);
@@ -158,7 +159,6 @@ int tiled_sync_all(mi_stack* s) {
     if (t->stc) MI_HIP(hipStreamSynchronize(t->stc));
     if (t->st1) MI_HIP(hipStreamSynchronize(t->st1));
     if (t->st2) MI_HIP(hipStreamSynchronize(t->st2));
-    if (t->st3) MI_HIP(hipStreamSynchronize(t->st3));
     t->streams_dirty = false;
     return MI_OK;
 }
@@ -171,7 +171,6 @@ void tiled_destroy(mi_stack* s) {
         if (t->evL0b[set]) (void)hipEventDestroy(t->evL0b[set]);
         if (t->evRest[set]) (void)hipEventDestroy(t->evRest[set]);
         if (t->evL0done[set]) (void)hipEventDestroy(t->evL0done[set]);
-        if (t->evPay[set]) (void)hipEventDestroy(t->evPay[set]);
     }
     for (auto e : t->evLvl) (void)hipEventDestroy(e);
     for (int i = 0; i < TiledState::NPIN; ++i) {
@@ -184,7 +183,6 @@ void tiled_destroy(mi_stack* s) {
     if (t->stc) (void)hipStreamDestroy(t->stc);
     if (t->st1 && t->st1 != s->stream) (void)hipStreamDestroy(t->st1);
     if (t->st2 && t->st2 != s->stream) (void)hipStreamDestroy(t->st2);
-    if (t->st3 && t->st3 != s->stream) (void)hipStreamDestroy(t->st3);
     delete t;
     tstate(s) = nullptr;
 }
@@ -460,7 +458,7 @@ int run_batch(mi_stack* s, const void* frames, size_t stride, int nb) {
     TiledState* t = tstate(s);
     const int L = s->L;
     const int set = (int)(t->batch_no & 1);
-    hipStream_t st0 = s->stream, st1 = t->st1, st2 = t->st2, st3 = t->st3;
+    hipStream_t st0 = s->stream, st1 = t->st1, st2 = t->st2;
     int rc;
     if ((rc = tiled_reserve(s, set, nb))) return rc;
     // Gb[set] is free once st2 finished batch k-2 (no-op for the first two batches)
@@ -480,16 +478,8 @@ int run_batch(mi_stack* s, const void* frames, size_t stride, int nb) {
     MI_HIP(hipStreamWaitEvent(st2, t->evL0i[set], 0));
     MI_HIP(hipStreamWaitEvent(st2, t->evL0b[set], 0));
     MI_HIP(hipStreamWaitEvent(st1, t->evL0i[set], 0));
-    // MI_ARITH_SEPARABLE: the payload pass of a level runs on st3 beside the next level's kernels (it is a scattered,
-    // latency-bound read of the winners' pixels that does not fill the GPU on its own)
-    if (s->sep) {
-        MI_HIP(hipStreamWaitEvent(st3, t->evL0i[set], 0));
-        MI_HIP(hipStreamWaitEvent(st3, t->evL0b[set], 0));
-        if ((rc = launch_payload_sep<TIn>(s, 0, set, frames, stride, nb, st3))) return rc;
-        MI_HIP(hipEventRecord(t->evL0done[set], st3));
-    } else {
-        MI_HIP(hipEventRecord(t->evL0done[set], st2));   // st2 waited for both level-0 kernels above
-    }
+    if (s->sep && (rc = launch_payload_sep<TIn>(s, 0, set, frames, stride, nb, st2))) return rc;
+    MI_HIP(hipEventRecord(t->evL0done[set], st2));   // st2 waited for both level-0 kernels above
     // coarser levels: interior tiles on st2, border tiles on st1 (disjoint tiles of one level run
     // side by side); both streams join after every level because level l+1 reads all of G_{l+1}
     static const int only_l0 = study_env("MI_ONLY_L0", 0);   // -DMI_STUDY: level 0 alone on the GPU (results are wrong)
@@ -514,11 +504,7 @@ int run_batch(mi_stack* s, const void* frames, size_t stride, int nb) {
         MI_HIP(hipEventRecord(eb, st1));
         MI_HIP(hipStreamWaitEvent(st2, eb, 0));
         MI_HIP(hipStreamWaitEvent(st1, ei, 0));
-        if (s->sep) {
-            MI_HIP(hipStreamWaitEvent(st3, ei, 0));
-            MI_HIP(hipStreamWaitEvent(st3, eb, 0));
-            if ((rc = launch_payload_sep<float>(s, l, set, t->Gb[set][l], t->gstride[l] * sizeof(float), nb, st3))) return rc;
-        }
+        if (s->sep && (rc = launch_payload_sep<float>(s, l, set, t->Gb[set][l], t->gstride[l] * sizeof(float), nb, st2))) return rc;
     }
     MI_HIP(hipGetLastError());
     if (!only_l0) {   // base level of the whole batch
@@ -538,10 +524,6 @@ int run_batch(mi_stack* s, const void* frames, size_t stride, int nb) {
                            t->gstride[L], nb, npix, s->first_index + s->n_pushed, s->n_pushed == 0, s->bEnt, s->bDev,
                            s->idxE, s->idxD, s->baseE, s->baseD);
         MI_HIP(hipGetLastError());
-    }
-    if (s->sep) {   // the batch's buffers are free (and the state final) once the payload passes are through as well
-        MI_HIP(hipEventRecord(t->evPay[set], st3));
-        MI_HIP(hipStreamWaitEvent(st2, t->evPay[set], 0));
     }
     MI_HIP(hipEventRecord(t->evRest[set], st2));
     t->streams_dirty = true;
