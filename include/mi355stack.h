@@ -98,7 +98,11 @@ typedef struct mi_stack_params {
     int32_t use_fma;       /* 1: fma chain (OpenCV AVX2 path) 0: mul+add (SSE baseline path)  */
     int32_t device;        /* HIP device ordinal                                              */
     int32_t impl;          /* MI_IMPL_*                                                       */
-    int32_t batch_frames;  /* frames consumed per fused launch (tiled impl); 0 = default      */
+    int32_t batch_frames;  /* frames per batch (tiled impl).  0 = automatic: host frames are staged in a ring of 32;
+                            * MI_ARITH_SEPARABLE takes a resident push as ONE batch of up to 256 frames while its
+                            * per-batch buffers fit a quarter of the free device memory (allocated on demand).
+                            * > 0: batches of exactly this many frames, buffers allocated by mi_stack_create (for
+                            * callers that push batch after batch and must not stall on an allocation)           */
     int32_t arith;         /* MI_ARITH_*; 0 = exact (default)                                  */
     int32_t reserved[4];
 } mi_stack_params_t;
