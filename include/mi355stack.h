@@ -289,6 +289,15 @@ MI_API int mi_apply_lut(int device, const void* host_src, void* host_dst, int he
                  const void* host_lut, int nlut);
 MI_API int mi_apply_lut_device(int device, void* stream, const void* dev_src, void* dev_dst, size_t npixels,
                         int dtype, const void* dev_lut, int nlut);
+/* The whole LINEAR correction of one device frame, in place, enqueued on `stream` without any host round trip: histogram
+ * (as mi_histogram_device) -> LinearMap's table (balance.py:87-105: ratio = reference mean / histogram mean over the bins
+ * [lo, hi), table[i] = trunc(clip(i * ratio, 0, max)), float64) -> table apply.  mode 1 (luminance): one table for the
+ * three channels; mode 0: one per channel, the channels below `first_channel` unchanged (1 = HSV / HLS: hue passes).
+ * ref_means: host array of the reference frame's means, one per corrected channel.  dev_hist_scratch: 3 * nbins uint32;
+ * dev_lut: 3 * nbins entries of the image dtype; dev_corr_out: NULL or device array that receives the ratios. */
+MI_API int mi_balance_linear_device(int device, void* stream, void* dev_img, void* dev_hist_scratch, void* dev_lut,
+                             int height, int width, int dtype, int mode, int subsample, int fast, double mask_size,
+                             int lo, int hi, int first_channel, const double* ref_means, double* dev_corr_out);
 
 /* 8-bit BGR <-> HSV / HLS (cv2.cvtColor COLOR_BGR2HSV, _HSV2BGR, _BGR2HLS, _HLS2BGR): the pre- and post-processing of the
  * HSV / HLS channel modes of BalanceFrames (balance.py:340-363: SVCorrection / LSCorrection balance S and V, or L and S,

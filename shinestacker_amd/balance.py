@@ -176,6 +176,7 @@ class Correction:
         self.dtype = np.dtype(dtype)
         self._shape = (height, width)
         nbins = _pixel_range(dtype)
+        self._dev_corr = None
         self._scratch = _lib.DeviceBuffer(3 * nbins * 4, self.device)
         self._dev_lut = _lib.DeviceBuffer(3 * nbins * self.dtype.itemsize, self.device)
         if self.corr_map not in _MAPS:
@@ -193,8 +194,37 @@ class Correction:
             C.c_double(float(self.mask_size)), out.ctypes.data))
         return [out[c] for c in range(self.channels)]
 
+    def _linear_device(self, idx, dev_img, stream, first_channel=0):
+        """LINEAR map: histogram -> table -> apply entirely on the device (mi_balance_linear_device), nothing waits for the
+        host; the correction factors land in a device array and are fetched by fetch_corrections()."""
+        import ctypes as C
+        m = self.corr_map
+        ncorr = len(m.reference)
+        if getattr(self, "_dev_corr", None) is None:
+            self._dev_corr = _lib.DeviceBuffer(8 * self.corrections.size, self.device)
+            self._corr_pending = []
+        ref = (C.c_double * ncorr)(*[float(r) for r in m.reference])
+        _lib.check(_lib.load().mi_balance_linear_device(
+            self.device, stream, dev_img, self._scratch.ptr, self._dev_lut.ptr, self._shape[0], self._shape[1],
+            _lib.DTYPE_CODE[self.dtype], self.hist_mode, int(self.subsample), int(bool(self.fast_subsampling)),
+            C.c_double(float(self.mask_size)), int(m.lo), int(min(m.hi, m.n)), int(first_channel), ref,
+            self._dev_corr.ptr + 8 * idx * self.corrections.shape[1]))
+        self._corr_pending.append(idx)
+
+    def fetch_corrections(self):
+        """Correction factors of the frames balanced by the device-only LINEAR path (synchronises the device)."""
+        if getattr(self, "_corr_pending", None):
+            _lib.check(_lib.load().mi_device_synchronize(self.device))
+            host = self._dev_corr.download(self.corrections.shape, np.float64)
+            for i in self._corr_pending:
+                self.corrections[i] = host[i]
+            self._corr_pending = []
+        return self.corrections
+
     def apply_correction_device(self, idx, dev_img, stream=None):
         """Balance the device frame in place."""
+        if isinstance(self.corr_map, LinearMap):
+            return self._linear_device(idx, dev_img, stream)
         correction = self.corr_map.correction(self.hist_device(dev_img, stream))
         t = np.ascontiguousarray(np.stack(self.tables(correction)).astype(self.dtype))
         self._dev_lut.upload(t)
@@ -268,7 +298,10 @@ class Ch2Correction(Correction):
     def apply_correction_device(self, idx, dev_img, stream=None):
         lib, n = _lib.load(), self._shape[0] * self._shape[1]
         _lib.check(lib.mi_cvt_color_device(self.device, stream, dev_img, dev_img, n, _lib.MI_U8, self.to_code))
-        Correction.apply_correction_device(self, idx, dev_img, stream)
+        if isinstance(self.corr_map, LinearMap):
+            self._linear_device(idx, dev_img, stream, first_channel=1)
+        else:
+            Correction.apply_correction_device(self, idx, dev_img, stream)
         _lib.check(lib.mi_cvt_color_device(self.device, stream, dev_img, dev_img, n, _lib.MI_U8, self.from_code))
 
 

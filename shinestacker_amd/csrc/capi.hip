@@ -1726,14 +1726,13 @@ int mi_ecc_similarity(int device, const void* host_ref, const void* host_mov, in
     return rc;
 }
 
-int mi_histogram_device(int device, void* stream, const void* dev_img, void* dev_scratch, int height,
-                        int width, int dtype, int mode, int subsample, int fast, double mask_size,
-                        int64_t* counts) {
-    if (!dev_img || !dev_scratch || !counts) return fail(MI_ERR_INVALID, "null argument");
+namespace {
+// histogram of a device frame into dev_scratch (uint32 counts, channel-major), enqueued on `st`, no synchronisation
+int hist_enqueue(int device, hipStream_t st, const void* dev_img, void* dev_scratch, int height, int width, int dtype, int mode,
+                 int subsample, int fast, double mask_size) {
     if (dtype != MI_U8 && dtype != MI_U16) return fail(MI_ERR_INVALID, "dtype must be MI_U8 or MI_U16");
     if (height < 1 || width < 1 || subsample < 1 || (mode != 0 && mode != 1)) return fail(MI_ERR_INVALID, "bad argument");
     MI_HIP(hipSetDevice(device));
-    hipStream_t st = (hipStream_t)stream;
     const int nbins = dtype == MI_U8 ? 256 : 65536, nch = mode == 0 ? 3 : 1;
     HistArgs a{};
     a.img = dev_img; a.h = height; a.w = width; a.s = subsample; a.fast = fast ? 1 : 0; a.gray = mode;
@@ -1753,6 +1752,18 @@ int mi_histogram_device(int device, void* stream, const void* dev_img, void* dev
     if (dtype == MI_U8) hipLaunchKernelGGL(hist_u8, dim3(nblk), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(hist_u16, dim3(nblk), dim3(256), 0, st, a);
     MI_HIP(hipGetLastError());
+    return MI_OK;
+}
+}  // namespace
+
+int mi_histogram_device(int device, void* stream, const void* dev_img, void* dev_scratch, int height,
+                        int width, int dtype, int mode, int subsample, int fast, double mask_size,
+                        int64_t* counts) {
+    if (!dev_img || !dev_scratch || !counts) return fail(MI_ERR_INVALID, "null argument");
+    hipStream_t st = (hipStream_t)stream;
+    int rc = hist_enqueue(device, st, dev_img, dev_scratch, height, width, dtype, mode, subsample, fast, mask_size);
+    if (rc) return rc;
+    const int nbins = dtype == MI_U8 ? 256 : 65536, nch = mode == 0 ? 3 : 1;
     std::vector<uint32_t> tmp((size_t)nch * nbins);
     MI_HIP(hipMemcpyAsync(tmp.data(), dev_scratch, tmp.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     MI_HIP(hipStreamSynchronize(st));
@@ -1802,6 +1813,28 @@ int mi_apply_lut_device(int device, void* stream, const void* dev_src, void* dev
     }
     MI_HIP(hipGetLastError());
     return MI_OK;
+}
+
+int mi_balance_linear_device(int device, void* stream, void* dev_img, void* dev_hist_scratch, void* dev_lut, int height,
+                             int width, int dtype, int mode, int subsample, int fast, double mask_size, int lo, int hi,
+                             int first_channel, const double* ref_means, double* dev_corr_out) {
+    if (!dev_img || !dev_hist_scratch || !dev_lut || !ref_means) return fail(MI_ERR_INVALID, "null argument");
+    const int nbins = dtype == MI_U8 ? 256 : 65536, ntab = mode == 0 ? 3 : 1;
+    if (first_channel < 0 || first_channel >= ntab) return fail(MI_ERR_INVALID, "bad first_channel %d", first_channel);
+    if (lo < 0 || hi > nbins || lo >= hi) return fail(MI_ERR_INVALID, "bad intensity interval [%d, %d)", lo, hi);
+    hipStream_t st = (hipStream_t)stream;
+    int rc = hist_enqueue(device, st, dev_img, dev_hist_scratch, height, width, dtype, mode, subsample, fast, mask_size);
+    if (rc) return rc;
+    LinRef ref{};
+    for (int c = 0; c < ntab - first_channel; ++c) ref.mean[c] = ref_means[c];
+    if (dtype == MI_U8)
+        hipLaunchKernelGGL((lut_linear_build<uint8_t>), dim3(ntab), dim3(256), 0, st, (const uint32_t*)dev_hist_scratch, nbins, lo, hi,
+                           first_channel, ref, (uint8_t*)dev_lut, dev_corr_out);
+    else
+        hipLaunchKernelGGL((lut_linear_build<uint16_t>), dim3(ntab), dim3(256), 0, st, (const uint32_t*)dev_hist_scratch, nbins, lo,
+                           hi, first_channel, ref, (uint16_t*)dev_lut, dev_corr_out);
+    MI_HIP(hipGetLastError());
+    return mi_apply_lut_device(device, stream, dev_img, dev_img, (size_t)height * width, dtype, dev_lut, ntab);
 }
 
 int mi_cvt_color_device(int device, void* stream, const void* dev_src, void* dev_dst, size_t npixels, int dtype, int code) {

@@ -132,6 +132,52 @@ __global__ __launch_bounds__(256) void lut_apply_u16(const uint16_t* __restrict_
     }
 }
 
+// ---------------------------------------------------------------- LINEAR correction tables built on the device
+// LinearMap (balance.py:87-105) without the host round trip: mean = sum(i * h[i]) / sum(h[i]) over [lo, hi) -- exact
+// integers, one float64 division, as np.average does --, ratio = reference mean / mean, table[i] = trunc(clip(i * ratio, 0,
+// vmax)) in float64.  One workgroup per table; tables below `first_channel` are the identity (the hue channel of HSV / HLS).
+// An empty histogram (np.average raises there) gives ratio 1.
+struct LinRef { double mean[3]; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void lut_linear_build(const uint32_t* __restrict__ counts, int nbins, int lo, int hi,
+                                                        int first_channel, LinRef ref, T* __restrict__ lut,
+                                                        double* __restrict__ corr_out) {
+    const int t = blockIdx.x, tid = threadIdx.x;
+    T* out = lut + (size_t)t * nbins;
+    if (t < first_channel) {
+        for (int i = tid; i < nbins; i += 256) out[i] = (T)i;
+        return;
+    }
+    const uint32_t* h = counts + (size_t)t * nbins;
+    unsigned long long s0 = 0, s1 = 0;
+    for (int i = lo + tid; i < hi; i += 256) {
+        const unsigned long long c = h[i];
+        s0 += c;
+        s1 += c * (unsigned long long)i;
+    }
+    __shared__ unsigned long long r0[256], r1[256];
+    __shared__ double s_ratio;
+    r0[tid] = s0; r1[tid] = s1;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (tid < st) { r0[tid] += r0[tid + st]; r1[tid] += r1[tid + st]; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const double ratio = r0[0] ? ref.mean[t - first_channel] / ((double)r1[0] / (double)r0[0]) : 1.0;
+        s_ratio = ratio;
+        if (corr_out) corr_out[t - first_channel] = ratio;
+    }
+    __syncthreads();
+    const double ratio = s_ratio, vmax = (double)(nbins - 1);
+    for (int i = tid; i < nbins; i += 256) {
+        double v = (double)i * ratio;
+        v = v < 0.0 ? 0.0 : (v > vmax ? vmax : v);
+        out[i] = (T)v;
+    }
+}
+
 // ---------------------------------------------------------------- 8-bit BGR <-> HSV / HLS
 // cv2.cvtColor(COLOR_BGR2HSV / HSV2BGR / BGR2HLS / HLS2BGR) on uint8 images: the pre- and post-processing of the
 // reference's SVCorrection / LSCorrection (balance.py:340-363; cv2 has no 16-bit form of these conversions, the

@@ -149,6 +149,41 @@ def test_resident_pipeline_with_balance(L, oracle, channel):
     assert np.array_equal(fused_bal, want)
 
 
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16])
+def test_linear_map_entirely_on_the_device(L, oracle, dtype):
+    """LINEAR corrections of frames resident in HBM run without a host round trip (mi_balance_linear_device: histogram ->
+    table -> apply): same frames and same correction factors as the host-array sub-action, for LUMI / RGB (/ HSV / HLS on
+    8-bit), sub-sampling, the circular mask and an intensity interval."""
+    from shinestacker_amd import balance as b
+    rng = np.random.default_rng(3)
+    h, w = 203, 300      # frames packed back to back must stay 4-byte aligned for the 8-bit table apply
+    hi = 256 if dtype == np.uint8 else 65536
+    ref = rng.integers(0, hi, (h, w, 3)).astype(dtype)
+    movs = [np.clip(ref.astype(np.float64) * f + o, 0, hi - 1).astype(dtype) for f, o in ((0.8, 3), (1.3, 0), (0.5, 7))]
+    classes = [b.LumiCorrection, b.RGBCorrection] + ([b.SVCorrection, b.LSCorrection] if dtype == np.uint8 else [])
+    opts = [dict(subsample=1), dict(subsample=2, fast_subsampling=True, mask_size=0.8),
+            dict(subsample=3, fast_subsampling=False, intensity_interval={'min': hi // 16, 'max': hi - hi // 8})]
+    fb = ref.nbytes
+    buf = L.DeviceBuffer(fb * 4)
+    for cls in classes:
+        for o in opts:
+            host = cls(corr_map="LINEAR", **o)
+            host.begin(ref, 4, 0)
+            want = [host.apply_correction(i + 1, m) for i, m in enumerate(movs)]
+            buf.upload(ref)
+            for i, m in enumerate(movs):
+                buf.upload(m, (i + 1) * fb)
+            dev = cls(corr_map="LINEAR", **o)
+            dev.begin_device(buf.ptr, h, w, dtype, 4)
+            for i in range(3):
+                dev.apply_correction_device(i + 1, buf.ptr + (i + 1) * fb)
+            for i in range(3):
+                got = buf.download((h, w, 3), dtype, (i + 1) * fb)
+                assert np.array_equal(got, want[i]), (cls.__name__, o, i)
+            assert np.array_equal(dev.fetch_corrections()[1:], np.asarray(host.corrections, np.float64)[1:]), (cls.__name__, o)
+    buf.free()
+
+
 def test_argument_errors(L):
     """Bad arguments come back as MI_ERR_INVALID -> ValueError with the library's message, never a crash."""
     import ctypes as C
