@@ -412,8 +412,10 @@ def main():
             v = verify(L, st, args, total_frames, world)
             line["verified"] = v.pop("ok")
             line["verify"] = v
+    do_other = world == 1 and not force_dist and not args.no_other_mode and args.source == "device"
+    fused_main = st.finish() if do_other and not args.no_verify else None   # outside the timed region
     st.close()
-    if world == 1 and not force_dist and not args.no_other_mode and args.source == "device":
+    if do_other:
         other = "exact" if args.arith == "separable" else "separable"
         k2 = max(1, min(3, args.steps))
         st2, dt2, prof2, _ = measure(other, k2, 1)
@@ -422,6 +424,12 @@ def main():
                               "steps": k2, "ms_per_step": dt2 / k2 * 1e3,
                               "roofline_frac": roofline(ms2, n2, b2) / HBM_PEAK_GBS,
                               "job_roofline_frac": (job_bytes_per_frame * total_frames * k2 / dt2) / (HBM_PEAK_GBS * 1e9)}
+        if fused_main is not None:
+            # the two arithmetic modes on the SAME full-size stack: how many values of the fused image differ, by how much
+            d = np.abs(fused_main.astype(np.int32) - st2.finish().astype(np.int32))
+            hist = np.bincount(np.minimum(d.ravel(), 3), minlength=4)
+            line["other_mode"]["fused_image_abs_diff_counts_0_1_2_3plus"] = [int(x) for x in hist]
+            line["other_mode"]["fused_image_values_differing"] = float((d != 0).mean())
         st2.close()
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

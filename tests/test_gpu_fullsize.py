@@ -21,12 +21,16 @@ def L(hiplib):
     return hiplib
 
 
+_FUSED = {}   # arith -> fused image of config 2, for the cross-mode comparison below
+
+
 @pytest.mark.parametrize("arith", ["exact", "separable"])
 def test_config2_256_frames_24mp_fp32(L, oracle, arith):
     """256 x 4000x6000x3 fp32 frames resident in HBM (73.7 GB), 6 levels + 63x94 base: the benchmarked
-    combination -- 8 batches with double-buffered Gaussians and the tapered tail -- verified exactly as bench.py
-    verifies its last step (band structure of the level-0 arg-max; level-0 energy / arg-max / fused Laplacian of
-    the top-left corner == oracle on the cropped frames)."""
+    combination -- exact: 8 batches with double-buffered Gaussians and the tapered tail; separable: one batch, level
+    after level, launches of 16 frames and frame chunks -- verified exactly as bench.py verifies its last step (band
+    structure of the level-0 arg-max; level-0 energy / arg-max / fused Laplacian of the top-left corner == oracle on
+    the cropped frames)."""
     if ROOT not in sys.path:
         sys.path.insert(0, ROOT)
     import bench
@@ -43,8 +47,22 @@ def test_config2_256_frames_24mp_fp32(L, oracle, arith):
     assert v["band_match"] > 0.9 and v["corner_equal"], v
     # the fused image: every frame is sharp in its own band around the same 64..191 ramp, so the result stays in range
     assert out.shape == (H, W, 3) and out.dtype == np.uint8 and 40 < out.mean() < 215
+    _FUSED[arith] = out
     st.close()
     buf.free()
+
+
+def test_config2_separable_within_tolerance_of_exact_at_full_size():
+    """The stated tolerance of MI_ARITH_SEPARABLE at the benchmark's size: against the reference-order arithmetic on the
+    SAME 256 x 24 MP stack the fused image differs on a fraction of a percent of its values, almost all by one count
+    (truncating cast at an integer boundary); larger differences are arg-max flips at near ties (a different frame's
+    Laplacian wins) and stay below 1e-5 of the values.  Measured: 0.12 % / 2.3e-6 / 1.1e-6 (1 / 2 / 3+ counts)."""
+    if len(_FUSED) < 2:
+        pytest.skip("needs both arithmetic modes of test_config2_256_frames_24mp_fp32 in the same session")
+    d = np.abs(_FUSED["exact"].astype(np.int16) - _FUSED["separable"].astype(np.int16))
+    hist = np.bincount(np.minimum(d.ravel(), 3), minlength=4) / d.size
+    assert hist[1] < 5e-3 and hist[2] < 1e-5 and hist[3] < 1e-5, hist
+    _FUSED.clear()
 
 
 def test_config5_two_bunches_50mp_u16_from_host(L, oracle):
