@@ -119,6 +119,16 @@ void dmap_laplacian_kernel(int ksize, DmK2& K) {
 inline dim3 dm_grid2(int h, int w) { return dim3(cdiv(w, 64), cdiv(h, 4)); }
 inline dim3 dm_grid1(size_t n) { return dim3((unsigned)((n + 255) / 256)); }
 
+// cv2.pyrDown: the LDS-tiled kernel when its two LDS images fit, else one thread per output
+template <typename TSrc, int C, typename F>
+void dm_pyrdown_launch(hipStream_t st, const TSrc* src, int h, int w, F* dst, int ho, int wo) {
+    constexpr int TH = dm_pyrdown_tile_rows<TSrc, C, F>();
+    if constexpr (TH > 0)
+        hipLaunchKernelGGL((dm_pyrdown_tile<TSrc, C, F, TH>), dim3(cdiv(wo, 64), cdiv(ho, TH)), dim3(256), 0, st, src, h, w, dst, ho, wo);
+    else
+        hipLaunchKernelGGL((dm_pyrdown<TSrc, C, F>), dm_grid2(ho, wo), dim3(256), 0, st, src, h, w, dst, ho, wo);
+}
+
 // pass 1 for the frame just stored in d->frames[i]
 template <typename T, typename F>
 int dmap_energy(mi_dmap* d, int i) {
@@ -136,9 +146,11 @@ int dmap_energy(mi_dmap* d, int i) {
         hipLaunchKernelGGL((dm_blur<true, F>), dm_grid2(h, w), dim3(256), 0, st, (const F*)tA, h, w, tB, taps);
         hipLaunchKernelGGL((dm_blur<false, F>), dm_grid2(h, w), dim3(256), 0, st, (const F*)tB, h, w, tC, taps);
         if (d->k2.ksize == 5)
-            hipLaunchKernelGGL((dm_laplacian<5, F>), dm_grid2(h, w), dim3(256), 0, st, (const F*)tC, h, w, en, gmax, d->k2);
+            hipLaunchKernelGGL((dm_laplacian_rows<5, F>), dim3(cdiv(w, 64), cdiv(h, 4 * DM_LAP_ROWS)), dim3(256), 0, st, (const F*)tC, h, w,
+                               en, gmax, d->k2);
         else if (d->k2.ksize == 3)
-            hipLaunchKernelGGL((dm_laplacian<3, F>), dm_grid2(h, w), dim3(256), 0, st, (const F*)tC, h, w, en, gmax, d->k2);
+            hipLaunchKernelGGL((dm_laplacian_rows<3, F>), dim3(cdiv(w, 64), cdiv(h, 4 * DM_LAP_ROWS)), dim3(256), 0, st, (const F*)tC, h, w,
+                               en, gmax, d->k2);
         else
             hipLaunchKernelGGL((dm_laplacian<0, F>), dm_grid2(h, w), dim3(256), 0, st, (const F*)tC, h, w, en, gmax, d->k2);
     }
@@ -173,14 +185,9 @@ int dmap_blend(mi_dmap* d) {
         hipLaunchKernelGGL((dm_weight<W>), dm_grid1(np), dim3(256), 0, st, (const W*)d->en[i], (const W*)d->tot, np,
                            avg ? 1 : 0, Wl(0));
         for (int l = 1; l < L; ++l) {
-            const dim3 g = dm_grid2(d->lh[l], d->lw[l]);
-            if (l == 1)
-                hipLaunchKernelGGL((dm_pyrdown<T, 3, F>), g, dim3(256), 0, st, frame, h, w, Gl(1), d->lh[1], d->lw[1]);
-            else
-                hipLaunchKernelGGL((dm_pyrdown<F, 3, F>), g, dim3(256), 0, st, (const F*)Gl(l - 1), d->lh[l - 1], d->lw[l - 1],
-                                   Gl(l), d->lh[l], d->lw[l]);
-            hipLaunchKernelGGL((dm_pyrdown<W, 1, W>), g, dim3(256), 0, st, (const W*)Wl(l - 1), d->lh[l - 1], d->lw[l - 1],
-                               Wl(l), d->lh[l], d->lw[l]);
+            if (l == 1) dm_pyrdown_launch<T, 3, F>(st, frame, h, w, Gl(1), d->lh[1], d->lw[1]);
+            else dm_pyrdown_launch<F, 3, F>(st, (const F*)Gl(l - 1), d->lh[l - 1], d->lw[l - 1], Gl(l), d->lh[l], d->lw[l]);
+            dm_pyrdown_launch<W, 1, W>(st, (const W*)Wl(l - 1), d->lh[l - 1], d->lw[l - 1], Wl(l), d->lh[l], d->lw[l]);
         }
         const size_t ntop = (size_t)d->lh[L - 1] * d->lw[L - 1];
         if (L == 1)
@@ -190,19 +197,19 @@ int dmap_blend(mi_dmap* d) {
             hipLaunchKernelGGL((dm_top_blend<F, F, W>), dm_grid1(ntop), dim3(256), 0, st, (const F*)Gl(L - 1), ntop,
                                (const W*)Wl(L - 1), Bl(L - 1), first);
         for (int l = L - 2; l >= 0; --l) {
-            const dim3 g = dm_grid2(d->lh[l], d->lw[l]);
+            const dim3 g = dm_grid2(cdiv(d->lh[l], 2), cdiv(d->lw[l], 2));   // one lane per 2 x 2 quad
             if (l == 0)
-                hipLaunchKernelGGL((dm_lap_blend<T, F, W>), g, dim3(256), 0, st, frame, h, w, (const F*)Gl(1), d->lh[1],
+                hipLaunchKernelGGL((dm_lap_blend_quad<T, F, W>), g, dim3(256), 0, st, frame, h, w, (const F*)Gl(1), d->lh[1],
                                    d->lw[1], (const W*)Wl(0), Bl(0), first);
             else
-                hipLaunchKernelGGL((dm_lap_blend<F, F, W>), g, dim3(256), 0, st, (const F*)Gl(l), d->lh[l], d->lw[l],
+                hipLaunchKernelGGL((dm_lap_blend_quad<F, F, W>), g, dim3(256), 0, st, (const F*)Gl(l), d->lh[l], d->lw[l],
                                    (const F*)Gl(l + 1), d->lh[l + 1], d->lw[l + 1], (const W*)Wl(l), Bl(l), first);
         }
     }
     // collapse in place (level l takes pyrUp of the finished level l+1), clip, cast
     for (int l = L - 2; l >= 0; --l)
-        hipLaunchKernelGGL((dm_collapse<F>), dm_grid2(d->lh[l], d->lw[l]), dim3(256), 0, st, (const F*)Bl(l + 1), d->lh[l + 1],
-                           d->lw[l + 1], (const F*)Bl(l), d->lh[l], d->lw[l], Bl(l));
+        hipLaunchKernelGGL((dm_collapse_quad<F>), dm_grid2(cdiv(d->lh[l], 2), cdiv(d->lw[l], 2)), dim3(256), 0, st,
+                           (const F*)Bl(l + 1), d->lh[l + 1], d->lw[l + 1], (const F*)Bl(l), d->lh[l], d->lw[l], Bl(l));
     hipLaunchKernelGGL((dm_finalize<T, F>), dm_grid1(np * 3), dim3(256), 0, st, (const F*)Bl(0), np * 3,
                        (F)(sizeof(T) == 1 ? 255 : 65535), (T*)d->out_dev);
     MI_HIP(hipGetLastError());

@@ -119,6 +119,47 @@ __device__ __forceinline__ void block_min_to(F v, F* gmin) {
 // |cv2.Laplacian(blurred, CV_64F, ksize)| -> float32, and the running global maximum.  KS = the aperture as a
 // compile-time constant (taps unrolled, kernel in registers) or 0 for any size; pixels whose window lies inside the
 // image skip the reflection maps.
+// KS > 0: a thread produces DM_LAP_ROWS vertically adjacent pixels from one (KS + ROWS - 1) x KS register patch -- every
+// source value is loaded once per thread instead of once per output; each output is still the row-major chain over its
+// own window, so the values do not change.  Launch over ceil(h / (4 * DM_LAP_ROWS)) block rows.
+constexpr int DM_LAP_ROWS = 4;
+template <int KS, typename F>
+__global__ __launch_bounds__(256) void dm_laplacian_rows(const F* __restrict__ src, int h, int w,
+                                                         F* __restrict__ out, F* __restrict__ gmax, DmK2 K) {
+    static_assert(KS > 0, "compile-time aperture");
+    constexpr int R = KS / 2, PH = KS + DM_LAP_ROWS - 1;
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * DM_LAP_ROWS;
+    F emax = 0;
+    if (x < w && y0 < h) {
+        const bool inside = x >= R && x + R < w && y0 >= R && y0 + DM_LAP_ROWS - 1 + R < h;
+        F p[PH][KS];
+#pragma unroll
+        for (int i = 0; i < PH; ++i) {
+            const F* row = src + (size_t)(inside ? y0 + i - R : r101_loop(y0 + i - R, h)) * w;
+#pragma unroll
+            for (int j = 0; j < KS; ++j) p[i][j] = row[inside ? x + j - R : r101_loop(x + j - R, w)];
+        }
+#pragma unroll
+        for (int q = 0; q < DM_LAP_ROWS; ++q) {
+            if (y0 + q >= h) break;
+            double s = 0.0;
+#pragma unroll
+            for (int i = 0; i < KS; ++i)
+#pragma unroll
+                for (int j = 0; j < KS; ++j) {
+                    const double k = K.k[i * KS + j];
+                    if (k == 0.0) continue;
+                    const double pr = k * (double)p[q + i][j];
+                    s = s + pr;
+                }
+            const F e = (F)fabs(s);
+            out[(size_t)(y0 + q) * w + x] = e;
+            emax = e > emax ? e : emax;
+        }
+    }
+    block_max_to(emax, gmax);
+}
+
 template <int KS, typename F>
 __global__ __launch_bounds__(256) void dm_laplacian(const F* __restrict__ src, int h, int w,
                                                     F* __restrict__ out, F* __restrict__ gmax, DmK2 K) {
@@ -374,6 +415,58 @@ __global__ __launch_bounds__(256) void dm_pyrdown(const TSrc* __restrict__ src, 
     }
 }
 
+// dm_pyrdown through LDS: a workgroup stages the source patch of a 64 x TH output tile (reflected border), runs the row
+// formula into a second LDS image and the column formula from there -- the same operations per output, every source value
+// read from HBM once instead of up to 25 times.  TH shrinks with the element size so that both images fit 64 KB of LDS;
+// 0 = does not fit (3-channel double): the caller keeps dm_pyrdown.
+template <typename TSrc, int C, typename F>
+constexpr int dm_pyrdown_tile_rows() {
+    return sizeof(TSrc) * C <= 6 && sizeof(F) * C <= 12 ? 16 : (sizeof(TSrc) * C <= 12 && sizeof(F) * C <= 12 ? 8 : (sizeof(F) * C <= 8 ? 8 : 0));
+}
+template <typename TSrc, int C, typename F, int TH>
+__global__ __launch_bounds__(256) void dm_pyrdown_tile(const TSrc* __restrict__ src, int h, int w, F* __restrict__ dst,
+                                                       int ho, int wo) {
+    constexpr int TW = 64, IW = 2 * (TW - 1) + 5, IH = 2 * (TH - 1) + 5;
+    __shared__ TSrc s_in[IH * IW * C];
+    __shared__ F s_row[IH * TW * C];
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH, tid = threadIdx.x;
+    for (int i = tid; i < IH * IW; i += 256) {
+        const int r = i / IW, q = i - r * IW;
+        const TSrc* px = src + ((size_t)r101_loop(2 * y0 - 2 + r, h) * w + r101_loop(2 * x0 - 2 + q, w)) * C;
+#pragma unroll
+        for (int c = 0; c < C; ++c) s_in[i * C + c] = px[c];
+    }
+    __syncthreads();
+    for (int i = tid; i < IH * TW; i += 256) {
+        const int r = i / TW, x = i - r * TW;
+        const TSrc* p = s_in + (r * IW + 2 * x) * C;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const F m2 = (F)p[c], m1 = (F)p[C + c], c0 = (F)p[2 * C + c], p1 = (F)p[3 * C + c], p2 = (F)p[4 * C + c];
+            F s = c0 * (F)6;
+            const F pr = (m1 + p1) * (F)4;
+            s = s + pr;
+            s = s + m2;
+            s_row[i * C + c] = s + p2;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < TH * TW; i += 256) {
+        const int yl = i / TW, x = i - yl * TW;
+        if (y0 + yl >= ho || x0 + x >= wo) continue;
+        const F* p = s_row + ((2 * yl) * TW + x) * C;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            F s = p[2 * TW * C + c] * (F)6;
+            const F pr = (p[TW * C + c] + p[3 * TW * C + c]) * (F)4;
+            s = s + pr;
+            s = s + p[c];
+            s = s + p[4 * TW * C + c];
+            dst[((size_t)(y0 + yl) * wo + x0 + x) * C + c] = s * (F)(1.0 / 256.0);
+        }
+    }
+}
+
 // one axis of cv2.pyrUp, unnormalised: sample i of a destination of nd samples from n source samples
 template <typename F, typename A>
 __device__ __forceinline__ F up_axis(int n, int nd, int i, A at) {
@@ -407,7 +500,86 @@ __device__ __forceinline__ F pyrup_at(const F* __restrict__ src, int hs, int ws,
     return v * (F)(1.0 / 64.0);
 }
 
-// Laplacian level (fine - pyrUp(coarse)) times the weight plane of that level, accumulated over frames (:104-110)
+// pyrUp for the 2 x 2 destination quad (2i .. 2i+1, 2j .. 2j+1) of a 3-channel image: the 3 x 3 source patch around (i, j)
+// is loaded once (rows / columns clamped into the source: the clamped entries are exactly the ones the edge rules of
+// up_axis never read), the column pass runs once per patch row and destination column, the row pass per destination pixel --
+// the same operations pyrup_at performs per pixel.  up[q][c]: q = 2 * (row parity) + (column parity).
+template <typename F>
+__device__ __forceinline__ F pick3(F a0, F a1, F a2, int k) { return k == 0 ? a0 : (k == 1 ? a1 : a2); }   // no indexed registers
+
+template <typename F>
+__device__ __forceinline__ void pyrup_quad3(const F* __restrict__ src, int hs, int ws, int hd, int wd, int i, int j,
+                                            F up[4][3]) {
+    F patch[3][3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const int r = min(max(i - 1 + a, 0), hs - 1);
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            const F* px = src + ((size_t)r * ws + min(max(j - 1 + b, 0), ws - 1)) * 3;
+            patch[a][b][0] = px[0]; patch[a][b][1] = px[1]; patch[a][b][2] = px[2];
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        F hx[3][2];   // column pass of patch row a at destination columns 2j, 2j+1
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+                hx[a][e] = up_axis<F>(ws, wd, 2 * j + e, [&](int q) { return pick3(patch[a][0][c], patch[a][1][c], patch[a][2][c], q - j + 1); });
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const F v = up_axis<F>(hs, hd, 2 * i + d, [&](int r) { return pick3(hx[0][e], hx[1][e], hx[2][e], r - i + 1); });
+                up[2 * d + e][c] = v * (F)(1.0 / 64.0);
+            }
+    }
+}
+
+// Laplacian level (fine - pyrUp(coarse)) times the weight plane of that level, accumulated over frames (:104-110).
+// One lane per 2 x 2 quad (launch over ceil(w / 2) x ceil(h / 2)).
+template <typename TFine, typename F, typename W>
+__global__ __launch_bounds__(256) void dm_lap_blend_quad(const TFine* __restrict__ fine, int h, int w,
+                                                         const F* __restrict__ coarse, int hc, int wc,
+                                                         const W* __restrict__ wgt, F* __restrict__ blend, int first) {
+    const int j = blockIdx.x * 64 + (threadIdx.x & 63), i = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (2 * j >= w || 2 * i >= h) return;
+    F up[4][3];
+    pyrup_quad3<F>(coarse, hc, wc, h, w, i, j, up);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int y = 2 * i + (q >> 1), x = 2 * j + (q & 1);
+        if (y >= h || x >= w) continue;
+        const size_t p = (size_t)y * w + x;
+        const F wv = (F)wgt[p];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const F lap = (F)fine[p * 3 + c] - up[q][c];
+            const F cur = lap * wv;
+            blend[p * 3 + c] = first ? cur : blend[p * 3 + c] + cur;
+        }
+    }
+}
+
+template <typename F>
+__global__ __launch_bounds__(256) void dm_collapse_quad(const F* __restrict__ coarse, int hc, int wc,
+                                                        const F* __restrict__ blend, int h, int w, F* __restrict__ out) {
+    const int j = blockIdx.x * 64 + (threadIdx.x & 63), i = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (2 * j >= w || 2 * i >= h) return;
+    F up[4][3];
+    pyrup_quad3<F>(coarse, hc, wc, h, w, i, j, up);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int y = 2 * i + (q >> 1), x = 2 * j + (q & 1);
+        if (y >= h || x >= w) continue;
+        const size_t p = (size_t)y * w + x;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) out[p * 3 + c] = up[q][c] + blend[p * 3 + c];
+    }
+}
+
 template <typename TFine, typename F, typename W>
 __global__ __launch_bounds__(256) void dm_lap_blend(const TFine* __restrict__ fine, int h, int w,
                                                     const F* __restrict__ coarse, int hc, int wc,
