@@ -430,6 +430,10 @@ def main():
             hist = np.bincount(np.minimum(d.ravel(), 3), minlength=4)
             line["other_mode"]["fused_image_abs_diff_counts_0_1_2_3plus"] = [int(x) for x in hist]
             line["other_mode"]["fused_image_values_differing"] = float((d != 0).mean())
+            line["other_mode"]["fused_image_max_abs_diff"] = int(d.max())
+            # 16-bit output: one 8-bit grey level is 257 counts, so the low bins above fill up with float32 rounding noise
+            line["other_mode"]["fused_image_values_off_by_more_than_1_of_255_full_scale"] = float(
+                (d > (65535 if out_dt == np.uint16 else 255) // 255).mean())
         st2.close()
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
