@@ -107,7 +107,7 @@ def test_separable_frame_chunks(L, oracle, dt):
     st.push_frames_device(buf.ptr + 50 * fb, 20)
     compare(L, st, so)
     st.close()
-    # the same through batches of 48 frames (chunks of 16) and 22
+    # the same with a named batch size: 70 frames > 48 -> two equal batches (36 + 34 frames), chunks of 16
     st = L.Stack(h, w, in_dtype=dt, out_dtype=np.uint8, arith="separable", min_size=8, batch_frames=48)
     st.push_frames_device(buf.ptr, n)
     compare(L, st, so)
