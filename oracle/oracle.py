@@ -538,16 +538,37 @@ def bgr2gray_int(img):
 
 
 def resize_area_int(img, s):
-    """cv2.resize(img, (0,0), fx=1/s, fy=1/s, INTER_AREA) for an integer factor [from memory: mean of
-    the s x s block; (sum+2)>>2 for s == 2, else round-half-even of sum * float32(1/s^2); parity
-    unpinned].  Whole blocks only."""
-    h, w = img.shape[0] // s * s, img.shape[1] // s * s
-    blk = img[:h, :w].reshape(h // s, s, w // s, s, -1).astype(np.uint32).sum(axis=(1, 3))
-    if s == 2:
-        out = (blk + 2) >> 2
-    else:
-        out = np.rint(blk.astype(np.float32) * np.float32(1.0 / (s * s))).astype(np.uint32)
-    return out.astype(img.dtype).reshape(h // s, w // s, *img.shape[2:])
+    """cv2.resize(img, (0,0), fx=1/s, fy=1/s, INTER_AREA) for an integer factor [from memory; parity unpinned]: output
+    size round-half-even(dim / s); whole s x s blocks -> (sum + 2) >> 2 for s == 2, else round-half-even of the float32
+    product sum * float32(1 / s^2); the partial blocks of a last row / column -> round-half-even of float32 sum / count
+    over the pixels that exist.  (The same rules as shinestacker_amd.align.img_subsample, written independently: whole
+    blocks by reshape, the hanging row / column block by block.)"""
+    if s == 1:
+        return img
+    h, w = img.shape[:2]
+    dh, dw = int(np.rint(h * (1.0 / s))), int(np.rint(w * (1.0 / s)))
+    tail = img.shape[2:]
+    out = np.zeros((dh, dw) + tail, np.int64)
+    fh, fw = min(h // s, dh), min(w // s, dw)          # whole blocks
+    if fh and fw:
+        blk = img[:fh * s, :fw * s].reshape(fh, s, fw, s, -1).astype(np.uint32).sum(axis=(1, 3))
+        whole = (blk + 2) >> 2 if s == 2 else np.rint(blk.astype(np.float32) * np.float32(1.0 / (s * s)))
+        out[:fh, :fw] = whole.reshape((fh, fw) + tail)
+
+    def partial(by, bx):
+        y0, y1, x0, x1 = by * s, min(by * s + s, h), bx * s, min(bx * s + s, w)
+        if y0 >= h or x0 >= w:
+            return
+        tot = img[y0:y1, x0:x1].astype(np.uint32).reshape((-1,) + tail).sum(axis=0)
+        out[by, bx] = np.rint(np.float32(tot) / np.float32((y1 - y0) * (x1 - x0)))
+
+    for by in range(fh, dh):
+        for bx in range(dw):
+            partial(by, bx)
+    for bx in range(fw, dw):
+        for by in range(fh):
+            partial(by, bx)
+    return out.astype(img.dtype)
 
 
 def balance_hist(img, lumi=False, subsample=1, fast=True, mask_size=0.0):

@@ -1,7 +1,8 @@
 """oracle/probe_cv2.py -- pin the cv2 primitives the day OpenCV is importable.   python -m oracle.probe_cv2
 
-TEST INFRASTRUCTURE.  The oracle restates filter2D, cvtColor(BGR2GRAY) on float32 and on integers, warpAffine,
-GaussianBlur and resize(INTER_AREA) from OpenCV's published algorithms [from memory] because OpenCV is neither
+TEST INFRASTRUCTURE.  The oracle restates filter2D, cvtColor(BGR2GRAY) on float32 and on integers, cvtColor BGR <-> HSV / HLS
+(8-bit), warpAffine, warpPerspective, GaussianBlur, resize(INTER_AREA) and DepthMapStack's Laplacian / pyrDown / pyrUp /
+bilateralFilter from OpenCV's published algorithms [from memory] because OpenCV is neither
 vendored in the reference (pyproject.toml:26, unpinned) nor installed in the build image: "parity unpinned".
 When `import cv2` works, this script runs the REAL primitives on the golden inputs of tests/golden/, reports for
 each one whether the restatement matches bit for bit (filter2D: which of use_fma in {1, 0}, or neither), and writes
@@ -63,14 +64,51 @@ def main():
     report["warp+blur_composite"] = {"matches": bool(np.array_equal(orc.warp_affine(frames[0], M), comp))}
     np.savez_compressed(os.path.join(GOLDEN, "cv2_warp.npz"), src=frames[0], M=M, warp=real_w, mask=mask, composite=comp)
 
-    # ---- resize INTER_AREA (utils.py:79-86)
+    # ---- resize INTER_AREA (utils.py:79-86): sizes that divide and sizes that do not (output size, partial blocks), 8 / 16 bit
     res = {}
-    for s in (2, 4, 8):
-        real_r = cv2.resize(frames[0], (0, 0), fx=1 / s, fy=1 / s, interpolation=cv2.INTER_AREA)
-        mine = orc.resize_area_int(frames[0], s)
-        res[str(s)] = bool(mine.shape == real_r.shape and np.array_equal(mine, real_r))
-        np.savez_compressed(os.path.join(GOLDEN, f"cv2_resize_area_{s}.npz"), src=frames[0], dst=real_r)
+    odd = np.ascontiguousarray(frames[0][: h - 3, : w - 5])
+    for name, src in (("even", frames[0]), ("odd", odd), ("odd16", odd.astype(np.uint16) * 257)):
+        for s in (2, 3, 4, 8):
+            real_r = cv2.resize(src, (0, 0), fx=1 / s, fy=1 / s, interpolation=cv2.INTER_AREA)
+            mine = orc.resize_area_int(src, s)
+            res[f"{name}_{s}"] = bool(mine.shape == real_r.shape and np.array_equal(mine, real_r))
+            np.savez_compressed(os.path.join(GOLDEN, f"cv2_resize_area_{name}_{s}.npz"), src=src, dst=real_r)
     report["resize_INTER_AREA"] = res
+
+    # ---- warpPerspective + mask (align.py:240-241, ALIGN_HOMOGRAPHY)
+    Hm = np.array([[0.9997, -0.0121, 2.9], [0.0119, 1.0004, -1.7], [1.5e-6, -2.0e-6, 1.0]], np.float64)
+    real_p = cv2.warpPerspective(frames[0], Hm, (w, h), borderMode=cv2.BORDER_REPLICATE)
+    report["warpPerspective"] = {"matches": bool(np.array_equal(orc.warp_perspective(frames[0], Hm, border_mode=1), real_p))}
+    np.savez_compressed(os.path.join(GOLDEN, "cv2_warp_perspective.npz"), src=frames[0], M=Hm, warp=real_p)
+
+    # ---- 8-bit BGR <-> HSV / HLS (balance.py:340-363)
+    cvt = {}
+    r = np.arange(0, 256, 3, dtype=np.uint8)
+    cube = np.stack(np.meshgrid(r, r, r, indexing="ij"), axis=-1).reshape(len(r), -1, 3)
+    for name, code, cvcode in (("BGR2HSV", orc.CVT_BGR2HSV, cv2.COLOR_BGR2HSV), ("BGR2HLS", orc.CVT_BGR2HLS, cv2.COLOR_BGR2HLS)):
+        real_c = cv2.cvtColor(cube, cvcode)
+        cvt[name] = bool(np.array_equal(orc.cvt_color_u8(cube, code), real_c))
+        back_code, back_cv = ((orc.CVT_HSV2BGR, cv2.COLOR_HSV2BGR) if name == "BGR2HSV" else (orc.CVT_HLS2BGR, cv2.COLOR_HLS2BGR))
+        real_b = cv2.cvtColor(real_c, back_cv)
+        cvt[name[4:] + "2BGR"] = bool(np.array_equal(orc.cvt_color_u8(real_c, back_code), real_b))
+        np.savez_compressed(os.path.join(GOLDEN, f"cv2_cvt_{name}.npz"), src=cube, dst=real_c, back=real_b)
+    report["cvtColor_HSV_HLS_u8"] = cvt
+
+    # ---- DepthMapStack's primitives (depth_map.py:28-62, :94-112) on the gray plane of the first frame
+    from oracle import depth_map_oracle as dmo
+    gray = real_g8.astype(np.float32)
+    dm = {}
+    dm["GaussianBlur_5"] = bool(np.array_equal(dmo.gaussian_blur(gray, 5), cv2.GaussianBlur(gray, (5, 5), 0)))
+    dm["Laplacian_64F_5"] = bool(np.array_equal(dmo.filter2d_f64(dmo.gaussian_blur(gray, 5), dmo.laplacian_kernel2d(5)),
+                                                cv2.Laplacian(cv2.GaussianBlur(gray, (5, 5), 0), cv2.CV_64F, ksize=5)))
+    dm["pyrDown"] = bool(np.array_equal(dmo.pyr_down(gray), cv2.pyrDown(gray)))
+    small = cv2.pyrDown(gray)
+    dm["pyrUp"] = bool(np.array_equal(dmo.pyr_up(small, (gray.shape[1], gray.shape[0])), cv2.pyrUp(small, dstsize=(gray.shape[1], gray.shape[0]))))
+    en = (gray / 255.0).astype(np.float32)
+    real_bi = cv2.bilateralFilter(en, 15, 25, 25)
+    mine_bi = dmo.bilateral_f32(en, 15, 25.0, 25.0)
+    dm["bilateralFilter_15"] = {"equal": bool(np.array_equal(mine_bi, real_bi)), "max_abs_diff": float(np.abs(mine_bi - real_bi).max())}
+    report["depth_map_primitives"] = dm
 
     print(json.dumps(report, indent=1))
     with open(os.path.join(GOLDEN, "cv2_probe_report.json"), "w") as fh:

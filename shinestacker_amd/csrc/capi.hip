@@ -1738,7 +1738,10 @@ int hist_enqueue(int device, hipStream_t st, const void* dev_img, void* dev_scra
     a.img = dev_img; a.h = height; a.w = width; a.s = subsample; a.fast = fast ? 1 : 0; a.gray = mode;
     if (subsample == 1) { a.hs = height; a.ws = width; }
     else if (fast) { a.hs = cdiv(height, subsample); a.ws = cdiv(width, subsample); }
-    else { a.hs = height / subsample; a.ws = width / subsample; }   // whole blocks only
+    else {   // cv2.resize's output size: round half to even of dim / s
+        a.hs = (int)std::nearbyint((double)height * (1.0 / subsample));
+        a.ws = (int)std::nearbyint((double)width * (1.0 / subsample));
+    }
     if (a.hs < 1 || a.ws < 1) return fail(MI_ERR_INVALID, "image smaller than the sub-sampling factor");
     a.masked = mask_size > 0.0;
     if (a.masked) {   // balance.py:165-175 on the sub-sampled grid

@@ -43,18 +43,23 @@ __device__ __forceinline__ void sub_pixel(const HistArgs& a, int sy, int sx, uin
         else { out[0] = p[0]; out[1] = p[1]; out[2] = p[2]; }
         return;
     }
+    // cv2.resize(INTER_AREA) by the integer factor [from memory, as align.img_subsample restates it]: a last row / column
+    // of blocks may hang over the image edge (the output size is round-half-even(dim / s)) and averages the pixels it has
+    const int ny = min(a.s, a.h - sy * a.s), nx = min(a.s, a.w - sx * a.s);
     uint32_t sum[3] = {0, 0, 0};
-    for (int dy = 0; dy < a.s; ++dy) {
+    for (int dy = 0; dy < ny; ++dy) {
         const T* row = img + ((size_t)(sy * a.s + dy) * a.w + (size_t)sx * a.s) * 3;
-        for (int dx = 0; dx < a.s; ++dx) {
+        for (int dx = 0; dx < nx; ++dx) {
             const T* p = row + dx * 3;
             if (a.gray) sum[0] += bgr2gray_int(p[0], p[1], p[2]);
             else { sum[0] += p[0]; sum[1] += p[1]; sum[2] += p[2]; }
         }
     }
     const float scale = 1.0f / (float)(a.s * a.s);
-    for (int c = 0; c < nch; ++c)
-        out[c] = a.s == 2 ? (sum[c] + 2u) >> 2 : (uint32_t)__float2int_rn((float)sum[c] * scale);
+    for (int c = 0; c < nch; ++c) {
+        if (ny * nx == a.s * a.s) out[c] = a.s == 2 ? (sum[c] + 2u) >> 2 : (uint32_t)__float2int_rn((float)sum[c] * scale);
+        else out[c] = (uint32_t)__float2int_rn((float)sum[c] / (float)(ny * nx));
+    }
 }
 
 // 8-bit: per-workgroup histogram in LDS, one flush per bin and workgroup
