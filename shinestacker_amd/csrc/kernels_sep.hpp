@@ -58,6 +58,13 @@ struct SepGeom {
     static constexpr int QY = TH / 2 + 2, QL = NW;            // quad rows x lanes per quad row
     static constexpr int HBH = TH + 4, HBS = XW;              // HB rows y0-2 .. y0+TH+1, columns as X
     static constexpr int LDS_FLOATS = GH * GS + NH * VS + NH * XS;
+    // Interior tiles of 8-bit frames keep the staged patch in its INPUT type (one dword per 4-element chunk instead of
+    // four): 27.5 KB of LDS instead of 51.9 and 64 VGPRs -> four workgroups per CU instead of three; P1 and P3 unpack on
+    // the fly.  Measured: level 0 of a 256 x 24 MP 8-bit stack 15.2 -> 14.5 ms.  (16-bit frames: 35.7 KB, but 70 VGPRs
+    // keep it at three workgroups -- no gain, not built.)
+    static constexpr int lds_floats(int esize, bool interior) {
+        return (interior && esize == 1 ? GH * (GD / 4) : GH * GS) + NH * VS + NH * XS;
+    }
     static_assert(GD % 4 == 0 && NW == 32, "tile width is fixed by the 32-lane quad rows");
     static_assert(QY * QL == NT, "one quad per lane");
     static_assert(HBH * HBS <= NH * VS, "HB aliases V");
@@ -104,12 +111,30 @@ __device__ __forceinline__ float dpp_wave_next(float v) {
 template <typename TIn> struct PreChunk;
 template <> struct PreChunk<float> {
     v4f v;
+    __device__ __forceinline__ void store_raw(uint32_t*) const {}                       // never used: fp32 stages as fp32
+    static __device__ __forceinline__ v4f unpack_raw(const uint32_t*) { return v4f{}; }
+    static __device__ __forceinline__ void unpack6(const uint32_t*, int, v2f*) {}
     __device__ __forceinline__ void load(const char* p) { __builtin_memcpy(&v, p, 16); }
     __device__ __forceinline__ void set(float a, float b, float c, float d) { v = v4f{a, b, c, d}; }
     __device__ __forceinline__ v4f get() const { return v; }
 };
 template <> struct PreChunk<uint8_t> {
     uint32_t v;
+    // raw LDS form: one dword = four elements
+    __device__ __forceinline__ void store_raw(uint32_t* q) const { *q = v; }
+    static __device__ __forceinline__ v4f unpack_raw(const uint32_t* q) {
+        const uint32_t w = *(const volatile uint32_t __attribute__((address_space(3)))*)(uint32_t)(uintptr_t)q;
+        return v4f{(float)(w & 0xffu), (float)((w >> 8) & 0xffu), (float)((w >> 16) & 0xffu), (float)(w >> 24)};
+    }
+    // six consecutive elements starting at element `e0` (even) of the row at `row`
+    static __device__ __forceinline__ void unpack6(const uint32_t* row, int e0, v2f* out) {
+        const uint32_t* q = row + (e0 >> 2);
+        const uint64_t w = ((uint64_t)q[1] << 32 | q[0]) >> (8 * (e0 & 3));
+        const uint32_t lo = (uint32_t)w, hi = (uint32_t)(w >> 32);
+        out[0] = v2f{(float)(lo & 0xffu), (float)((lo >> 8) & 0xffu)};
+        out[1] = v2f{(float)((lo >> 16) & 0xffu), (float)(lo >> 24)};
+        out[2] = v2f{(float)(hi & 0xffu), (float)((hi >> 8) & 0xffu)};
+    }
     __device__ __forceinline__ void load(const char* p) { __builtin_memcpy(&v, p, 4); }
     __device__ __forceinline__ void set(float a, float b, float c, float d) {
         v = (uint32_t)a | ((uint32_t)b << 8) | ((uint32_t)c << 16) | ((uint32_t)d << 24);
@@ -120,6 +145,9 @@ template <> struct PreChunk<uint8_t> {
 };
 template <> struct PreChunk<uint16_t> {
     uint32_t v0, v1;
+    __device__ __forceinline__ void store_raw(uint32_t*) const {}                       // never used: stages as fp32
+    static __device__ __forceinline__ v4f unpack_raw(const uint32_t*) { return v4f{}; }
+    static __device__ __forceinline__ void unpack6(const uint32_t*, int, v2f*) {}
     __device__ __forceinline__ void load(const char* p) {
         uint64_t t;
         __builtin_memcpy(&t, p, 8);
@@ -140,8 +168,11 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
     using G = SepGeom<TH, NT>;
     constexpr int TW = G::TW;
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr bool RAW = INTERIOR && sizeof(TIn) == 1;   // staged patch kept in the input type (see SepGeom::lds_floats)
+    constexpr int RD = 1;                                // dwords per 4-element chunk in that form
     float* sG = smem;
-    float* sV = sG + G::GH * G::GS;
+    uint32_t* sGr = reinterpret_cast<uint32_t*>(smem);
+    float* sV = smem + (G::lds_floats((int)sizeof(TIn), INTERIOR) - G::NH * G::VS - G::NH * G::XS);
     float* sX = sV + G::NH * G::VS;
     float* sHB = sV;   // V is dead once P2 has read it
     const int tid = threadIdx.x;
@@ -266,7 +297,8 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
 #pragma unroll
         for (int n = 0; n < G::NPRE; ++n) {
             if ((n + 1) * NT > G::NCH && lt + n * NT >= G::NCH) continue;
-            *reinterpret_cast<v4f*>(sG + 4 * (lt + n * NT)) = pre[n].get();
+            if constexpr (RAW) pre[n].store_raw(sGr + RD * (lt + n * NT));
+            else *reinterpret_cast<v4f*>(sG + 4 * (lt + n * NT)) = pre[n].get();
         }
         __syncthreads();
         if (b + 1 < nfr && !MI_ABL(16)) prefetch(b + 1);
@@ -276,10 +308,16 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
             const int rp = lt / CPR, g = lt - rp * CPR;
             v2f a0, a1, b0, b1;   // (row 2rp | 2rp+1) x (floats 4g, 4g+1 | 4g+2, 4g+3)
             if constexpr (INTERIOR) {
-                const float* p = sG + mul24(4 * rp, G::GS) + 4 * g;
                 v4f r[7];
+                if constexpr (RAW) {
+                    const uint32_t* p = sGr + RD * (mul24(4 * rp, CPR) + g);
 #pragma unroll
-                for (int t = 0; t < 7; ++t) r[t] = lds_load4(p + t * G::GS);
+                    for (int t = 0; t < 7; ++t) r[t] = PreChunk<TIn>::unpack_raw(p + t * (RD * CPR));
+                } else {
+                    const float* p = sG + mul24(4 * rp, G::GS) + 4 * g;
+#pragma unroll
+                    for (int t = 0; t < 7; ++t) r[t] = lds_load4(p + t * G::GS);
+                }
                 a0 = s5(r[0].xy, r[1].xy, r[2].xy, r[3].xy, r[4].xy, k0, k1, k2);
                 a1 = s5(r[0].zw, r[1].zw, r[2].zw, r[3].zw, r[4].zw, k0, k1, k2);
                 b0 = s5(r[2].xy, r[3].xy, r[4].xy, r[5].xy, r[6].xy, k0, k1, k2);
@@ -367,12 +405,18 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
             if constexpr (INTERIOR) {
                 const float* xr = sX + mul24(qy3, G::XS) + 2 * ql3;           // X rows qy, qy+1, qy+2
                 const v2f xa = lds_load2s(xr), xb = lds_load2s(xr + G::XS), xc = lds_load2s(xr + 2 * G::XS);
-                const float* gp = sG + mul24(2 * qy3 + 4, G::GS) + 6 * ql3 + 6;   // patch rows 2qy+4, +5; columns 2ql+2, +3
-                v2f ge[3], go[3];
+                v2f ge[3], go[3];   // patch rows 2qy+4, +5; columns 2ql+2, +3: six elements per row
+                if constexpr (RAW) {
+                    const uint32_t* rowp = sGr + mul24(2 * qy3 + 4, RD * CPR);
+                    PreChunk<TIn>::unpack6(rowp, 6 * ql3 + 6, ge);
+                    PreChunk<TIn>::unpack6(rowp + RD * CPR, 6 * ql3 + 6, go);
+                } else {
+                    const float* gp = sG + mul24(2 * qy3 + 4, G::GS) + 6 * ql3 + 6;
 #pragma unroll
-                for (int t = 0; t < 3; ++t) {
-                    ge[t] = lds_load2s(gp + 2 * t);
-                    go[t] = lds_load2s(gp + G::GS + 2 * t);
+                    for (int t = 0; t < 3; ++t) {
+                        ge[t] = lds_load2s(gp + 2 * t);
+                        go[t] = lds_load2s(gp + G::GS + 2 * t);
+                    }
                 }
                 const v2f ev = ex_even(xa, xb, xc, ce, cc), od = ex_odd(xb, xc, co);
                 const v2f gge = {gray_of<true>(ge[0].x, ge[0].y, ge[1].x), gray_of<true>(ge[1].y, ge[2].x, ge[2].y)};
@@ -449,7 +493,7 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
 #define MI_SEP_BD_WAVES 1
 #endif
 template <typename TIn, bool INTERIOR, int TH, int NT>
-__global__ __launch_bounds__(NT, INTERIOR ? 1 : MI_SEP_BD_WAVES) void level_sep(LevelArgs a) {
+__global__ __launch_bounds__(NT, INTERIOR ? (sizeof(TIn) == 1 ? 8 : 1) : MI_SEP_BD_WAVES) void level_sep(LevelArgs a) {
     level_sep_body<TIn, INTERIOR, TH, NT>(a);
 }
 template <typename TIn, bool INTERIOR, int TH, int NT>

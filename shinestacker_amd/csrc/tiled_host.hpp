@@ -362,13 +362,14 @@ int launch_level_sep(mi_stack* s, int l, int set, const void* src, size_t src_st
     a.frame_idx0 = s->first_index + s->n_pushed;
     for (int i = 0; i < 3; ++i) a.k1d[i] = s->k1d[i];
     a.ablate = study_env("MI_ABLATE", 0);   // -DMI_STUDY builds only (results are wrong when set)
-    const size_t lds = (size_t)SG::LDS_FLOATS * sizeof(float);
+    const size_t lds = (size_t)SG::LDS_FLOATS * sizeof(float);                                     // border tiles
+    const size_t lds_in = (size_t)SG::lds_floats((int)sizeof(TIn), true) * sizeof(float);          // interior tiles
     auto kin = L0_NAME ? level_sep<TIn, true, TH, NT> : level_sep_coarse<TIn, true, TH, NT>;
     auto kbd = level_sep<TIn, false, TH, NT>;
     static thread_local bool attr_set = false;
     if (!attr_set) {
         int rc;
-        if ((rc = set_lds_once(kin, lds)) || (rc = set_lds_once(kbd, lds))) return rc;
+        if ((rc = set_lds_once(kin, lds_in)) || (rc = set_lds_once(kbd, lds))) return rc;
         attr_set = true;
     }
     const double bytes = ((double)(l == 0 ? dtype_size(s->p.in_dtype) : 4) * 3.0 * a.h * a.w + 24.0 * a.hn * a.wn) * nb;
@@ -426,7 +427,7 @@ int launch_level_sep(mi_stack* s, int l, int set, const void* src, size_t src_st
         ps.r.launches = nlaunch;
         for (int f0 = 0; f0 < nb; f0 += step) {
             frames_of(f0);
-            hipLaunchKernelGGL(kin, dim3(cdiv(nsb, 8) * 8 * SB * SB, nchunks), dim3(NT), lds, st_in, a);
+            hipLaunchKernelGGL(kin, dim3(cdiv(nsb, 8) * 8 * SB * SB, nchunks), dim3(NT), lds_in, st_in, a);
         }
     }
     if (nchunks > 1) {
