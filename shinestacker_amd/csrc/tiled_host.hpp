@@ -6,12 +6,13 @@
 //   st1             : level-0 border kernel of batch k, then the border kernels of levels 1..L-1
 //   st2             : interior kernels of levels 1..L-1 (joined with st1 after every level) and
 //                     the base features of batch k
-// Level 0 of batch k+1 runs while st2 still works on batch k, so the latency-bound small
-// levels hide behind the bandwidth-bound level-0 kernel.  The per-batch Gaussian images
-// Gb[set][l] are double-buffered (set = k & 1); events order producers and consumers.
-// Selection state is only ever touched by one stream per level (level 0: st0/st1 on
-// disjoint pixels; levels >= 1 and base: st2), so stream order alone keeps the
-// first-max semantics.
+// MI_ARITH_EXACT: batches of 32 frames; level 0 of batch k+1 runs while st2 still works on batch k, so the
+// latency-bound small levels hide behind the level-0 kernel.  MI_ARITH_SEPARABLE: a resident push is ONE batch
+// (up to 256 frames), processed level after level -- many-tile levels as consecutive launches of 16 frames,
+// few-tile levels as parallel frame chunks + merge (launch_level_sep), the payload pass of a level behind it on st2.
+// The per-batch Gaussian images Gb[set][l] are double-buffered (set = k & 1) and allocated on demand; events
+// order producers and consumers.  Selection state is only ever touched by one stream per level (level 0: st0/st1
+// on disjoint pixels; levels >= 1 and base: st2), so stream order alone keeps the first-max semantics.
 #pragma once
 
 namespace mi {
