@@ -158,6 +158,44 @@ def test_separable_mixed_pushes_grow_the_batch_buffers(L, oracle):
     buf.free()
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_separable_tiled_equals_simple_on_random_shapes(L, seed):
+    """Randomised cross-check of the two implementations of the separable arithmetic (LDS-tiled with frame chunks /
+    consecutive launches / merges vs one thread per output, one frame at a time): random sizes (odd, narrow, a single
+    tile row or column), frame counts that straddle the chunking rules, input types, kernel parameters; resident push
+    in one or several pieces.  Every level's energy / arg-max / Laplacian and the fused image must be identical."""
+    rng = np.random.default_rng(1000 + seed)
+    h, w = int(rng.integers(33, 420)), int(rng.integers(33, 640))
+    n = int(rng.choice([1, 2, 7, 16, 31, 32, 33, 47, 64, 65]))
+    dt = [np.uint8, np.uint16, np.float32][seed % 3]
+    hi = 65536 if dt == np.uint16 else 256
+    frames = [rng.integers(0, hi, (h, w, 3)).astype(dt) for _ in range(min(n, 9))]
+    frames = [frames[int(k)] for k in rng.integers(0, len(frames), n)]           # many exact duplicates: ties across chunks
+    kw = dict(in_dtype=dt, out_dtype=np.uint16 if dt == np.uint16 else np.uint8, arith="separable",
+              min_size=int(rng.choice([8, 16, 32])), gen_kernel=float(rng.choice([0.3, 0.4, 0.5])))
+    a = L.Stack(h, w, impl=1, **kw)
+    for f in frames:
+        a.push_frame(f)
+    fb = frames[0].nbytes
+    buf = L.DeviceBuffer(fb * n)
+    for i, f in enumerate(frames):
+        buf.upload(f, i * fb)
+    b = L.Stack(h, w, impl=2, **kw)
+    cut = int(rng.integers(0, n + 1))
+    if cut:
+        b.push_frames_device(buf.ptr, cut, fb)
+    if n - cut:
+        b.push_frames_device(buf.ptr + cut * fb, n - cut, fb)
+    assert a.levels == b.levels
+    for lv in range(a.levels):
+        for tap in (L.TAP_ENERGY, L.TAP_INDEX, L.TAP_FUSED_LAP):
+            assert np.array_equal(a.tap(tap, lv), b.tap(tap, lv)), (seed, h, w, n, dt, lv, tap)
+    assert np.array_equal(a.finish(), b.finish()), (seed, h, w, n, dt)
+    a.close()
+    b.close()
+    buf.free()
+
+
 def test_pyramid_stack_arith_option(L, oracle):
     """PyramidStack(arith="separable") -- the keyword the drop-in class adds -- fuses with the separable arithmetic
     (== its oracle), the default stays the reference's evaluation order, and bad combinations are refused."""
