@@ -222,3 +222,45 @@ def test_argument_errors(L):
     with pytest.raises(ValueError):
         al.estimate_batch([buf.ptr] * 17)                                     # more than 16 frames
     al.close()
+
+
+def test_argument_errors_of_the_round_2_entry_points(L):
+    """mi_cvt_color, mi_balance_linear_device, mi_warp_perspective, the separable parameters: bad arguments come back as
+    error codes with a message (ValueError / InvalidOptionError), never as a crash or a silent result."""
+    import ctypes as C
+    from shinestacker_amd.errors import InvalidOptionError
+    lib = L.load()
+    img = np.zeros((16, 16, 3), np.uint8)
+    with pytest.raises(ValueError):
+        L.cvt_color(img, 7)                                                   # unknown conversion code
+    with pytest.raises(InvalidOptionError):
+        L.cvt_color(img.astype(np.uint16), 0)                                 # 16-bit: refused like cv2
+    buf, scr, lut = L.DeviceBuffer(img.nbytes), L.DeviceBuffer(3 * 256 * 4), L.DeviceBuffer(3 * 256)
+    ref = (C.c_double * 3)(100.0, 100.0, 100.0)
+    ok = dict(device=0, stream=None)
+    def linear(**kw):
+        a = dict(h=16, w=16, dtype=0, mode=1, sub=1, fast=1, mask=0.0, lo=0, hi=256, first=0, refp=ref, img=buf.ptr)
+        a.update(kw)
+        return lib.mi_balance_linear_device(0, None, a["img"], scr.ptr, lut.ptr, a["h"], a["w"], a["dtype"], a["mode"], a["sub"],
+                                            a["fast"], C.c_double(a["mask"]), a["lo"], a["hi"], a["first"], a["refp"], None)
+    assert linear() == 0
+    for bad in (dict(img=None), dict(refp=None), dict(lo=10, hi=10), dict(hi=300), dict(first=1), dict(mode=0, first=3),
+                dict(dtype=2), dict(sub=0), dict(h=0)):
+        with pytest.raises(ValueError):
+            L.check(linear(**bad))
+    M = (C.c_double * 9)(1, 0, 0, 0, 1, 0, 0, 0, 1)
+    bv = (C.c_double * 4)(0, 0, 0, 0)
+    with pytest.raises(ValueError):                                          # blurred border without scratch buffers
+        L.check(lib.mi_warp_perspective_device(0, None, buf.ptr, buf.ptr, None, None, 16, 16, 0, M, 2, bv, 21, 50.0))
+    with pytest.raises(ValueError):
+        L.check(lib.mi_warp_perspective_device(0, None, buf.ptr, buf.ptr, None, None, 16, 16, 2, M, 1, bv, 21, 50.0))   # float frames
+    with pytest.raises(InvalidOptionError):
+        L.Stack(64, 64, arith="quick")
+    with pytest.raises((InvalidOptionError, ValueError)):
+        L.Stack(64, 64, arith="separable", float_type=L.MI_F64)
+    st = L.Stack(64, 96, arith="separable")
+    st.sync_level(0)                                                          # nothing pushed yet: returns
+    st.sync_level(3)
+    st.close()
+    for b in (buf, scr, lut):
+        b.free()
