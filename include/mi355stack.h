@@ -294,7 +294,9 @@ MI_API int mi_apply_lut_device(int device, void* stream, const void* dev_src, vo
  * [lo, hi), table[i] = trunc(clip(i * ratio, 0, max)), float64) -> table apply.  mode 1 (luminance): one table for the
  * three channels; mode 0: one per channel, the channels below `first_channel` unchanged (1 = HSV / HLS: hue passes).
  * ref_means: host array of the reference frame's means, one per corrected channel.  dev_hist_scratch: 3 * nbins uint32;
- * dev_lut: 3 * nbins entries of the image dtype; dev_corr_out: NULL or device array that receives the ratios. */
+ * dev_lut: 3 * nbins entries of the image dtype; dev_corr_out: NULL or device array that receives the ratios.
+ * A histogram that is empty inside [lo, hi) -- np.average raises ZeroDivisionError in the reference there, which an
+ * asynchronous call cannot do -- gives ratio 1 (the channel is left unchanged). */
 MI_API int mi_balance_linear_device(int device, void* stream, void* dev_img, void* dev_hist_scratch, void* dev_lut,
                              int height, int width, int dtype, int mode, int subsample, int fast, double mask_size,
                              int lo, int hi, int first_channel, const double* ref_means, double* dev_corr_out);
