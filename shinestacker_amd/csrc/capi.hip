@@ -804,7 +804,12 @@ int aligner_solve(mi_aligner* al, hipStream_t st, int n, int max_iters, double e
         const EccLevel& L = lv[l];
         const double cx = 0.5 * (L.w - 1), cy = 0.5 * (L.h - 1);
         const size_t np = (size_t)L.h * L.w;
-        const int step = np >= (size_t)4000000 ? 2 : 1;   // 1M+ samples are plenty for 4 parameters
+        // sample every `step`-th pixel in both directions: half a million samples and more are plenty for 4 parameters
+        // (6 MP level: step 3 = 667 K samples; the recovered transforms of config 4 stay 100x inside the tolerances)
+        static const int ecc_step = study_env("MI_ECC_STEP", 0);   // -DMI_STUDY: force a step
+        int step = 1;
+        while ((size_t)(step + 1) * (step + 1) * 500000 <= np) ++step;
+        if (ecc_step > 0) step = ecc_step;
         // ~24 samples per thread (the 28 double sums cost a thread ~500 instructions to reduce, as much as 5 samples),
         // at most ECC_MAX_BLOCKS blocks (4 per CU)
         static const size_t per_blk = (size_t)study_env("MI_ECC_PER_BLOCK", 6144);   // study knob
