@@ -71,3 +71,21 @@ def test_product_does_not_import_oracle():
                 txt = open(os.path.join(dirpath, fn)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), fn
                 assert "liboracle" not in txt, fn
+
+
+def test_release_library_reads_no_environment_variable():
+    """The timing-study knobs (MI_ABLATE, MI_TAPER, MI_SERIAL, MI_CHUNK, MI_LAUNCH_FRAMES, ...) exist only in the -DMI_STUDY
+    build: the shipped library neither imports getenv nor contains their names, so a stray environment variable cannot
+    change a user's stack."""
+    import re
+    import subprocess
+    from shinestacker_amd import build as b
+    lib = b.LIB if os.path.exists(b.LIB) else b.build_extension()
+    data = open(lib, "rb").read()
+    names = set(re.findall(rb"MI_[A-Z][A-Z0-9_]{3,}", data))
+    knobs = {n for n in names if n in (b"MI_ABLATE", b"MI_TAPER", b"MI_SERIAL", b"MI_CHUNK", b"MI_LAUNCH_FRAMES", b"MI_ONLY_L0",
+                                         b"MI_WIDE_LEVELS", b"MI_BD_PRIO", b"MI_CO_PRIO", b"MI_PAR_TILES", b"MI_ECC_STEP",
+                                         b"MI_ECC_PER_BLOCK")}
+    assert not knobs, knobs
+    und = subprocess.run(["nm", "-D", "--undefined-only", lib], capture_output=True, text=True).stdout
+    assert "getenv" not in und
