@@ -23,7 +23,7 @@ def report(N, H, W, dt, recovered, truth, ref, cx, cy, where, shape):
     for f in range(N):
         if f == ref:
             continue
-        m = recovered[k]
+        m = np.asarray(recovered[k])[:2]   # ALIGN_HOMOGRAPHY: the similarity sits in the first two rows of the 3 x 3 matrix
         k += 1
         A = truth[f][:, :2]
         Ai = np.linalg.inv(A)
@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--width", type=int, default=6000)
     ap.add_argument("--balance", action="store_true", help="also balance every frame (LUMI / LINEAR, sub-sample 8)")
     ap.add_argument("--resident", action="store_true", help="frames resident in HBM (mi_aligner_* + device warp)")
+    ap.add_argument("--homography", action="store_true", help="ALIGN_HOMOGRAPHY: the estimate applied with warpPerspective (resident mode)")
     ap.add_argument("--batch", type=int, default=16, help="warped frames per push into the stacker (resident mode)")
     ap.add_argument("--step-process", action="store_true", help="the reference's chained order (resident mode)")
     ap.add_argument("--arith", default="exact", choices=["exact", "separable"], help="stacker arithmetic (resident mode)")
@@ -92,9 +93,10 @@ def main():
             buf.upload(fr, f * fb)
         out = L.DeviceBuffer(fb)
         bal = {'channel': 'LUMI', 'corr_map': 'LINEAR', 'subsample': 8} if args.balance else None
-        align_and_stack_device(buf.ptr, min(N, 4), H, W, np.uint8, out_dev=out.ptr, balance=bal, arith=args.arith, step_process=args.step_process, batch_frames=args.batch)   # warm-up
+        acfg = {'transform': 'ALIGN_HOMOGRAPHY'} if args.homography else None
+        align_and_stack_device(buf.ptr, min(N, 4), H, W, np.uint8, out_dev=out.ptr, balance=bal, arith=args.arith, step_process=args.step_process, batch_frames=args.batch, alignment_config=acfg)   # warm-up
         t0 = time.perf_counter()
-        _, tr, ccs = align_and_stack_device(buf.ptr, N, H, W, np.uint8, ref_idx=ref, out_dev=out.ptr, balance=bal, arith=args.arith, step_process=args.step_process, batch_frames=args.batch)
+        _, tr, ccs = align_and_stack_device(buf.ptr, N, H, W, np.uint8, ref_idx=ref, out_dev=out.ptr, balance=bal, arith=args.arith, step_process=args.step_process, batch_frames=args.batch, alignment_config=acfg)
         dt = time.perf_counter() - t0
         recovered = {k: m.copy() for k, m in enumerate(t for t in tr if t is not None)}
         for m in recovered.values():
