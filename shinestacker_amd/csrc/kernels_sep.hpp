@@ -117,6 +117,7 @@ template <> struct PreChunk<float> {
     __device__ __forceinline__ void load(const char* p) { __builtin_memcpy(&v, p, 16); }
     __device__ __forceinline__ void set(float a, float b, float c, float d) { v = v4f{a, b, c, d}; }
     __device__ __forceinline__ v4f get() const { return v; }
+    __device__ __forceinline__ void rot2() { v = v4f{v.z, v.w, v.x, v.y}; }   // rotate by two elements
 };
 template <> struct PreChunk<uint8_t> {
     uint32_t v;
@@ -136,6 +137,7 @@ template <> struct PreChunk<uint8_t> {
         out[2] = v2f{(float)(hi & 0xffu), (float)((hi >> 8) & 0xffu)};
     }
     __device__ __forceinline__ void load(const char* p) { __builtin_memcpy(&v, p, 4); }
+    __device__ __forceinline__ void rot2() { v = (v >> 16) | (v << 16); }
     __device__ __forceinline__ void set(float a, float b, float c, float d) {
         v = (uint32_t)a | ((uint32_t)b << 8) | ((uint32_t)c << 16) | ((uint32_t)d << 24);
     }
@@ -154,6 +156,7 @@ template <> struct PreChunk<uint16_t> {
         v0 = (uint32_t)t;
         v1 = (uint32_t)(t >> 32);
     }
+    __device__ __forceinline__ void rot2() { const uint32_t t = v0; v0 = v1; v1 = t; }
     __device__ __forceinline__ void set(float a, float b, float c, float d) {
         v0 = (uint32_t)a | ((uint32_t)b << 16);
         v1 = (uint32_t)c | ((uint32_t)d << 16);
@@ -192,6 +195,7 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
         if (tyi >= nty || txi >= ntx) return;
         y0 = a.iy0 + tyi * TH;
         x0 = a.ix0 + txi * TW;
+        if (y0 >= h || x0 >= w) return;
     } else {
         // every tile of the TH x TW grid that is not inside the interior rectangle: rows above and below it,
         // then the side columns of the rows it spans
@@ -241,7 +245,7 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const int y = oy + (p >> 1), x = ox + (p & 1);
-        const bool valid = own_tile && (INTERIOR || (y < h && x < w));
+        const bool valid = own_tile && y < h && x < w;   // edge tiles may overhang the image
         if (!fresh && valid) {
             const size_t px = (size_t)y * w + x;
             bE[p] = st_e[px];
@@ -253,13 +257,45 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
     }
 
     // ---- staging: chunk id = tid + n * NT covers patch row id / 51, floats 4 * (id % 51) .. +3
+    //
+    // The INTERIOR instantiation serves interior tiles AND edge tiles (`edge`, uniform per workgroup).  An edge tile puts
+    // the REFLECT101 image of its surroundings into the staged patch and then runs the interior code unchanged: the cells
+    // of G_{l+1}, X and Q that code computes beyond an image edge are then the bit-identical twins of the cells
+    // REFLECT101 prescribes (on the zero-stuffed grid for the expand, on Q for the blur) -- s5 and the expand taps are
+    // symmetric and float addition commutes -- PROVIDED the far edge the tile touches has an even size (the mirror about
+    // row n-1 = 2(n/2)-1 then maps G_{l+1} row n/2+k onto row n/2-1-k; an odd size does not, and those tiles stay with the
+    // general border instantiation: the host draws the line, launch_level_sep).  Pinned on the CPU by
+    // tests/test_oracle.py::test_sep_natural_extension and on the GPU by the odd/even size cases of test_gpu_separable.py.
+    // Staging an edge tile: mirrored ROWS arrive through the row part of the chunk offsets; mirrored COLUMNS are copied
+    // inside LDS after the staging barrier (6 columns per side; edge tiles pay one more barrier per frame).  Patch rows
+    // start 2 elements off the 4-element chunk grid of an image row, so the chunk that straddles an image edge holds 2
+    // in-image elements: it is loaded 2 elements further inside the row and stored rotated by 2.
     constexpr int CPR = G::GD / 4;   // chunks per patch row
     PreChunk<TIn> pre[G::NPRE];
-    uint32_t goff[G::NPRE];          // interior: byte offset of the chunk inside a frame
+    uint32_t goff[G::NPRE];          // interior / edge: byte offset of the chunk inside a frame
+    bool edge = false;
+    int colL = -1, colR = -1;        // edge: the straddling chunk column at the left / right image edge (-1: none)
+    int peR = -1;                    // edge: patch column of the image's last column when the patch crosses it
+    if constexpr (INTERIOR) {
+        edge = y0 < 6 || x0 < 6 || y0 + TH + 6 > h || x0 + TW + 6 > w;
+        const int rel = (w - (x0 - 6)) * 3;               // elements from the patch row start to the image row end
+        if (edge) {
+            if (x0 < 6) colL = 4;                          // elements 16 .. 19: columns -1 | 0
+            if (rel < G::GD) { peR = w - 1 - (x0 - 6); if ((rel & 3) == 2) colR = (rel - 2) >> 2; }
+        }
 #pragma unroll
-    for (int n = 0; n < G::NPRE; ++n) {
-        const int id = tid + n * NT, row = id / CPR, col = id - row * CPR;
-        goff[n] = (uint32_t)(((y0 - 6 + row) * w + (x0 - 6)) * 3 + 4 * col) * (uint32_t)sizeof(TIn);
+        for (int n = 0; n < G::NPRE; ++n) {
+            const int id = tid + n * NT, row = id / CPR, col = id - row * CPR;
+            int e0 = 4 * col;                              // first element of the chunk, relative to the patch row start
+            int gy = y0 - 6 + row;
+            if (edge) {
+                gy = map_clamp(gy, h);
+                if (col == colL) e0 += 2;
+                else if (col == colR) e0 -= 2;
+                e0 = clampi(e0, -(x0 - 6) * 3, rel - 4);   // chunks outside the image: anything inside the row
+            }
+            goff[n] = (uint32_t)((gy * w + (x0 - 6)) * 3 + e0) * (uint32_t)sizeof(TIn);
+        }
     }
     auto prefetch = [&](int b) {
         const char* frb = src0 + (size_t)b * a.src_stride;
@@ -294,11 +330,38 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
         int lt = tid;
         asm volatile("" : "+v"(lt));   // per-frame addresses are rebuilt from this, not hoisted out of the loop
         // ---------------- P0: stage
+        if (INTERIOR && edge) {
 #pragma unroll
-        for (int n = 0; n < G::NPRE; ++n) {
-            if ((n + 1) * NT > G::NCH && lt + n * NT >= G::NCH) continue;
-            if constexpr (RAW) pre[n].store_raw(sGr + RD * (lt + n * NT));
-            else *reinterpret_cast<v4f*>(sG + 4 * (lt + n * NT)) = pre[n].get();
+            for (int n = 0; n < G::NPRE; ++n) {
+                const int id = lt + n * NT;
+                if ((n + 1) * NT > G::NCH && id >= G::NCH) continue;
+                const int col = id - (id / CPR) * CPR;
+                PreChunk<TIn> c = pre[n];
+                if (col == colL || col == colR) c.rot2();
+                if constexpr (RAW) c.store_raw(sGr + RD * id);
+                else *reinterpret_cast<v4f*>(sG + 4 * id) = c.get();
+            }
+            __syncthreads();
+            // mirrored columns: patch column pc <- 12 - pc on the left, pc <- 2 peR - pc on the right (6 columns each)
+            for (int e = lt; e < G::GH * 18; e += NT) {
+                const int r = e / 18, k = e - r * 18, pc = k / 3, c = k - pc * 3;
+                if constexpr (RAW) {
+                    uint8_t* rowp = reinterpret_cast<uint8_t*>(sGr) + mul24(r, 4 * RD * CPR);
+                    if (colL >= 0) rowp[3 * pc + c] = rowp[3 * (12 - pc) + c];
+                    if (peR >= 0 && peR + 1 + pc < G::GW) rowp[3 * (peR + 1 + pc) + c] = rowp[3 * (peR - 1 - pc) + c];
+                } else {
+                    float* rowp = sG + mul24(r, G::GS);
+                    if (colL >= 0) rowp[3 * pc + c] = rowp[3 * (12 - pc) + c];
+                    if (peR >= 0 && peR + 1 + pc < G::GW) rowp[3 * (peR + 1 + pc) + c] = rowp[3 * (peR - 1 - pc) + c];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int n = 0; n < G::NPRE; ++n) {
+                if ((n + 1) * NT > G::NCH && lt + n * NT >= G::NCH) continue;
+                if constexpr (RAW) pre[n].store_raw(sGr + RD * (lt + n * NT));
+                else *reinterpret_cast<v4f*>(sG + 4 * (lt + n * NT)) = pre[n].get();
+            }
         }
         __syncthreads();
         if (b + 1 < nfr && !MI_ABL(16)) prefetch(b + 1);
@@ -379,7 +442,7 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
             {
                 const int i = y0 / 2 - 2 + r, j = x0 / 2 - 2 + jp;
                 bool st = r >= 2 && r < G::NH - 2 && jp >= 2 && jp < G::NW - 2 && !MI_ABL(32);
-                if constexpr (!INTERIOR) st = st && i < hn && j < wn;
+                st = st && i < hn && j < wn;   // edge / border tiles overhang the image
                 if (st) {
                     float* gp = gnext0 + (size_t)b * a.gnext_stride + ((size_t)i * wn + j) * 3;
                     if (MI_SEP_NT_STORE) {
@@ -476,7 +539,7 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const int y = oy + (p >> 1), x = ox + (p & 1);
-        if (own_tile && (INTERIOR || (y < h && x < w))) {
+        if (own_tile && y < h && x < w) {
             const size_t px = (size_t)y * w + x;
             if (bI[p] >= 0) {   // only pixels a frame of this launch won are written back (a fresh state: all of them)
                 st_e[px] = bE[p];

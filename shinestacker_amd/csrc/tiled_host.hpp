@@ -350,10 +350,20 @@ int launch_level_sep(mi_stack* s, int l, int set, const void* src, size_t src_st
     a.w = s->lw[l];
     a.hn = s->lh[l + 1];
     a.wn = s->lw[l + 1];
-    a.iy0 = cdiv(6, TH) * TH;
-    a.ix0 = cdiv(6, TW) * TW;
-    a.iy1 = (a.h - 6) / TH * TH;
-    a.ix1 = (a.w - 6) / TW * TW;
+    // The "interior" launch covers every tile whose staged patch may be mirrored into place (kernels_sep.hpp, edge tiles):
+    // all of the grid, except the tile rows / columns that reach an ODD far edge (those stay with the border kernel), and
+    // nothing at all on levels too small for a single reflection per side.
+    static const int edge_fold = study_env("MI_EDGE_FOLD", 1);   // -DMI_STUDY: 0 = the round-2 interior / border split
+    if (edge_fold && a.h >= 16 && a.w >= 16) {
+        a.iy0 = a.ix0 = 0;
+        a.iy1 = (a.h & 1) ? std::max(0, (a.h - 6) / TH * TH) : cdiv(a.h, TH) * TH;
+        a.ix1 = (a.w & 1) ? std::max(0, (a.w - 6) / TW * TW) : cdiv(a.w, TW) * TW;
+    } else {
+        a.iy0 = cdiv(6, TH) * TH;
+        a.ix0 = cdiv(6, TW) * TW;
+        a.iy1 = (a.h - 6) / TH * TH;
+        a.ix1 = (a.w - 6) / TW * TW;
+    }
     if (a.iy1 <= a.iy0 || a.ix1 <= a.ix0) a.iy0 = a.iy1 = a.ix0 = a.ix1 = 0;
     const int nyi = (a.iy1 - a.iy0) / TH, nxi = (a.ix1 - a.ix0) / TW;
     a.best_e = s->bestE[l];
@@ -374,7 +384,7 @@ int launch_level_sep(mi_stack* s, int l, int set, const void* src, size_t src_st
         attr_set = true;
     }
     const double bytes = ((double)(l == 0 ? dtype_size(s->p.in_dtype) : 4) * 3.0 * a.h * a.w + 24.0 * a.hn * a.wn) * nb;
-    const double frac_in = (double)(a.iy1 - a.iy0) * (a.ix1 - a.ix0) / ((double)a.h * a.w);
+    const double frac_in = (double)(std::min(a.iy1, a.h) - a.iy0) * (std::min(a.ix1, a.w) - a.ix0) / ((double)a.h * a.w);
     const int ntiles = cdiv(a.w, TW) * cdiv(a.h, TH);
     const size_t npx = (size_t)a.h * a.w;
     bool parallel = false;

@@ -45,6 +45,13 @@ CASES = [
     (500, 750, 6, np.float32, 32, 0.5, 4),
     (97, 1031, 3, np.uint8, 8, 0.3, 0),       # one tile row, many tile columns
     (640, 90, 3, np.uint16, 8, 0.4, 0),       # many tile rows, two tile columns
+    # edge tiles (staged through the mirror, interior code): even sizes with whole and partial tiles at the far edges,
+    # a far edge exactly on a tile boundary, images narrower than one tile + halo, the smallest level that folds (16)
+    (112, 224, 4, np.uint8, 8, 0.4, 0),
+    (284, 458, 4, np.float32, 16, 0.4, 3),
+    (30, 58, 3, np.uint16, 8, 0.4, 0),
+    (256, 64, 5, np.uint8, 8, 0.35, 0),
+    (230, 342, 4, np.uint8, 8, 0.4, 0),       # even / odd alternate down the levels: edge and border tiles side by side
 ]
 
 

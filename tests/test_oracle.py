@@ -161,3 +161,23 @@ def test_nofma_differs_from_fma(oracle):
     oracle.lib().orc_reduce_f32(np.ascontiguousarray(fr), 67, 101, 3, k, b, 0)
     assert not np.array_equal(a, b)
     assert np.allclose(a, b, rtol=1e-5)
+
+
+@pytest.mark.parametrize("h,w,exact", [(64, 96, True), (66, 100, True), (63, 96, False), (64, 95, False)])
+def test_sep_natural_extension(h, w, exact):
+    """What the edge tiles of csrc/kernels_sep.hpp rely on: run on the REFLECT101-padded image, the separable arithmetic
+    reproduces -- bit for bit, inside the original frame -- what it computes on the image itself (where REFLECT101 acts on
+    the zero-stuffed expand grid and on Q), provided the far edges have even sizes; an odd far edge does not."""
+    from oracle import oracle as orc
+    rng = np.random.default_rng(h * 1000 + w)
+    img = rng.integers(0, 256, (h, w, 3)).astype(np.uint8)
+    P = 12
+    pad = np.pad(img, ((P, P), (P, P), (0, 0)), mode="reflect")
+    out = []
+    for im in (img, pad):
+        so = orc.StreamingOracle(im.shape[0], im.shape[1], np.uint8, arith="separable", levels=1)
+        g = so.push_frame(im)
+        out.append((so.best_e[0].copy(), g[1].copy()))
+    (e, g1), (ep, g1p) = out
+    assert np.array_equal(g1p[P // 2:P // 2 + g1.shape[0], P // 2:P // 2 + g1.shape[1]], g1)
+    assert np.array_equal(ep[P:P + h, P:P + w], e) == exact
