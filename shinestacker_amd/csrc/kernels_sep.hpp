@@ -58,12 +58,12 @@ struct SepGeom {
     static constexpr int QY = TH / 2 + 2, QL = NW;            // quad rows x lanes per quad row
     static constexpr int HBH = TH + 4, HBS = XW;              // HB rows y0-2 .. y0+TH+1, columns as X
     static constexpr int LDS_FLOATS = GH * GS + NH * VS + NH * XS;
-    // Interior tiles of 8-bit frames keep the staged patch in its INPUT type (one dword per 4-element chunk instead of
-    // four): 27.5 KB of LDS instead of 51.9 and 64 VGPRs -> four workgroups per CU instead of three; P1 and P3 unpack on
-    // the fly.  Measured: level 0 of a 256 x 24 MP 8-bit stack 15.2 -> 14.5 ms.  (16-bit frames: 35.7 KB, but 70 VGPRs
-    // keep it at three workgroups -- no gain, not built.)
+    // Interior tiles of 8- and 16-bit frames keep the staged patch in its INPUT type (one / two dwords per 4-element chunk
+    // instead of four): 27.5 / 35.6 KB of LDS instead of 51.9 and 64 VGPRs -> four workgroups per CU instead of three; P1
+    // and P3 unpack on the fly.  Measured: level 0 of a 256 x 24 MP 8-bit stack 15.2 -> 14.5 ms (round 2); 16-bit frames
+    // followed in round 3, once buffer addressing had brought that instantiation from 70 to 64 VGPRs.
     static constexpr int lds_floats(int esize, bool interior) {
-        return (interior && esize == 1 ? GH * (GD / 4) : GH * GS) + NH * VS + NH * XS;
+        return (interior && esize <= 2 ? GH * (GD / 4) * esize : GH * GS) + NH * VS + NH * XS;
     }
     static_assert(GD % 4 == 0 && NW == 32, "tile width is fixed by the 32-lane quad rows");
     static_assert(QY * QL == NT, "one quad per lane");
@@ -107,6 +107,15 @@ __device__ __forceinline__ float dpp_wave_next(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
 }
 
+// Buffer addressing for the per-frame streams: a 128-bit resource (uniform: base of the frame + its size, rebuilt per frame
+// with scalar instructions) + ONE 32-bit lane offset per access -- no 64-bit lane addresses in the frame loop, and
+// accesses outside [0, size) return zero instead of faulting (an edge tile's don't-care chunks may point anywhere).
+typedef __amdgpu_buffer_rsrc_t BufRsrc;
+typedef uint32_t v2u __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ BufRsrc make_rsrc(const void* base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);   // gfx9 raw buffer
+}
+
 // 4 consecutive input elements as floats; raw form kept in registers across the frame loop for 8/16-bit input
 template <typename TIn> struct PreChunk;
 template <> struct PreChunk<float> {
@@ -115,6 +124,9 @@ template <> struct PreChunk<float> {
     static __device__ __forceinline__ v4f unpack_raw(const uint32_t*) { return v4f{}; }
     static __device__ __forceinline__ void unpack6(const uint32_t*, int, v2f*) {}
     __device__ __forceinline__ void load(const char* p) { __builtin_memcpy(&v, p, 16); }
+    __device__ __forceinline__ void load(BufRsrc r, uint32_t off) {
+        v = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+    }
     __device__ __forceinline__ void set(float a, float b, float c, float d) { v = v4f{a, b, c, d}; }
     __device__ __forceinline__ v4f get() const { return v; }
     __device__ __forceinline__ void rot2() { v = v4f{v.z, v.w, v.x, v.y}; }   // rotate by two elements
@@ -137,6 +149,7 @@ template <> struct PreChunk<uint8_t> {
         out[2] = v2f{(float)(hi & 0xffu), (float)((hi >> 8) & 0xffu)};
     }
     __device__ __forceinline__ void load(const char* p) { __builtin_memcpy(&v, p, 4); }
+    __device__ __forceinline__ void load(BufRsrc r, uint32_t off) { v = __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0); }
     __device__ __forceinline__ void rot2() { v = (v >> 16) | (v << 16); }
     __device__ __forceinline__ void set(float a, float b, float c, float d) {
         v = (uint32_t)a | ((uint32_t)b << 8) | ((uint32_t)c << 16) | ((uint32_t)d << 24);
@@ -147,14 +160,31 @@ template <> struct PreChunk<uint8_t> {
 };
 template <> struct PreChunk<uint16_t> {
     uint32_t v0, v1;
-    __device__ __forceinline__ void store_raw(uint32_t*) const {}                       // never used: stages as fp32
-    static __device__ __forceinline__ v4f unpack_raw(const uint32_t*) { return v4f{}; }
-    static __device__ __forceinline__ void unpack6(const uint32_t*, int, v2f*) {}
+    // raw LDS form: two dwords = four elements
+    __device__ __forceinline__ void store_raw(uint32_t* q) const { *reinterpret_cast<v2u*>(q) = v2u{v0, v1}; }
+    static __device__ __forceinline__ v4f unpack_raw(const uint32_t* q) {
+        const v2u w = *(const volatile v2u __attribute__((address_space(3)))*)(uint32_t)(uintptr_t)q;
+        return v4f{(float)(w.x & 0xffffu), (float)(w.x >> 16), (float)(w.y & 0xffffu), (float)(w.y >> 16)};
+    }
+    // six consecutive elements starting at element `e0` (even) of the row at `row`
+    static __device__ __forceinline__ void unpack6(const uint32_t* row, int e0, v2f* out) {
+        const uint32_t* q = row + (e0 >> 1);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const uint32_t w = q[k];
+            out[k] = v2f{(float)(w & 0xffffu), (float)(w >> 16)};
+        }
+    }
     __device__ __forceinline__ void load(const char* p) {
         uint64_t t;
         __builtin_memcpy(&t, p, 8);
         v0 = (uint32_t)t;
         v1 = (uint32_t)(t >> 32);
+    }
+    __device__ __forceinline__ void load(BufRsrc r, uint32_t off) {
+        const v2u t = __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0);
+        v0 = t.x;
+        v1 = t.y;
     }
     __device__ __forceinline__ void rot2() { const uint32_t t = v0; v0 = v1; v1 = t; }
     __device__ __forceinline__ void set(float a, float b, float c, float d) {
@@ -171,8 +201,8 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
     using G = SepGeom<TH, NT>;
     constexpr int TW = G::TW;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr bool RAW = INTERIOR && sizeof(TIn) == 1;   // staged patch kept in the input type (see SepGeom::lds_floats)
-    constexpr int RD = 1;                                // dwords per 4-element chunk in that form
+    constexpr bool RAW = INTERIOR && sizeof(TIn) <= 2;   // staged patch kept in the input type (see SepGeom::lds_floats)
+    constexpr int RD = (int)sizeof(TIn);                 // dwords per 4-element chunk in that form
     float* sG = smem;
     uint32_t* sGr = reinterpret_cast<uint32_t*>(smem);
     float* sV = smem + (G::lds_floats((int)sizeof(TIn), INTERIOR) - G::NH * G::VS - G::NH * G::XS);
@@ -297,14 +327,16 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
             goff[n] = (uint32_t)((gy * w + (x0 - 6)) * 3 + e0) * (uint32_t)sizeof(TIn);
         }
     }
+    const uint32_t frame_bytes = (uint32_t)h * (uint32_t)w * 3u * (uint32_t)sizeof(TIn);
     auto prefetch = [&](int b) {
         const char* frb = src0 + (size_t)b * a.src_stride;
+        const BufRsrc rs = make_rsrc(frb, frame_bytes);
 #pragma unroll
         for (int n = 0; n < G::NPRE; ++n) {
             const int id = tid + n * NT;
             if ((n + 1) * NT > G::NCH && id >= G::NCH) continue;
             if constexpr (INTERIOR) {
-                pre[n].load(frb + goff[n]);
+                pre[n].load(rs, goff[n]);
             } else {
                 const TIn* fr = (const TIn*)frb;
                 const int row = id / CPR, col = id - row * CPR;
@@ -346,7 +378,7 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
             for (int e = lt; e < G::GH * 18; e += NT) {
                 const int r = e / 18, k = e - r * 18, pc = k / 3, c = k - pc * 3;
                 if constexpr (RAW) {
-                    uint8_t* rowp = reinterpret_cast<uint8_t*>(sGr) + mul24(r, 4 * RD * CPR);
+                    TIn* rowp = reinterpret_cast<TIn*>(sGr) + mul24(r, G::GD);
                     if (colL >= 0) rowp[3 * pc + c] = rowp[3 * (12 - pc) + c];
                     if (peR >= 0 && peR + 1 + pc < G::GW) rowp[3 * (peR + 1 + pc) + c] = rowp[3 * (peR - 1 - pc) + c];
                 } else {
@@ -365,6 +397,7 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
         }
         __syncthreads();
         if (b + 1 < nfr && !MI_ABL(16)) prefetch(b + 1);
+        const BufRsrc gn_rs = make_rsrc(gnext0 + (size_t)b * a.gnext_stride, (uint32_t)hn * (uint32_t)wn * 12u);
 
         // ---------------- P1: vertical reduce, 2 V rows x one float4 column group per lane
         if (lt < (G::NH / 2) * CPR && !MI_ABL(1)) {
@@ -444,14 +477,12 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
                 bool st = r >= 2 && r < G::NH - 2 && jp >= 2 && jp < G::NW - 2 && !MI_ABL(32);
                 st = st && i < hn && j < wn;   // edge / border tiles overhang the image
                 if (st) {
-                    float* gp = gnext0 + (size_t)b * a.gnext_stride + ((size_t)i * wn + j) * 3;
-                    if (MI_SEP_NT_STORE) {
-                        __builtin_nontemporal_store(n[0], gp);
-                        __builtin_nontemporal_store(n[1], gp + 1);
-                        __builtin_nontemporal_store(n[2], gp + 2);
-                    } else {
-                        gp[0] = n[0]; gp[1] = n[1]; gp[2] = n[2];
-                    }
+                    typedef uint32_t v3u __attribute__((ext_vector_type(3)));
+                    const v3u pv = {__builtin_bit_cast(uint32_t, n[0]), __builtin_bit_cast(uint32_t, n[1]),
+                                    __builtin_bit_cast(uint32_t, n[2])};
+                    // one 12-byte buffer store, non-temporal (aux bit 1 = NT on gfx94x / gfx950): written once, read by
+                    // the next level's launch much later
+                    __builtin_amdgcn_raw_buffer_store_b96(pv, gn_rs, (uint32_t)mul24(mul24(i, wn) + j, 12), 0, MI_SEP_NT_STORE ? 2 : 0);
                 }
             }
             // gray of the pixel, its neighbours along the row by DPP, expanded columns 2j' (even) and 2j'+1 (odd)
@@ -556,7 +587,7 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
 #define MI_SEP_BD_WAVES 1
 #endif
 template <typename TIn, bool INTERIOR, int TH, int NT>
-__global__ __launch_bounds__(NT, INTERIOR ? (sizeof(TIn) == 1 ? 8 : 1) : MI_SEP_BD_WAVES) void level_sep(LevelArgs a) {
+__global__ __launch_bounds__(NT, INTERIOR ? (sizeof(TIn) <= 2 ? 8 : 1) : MI_SEP_BD_WAVES) void level_sep(LevelArgs a) {
     level_sep_body<TIn, INTERIOR, TH, NT>(a);
 }
 template <typename TIn, bool INTERIOR, int TH, int NT>
