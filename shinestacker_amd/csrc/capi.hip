@@ -1415,8 +1415,8 @@ int mi_combine_select(int device, void* stream, int n, const void* cand_e, const
 }
 
 int mi_combine_winner(int device, void* stream, int n, const void* cand_e, size_t npix, void* win) {
+    if (npix == 0) return MI_OK;   // an empty chunk (its buffers may be null pointers) is a no-op
     if (n < 1 || n > CB_MAXR || !cand_e || !win) return fail(MI_ERR_INVALID, "bad argument (1 <= ranks <= %d)", CB_MAXR);
-    if (npix == 0) return MI_OK;
     MI_HIP(hipSetDevice(device));
     hipLaunchKernelGGL(combine_winner, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n,
                        (const float*)cand_e, npix, (uint8_t*)win);
@@ -1429,7 +1429,11 @@ size_t mi_combine_plan_bytes(size_t npix, int n_ranks) {
 }
 
 int mi_combine_plan(int device, void* stream, const void* win, size_t npix, int n_ranks, void* plan, int64_t* totals) {
-    if (n_ranks < 1 || n_ranks > CB_MAXR || !win || !plan || !totals) return fail(MI_ERR_INVALID, "bad argument");
+    if (n_ranks < 1 || n_ranks > CB_MAXR || !totals || (npix && (!win || !plan))) return fail(MI_ERR_INVALID, "bad argument");
+    if (npix == 0) {   // nothing to plan: no launch, no synchronisation
+        for (int r = 0; r < n_ranks; ++r) totals[r] = 0;
+        return MI_OK;
+    }
     MI_HIP(hipSetDevice(device));
     const size_t nblocks = (npix + CB_PX - 1) / CB_PX;
     uint32_t* counts = (uint32_t*)plan;
@@ -1451,9 +1455,9 @@ int mi_combine_plan(int device, void* stream, const void* win, size_t npix, int 
 
 int mi_combine_pack(int device, void* stream, const void* win, size_t npix, int n_ranks, int rank, const void* plan,
                     const void* src, int width, void* out) {
+    if (npix == 0) return MI_OK;
     if (n_ranks < 1 || n_ranks > CB_MAXR || rank < 0 || rank >= n_ranks || !win || !plan || !src || !out || width < 1)
         return fail(MI_ERR_INVALID, "bad argument");
-    if (npix == 0) return MI_OK;
     MI_HIP(hipSetDevice(device));
     hipLaunchKernelGGL((combine_move<true>), dim3((unsigned)((npix + CB_PX - 1) / CB_PX)), dim3(256), 0, (hipStream_t)stream,
                        (const uint8_t*)win, npix, n_ranks, rank, (const uint32_t*)plan, (const float*)src,
@@ -1464,9 +1468,9 @@ int mi_combine_pack(int device, void* stream, const void* win, size_t npix, int 
 
 int mi_combine_unpack(int device, void* stream, const void* win, size_t npix, int n_ranks, int rank, const void* plan,
                       const void* const* dev_bufs, int width, void* dst) {
+    if (npix == 0) return MI_OK;
     if (n_ranks < 1 || n_ranks > CB_MAXR || rank < 0 || rank >= n_ranks || !win || !plan || !dev_bufs || !dst || width < 1)
         return fail(MI_ERR_INVALID, "bad argument");
-    if (npix == 0) return MI_OK;
     MI_HIP(hipSetDevice(device));
     hipLaunchKernelGGL((combine_move<false>), dim3((unsigned)((npix + CB_PX - 1) / CB_PX)), dim3(256), 0, (hipStream_t)stream,
                        (const uint8_t*)win, npix, n_ranks, rank, (const uint32_t*)plan, (const float*)nullptr,
@@ -1522,6 +1526,12 @@ int warp_device_impl(int device, void* stream, const void* dev_src, void* dev_ds
         sum = 1.0 / sum;
         for (int i = 0; i < blur_ksize; ++i) g.k[i] = (float)(t[i] * sum);
     }
+    // The tile scratch (counter / bitmap / list) is cached per (device, stream): two host threads that warp on the SAME
+    // stream -- the two step_process chains of pipeline._align_chains_device on the default stream -- must not interleave
+    // their enqueue sequences (memset, warp marks tiles, bitmap -> list, blur, scatter), or one warp's memset lands between
+    // the other's marks and its list.  One lock across the whole sequence; the stream then runs the sequences in order.
+    static std::mutex enqueue_mu;
+    std::lock_guard<std::mutex> lk(enqueue_mu);
     if (dtype == MI_U8)
         return warp_launch<uint8_t>(device, (hipStream_t)stream, dev_src, dev_tmp, dev_dst, (uint8_t*)dev_mask, height, width, a,
                                     blur, g, persp ? &pa : nullptr);

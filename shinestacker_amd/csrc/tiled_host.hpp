@@ -217,13 +217,33 @@ constexpr int ilcm(int a, int b) {
     return a / x * b;
 }
 
+// MI_ARITH_SEPARABLE: interior and border tiles of level l on the separable kernel (kernels_sep.hpp); one tile
+// grid (28 x 56, origin at the image corner) for both, the interior rectangle = the whole tiles whose 6-pixel
+// halo stays inside the image.
+// How a level with `tiles` workgroups walks the `nb` frames of a batch.  A workgroup visits its frames one after the
+// other, so (a) a level with few tiles is latency-bound unless the batch is cut into chunks that run side by side
+// (blockIdx.y; about four rounds of workgroups for the GPU's 768 slots, chunks of 16 to 32 frames, partial maxima merged
+// afterwards), and (b) over a long walk neighbouring workgroups drift apart in time and stop sharing their halos in L2
+// (measured on 24 MP frames: 256 frames in one launch cost 3.1 ms per 32 frames, launches of 32 frames 2.9 ms, of 16
+// frames 2.7 ms, of 8 frames 2.75 ms), so a level with many tiles runs as consecutive launches of 16 frames.  Returns the frames per chunk / per launch.
+constexpr int SEP_LAUNCH_FRAMES = 16;
+inline int level_chunk_frames(int nb, int tiles, bool* parallel) {
+    static const int on = study_env("MI_CHUNK", 1);           // -DMI_STUDY: 0 = never in parallel chunks
+    static const int lf = study_env("MI_LAUNCH_FRAMES", SEP_LAUNCH_FRAMES);
+    static const int par = study_env("MI_PAR_TILES", 3072);   // -DMI_STUDY: tile count below which chunks run side by side
+    const int c = par / std::max(tiles, 1);
+    *parallel = on && c > 1 && nb >= 32;
+    if (!*parallel) return std::min(nb, lf);
+    return std::min(lf, std::max(16, cdiv(cdiv(nb, c), 4) * 4));
+}
+
 // Launch the interior and border kernels of level l for `nb` frames.
 //   interior kernel: tile config A (TH, TW, NT, padded LDS), stream st_in
 //   border kernel  : tile config B (BH, BW, BNT, unpadded LDS: small enough to co-reside
 //                    with two level-0 interior workgroups on one CU), stream st_bd
 template <typename TIn, bool FMA, int TH, int TW, int NT, bool PADA, int BH, int BW, int BNT, bool COARSE_NAME = false>
 int launch_level(mi_stack* s, int l, int set, const void* src, size_t src_stride, int nb,
-                 hipStream_t st_in, hipStream_t st_bd) {
+                 hipStream_t st_in, hipStream_t st_bd, hipEvent_t ev_bd) {
     using GA = TileGeom<TH, TW, NT, PADA>;
     using GB = TileGeom<BH, BW, BNT, false>;
     TiledState* t = tstate(s);
@@ -297,39 +317,69 @@ int launch_level(mi_stack* s, int l, int set, const void* src, size_t src_stride
     const double bytes = ((double)(l == 0 ? dtype_size(s->p.in_dtype) : 4) * 3.0 * a.h * a.w +
                           24.0 * a.hn * a.wn) * nb;
     const double frac_in = (double)(a.iy1 - a.iy0) * (a.ix1 - a.ix0) / ((double)a.h * a.w);
-    {   // border first: its few, latency-bound workgroups should claim their slots early
-        const int tbx = cdiv(a.w, BW), tby = cdiv(a.h, BH);
-        const int nborder = tbx * tby - ((a.iy1 - a.iy0) / BH) * ((a.ix1 - a.ix0) / BW);
-        ProfScope ps(s, MI_PROF_LEVEL, bytes * (1.0 - frac_in), st_bd);
-        if (nborder > 0 && !MI_ABL(256)) hipLaunchKernelGGL(kbd, dim3(nborder), dim3(BNT), ldsB, st_bd, a);
+    // Frames per launch / per chunk exactly as for the separable kernel (level_chunk_frames): levels with many tiles as
+    // consecutive launches of 16 frames, levels with few tiles as frame chunks side by side + merge_chunks.
+    const int tbx = cdiv(a.w, BW), tby = cdiv(a.h, BH);
+    const int nborder = tbx * tby - ((a.iy1 - a.iy0) / BH) * ((a.ix1 - a.ix0) / BW);
+    const int ntiles = nyi * nxi + nborder;
+    const size_t npx = (size_t)a.h * a.w;
+    bool parallel = false;
+    const int fc = level_chunk_frames(nb, ntiles, &parallel);
+    const int nchunks = parallel ? cdiv(nb, fc) : 1;
+    if (nchunks > 1) {
+        const size_t need = npx * (size_t)(nchunks - 1);
+        if (t->part_cap[l] < need) {   // grows only; the buffers may still be in use by the previous batch
+            int rc;
+            if ((rc = tiled_sync_all(s))) return rc;
+            MI_HIP(hipStreamSynchronize(s->stream));
+            dev_release(s, t->partE[l]);
+            dev_release(s, t->partI[l]);
+            t->partE[l] = nullptr;
+            t->partI[l] = nullptr;
+            t->part_cap[l] = 0;
+            if ((rc = dev_alloc_t(s, &t->partE[l], need)) || (rc = dev_alloc_t(s, &t->partI[l], need))) return rc;
+            t->part_cap[l] = need;
+        }
+        a.part_e = t->partE[l];
+        a.part_idx = t->partI[l];
+        a.part_stride = npx;
     }
-    if MI_ABL(512) {
-    } else if (nyi > 0) {
+    const int first = a.first, idx0 = a.frame_idx0;
+    const int step = parallel ? nb : fc, nlaunch = cdiv(nb, step);
+    auto frames_of = [&](int f0) {
+        const int nf = parallel ? nb : std::min(fc, nb - f0);
+        a.src = (const char*)src + (size_t)f0 * src_stride;
+        a.gnext = t->Gb[set][l + 1] + (size_t)f0 * a.gnext_stride;
+        a.nframes = nf;
+        a.chunk_frames = parallel ? fc : nf;
+        a.first = first && f0 == 0;
+        a.frame_idx0 = idx0 + f0;
+    };
+    if (nborder > 0 && !MI_ABL(256)) {   // border first: its few, latency-bound workgroups should claim their slots early
+        ProfScope ps(s, MI_PROF_LEVEL, bytes * (1.0 - frac_in), st_bd);
+        ps.r.launches = nlaunch;
+        for (int f0 = 0; f0 < nb; f0 += step) {
+            frames_of(f0);
+            hipLaunchKernelGGL(kbd, dim3(nborder, nchunks), dim3(BNT), ldsB, st_bd, a);
+        }
+    }
+    if (!MI_ABL(512) && nyi > 0) {
         const int nsb = cdiv(nxi, SB) * cdiv(nyi, SB);
         ProfScope ps(s, l == 0 ? MI_PROF_LEVEL0 : MI_PROF_LEVEL, bytes * frac_in, st_in);
-        hipLaunchKernelGGL(kin, dim3(cdiv(nsb, 8) * 8 * SB * SB), dim3(NT), ldsA, st_in, a);
+        ps.r.launches = nlaunch;
+        for (int f0 = 0; f0 < nb; f0 += step) {
+            frames_of(f0);
+            hipLaunchKernelGGL(kin, dim3(cdiv(nsb, 8) * 8 * SB * SB, nchunks), dim3(NT), ldsA, st_in, a);
+        }
+    }
+    if (nchunks > 1) {
+        MI_HIP(hipEventRecord(ev_bd, st_bd));
+        MI_HIP(hipStreamWaitEvent(st_in, ev_bd, 0));
+        ProfScope ps(s, MI_PROF_LEVEL, 0.0, st_in);
+        hipLaunchKernelGGL(merge_chunks, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, st_in, s->bestE[l], s->bestIdx[l],
+                           t->partE[l], t->partI[l], npx, nchunks - 1, npx);
     }
     return MI_OK;
-}
-
-// MI_ARITH_SEPARABLE: interior and border tiles of level l on the separable kernel (kernels_sep.hpp); one tile
-// grid (28 x 56, origin at the image corner) for both, the interior rectangle = the whole tiles whose 6-pixel
-// halo stays inside the image.
-// How a level with `tiles` workgroups walks the `nb` frames of a batch.  A workgroup visits its frames one after the
-// other, so (a) a level with few tiles is latency-bound unless the batch is cut into chunks that run side by side
-// (blockIdx.y; about four rounds of workgroups for the GPU's 768 slots, chunks of 16 to 32 frames, partial maxima merged
-// afterwards), and (b) over a long walk neighbouring workgroups drift apart in time and stop sharing their halos in L2
-// (measured on 24 MP frames: 256 frames in one launch cost 3.1 ms per 32 frames, launches of 32 frames 2.9 ms, of 16
-// frames 2.7 ms, of 8 frames 2.75 ms), so a level with many tiles runs as consecutive launches of 16 frames.  Returns the frames per chunk / per launch.
-constexpr int SEP_LAUNCH_FRAMES = 16;
-inline int sep_chunk_frames(int nb, int tiles, bool* parallel) {
-    static const int on = study_env("MI_CHUNK", 1);           // -DMI_STUDY: 0 = never in parallel chunks
-    static const int lf = study_env("MI_LAUNCH_FRAMES", SEP_LAUNCH_FRAMES);
-    static const int par = study_env("MI_PAR_TILES", 3072);   // -DMI_STUDY: tile count below which chunks run side by side
-    const int c = par / std::max(tiles, 1);
-    *parallel = on && c > 1 && nb >= 32;
-    if (!*parallel) return std::min(nb, lf);
-    return std::min(lf, std::max(16, cdiv(cdiv(nb, c), 4) * 4));
 }
 
 // `ev_bd`: recorded on st_bd behind the border kernel when the level ran in chunks (the merge on st_in waits for it).
@@ -388,7 +438,7 @@ int launch_level_sep(mi_stack* s, int l, int set, const void* src, size_t src_st
     const int ntiles = cdiv(a.w, TW) * cdiv(a.h, TH);
     const size_t npx = (size_t)a.h * a.w;
     bool parallel = false;
-    const int fc = sep_chunk_frames(nb, ntiles, &parallel);
+    const int fc = level_chunk_frames(nb, ntiles, &parallel);
     const int nchunks = parallel ? cdiv(nb, fc) : 1;
     if (nchunks > 1) {
         const size_t need = npx * (size_t)(nchunks - 1);
@@ -465,6 +515,22 @@ int launch_payload_sep(mi_stack* s, int l, int set, const void* src, size_t src_
     return MI_OK;
 }
 
+// MI_ARITH_EXACT: the same for the reference-order arithmetic (exact_payload, kernels_tiled.hpp)
+template <typename TIn, bool FMA>
+int launch_payload_exact(mi_stack* s, int l, int set, const void* src, size_t src_stride, int nb, hipStream_t st) {
+    TiledState* t = tstate(s);
+    const dim3 blk(32, 8);
+    const dim3 grd(cdiv(cdiv(s->lw[l], 2), blk.x), cdiv(cdiv(s->lh[l], 2), blk.y));
+    K6 K{};
+    for (int i = 0; i < 3; ++i)
+        for (int j = i; j < 3; ++j) K.c[i == 0 ? j : (i == 1 ? 2 + j : 5)] = s->K.k[i * 5 + j];
+    ProfScope ps(s, MI_PROF_LEVEL, 0.0, st);
+    hipLaunchKernelGGL((exact_payload<TIn, FMA>), grd, blk, 0, st, src, src_stride, (const float*)t->Gb[set][l + 1],
+                       t->gstride[l + 1], nb, s->lh[l], s->lw[l], s->lh[l + 1], s->lw[l + 1], (const int32_t*)s->bestIdx[l],
+                       s->first_index + s->n_pushed, s->bestLap[l], K);
+    return MI_OK;
+}
+
 template <typename TIn, bool FMA>
 int run_batch(mi_stack* s, const void* frames, size_t stride, int nb) {
     TiledState* t = tstate(s);
@@ -483,14 +549,16 @@ int run_batch(mi_stack* s, const void* frames, size_t stride, int nb) {
     if (s->sep) rc = launch_level_sep<TIn, true>(s, 0, set, frames, stride, nb, st0, st1, t->evL0b[set]);
     else
         rc = launch_level<TIn, FMA, MI_TILE0_H, MI_TILE0_W, MI_TILE0_NT, MI_TILE_PAD != 0, MI_TILE_H, MI_TILE_W, MI_TILE_NT>(
-            s, 0, set, frames, stride, nb, st0, st1);
+            s, 0, set, frames, stride, nb, st0, st1, t->evL0b[set]);
     if (rc) return rc;
     MI_HIP(hipEventRecord(t->evL0i[set], st0));
     MI_HIP(hipEventRecord(t->evL0b[set], st1));
     MI_HIP(hipStreamWaitEvent(st2, t->evL0i[set], 0));
     MI_HIP(hipStreamWaitEvent(st2, t->evL0b[set], 0));
     MI_HIP(hipStreamWaitEvent(st1, t->evL0i[set], 0));
-    if (s->sep && (rc = launch_payload_sep<TIn>(s, 0, set, frames, stride, nb, st2))) return rc;
+    if ((rc = s->sep ? launch_payload_sep<TIn>(s, 0, set, frames, stride, nb, st2)
+                     : launch_payload_exact<TIn, FMA>(s, 0, set, frames, stride, nb, st2)))
+        return rc;
     MI_HIP(hipEventRecord(t->evL0done[set], st2));   // st2 waited for both level-0 kernels above
     // coarser levels: interior tiles on st2, border tiles on st1 (disjoint tiles of one level run
     // side by side); both streams join after every level because level l+1 reads all of G_{l+1}
@@ -505,10 +573,10 @@ int run_batch(mi_stack* s, const void* frames, size_t stride, int nb) {
                                                 t->evLvl[(set * (L + 1) + l) * 2 + 1]);
         else if (wide)
             rc = launch_level<float, FMA, MI_TILE0_H, MI_TILE0_W, MI_TILE0_NT, MI_TILE_PAD != 0, MI_TILE_H, MI_TILE_W, MI_TILE_NT, true>(
-                s, l, set, t->Gb[set][l], t->gstride[l] * sizeof(float), nb, st2, st1);
+                s, l, set, t->Gb[set][l], t->gstride[l] * sizeof(float), nb, st2, st1, t->evLvl[(set * (L + 1) + l) * 2 + 1]);
         else
             rc = launch_level<float, FMA, MI_TILE_H, MI_TILE_W, MI_TILE_NT, false, MI_TILE_H, MI_TILE_W, MI_TILE_NT>(
-                s, l, set, t->Gb[set][l], t->gstride[l] * sizeof(float), nb, st2, st1);
+                s, l, set, t->Gb[set][l], t->gstride[l] * sizeof(float), nb, st2, st1, t->evLvl[(set * (L + 1) + l) * 2 + 1]);
         if (rc)
             return rc;
         hipEvent_t ei = t->evLvl[(set * (L + 1) + l) * 2], eb = t->evLvl[(set * (L + 1) + l) * 2 + 1];
@@ -516,7 +584,9 @@ int run_batch(mi_stack* s, const void* frames, size_t stride, int nb) {
         MI_HIP(hipEventRecord(eb, st1));
         MI_HIP(hipStreamWaitEvent(st2, eb, 0));
         MI_HIP(hipStreamWaitEvent(st1, ei, 0));
-        if (s->sep && (rc = launch_payload_sep<float>(s, l, set, t->Gb[set][l], t->gstride[l] * sizeof(float), nb, st2))) return rc;
+        if ((rc = s->sep ? launch_payload_sep<float>(s, l, set, t->Gb[set][l], t->gstride[l] * sizeof(float), nb, st2)
+                         : launch_payload_exact<float, FMA>(s, l, set, t->Gb[set][l], t->gstride[l] * sizeof(float), nb, st2)))
+            return rc;
     }
     MI_HIP(hipGetLastError());
     if (!only_l0) {   // base level of the whole batch
@@ -577,7 +647,7 @@ int tiled_push(mi_stack* s, const void* dev_frames, int n, size_t stride) {
     // frames: every kernel has the GPU to itself, a pixel's winning Laplacian is filled in once, and the small levels run
     // in frame chunks); longer pushes are cut into equal batches.  MI_ARITH_EXACT keeps batches of `bcap` frames.
     int sep_nb = 0;
-    if (s->sep && n > 0) {
+    if (n > 0) {
         if (t->dev_cap == 0) {
             if (s->p.batch_frames > 0) t->dev_cap = s->p.batch_frames;
             else {

@@ -108,13 +108,17 @@ def align_and_stack(frames, ref_idx=-1, estimator=None, alignment_config=None, f
 
 
 def _align_chains_device(lib, dev_frames, aligned, n_frames, height, width, dt, ref_idx, cfg, min_correlation, max_iters,
-                         device):
+                         device, corr=None):
     """`step_process=True` (stack_framework.py:214-232, the documented default of the reference's jobs): frame ref+1 is
     aligned to the reference frame, ref+2 to the ALIGNED ref+1, ... and ref-1, ref-2, ... the same way downwards -- two
     serial chains.  Every step needs the previous step's warped frame, so the batched estimator does not apply; the two
     chains are independent and run side by side (one host thread and one estimator handle each).  Aligned frames are
-    written to `aligned` at their own index.  Returns (transforms, correlation coefficients)."""
+    written to `aligned` at their own index.  `corr` (a BalanceFrames correction, already begun on the reference frame):
+    every aligned frame is balanced BEFORE it becomes the next step's reference, as the reference's CombinedActions does
+    (the step reference is read back from the output directory, i.e. after align AND balance,
+    stack_framework.py:259-262, :282-289).  Returns (transforms, correlation coefficients)."""
     import threading
+    corr_lock = threading.Lock()   # one correction object (its histogram / table scratch) serves both chains
     fb = height * width * 3 * dt.itemsize
     mode = _BORDER_CODE[cfg['border_mode']]
     bv = (C.c_double * 4)(*(list(cfg['border_value']) + [0, 0, 0, 0])[:4])
@@ -123,6 +127,7 @@ def _align_chains_device(lib, dev_frames, aligned, n_frames, height, width, dt, 
     _lib.check(lib.mi_memcpy_d2d(device, aligned + ref_idx * fb, dev_frames + ref_idx * fb, fb))   # align.py:279-280
 
     def chain(indices):
+        aligner = tmp = mask = None
         try:
             aligner = _lib.Aligner(height, width, dt, subsample=max(1, int(cfg['subsample'])), device=device,
                                    fast=bool(cfg['fast_subsampling']))
@@ -140,11 +145,19 @@ def _align_chains_device(lib, dev_frames, aligned, n_frames, height, width, dt, 
                 warp = lib.mi_warp_perspective_device if homography else lib.mi_warp_affine_device
                 _lib.check(warp(device, None, dev_frames + i * fb, aligned + i * fb, tmp.ptr, mask.ptr, height, width,
                                 _lib.DTYPE_CODE[dt], arr, mode, bv, 21, float(cfg['border_blur'])))
-                _lib.check(lib.mi_device_synchronize(device))    # the next step's reference is this warp's output
+                if corr is not None:
+                    with corr_lock:
+                        corr.apply_correction_device(i, aligned + i * fb, None)
+                _lib.check(lib.mi_device_synchronize(device))    # the next step's reference is this step's output
                 prev = i
-            aligner.close()
         except Exception as e:  # noqa: BLE001  re-raised on the calling thread
             errors.append(e)
+        finally:   # a chain that raises must not leak its estimator handle and buffers
+            if aligner is not None:
+                aligner.close()
+            for b in (tmp, mask):
+                if b is not None:
+                    b.free()
 
     threads = [threading.Thread(target=chain, args=(list(range(ref_idx + 1, n_frames)),)),
                threading.Thread(target=chain, args=(list(range(ref_idx - 1, -1, -1)),))]
@@ -216,16 +229,14 @@ def align_and_stack_device(dev_frames, n_frames, height, width, dtype, ref_idx=-
     lib = _lib.load()
     if step_process:
         aligned = _lib.DeviceBuffer(fb * n_frames, device)
+        corr = None
+        if balance is not None:
+            corr = _make_correction(balance, device)
+            corr.begin_device(dev_frames + ref_idx * fb, height, width, dt, n_frames)
         transforms, ccs = _align_chains_device(lib, dev_frames, aligned.ptr, n_frames, height, width, dt, ref_idx, cfg,
-                                               min_correlation, max_iters, device)
+                                               min_correlation, max_iters, device, corr)
         stack = _lib.Stack(height, width, in_dtype=dt, out_dtype=dt, device=device, **stack_kwargs)
         try:
-            if balance is not None:
-                corr = _make_correction(balance, device)
-                corr.begin_device(aligned.ptr + ref_idx * fb, height, width, dt, n_frames)
-                for i in range(n_frames):
-                    if i != ref_idx:
-                        corr.apply_correction_device(i, aligned.ptr + i * fb, stack.stream)
             stack.push_frames_device(aligned.ptr, n_frames, fb)
             if out_dev is not None:
                 stack.finish_device(out_dev)

@@ -273,3 +273,44 @@ def test_device_area_subsampling_equals_host_resize(L, oracle, dtype, s):
     m_fast, _, _ = al.estimate(buf.ptr + ref.nbytes)
     al.close()
     assert not np.array_equal(m_fast, m_dev)
+
+
+def test_step_process_chains_balance_before_the_next_reference(L, oracle):
+    """step_process with BalanceFrames: the reference's CombinedActions reads the step reference back from the output
+    directory, i.e. AFTER align and balance (stack_framework.py:259-262, :282-289).  The resident pipeline must register
+    frame i against the aligned AND balanced frame i-1 -- checked against the same steps through the single-frame entry
+    points and the host form of the correction classes."""
+    from shinestacker_amd import constants
+    from shinestacker_amd.pipeline import _make_correction, align_and_stack_device
+    h, w, n = 256, 384, 5
+    ref_idx = n // 2
+    frames = []
+    for f in range(n):
+        d = f - ref_idx
+        T = similarity(0.1 * d, 1 + 3e-4 * d, 1.2 * d, -0.7 * d, (w - 1) / 2, (h - 1) / 2)
+        ref, mov = make_pair(oracle, T, h=h, w=w, seed=21, noise=2.0)
+        img = ref if d == 0 else mov
+        # a per-frame exposure change for the balance to undo
+        frames.append(np.clip(img.astype(np.float32) * (1.0 + 0.04 * d), 0, 255).astype(np.uint8))
+    fb = frames[0].nbytes
+    buf = L.DeviceBuffer(n * fb)
+    for f, fr in enumerate(frames):
+        buf.upload(fr, f * fb)
+    bal = dict(channel=constants.BALANCE_LUMI, corr_map=constants.BALANCE_LINEAR, subsample=1)
+    fused, tr, _ = align_and_stack_device(buf.ptr, n, h, w, np.uint8, alignment_config={'subsample': 1}, step_process=True,
+                                          balance=bal)
+    corr = _make_correction(bal, 0)
+    corr.begin(frames[ref_idx], n, ref_idx)
+    out = {ref_idx: frames[ref_idx]}
+    for chain in (range(ref_idx + 1, n), range(ref_idx - 1, -1, -1)):
+        prev = ref_idx
+        for i in chain:
+            m, _, _ = L.ecc_similarity(out[prev], frames[i])
+            assert np.allclose(m, tr[i], rtol=0, atol=1e-9), i
+            out[i] = corr.apply_correction(i, L.warp_affine(frames[i], tr[i]))
+            prev = i
+    so = oracle.StreamingOracle(h, w, np.uint8, keep_gauss=False)
+    for i in range(n):
+        so.push_frame(out[i])
+    assert np.array_equal(fused, so.finish())
+    buf.free()
