@@ -50,7 +50,7 @@ def img_subsample(img, subsample, fast=True):
     s = int(subsample)
     if s == 1:
         return img
-    if have_opencv():   # pragma: no cover - OpenCV is not part of this image
+    if have_opencv():
         import cv2
         return cv2.resize(img, (0, 0), fx=1 / s, fy=1 / s, interpolation=cv2.INTER_AREA)
     h, w = img.shape[:2]
@@ -103,54 +103,54 @@ def opencv_estimator(img_0_sub, img_1_sub, feature_config, matching_config, alig
     validate_align_config(detector_name, descriptor_name, match_method)
     try:
         import cv2
-    except ImportError as e:  # pragma: no cover - OpenCV is not part of this image
+    except ImportError as e:
         raise RuntimeError(
             "opencv_estimator needs OpenCV (cv2), which is not installed; use estimator='auto' / ecc_estimator(), or "
             "pass estimator=callable(img_0_sub, img_1_sub, feature_cfg, matching_cfg, alignment_cfg) "
             "-> (n_good_matches, M)") from e
-    c = constants  # pragma: no cover
+    c = constants
 
-    def gray8(im):  # pragma: no cover  (utils.py:37-43 img_bw_8bit)
+    def gray8(im):  # (utils.py:37-43 img_bw_8bit)
         im = (im >> 8).astype('uint8') if im.dtype == np.uint16 else im
         return cv2.cvtColor(im, cv2.COLOR_BGR2GRAY) if im.ndim == 3 else im
-    det_map = {c.DETECTOR_SIFT: cv2.SIFT_create, c.DETECTOR_ORB: cv2.ORB_create,  # pragma: no cover
+    det_map = {c.DETECTOR_SIFT: cv2.SIFT_create, c.DETECTOR_ORB: cv2.ORB_create,
                c.DETECTOR_SURF: cv2.FastFeatureDetector_create, c.DETECTOR_AKAZE: cv2.AKAZE_create,
                c.DETECTOR_BRISK: cv2.BRISK_create}
-    des_map = {c.DESCRIPTOR_SIFT: cv2.SIFT_create, c.DESCRIPTOR_ORB: cv2.ORB_create,  # pragma: no cover
+    des_map = {c.DESCRIPTOR_SIFT: cv2.SIFT_create, c.DESCRIPTOR_ORB: cv2.ORB_create,
                c.DESCRIPTOR_AKAZE: cv2.AKAZE_create, c.DESCRIPTOR_BRISK: cv2.BRISK_create}
-    g0, g1 = gray8(img_0_sub), gray8(img_1_sub)  # pragma: no cover
-    det = det_map[detector_name]()  # pragma: no cover
-    if detector_name == descriptor_name and detector_name in (c.DETECTOR_SIFT, c.DETECTOR_AKAZE, c.DETECTOR_BRISK):  # pragma: no cover
+    g0, g1 = gray8(img_0_sub), gray8(img_1_sub)
+    det = det_map[detector_name]()
+    if detector_name == descriptor_name and detector_name in (c.DETECTOR_SIFT, c.DETECTOR_AKAZE, c.DETECTOR_BRISK):
         kp0, d0 = det.detectAndCompute(g0, None)
         kp1, d1 = det.detectAndCompute(g1, None)
-    else:  # pragma: no cover
+    else:
         des = des_map[descriptor_name]()
         kp0, d0 = des.compute(g0, det.detect(g0, None))
         kp1, d1 = des.compute(g1, det.detect(g1, None))
-    if match_method == c.MATCHING_KNN:  # pragma: no cover
+    if match_method == c.MATCHING_KNN:
         flann = cv2.FlannBasedMatcher({'algorithm': matching_config['flann_idx_kdtree'], 'trees': matching_config['flann_trees']},
                                       {'checks': matching_config['flann_checks']})
         good = [m for m, n in flann.knnMatch(d0, d1, k=2) if m.distance < matching_config['threshold'] * n.distance]
-    elif match_method == c.MATCHING_NORM_HAMMING:  # pragma: no cover
+    elif match_method == c.MATCHING_NORM_HAMMING:
         good = sorted(cv2.BFMatcher(cv2.NORM_HAMMING, crossCheck=True).match(d0, d1), key=lambda x: x.distance)
-    else:  # pragma: no cover
+    else:
         raise InvalidOptionError('match_method', match_method, f". Valid options are: {c.MATCHING_KNN}, {c.MATCHING_NORM_HAMMING}")
-    transform = alignment_config['transform']  # pragma: no cover
-    if len(good) < (4 if transform == c.ALIGN_HOMOGRAPHY else 3):  # pragma: no cover
+    transform = alignment_config['transform']
+    if len(good) < (4 if transform == c.ALIGN_HOMOGRAPHY else 3):
         return len(good), None
-    method = {'RANSAC': cv2.RANSAC, 'LMEDS': cv2.LMEDS}.get(alignment_config['align_method'])  # pragma: no cover
-    if method is None:  # pragma: no cover
+    method = {'RANSAC': cv2.RANSAC, 'LMEDS': cv2.LMEDS}.get(alignment_config['align_method'])
+    if method is None:
         raise InvalidOptionError('align_method', alignment_config['align_method'], f". Valid options are: {c.ALIGN_RANSAC}, {c.ALIGN_LMEDS}")
-    src = np.float32([kp0[m.queryIdx].pt for m in good]).reshape(-1, 1, 2)  # pragma: no cover
-    dst = np.float32([kp1[m.trainIdx].pt for m in good]).reshape(-1, 1, 2)  # pragma: no cover
-    if transform == c.ALIGN_HOMOGRAPHY:  # pragma: no cover
+    src = np.float32([kp0[m.queryIdx].pt for m in good]).reshape(-1, 1, 2)
+    dst = np.float32([kp1[m.trainIdx].pt for m in good]).reshape(-1, 1, 2)
+    if transform == c.ALIGN_HOMOGRAPHY:
         m, _ = cv2.findHomography(src, dst, method=method, ransacReprojThreshold=alignment_config['rans_threshold'],
                                   maxIters=alignment_config['max_iters'])
-    else:  # pragma: no cover
+    else:
         m, _ = cv2.estimateAffinePartial2D(src, dst, method=method, ransacReprojThreshold=alignment_config['rans_threshold'],
                                            confidence=alignment_config['align_confidence'] / 100.0,
                                            refineIters=alignment_config['refine_iters'])
-    return len(good), m  # pragma: no cover
+    return len(good), m
 
 
 def have_opencv():

@@ -469,21 +469,21 @@ int finish_impl(mi_stack* s) {
     }
     for (int l = L - 1; l >= 1; --l) {
         float* out = bufs[l & 1];
-        hipLaunchKernelGGL((collapse_simple<FMA>), grid2d(s->lw[l], s->lh[l], blk), blk, 0,
-                           s->stream, up, s->lh[l + 1], s->lw[l + 1], s->bestLap[l], s->lh[l],
-                           s->lw[l], out, s->K);
+        hipLaunchKernelGGL((collapse_exact_quad<FMA, float>), grid2d(cdiv(s->lw[l], 2), cdiv(s->lh[l], 2), blk), blk, 0,
+                           s->stream, up, s->lh[l + 1], s->lw[l + 1], (const float*)s->bestLap[l], s->lh[l],
+                           s->lw[l], s->maxv, out, s->K);
         up = out;
     }
     s->collapse_src = up;     // level-1 image (or the fused base): what the collapsed-image tap restarts from
     s->have_clipped = false;
     if (L >= 1) {             // finest step fused with clip(abs) and the cast
-        const dim3 g0 = grid2d(s->lw[0], s->lh[0], blk);
+        const dim3 g0 = grid2d(cdiv(s->lw[0], 2), cdiv(s->lh[0], 2), blk);
         if (s->p.out_dtype == MI_U8)
-            hipLaunchKernelGGL((collapse_final<FMA, uint8_t>), g0, blk, 0, s->stream, up, s->lh[1], s->lw[1], s->bestLap[0],
-                               s->lh[0], s->lw[0], s->maxv, (uint8_t*)s->out_dev, s->K);
+            hipLaunchKernelGGL((collapse_exact_quad<FMA, uint8_t>), g0, blk, 0, s->stream, up, s->lh[1], s->lw[1],
+                               (const float*)s->bestLap[0], s->lh[0], s->lw[0], s->maxv, (uint8_t*)s->out_dev, s->K);
         else
-            hipLaunchKernelGGL((collapse_final<FMA, uint16_t>), g0, blk, 0, s->stream, up, s->lh[1], s->lw[1], s->bestLap[0],
-                               s->lh[0], s->lw[0], s->maxv, (uint16_t*)s->out_dev, s->K);
+            hipLaunchKernelGGL((collapse_exact_quad<FMA, uint16_t>), g0, blk, 0, s->stream, up, s->lh[1], s->lw[1],
+                               (const float*)s->bestLap[0], s->lh[0], s->lw[0], s->maxv, (uint16_t*)s->out_dev, s->K);
         MI_HIP(hipGetLastError());
         return MI_OK;
     }
