@@ -21,10 +21,19 @@
  *    a pixel whose four taps are all outside takes the constant directly;
  *  - the all-ones uint8 mask warped with constant 0 is therefore 1 iff the in-image 15-bit
  *    weights sum to >= 16384.
- *  - GaussianBlur: OpenCV uses a fixed-point separable path for 8/16-bit; it is NOT restated.
- *    Here: float32 kernel = float32(getGaussianKernel(21, sigma)) (double exp, normalised),
- *    horizontal pass then vertical pass in float32, taps in index order, REFLECT101, final
- *    round-half-even + saturate.  Only pixels with mask == 0 (out-of-frame filler) use it.
+ *  - GaussianBlur on 8- and 16-bit images: OpenCV's bit-exact FIXED-POINT separable path (smooth.dispatch.cpp
+ *    "running bit-exact version", fixedpoint.inl.hpp) [from memory, parity unpinned]:
+ *      kernel   getGaussianKernelBitExact: t_i = exp(x_i^2 * (-0.125 / sigma^2)) with x_i = 2 i - (n - 1), normalised by
+ *               1 / sum in double (OpenCV uses its softdouble exp; a last-bit difference of exp cannot survive the
+ *               quantisation below except on an exact rounding tie), then getGaussianKernelFixedPoint_ED: 8 (8-bit
+ *               images, ufixedpoint16) or 16 (16-bit images, ufixedpoint32) fractional bits, outer taps rounded half to
+ *               even from the outside in with the rounding error carried to the next tap (error diffusion), mirrored,
+ *               and the CENTRE tap takes what is left so that the taps sum to exactly 1.0;
+ *      rows     R = sum_x k_x * src (8.8 / 16.16 fixed point: exact, the sum cannot overflow because sum k = 1.0);
+ *      columns  S = sum_y k_y * R   (16.16 / 32.32), result (S + half) >> 16 / 32 -- round half up, saturated;
+ *      border   REFLECT101 (cv2's BORDER_DEFAULT).  Integer sums: the order of the taps does not matter.
+ *    Only pixels with mask == 0 (out-of-frame filler) use it.  (Rounds 1-2 evaluated a float32 blur here; OpenCV's
+ *    IPP-backed builds may take yet another path for some sizes -- oracle/probe_cv2.py compares on a box with OpenCV.)
  */
 #include <math.h>
 #include <stdint.h>
@@ -197,11 +206,40 @@ ORC_API void orc_gauss_kernel_f32(int ksize, double sigma, float* k) {
     free(t);
 }
 
-/* out = valid ? warp : gaussian_blur(warp)   (blur: see header) */
+/* cv2's fixed-point Gaussian taps (see header): `bits` fractional bits, k[ksize], sum(k) == 1 << bits */
+ORC_API void orc_gauss_kernel_fixed(int ksize, double sigma, int bits, uint32_t* k) {
+    const int n = ksize, n2 = (n - 1) / 2;
+    double* t = (double*)malloc(sizeof(double) * (n2 + 1));
+    if (sigma <= 0) sigma = n * 0.15 + 0.35;
+    const double scale2x = -0.125 / (sigma * sigma);
+    double sum = 0.0;
+    for (int i = 0, x = 1 - n; i < n2; ++i, x += 2) {
+        t[i] = exp((double)(x * x) * scale2x);
+        sum += t[i];
+    }
+    sum *= 2.0;
+    sum += 1.0;
+    const double mul1 = 1.0 / sum;
+    const double fixed_1 = (double)(1u << bits);
+    int64_t acc = 0;
+    double carry = 0.0;
+    for (int i = 0; i < n2; ++i) {
+        const double adj = t[i] * mul1 * fixed_1 + carry;
+        const int64_t v = (int64_t)nearbyint(adj);   /* cvRound: half to even */
+        carry = adj - (double)v;
+        k[i] = k[n - 1 - i] = (uint32_t)v;
+        acc += 2 * v;
+    }
+    k[n2] = (uint32_t)(((int64_t)1 << bits) - acc);
+    free(t);
+}
+
+/* out = valid ? warp : GaussianBlur(warp)   (cv2's fixed-point blur: see header) */
 ORC_API void orc_border_blur_composite(const void* warp_, const uint8_t* valid, void* out_, int h, int w,
                                        int dtype, int ksize, double sigma) {
-    float* k = (float*)malloc(sizeof(float) * ksize);
-    orc_gauss_kernel_f32(ksize, sigma, k);
+    const int bits = dtype == 0 ? 8 : 16;
+    uint32_t* k = (uint32_t*)malloc(sizeof(uint32_t) * ksize);
+    orc_gauss_kernel_fixed(ksize, sigma, bits, k);
     const int r = ksize / 2;
     const uint8_t* s8 = (const uint8_t*)warp_;
     const uint16_t* s16 = (const uint16_t*)warp_;
@@ -217,21 +255,19 @@ ORC_API void orc_border_blur_composite(const void* warp_, const uint8_t* valid, 
                     if (dtype == 0) d8[o] = s8[o]; else d16[o] = s16[o];
                     continue;
                 }
-                float acc = 0.0f;
+                uint64_t acc = 0;
                 for (int dy = 0; dy < ksize; ++dy) {
                     int yy = r101(y + dy - r, h);
-                    float row = 0.0f;
+                    uint64_t row = 0;
                     for (int dx = 0; dx < ksize; ++dx) {
                         int xx = r101(x + dx - r, w);
-                        float v = dtype == 0 ? (float)s8[((size_t)yy * w + xx) * 3 + c]
-                                             : (float)s16[((size_t)yy * w + xx) * 3 + c];
-                        volatile float p = k[dx] * v;
-                        row = row + p;
+                        uint64_t v = dtype == 0 ? s8[((size_t)yy * w + xx) * 3 + c] : s16[((size_t)yy * w + xx) * 3 + c];
+                        row += k[dx] * v;
                     }
-                    volatile float q = k[dy] * row;
-                    acc = acc + q;
+                    acc += k[dy] * row;
                 }
-                int rr = clampi((int)lrintf(acc), 0, maxv);
+                uint64_t rr = (acc + ((uint64_t)1 << (2 * bits - 1))) >> (2 * bits);
+                if (rr > (uint64_t)maxv) rr = (uint64_t)maxv;
                 if (dtype == 0) d8[o] = (uint8_t)rr; else d16[o] = (uint16_t)rr;
             }
     free(k);

@@ -116,6 +116,7 @@ def lib():
         L.orc_border_blur_composite.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                                 C.c_int, C.c_int, C.c_double]
         L.orc_gauss_kernel_f32.argtypes = [C.c_int, C.c_double, _f32p]
+        L.orc_gauss_kernel_fixed.argtypes = [C.c_int, C.c_double, C.c_int, np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")]
         L.orc_invert_affine.argtypes = [_f64p, _f64p]
         _lib = L
     return _lib
@@ -505,6 +506,24 @@ def warp_affine(img, M, border_mode=BORDER_REPLICATE_BLUR, border_value=(0, 0, 0
         lib().orc_border_blur_composite(warp.ctypes.data, valid.ctypes.data, out.ctypes.data, h, w, dt,
                                         blur_ksize, float(blur_sigma))
     return (out, valid) if want_mask else out
+
+
+def gaussian_blur_fixed(img, ksize=21, sigma=50.0):
+    """cv2.GaussianBlur(img, (ksize, ksize), sigmaX=sigma) of an HxWx3 uint8 / uint16 image: OpenCV's bit-exact fixed-point
+    path as align_oracle.c restates it [from memory, parity unpinned] (the blur behind align.py:249)."""
+    img = np.ascontiguousarray(img)
+    h, w = img.shape[:2]
+    out = np.empty_like(img)
+    nothing_valid = np.zeros((h, w), np.uint8)
+    lib().orc_border_blur_composite(img.ctypes.data, nothing_valid.ctypes.data, out.ctypes.data, h, w,
+                                    0 if img.dtype == np.uint8 else 1, int(ksize), float(sigma))
+    return out
+
+
+def gauss_kernel_fixed(ksize, sigma, bits):
+    k = np.zeros(ksize, np.uint32)
+    lib().orc_gauss_kernel_fixed(int(ksize), float(sigma), int(bits), k)
+    return k
 
 
 def warp_perspective(img, M, border_mode=BORDER_REPLICATE_BLUR, border_value=(0, 0, 0, 0),

@@ -60,6 +60,12 @@ def main():
     blurred = cv2.GaussianBlur(real_w, (21, 21), sigmaX=50)
     comp = real_w.copy()
     comp[cv2.cvtColor(mask, cv2.COLOR_BGR2GRAY) == 0] = blurred[cv2.cvtColor(mask, cv2.COLOR_BGR2GRAY) == 0]
+    # the blur on its own, 8 and 16 bit (OpenCV's fixed-point path as align_oracle.c restates it)
+    src16 = frames[0].astype(np.uint16) * 257
+    blurred16 = cv2.GaussianBlur(src16, (21, 21), sigmaX=50)
+    report["GaussianBlur_21_fixed"] = {"u8": bool(np.array_equal(orc.gaussian_blur_fixed(real_w, 21, 50.0), blurred)),
+                                       "u16": bool(np.array_equal(orc.gaussian_blur_fixed(src16, 21, 50.0), blurred16))}
+    np.savez_compressed(os.path.join(GOLDEN, "cv2_gaussian_blur.npz"), src_u8=real_w, dst_u8=blurred, src_u16=src16, dst_u16=blurred16)
     report["warpAffine"] = {"matches": bool(np.array_equal(orc.warp_affine(frames[0], M, border_mode=1), real_w))}
     report["warp+blur_composite"] = {"matches": bool(np.array_equal(orc.warp_affine(frames[0], M), comp))}
     np.savez_compressed(os.path.join(GOLDEN, "cv2_warp.npz"), src=frames[0], M=M, warp=real_w, mask=mask, composite=comp)

@@ -1514,17 +1514,31 @@ int warp_device_impl(int device, void* stream, const void* dev_src, void* dev_ds
     for (int c = 0; c < 3; ++c) a.border[c] = border_value ? round_sat(border_value[c], hi) : 0;
     GaussArgs g{};
     if (blur) {
-        // cv::getGaussianKernel(ksize, sigma) in double, stored as float32 [from memory]
+        // OpenCV's fixed-point taps for 8- / 16-bit images (getGaussianKernelBitExact + getGaussianKernelFixedPoint_ED,
+        // restated in oracle/align_oracle.c::orc_gauss_kernel_fixed [from memory]): exp(x^2 * (-0.125 / sigma^2)) at
+        // x = 2i - (n - 1), normalised in double; outer taps rounded half to even with the error carried inwards, the
+        // centre tap takes the rest so that the sum is exactly 1 << bits
         g.ksize = blur_ksize;
-        double t[32], sum = 0.0;
-        const double scale2x = -0.5 / (blur_sigma * blur_sigma);
-        for (int i = 0; i < blur_ksize; ++i) {
-            const double x = i - (blur_ksize - 1) * 0.5;
-            t[i] = std::exp(scale2x * x * x);
+        const int n = blur_ksize, n2 = (n - 1) / 2, bits = dtype == MI_U8 ? 8 : 16;
+        const double sg = blur_sigma > 0 ? blur_sigma : n * 0.15 + 0.35;
+        const double scale2x = -0.125 / (sg * sg);
+        double t[16], sum = 0.0;
+        for (int i = 0, x = 1 - n; i < n2; ++i, x += 2) {
+            t[i] = std::exp((double)(x * x) * scale2x);
             sum += t[i];
         }
-        sum = 1.0 / sum;
-        for (int i = 0; i < blur_ksize; ++i) g.k[i] = (float)(t[i] * sum);
+        sum = sum * 2.0 + 1.0;
+        const double mul1 = 1.0 / sum, fixed_1 = (double)(1u << bits);
+        int64_t acc = 0;
+        double carry = 0.0;
+        for (int i = 0; i < n2; ++i) {
+            const double adj = t[i] * mul1 * fixed_1 + carry;
+            const int64_t v = (int64_t)std::nearbyint(adj);
+            carry = adj - (double)v;
+            g.k[i] = g.k[n - 1 - i] = (uint32_t)v;
+            acc += 2 * v;
+        }
+        g.k[n2] = (uint32_t)(((int64_t)1 << bits) - acc);
     }
     // The tile scratch (counter / bitmap / list) is cached per (device, stream): two host threads that warp on the SAME
     // stream -- the two step_process chains of pipeline._align_chains_device on the default stream -- must not interleave

@@ -393,8 +393,10 @@ __global__ __launch_bounds__(256) void warp_affine_tiled(const T* __restrict__ s
     }
 }
 
+// cv2.GaussianBlur on 8- / 16-bit images = OpenCV's bit-exact fixed-point path (oracle/align_oracle.c header): integer taps
+// with 8 / 16 fractional bits that sum to exactly 1.0
 struct GaussArgs {
-    float k[32];
+    uint32_t k[32];
     int ksize;
 };
 
@@ -441,6 +443,14 @@ __device__ __forceinline__ uint2 load_px3_raw(const T* __restrict__ img, size_t 
     return v;
 }
 template <typename T>
+__device__ __forceinline__ void decode_px3u(uint2 v, uint32_t out[3]) {
+    if constexpr (sizeof(T) == 1) {
+        out[0] = v.x & 255u; out[1] = (v.x >> 8) & 255u; out[2] = (v.x >> 16) & 255u;
+    } else {
+        out[0] = v.x & 65535u; out[1] = v.x >> 16; out[2] = v.y;
+    }
+}
+template <typename T>
 __device__ __forceinline__ void decode_px3(uint2 v, float out[3]) {
     if constexpr (sizeof(T) == 1) {
         out[0] = (float)(v.x & 255u); out[1] = (float)((v.x >> 8) & 255u); out[2] = (float)((v.x >> 16) & 255u);
@@ -449,67 +459,20 @@ __device__ __forceinline__ void decode_px3(uint2 v, float out[3]) {
     }
 }
 
-// gaussian_blur(img) at one pixel: horizontal pass then vertical pass in float32, taps in index
-// order, REFLECT101, round-half-even + saturate (align_oracle.c)
-// `kof(i)` returns tap i of the Gaussian: the callers keep the taps in a VGPR (lane i holds tap i) and read them
-// with v_readlane -- indexing the kernel-argument array with a loop counter costs a scalar load and an lgkmcnt
-// wait per tap, ~0.15 us each, 441 of them per pixel
-template <typename T, typename KOf>
-__device__ __forceinline__ void blur_at(const T* __restrict__ img, int h, int w, int y, int x, const GaussArgs& g,
-                                        int out[3], KOf kof) {
-    const int r = g.ksize / 2;
-    const int maxv = sizeof(T) == 1 ? 255 : 65535;
-    const size_t last = (size_t)h * w - 1;
-    float acc[3] = {0.f, 0.f, 0.f};
-    for (int dy = 0; dy < g.ksize; ++dy) {
-        const int yy = r101_loop(y + dy - r, h);
-        float row[3] = {0.f, 0.f, 0.f};
-        // the window row's loads are issued together (groups of 16: two round trips per window row), not one per
-        // dependent multiply-add: the few hundred waves of a frame's masked pixels have nothing else to hide latency
-        for (int d0 = 0; d0 < g.ksize; d0 += 16) {
-            uint2 raw[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int dx = min(d0 + u, g.ksize - 1);
-                raw[u] = load_px3_raw<T>(img, (size_t)yy * w + r101_loop(x + dx - r, w), last);
-            }
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                if (d0 + u < g.ksize) {
-                    float p[3];
-                    decode_px3<T>(raw[u], p);
-                    const float k = kof(d0 + u);
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        const float pr = k * p[c];
-                        row[c] = row[c] + pr;
-                    }
-                }
-            }
-        }
-        const float kd = kof(dy);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float q = kd * row[c];
-            acc[c] = acc[c] + q;
-        }
-    }
-#pragma unroll
-    for (int c = 0; c < 3; ++c) out[c] = min(max((int)rintf(acc[c]), 0), maxv);
-}
-
 // out = valid ? warp : gaussian_blur(warp), in place on `img`.  The pixels whose mask is 0 form a frame along the
 // borders (a few columns at the sides, wedges where the frame rotated: some ten thousand of the 24 million pixels of a
 // frame that moved by a few pixels).  Their 21 x 21 windows overlap almost completely, so the separable blur is
 // evaluated densely, but only on the 32 x 64 tiles that contain a masked pixel:
 //   scan     tiles with a masked pixel are marked in a bitmap (16 mask bytes per lane and step), the bitmap becomes a list;
 //   blur     one workgroup per listed tile: the tile + r halo of the untouched image -> LDS (raw pixels), the horizontal
-//            pass for every row of the patch -> LDS (float, planar), the vertical pass for the tile's masked pixels ->
-//            `side` (same index as the image);
+//            pass for every row of the patch -> LDS (fixed point, planar), the vertical pass for the tile's masked
+//            pixels -> `side` (same index as the image);
 //   scatter  the masked pixels of the listed tiles take their value from `side`.
-// Arithmetic = align_oracle.c: horizontal then vertical pass in float32, taps in index order, a multiplication and an
-// addition per tap (no fma), REFLECT101, round-half-even + saturate.  (Round 1 walked every 64-pixel chunk of the mask
-// inside the blur pass and evaluated each masked pixel's 441 taps on its own: 80-160 us per 24 MP frame; this: ~30.)
+// Arithmetic = align_oracle.c = OpenCV's bit-exact fixed-point GaussianBlur for 8- / 16-bit images: integer taps with 8 /
+// 16 fractional bits (sum exactly 1.0), exact integer row and column sums, REFLECT101, round half up + saturate.  (Rounds
+// 1-2 evaluated a float32 blur here -- a known deviation from cv2 on 8-bit frames, closed in round 3.  Round 1 also
+// walked every 64-pixel chunk of the mask inside the blur pass and evaluated each masked pixel's 441 taps on its own:
+// 80-160 us per 24 MP frame; this: ~30.)
 constexpr int BT_H = 32, BT_W = 64;
 
 __global__ __launch_bounds__(256) void mask_scan_tiles(const uint8_t* __restrict__ valid, int h, int w, int tiles_x,
@@ -586,12 +549,14 @@ __global__ __launch_bounds__(256) void border_blur_tiles(const T* __restrict__ i
     const int PH = BT_H + 2 * r, PW = BT_W + 2 * r;
     constexpr int RAW = sizeof(T) == 1 ? 1 : 2;            // dwords per staged pixel
     uint32_t* sP = s_blur;                                  // PH x PW raw pixels
-    float* sH = reinterpret_cast<float*>(s_blur + PH * PW * RAW);   // [3][PH][BT_W] horizontal pass
-    const int maxv = sizeof(T) == 1 ? 255 : 65535;
+    uint32_t* sH = s_blur + PH * PW * RAW;   // [3][PH][BT_W] horizontal pass: 8.8 / 16.16 fixed point
+    constexpr int BITS = sizeof(T) == 1 ? 8 : 16;           // fractional bits of the taps
+    typedef typename std::conditional<sizeof(T) == 1, uint32_t, uint64_t>::type Acc;   // column sums: 16.16 / 32.32
+    const uint32_t maxv = sizeof(T) == 1 ? 255u : 65535u;
     const size_t last = (size_t)h * w - 1;
     const int lane = threadIdx.x & 63;
-    const float kreg = g.k[lane & 31];   // lane i holds tap i (ksize <= 31): v_readlane instead of a scalar load per tap
-    auto kof = [&](int i) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(kreg), i)); };
+    const uint32_t kreg = g.k[lane & 31];   // lane i holds tap i (ksize <= 31): v_readlane instead of a scalar load per tap
+    auto kof = [&](int i) { return (uint32_t)__builtin_amdgcn_readlane((int)kreg, i); };
     const uint32_t n = *cnt;
     for (uint32_t e = blockIdx.x; e < n; e += gridDim.x) {
         const int t = (int)list[e];
@@ -655,8 +620,8 @@ __global__ __launch_bounds__(256) void border_blur_tiles(const T* __restrict__ i
             for (int i = threadIdx.x; i < nrows * ncols; i += 256) {
                 const int py = ra + i / ncols, cx = s_cols[i % ncols];
                 const uint32_t* p = sP + (py * PW + cx) * RAW;
-                float row[3] = {0.f, 0.f, 0.f};
-                for (int d0 = 0; d0 < ks; d0 += 7) {   // seven taps' LDS reads in flight at a time, added in index order
+                uint32_t row[3] = {0u, 0u, 0u};      // exact: sum k = 1.0, so the sums stay below 2^16 / 2^32
+                for (int d0 = 0; d0 < ks; d0 += 7) {   // seven taps' LDS reads in flight at a time
                     uint2 rw[7];
 #pragma unroll
                     for (int u = 0; u < 7; ++u) {
@@ -667,14 +632,11 @@ __global__ __launch_bounds__(256) void border_blur_tiles(const T* __restrict__ i
 #pragma unroll
                     for (int u = 0; u < 7; ++u) {
                         if (d0 + u < ks) {
-                            float v[3];
-                            decode_px3<T>(rw[u], v);
-                            const float k = kof(d0 + u);   // v_readlane ignores EXEC: fine in divergent code
+                            uint32_t v[3];
+                            decode_px3u<T>(rw[u], v);
+                            const uint32_t k = kof(d0 + u);   // v_readlane ignores EXEC: fine in divergent code
 #pragma unroll
-                            for (int c = 0; c < 3; ++c) {
-                                const float pr = k * v[c];
-                                row[c] = row[c] + pr;
-                            }
+                            for (int c = 0; c < 3; ++c) row[c] += k * v[c];
                         }
                     }
                 }
@@ -687,18 +649,18 @@ __global__ __launch_bounds__(256) void border_blur_tiles(const T* __restrict__ i
             for (int j = 0; j < BT_H / 4; ++j) {
                 if (!((mymask >> j) & 1u)) continue;
                 const int yy = yy0 + 4 * j;
-                float acc[3] = {0.f, 0.f, 0.f};
+                Acc acc[3] = {0, 0, 0};
                 for (int dy = 0; dy < ks; ++dy) {
-                    const float kd = kof(dy);
+                    const uint32_t kd = kof(dy);
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        const float qv = kd * sH[(c * PH + yy + dy) * BT_W + xx];
-                        acc[c] = acc[c] + qv;
-                    }
+                    for (int c = 0; c < 3; ++c) acc[c] += (Acc)kd * (Acc)sH[(c * PH + yy + dy) * BT_W + xx];
                 }
                 const size_t pi = (size_t)(y0 + yy) * w + (x0 + xx);
 #pragma unroll
-                for (int c = 0; c < 3; ++c) side[pi * 3 + c] = (T)min(max((int)rintf(acc[c]), 0), maxv);
+                for (int c = 0; c < 3; ++c) {   // round half up, saturate (ufixedpoint -> integer)
+                    const Acc rr = (acc[c] + ((Acc)1 << (2 * BITS - 1))) >> (2 * BITS);
+                    side[pi * 3 + c] = (T)(rr > (Acc)maxv ? (Acc)maxv : rr);
+                }
             }
         }
         __syncthreads();   // the next tile's passes overwrite the LDS arrays

@@ -181,3 +181,32 @@ def test_sep_natural_extension(h, w, exact):
     (e, g1), (ep, g1p) = out
     assert np.array_equal(g1p[P // 2:P // 2 + g1.shape[0], P // 2:P // 2 + g1.shape[1]], g1)
     assert np.array_equal(ep[P:P + h, P:P + w], e) == exact
+
+
+def test_fixed_point_gaussian_blur_restatement():
+    """cv2.GaussianBlur on 8- / 16-bit images as oracle/align_oracle.c restates it (OpenCV's bit-exact fixed-point path,
+    [from memory], the blur of align.py:249): taps sum to exactly 1.0 in fixed point, are symmetric, the centre takes the
+    remainder of the error diffusion; the blurred image stays within one count of the float64 Gaussian blur; a constant
+    image stays constant (sum of taps == 1.0 and round-half-up)."""
+    from oracle import oracle as orc
+    for ks, sg, bits in [(21, 50.0, 8), (21, 50.0, 16), (5, 1.0, 8), (21, 3.0, 8), (31, 12.5, 16), (1, 2.0, 8)]:
+        k = orc.gauss_kernel_fixed(ks, sg, bits).astype(np.int64)
+        assert k.sum() == 1 << bits and np.array_equal(k, k[::-1]) and (k >= 0).all()
+        x = np.arange(ks) - (ks - 1) / 2
+        ideal = np.exp(-x * x / (2 * sg * sg))
+        ideal /= ideal.sum()
+        assert np.abs(k / float(1 << bits) - ideal).max() <= 1.5 / (1 << bits)
+    assert list(orc.gauss_kernel_fixed(5, 1.0, 8)) == [14, 62, 104, 62, 14]
+    rng = np.random.default_rng(4)
+    for dt, hi in ((np.uint8, 256), (np.uint16, 65536)):
+        img = rng.integers(0, hi, (37, 53, 3)).astype(dt)
+        got = orc.gaussian_blur_fixed(img, 21, 50.0).astype(np.float64)
+        x = np.arange(21) - 10.0
+        k = np.exp(-x * x / 5000.0)
+        k /= k.sum()
+        pad = np.pad(img.astype(np.float64), ((10, 10), (10, 10), (0, 0)), mode="reflect")
+        rows = sum(k[i] * pad[:, i:i + 53] for i in range(21))
+        want = sum(k[i] * rows[i:i + 37] for i in range(21))
+        assert np.abs(got - want).max() <= (1.5 if dt == np.uint8 else 160.0)   # the taps have 8 / 16 fractional bits
+        flat = np.full((30, 40, 3), hi - 1, dt)
+        assert np.array_equal(orc.gaussian_blur_fixed(flat, 21, 50.0), flat)

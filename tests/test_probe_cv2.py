@@ -23,8 +23,8 @@ def _fake_cv2(orc):
         return orc.warp_perspective(img, M, border_mode=1)
 
     def GaussianBlur(img, ksize, sigma=0, sigmaX=None):
-        if img.dtype == np.uint8:      # the composite's blur: OpenCV's fixed-point 8-bit blur is not restated anywhere
-            return img.copy()
+        if img.ndim == 3 and img.dtype in (np.uint8, np.uint16):   # the composite's blur: the restated fixed-point path
+            return orc.gaussian_blur_fixed(img, ksize[0], sigma if sigmaX is None else sigmaX)
         return blur0(img, ksize, sigma if sigmaX is None else sigmaX)
 
     cv2.warpAffine, cv2.warpPerspective, cv2.GaussianBlur = warpAffine, warpPerspective, GaussianBlur
@@ -42,6 +42,7 @@ def test_probe_script_runs_with_a_stand_in_cv2(oracle, tmp_path, monkeypatch, ca
     report = json.loads((tmp_path / "cv2_probe_report.json").read_text())
     assert report["filter2D"]["matches_use_fma"] == [1] or 1 in report["filter2D"]["matches_use_fma"]
     assert report["cvtColor_u8"]["matches"] and report["warpAffine"]["matches"] and report["warpPerspective"]["matches"]
+    assert report["warp+blur_composite"]["matches"] and report["GaussianBlur_21_fixed"] == {"u8": True, "u16": True}
     assert all(report["resize_INTER_AREA"].values()) and len(report["resize_INTER_AREA"]) == 12
     assert all(report["cvtColor_HSV_HLS_u8"].values()) and len(report["cvtColor_HSV_HLS_u8"]) == 4
     dm = report["depth_map_primitives"]
