@@ -21,7 +21,7 @@ def L(hiplib):
     return hiplib
 
 
-_FUSED = {}   # arith -> fused image of config 2, for the cross-mode comparison below
+_FUSED = {}   # arith -> fused image of config 2 (kept for interactive comparisons; the parity test below runs its own stacks)
 
 
 @pytest.mark.parametrize("arith", ["exact", "separable"])
@@ -52,17 +52,36 @@ def test_config2_256_frames_24mp_fp32(L, oracle, arith):
     buf.free()
 
 
-def test_config2_separable_within_tolerance_of_exact_at_full_size():
-    """The stated tolerance of MI_ARITH_SEPARABLE at the benchmark's size: against the reference-order arithmetic on the
-    SAME 256 x 24 MP stack the fused image differs on a fraction of a percent of its values, almost all by one count
-    (truncating cast at an integer boundary); larger differences are arg-max flips at near ties (a different frame's
-    Laplacian wins) and stay below 1e-5 of the values.  Measured: 0.12 % / 2.3e-6 / 1.1e-6 (1 / 2 / 3+ counts)."""
-    if len(_FUSED) < 2:
-        pytest.skip("needs both arithmetic modes of test_config2_256_frames_24mp_fp32 in the same session")
-    d = np.abs(_FUSED["exact"].astype(np.int16) - _FUSED["separable"].astype(np.int16))
-    hist = np.bincount(np.minimum(d.ravel(), 3), minlength=4) / d.size
-    assert hist[1] < 5e-3 and hist[2] < 1e-5 and hist[3] < 1e-5, hist
+def test_config2_parity_report_between_the_arithmetics_at_full_size(L):
+    """SURVEY 8(d) "parity reporting" at the benchmark's own size (tools/parity_report.py): MI_ARITH_SEPARABLE against the
+    reference-order arithmetic on the SAME 256 x 24 MP stack.  Per level the Gaussian and running-max-energy differences
+    stay inside the stated forward-error bounds; the arg-max differs on a few dozen of 32 M pyramid pixels, and for every
+    one of them both candidate frames -- pushed alone through both arithmetics -- are a near tie; the fused image
+    differs on a fraction of a percent of its values, almost all by one count (truncating cast at an integer boundary),
+    and every value off by two or more counts lies in the collapse footprint of a flipped selection.
+    Measured (round 3): no flip at level 0, 13 / 12 / 4 / 4 / 3 at levels 1-5, largest gap 0.2 % of the bound; final
+    image 88 170 values off by one count, 169 by two, 78 by more (max 10) of 72 M."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import parity_report
     _FUSED.clear()
+    H, W, N = 4000, 6000, 256
+    buf = L.DeviceBuffer(H * W * 3 * 4 * N)
+    L.synth_frames_device(buf.ptr, np.float32, H, W, 0, N, N)
+    rep = parity_report.report(L, buf.ptr, N, H, W, np.float32)
+    buf.free()
+    assert rep["ok"], rep
+    for row in rep["levels"]:
+        assert row["energy_diff_over_bound_max"] <= 1.0 and row["selection_mismatch_rate"] < 1e-3, row
+        if row["level"] >= 1:
+            assert row["gauss_abs_diff_max_lsb"] <= row["gauss_bound_lsb"], row
+    nt = rep["near_tie"]
+    assert nt["checked"] == nt["pixels"] and nt.get("not_a_near_tie", 0) == 0 and nt.get("winner_energy_reproduced", True), nt
+    hist = np.array(rep["final_abs_diff_counts_0_1_2_3plus"], float) / (H * W * 3)
+    assert hist[1] < 5e-3 and hist[2] < 1e-5 and hist[3] < 1e-5, hist
+    assert rep["final_pixels_off_by_2plus_outside_a_flip_footprint"] == 0 and rep["flip_footprint_fraction_of_image"] < 0.01, rep
+    assert rep["base"]["fused_base_abs_diff_max_lsb"] < 0.9, rep["base"]
 
 
 def test_config5_two_bunches_50mp_u16_from_host(L, oracle):
