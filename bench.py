@@ -60,6 +60,10 @@ def parse():
     ap.add_argument("--cpu-refshaped", type=int, default=0,
                     help="also time the reference-SHAPED restatement (all pyramids resident, full-size 25-tap "
                          "filters) on this many frames (SURVEY 8(d) leg (i): 8; ~5 s per 24 MP frame; off by default)")
+    ap.add_argument("--force-combine", action="store_true",
+                    help="world 1 only: run the cross-GPU exchange's per-rank kernel work (winner map, plan, pack, unpack) "
+                         "inside every step although nothing has to move -> combine_ms (timing of the local part of the "
+                         "exchange on a box with one GPU; the fabric part needs the driver's multi-GPU run)")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU: every rank runs the CPU oracle on its block of a small stack and the ranks combine over "
                          "gloo with the same protocol (multigpu.combine_winners) -- exercises the launch contract, the "
@@ -257,7 +261,7 @@ def main():
     dist = None
     # the host driver only supports dmabuf IPC: without this RCCL's buffer sharing across processes fails
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    force_dist = os.environ.get("MI_BENCH_FORCE_COMBINE") == "1"  # exercise the combine at world 1
+    force_dist = os.environ.get("MI_BENCH_FORCE_COMBINE") == "1" or args.force_combine  # exercise the combine at world 1
     backend = os.environ.get("MI_BENCH_BACKEND", "nccl")
     if world > 1 or force_dist:
         # torch ships its own HIP runtime: it must be loaded BEFORE libmi355stack.so pulls in
@@ -311,8 +315,9 @@ def main():
         combiner = None
         if world > 1 or force_dist:
             from shinestacker_amd import multigpu
-            combiner = multigpu.Combiner(st, dist.group.WORLD)
+            combiner = multigpu.Combiner(st, dist.group.WORLD, force=world == 1)
         phase = {"compute": 0.0, "combine": 0.0, "collapse": 0.0}
+        cphase = {}
 
         def step(timed=False):
             st.reset()
@@ -338,6 +343,8 @@ def main():
                     phase["compute"] += t1 - t0
                     phase["combine"] += t2 - t1
                     phase["collapse"] += t3 - t2
+                    for k, v in combiner.timings.items():
+                        cphase[k] = cphase.get(k, 0.0) + v
             else:
                 st.finish_device()
 
@@ -357,6 +364,7 @@ def main():
             dt_s = float(t.item())
         prof = {k: st.profile_get(v) for k, v in (("level0", L.PROF_LEVEL0), ("levels", L.PROF_LEVEL),
                                                   ("base", L.PROF_BASE), ("collapse", L.PROF_COLLAPSE))}
+        phase.update({"combine_" + k[:-3]: v * 1e-3 for k, v in cphase.items()})   # "..._ms" -> seconds, like the others
         return st, dt_s, prof, phase
 
     st, dt_s, prof, phase = measure(args.arith, args.steps, args.warmup)
@@ -386,6 +394,9 @@ def main():
         breakdown = {k: v[0] / args.steps for k, v in prof.items()}
         if world > 1 or force_dist:
             breakdown.update({f"{k}_ms_host": v / args.steps * 1e3 for k, v in phase.items()})
+            # combine_ms: host time of the exchange proper per step (both phases; the waits for this rank's own levels are
+            # listed beside it: wait_rest ~ 0 means the coarser levels were hidden behind the level-0 exchange)
+            line_combine_ms = (phase.get("combine_exchange_level0", 0.0) + phase.get("combine_exchange_rest", 0.0)) / args.steps * 1e3
         line = {
             "metric": "Mpixels/s fused (pyramid build+select+collapse)",
             "value": value, "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps,
@@ -408,6 +419,11 @@ def main():
             "job_roofline_frac": (job_bytes_per_frame * total_frames * args.steps / dt_s)
                                  / (HBM_PEAK_GBS * 1e9 * world),
         }
+        if world > 1 or force_dist:
+            line["combine_ms"] = line_combine_ms
+            line["combine_note"] = ("world 1, --force-combine: the per-rank kernel work of the exchange on this rank's own "
+                                    "rows, nothing crosses a link" if world == 1 else
+                                    "winners-only exchange over RCCL: level 0 while the coarser levels still run, then the rest")
         if not args.no_verify:
             v = verify(L, st, args, total_frames, world)
             line["verified"] = v.pop("ok")

@@ -169,7 +169,58 @@ class TorchWinnerOps:
                 rows[win == r] = b.view(-1, width)
 
 
-def combine_winners(e_all, l_all, i_all, group, ops, width=3, with_index=True, root_energy=True):
+class DirectComm:
+    """The collectives of `combine_winners` straight on the tensors handed in: RCCL for device tensors under the "nccl"
+    backend (xGMI, one process per GPU), gloo for CPU tensors."""
+
+    def __init__(self, group):
+        self.group = group
+
+    def all_to_all(self, out, inp, out_splits, in_splits):
+        dist.all_to_all_single(out, inp, output_split_sizes=out_splits, input_split_sizes=in_splits, group=self.group)
+
+    def all_gather(self, out, inp):
+        dist.all_gather_into_tensor(out, inp, group=self.group)
+
+    def send_to_root(self, tensors):
+        root = dist.get_global_rank(self.group, 0)
+        for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, b, root, self.group) for b in tensors]):
+            req.wait()
+
+    def recv_at_root(self, bufs_by_rank):
+        ops_ = [dist.P2POp(dist.irecv, b, dist.get_global_rank(self.group, r), self.group) for r, b in bufs_by_rank]
+        if ops_:
+            for req in dist.batch_isend_irecv(ops_):
+                req.wait()
+
+
+class HostStagedComm(DirectComm):
+    """The same collectives for DEVICE tensors over a backend that only moves host memory (gloo): every buffer is staged
+    through the host.  This is the seam that lets `Combiner.combine_winners` -- the HIP kernels mi_combine_winner / plan /
+    pack / unpack on device-resident state -- run with world > 1 on a box with ONE GPU (two processes sharing it,
+    tests/test_gpu_combine.py); it is also a working, if slow, fallback for nodes without peer access."""
+
+    def all_to_all(self, out, inp, out_splits, in_splits):
+        o = torch.empty(out.shape, dtype=out.dtype)
+        super().all_to_all(o, inp.cpu(), out_splits, in_splits)
+        out.copy_(o)
+
+    def all_gather(self, out, inp):
+        o = torch.empty(out.shape, dtype=out.dtype)
+        super().all_gather(o, inp.cpu())
+        out.copy_(o)
+
+    def send_to_root(self, tensors):
+        super().send_to_root([t.cpu() for t in tensors])
+
+    def recv_at_root(self, bufs_by_rank):
+        host = [(r, torch.empty(b.shape, dtype=b.dtype)) for r, b in bufs_by_rank]
+        super().recv_at_root(host)
+        for (_, b), (_, h) in zip(bufs_by_rank, host):
+            b.copy_(h)
+
+
+def combine_winners(e_all, l_all, i_all, group, ops, width=3, with_index=True, root_energy=True, comm=None, force=False):
     """Cross-rank first-max of a flat state (e_all (n,), l_all (n*width,), i_all (n,) or None), result on rank 0.
     Same outcome as `combine_all`, less traffic -- the payload crosses the fabric once, not twice:
 
@@ -179,44 +230,55 @@ def combine_winners(e_all, l_all, i_all, group, ops, width=3, with_index=True, r
       4. every rank packs the payload rows it won (pixel order) and sends them straight to rank 0, which unpacks
          them into place -- 12 B/pixel in total INTO rank 0, spread over its 7 links, instead of 12 B/pixel all-to-all
          plus 12 B/pixel to rank 0.  Optionally the winners' energies / indices travel the same way.
+
+    `comm`: how the collectives move the tensors (default `DirectComm(group)`; `HostStagedComm` stages device tensors
+    through the host).  `force`: run the local steps at world 1 as well -- rank 0 then packs the rows it won and unpacks
+    them from its own buffer, which moves nothing anywhere and only serves to TIME the per-rank kernel work
+    (bench.py `combine_ms`).
     """
-    world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
+    world = dist.get_world_size(group) if group is not None else 1
+    rank = dist.get_rank(group) if group is not None else 0
     n = e_all.numel()
-    if world == 1 or n == 0:
+    if (world == 1 and not force) or n == 0:
         return
+    comm = comm or DirectComm(group)
     bounds = chunk_bounds(n, world)
     sizes = [b - a for a, b in bounds]
     per = -(-n // world)
     mine = sizes[rank]
-    cand = torch.empty(world * mine, dtype=e_all.dtype, device=e_all.device)
-    dist.all_to_all_single(cand, e_all, output_split_sizes=[mine] * world, input_split_sizes=sizes, group=group)
+    if world > 1:
+        cand = torch.empty(world * mine, dtype=e_all.dtype, device=e_all.device)
+        comm.all_to_all(cand, e_all, [mine] * world, sizes)
+    else:
+        cand = e_all
     win_chunk = ops.winner(cand.view(world, mine))
-    padded = torch.zeros(per, dtype=torch.uint8, device=e_all.device)
-    padded[:mine] = win_chunk
-    gathered = torch.empty(world * per, dtype=torch.uint8, device=e_all.device)
-    dist.all_gather_into_tensor(gathered, padded, group=group)
-    win = gathered[:n]          # chunk r starts at r * per: the padded layout IS the pixel order
-    plan, totals = ops.plan(win, world)
+    if world > 1:
+        padded = torch.zeros(per, dtype=torch.uint8, device=e_all.device)
+        padded[:mine] = win_chunk
+        gathered = torch.empty(world * per, dtype=torch.uint8, device=e_all.device)
+        comm.all_gather(gathered, padded)
+        win = gathered[:n]          # chunk r starts at r * per: the padded layout IS the pixel order
+    else:
+        win = win_chunk
+    plan, totals = ops.plan(win, max(world, 2))
     arrays = [(l_all, width)]
     if root_energy:
         arrays.append((e_all, 1))
     if with_index and i_all is not None:
         arrays.append((i_all.view(torch.float32), 1))   # moved bit for bit
-    root = dist.get_global_rank(group, 0)
+    if world == 1:      # force: a sender's and the root's kernel work on this rank's own rows (rank 0 "won" them all;
+        for arr, w in arrays:                       # unpacked as if by a second rank: every row lands where it was)
+            own = ops.pack(win, plan, 2, 0, arr, w, totals[0])
+            ops.unpack(win, plan, 2, 1, [own, None], arr, w)
+        return
     if rank != 0:
         packed = [ops.pack(win, plan, world, rank, arr, w, totals[rank]) for arr, w in arrays]
         if totals[rank]:
-            for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, b, root, group) for b in packed]):
-                req.wait()
+            comm.send_to_root(packed)
     else:
         for arr, w in arrays:
             bufs = [None] + [torch.empty(totals[r] * w, dtype=arr.dtype, device=arr.device) for r in range(1, world)]
-            ops_ = [dist.P2POp(dist.irecv, bufs[r], dist.get_global_rank(group, r), group)
-                    for r in range(1, world) if totals[r]]
-            if ops_:
-                for req in dist.batch_isend_irecv(ops_):
-                    req.wait()
+            comm.recv_at_root([(r, bufs[r]) for r in range(1, world) if totals[r]])
             ops.unpack(win, plan, world, 0, bufs, arr, w)
 
 
@@ -236,11 +298,16 @@ def wrap_device(ptr, n, dtype, device):
 class Combiner:
     """Cross-GPU combine for a `_lib.Stack` on every rank of `group`."""
 
-    def __init__(self, stack, group=None):
+    def __init__(self, stack, group=None, comm=None, force=False):
         self.stack = stack
-        self.group = group if group is not None else dist.group.WORLD
+        # force (timing at world 1) works without any process group
+        self.group = group if group is not None else (dist.group.WORLD if dist.is_initialized() else None)
         self.device = stack.device
+        self.comm = comm        # None: DirectComm (RCCL on device tensors); HostStagedComm: device tensors over gloo
+        self.force = force      # run the local kernels at world 1 too (timing only)
         self._slabs = None
+        self._keep = []         # receive buffers / pointer tables the enqueued unpack kernels still read
+        self.timings = {}       # host milliseconds of the last combine_winners(): see there
 
     def _select_hip(self, cand_e, cand_l, cand_i):
         world, m = cand_e.shape
@@ -286,7 +353,9 @@ class Combiner:
         stream = torch.cuda.current_stream(arr.device).cuda_stream
         _lib.check(_lib.load().mi_combine_unpack(self.device, C.c_void_p(stream), win.data_ptr(), win.numel(), world, rank,
                                                  plan.data_ptr(), ptrs.data_ptr(), width, arr.data_ptr()))
-        torch.cuda.current_stream(arr.device).synchronize()   # `ptrs` and the receive buffers go out of scope
+        # no synchronisation per array: the pointer table and the receive buffers stay alive until combine_winners()
+        # synchronises once at its end
+        self._keep.append((ptrs, bufs, win, plan))
 
     def combine_winners(self, with_index=False, root_energy=False):
         """The winners-only protocol (`combine_winners`) in two phases: level 0 -- 3/4 of the state, final as soon as
@@ -299,12 +368,26 @@ class Combiner:
             self._slabs = (wrap_device(e_ptr, n, torch.float32, self.device), wrap_device(l_ptr, n * 3, torch.float32, self.device),
                            wrap_device(i_ptr, n, torch.int32, self.device), n0)
         e, l, i, n0 = self._slabs
+        import time
+        ts = torch.cuda.current_stream(torch.device("cuda", self.device))
+        kw = dict(with_index=with_index, root_energy=root_energy, comm=self.comm, force=self.force)
+        t0 = time.perf_counter()
         st.sync_level(0)
+        t1 = time.perf_counter()
         if n0:
-            combine_winners(e[:n0], l[:3 * n0], i[:n0], self.group, self, with_index=with_index, root_energy=root_energy)
-        st.sync()
-        combine_winners(e[n0:], l[3 * n0:], i[n0:], self.group, self, with_index=with_index, root_energy=root_energy)
-        torch.cuda.current_stream(torch.device("cuda", self.device)).synchronize()
+            combine_winners(e[:n0], l[:3 * n0], i[:n0], self.group, self, **kw)
+        t2 = time.perf_counter()
+        st.sync()       # the coarser levels + base of this rank: they ran on the stacker's streams beside the exchange above
+        t3 = time.perf_counter()
+        combine_winners(e[n0:], l[3 * n0:], i[n0:], self.group, self, **kw)
+        ts.synchronize()
+        t4 = time.perf_counter()
+        self._keep.clear()
+        # wait_level0: host wait for this rank's level-0 state; exchange_level0: the level-0 exchange (enqueue + collectives,
+        # its unpack kernels may still be running); wait_rest: what was LEFT of the coarser levels after that exchange
+        # (0 = they were hidden behind it); exchange_rest: the coarse levels' exchange + the final synchronisation
+        self.timings = {"wait_level0_ms": (t1 - t0) * 1e3, "exchange_level0_ms": (t2 - t1) * 1e3,
+                        "wait_rest_ms": (t3 - t2) * 1e3, "exchange_rest_ms": (t4 - t3) * 1e3}
 
     def combine(self, with_index=True, root_energy=True):
         """Call on every rank after its frames were pushed; rank 0 may then finish().

@@ -68,3 +68,107 @@ def test_winner_kernels_and_protocol_world_1():
     r = subprocess.run([sys.executable, "-c", SCRIPT], env=env, capture_output=True, text=True, timeout=600,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert "WINNERS_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+TWO_RANKS = r'''
+import os, sys, json
+import numpy as np
+import torch, torch.distributed as dist
+torch.cuda.init()
+sys.path.insert(0, os.getcwd())
+from shinestacker_amd import _lib as L
+from shinestacker_amd.multigpu import Combiner, HostStagedComm
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)      # ONE GPU for both processes: RCCL refuses that
+H, W, N = 300, 452, 12
+rng = np.random.default_rng(17)
+frames = [rng.integers(0, 256, (H, W, 3), dtype=np.uint8) for _ in range(N)]
+frames[7] = frames[1].copy()      # the same frame on both ranks: exact ties across ranks, the lower global index must win
+frames[9] = frames[4].copy()
+frames[3] = frames[1].copy()      # ... and inside one rank
+per = N // world
+for arith in ("exact", "separable"):
+    st = L.Stack(H, W, arith=arith)
+    st.set_first_index(rank * per)
+    for f in frames[rank * per:(rank + 1) * per]:
+        st.push_frame(f)
+    cb = Combiner(st, comm=HostStagedComm(dist.group.WORLD))      # the library's HIP kernels, not TorchWinnerOps
+    assert type(cb).winner is Combiner.winner
+    cb.combine_winners(with_index=True, root_energy=True)
+    if rank == 0:
+        whole = L.Stack(H, W, arith=arith)
+        for f in frames:
+            whole.push_frame(f)
+        for lv in range(st.levels):
+            for tap in (L.TAP_ENERGY, L.TAP_INDEX, L.TAP_FUSED_LAP):
+                assert np.array_equal(st.tap(tap, lv), whole.tap(tap, lv)), (arith, lv, tap)
+        assert np.array_equal(st.finish(), whole.finish()), arith
+        whole.close()
+        print("TIMINGS", arith, json.dumps(cb.timings))
+    # the image alone needs the winners' Laplacians / base pixels only
+    st2 = L.Stack(H, W, arith=arith)
+    st2.set_first_index(rank * per)
+    for f in frames[rank * per:(rank + 1) * per]:
+        st2.push_frame(f)
+    Combiner(st2, comm=HostStagedComm(dist.group.WORLD)).combine_winners(with_index=False, root_energy=False)
+    if rank == 0:
+        ref = L.Stack(H, W, arith=arith)
+        for f in frames:
+            ref.push_frame(f)
+        assert np.array_equal(st2.finish(), ref.finish()), arith
+        ref.close()
+    st.close(); st2.close()
+dist.barrier()
+dist.destroy_process_group()
+if rank == 0:
+    print("TWO_RANKS_OK")
+'''
+
+
+def test_device_combine_with_two_ranks_on_one_gpu(tmp_path):
+    """`Combiner.combine_winners` with world == 2 and the library's HIP kernels (mi_combine_winner / plan / pack / unpack on
+    the device-resident slabs): two processes share the one GPU, the collectives travel over gloo through the host
+    (`HostStagedComm`) because RCCL refuses two ranks on one device.  Cross-rank duplicate frames: the first maximum in
+    global frame order must win (pyramid.py:48-55).  Both arithmetics, both exchange variants."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    script = tmp_path / "two_ranks.py"
+    script.write_text(TWO_RANKS)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
+                       env=env, capture_output=True, text=True, timeout=900,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert "TWO_RANKS_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+FORCED = r'''
+import os, sys, json
+import numpy as np
+import torch
+torch.cuda.init()
+sys.path.insert(0, os.getcwd())
+from shinestacker_amd import _lib as L
+from shinestacker_amd.multigpu import Combiner
+rng = np.random.default_rng(5)
+frames = [rng.integers(0, 256, (200, 296, 3), dtype=np.uint8) for _ in range(5)]
+a = L.Stack(200, 296, arith="separable")
+for f in frames: a.push_frame(f)
+want = a.finish()
+b = L.Stack(200, 296, arith="separable")
+for f in frames: b.push_frame(f)
+cb = Combiner(b, force=True)
+cb.combine_winners()
+assert np.array_equal(b.finish(), want)
+assert set(cb.timings) == {"wait_level0_ms", "exchange_level0_ms", "wait_rest_ms", "exchange_rest_ms"}
+print("FORCED_OK", json.dumps(cb.timings))
+'''
+
+
+def test_forced_combine_at_world_1_runs_the_kernels_and_changes_nothing():
+    """bench.py's `combine_ms`: the per-rank kernel work of the exchange (winner map, plan, pack, unpack) run on a single
+    rank's own rows -- nothing moves, the result is unchanged, the phases are timed."""
+    r = subprocess.run([sys.executable, "-c", FORCED], capture_output=True, text=True, timeout=600,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert "FORCED_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
