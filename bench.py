@@ -57,9 +57,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=64,
                     help="frames of the CPU-baseline sample (about 10 s of CPU work at 24 MP on 16 cores)")
-    ap.add_argument("--cpu-refshaped", type=int, default=0,
+    ap.add_argument("--cpu-refshaped", type=int, default=4,
                     help="also time the reference-SHAPED restatement (all pyramids resident, full-size 25-tap "
-                         "filters) on this many frames (SURVEY 8(d) leg (i): 8; ~5 s per 24 MP frame; off by default)")
+                         "filters, argmax over the frame axis: SURVEY 8(d) leg (i)) on this many frames (~4 s per 24 MP "
+                         "frame; 0 = skip)")
     ap.add_argument("--force-combine", action="store_true",
                     help="world 1 only: run the cross-GPU exchange's per-rank kernel work (winner map, plan, pack, unpack) "
                          "inside every step although nothing has to move -> combine_ms (timing of the local part of the "
@@ -71,6 +72,16 @@ def parse():
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic.json"),
                     help="per-launch HBM bytes from the PMC passes (tools/pmc_traffic.py)")
     return ap.parse_args()
+
+
+def kernel_source_sha():
+    """provenance of profiles/traffic.json: sha256 over the sources of the level kernels and their launch schedule"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("kernels_sep.hpp", "kernels_tiled.hpp", "tiled_host.hpp"):
+        with open(os.path.join(ROOT, "shinestacker_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def cpu_model():
@@ -381,13 +392,24 @@ def main():
         ms_per_step = dt_s / args.steps * 1e3
         value = total_frames * H * W * args.steps / dt_s / 1e6
         achieved = roofline(ms_level, n_level, bytes_level)
-        traffic = None
+        # roofline.traffic: PMC bytes per launch of the dominant kernel from the separate --pmc passes of tools/profile.sh
+        # (profiles/traffic.json).  The entry names the kernel sources it was measured on (sha256) and the workload; a
+        # number measured on other sources or another input type is refused (null + the reason), never silently reused.
+        traffic, traffic_note = None, None
         try:
             with open(args.traffic_json) as fh:
                 tj = json.load(fh)
-            traffic = tj.get(args.arith, tj).get("hbm_bytes_per_launch")
-        except (OSError, AttributeError, ValueError):
-            pass
+            ent = tj.get(args.arith, {})
+            if ent.get("source_sha") != kernel_source_sha():
+                traffic_note = (f"profiles/traffic.json[{args.arith}] was measured on kernel sources {ent.get('source_sha')}, "
+                                f"these are {kernel_source_sha()}: re-run tools/profile_r03.sh")
+            elif ent.get("dtype", "f32") != args.dtype or ent.get("frames_per_launch") is None:
+                traffic_note = f"profiles/traffic.json[{args.arith}] is for dtype {ent.get('dtype')}, this run is {args.dtype}"
+            else:
+                traffic = ent.get("hbm_bytes_per_launch")
+                traffic_note = f"{ent.get('kernel')}; {ent.get('dispatches')} dispatches; {ent.get('note', '')}"
+        except (OSError, AttributeError, ValueError) as e:
+            traffic_note = f"profiles/traffic.json unreadable: {e}"
         kernel = {"separable": "level_sep<level 0> (stage + separable reduce + gray Laplacian + separable energy + "
                                "select; one launch = 16 frames of the resident push)",
                   "exact": "level_fused<level 0> (stage+reduce+laplacian+energy+select, one launch per frame batch)"}
@@ -411,7 +433,7 @@ def main():
                        "device": L.device_name(device),
                        "parallelism": f"{total_frames} frames in contiguous blocks of {F} over {world} GPU(s)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
                          "kernel": kernel[args.arith] if tiled else "simple impl: all level kernels of one frame",
                          "algorithmic_bytes_per_launch": bytes_level / max(n_level, 1),
                          "avg_launch_ms": ms_level / max(n_level, 1), "launches": n_level},
