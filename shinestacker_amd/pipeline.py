@@ -326,3 +326,70 @@ def align_and_stack_device(dev_frames, n_frames, height, width, dtype, ref_idx=-
         aligner.close()
         stack.close()
     return out, transforms, ccs
+
+
+def bunches_then_stack(get_frame, n_frames, height, width, dtype, frames=constants.DEFAULT_FRAMES,
+                       overlap=constants.DEFAULT_OVERLAP, device=0, out_dev=None, on_bunch=None, on_final=None,
+                       check_running=None, stacks=None, **stack_kwargs):
+    """BASELINE config 5's two-stage flow in memory (the reference's `FocusStackBunch` followed by `FocusStack`,
+    stack.py:61-113, examples/stack-from-frames): the frames are fused in bunches of `frames` with `overlap` shared
+    (`get_bunches`), every bunch result is the stacker's OUTPUT type -- truncated to the input dtype exactly as the file
+    the reference writes between the two actions (stack.py:33-36, pyramid.py:179) -- and the bunch results are fused once
+    more.  Stage 1 takes the frames from HOST memory through the pinned asynchronous upload of `mi_stack_push_frame`
+    (`get_frame(i) -> H x W x 3 array`; decode / generate, PCIe and kernels overlap); the bunch results never leave the
+    device: they are written side by side into one buffer and stage 2 consumes them in place.
+
+    The reference fuses the bunches in the order `chunks[count - 1]` (stack.py:97: the last one first); every bunch is an
+    independent stack and the second action reads the results sorted by the name of each bunch's first frame, i.e. in
+    bunch order -- which is the order used here.
+
+    `on_bunch(k, stack)` / `on_final(stack, results_buffer)`: called after a bunch's / the final stack's frames were pushed and before it is
+    finished (tests tap the selection state there).  `stacks`: an optional pair of `_lib.Stack` handles (stage 1, stage 2)
+    to reuse -- a handle owns pinned upload buffers and gigabytes of device buffers whose allocation costs more than a
+    short job; they are reset, not closed.  Returns the fused image (or None when `out_dev` is given) and the list of
+    bunches (frame indices)."""
+    from .actions import get_bunches
+    _lib.require_device()
+    if overlap >= frames:
+        raise InvalidOptionError("overlap", overlap, "overlap must be smaller than batch size")
+    dt = np.dtype(dtype)
+    fb = height * width * 3 * dt.itemsize
+    bunches = get_bunches(list(range(n_frames)), frames, overlap)
+    if not bunches:
+        raise ValueError("no frames")
+    results = _lib.DeviceBuffer(fb * len(bunches), device)
+    st = stacks[0] if stacks else _lib.Stack(height, width, in_dtype=dt, out_dtype=dt, device=device, **stack_kwargs)
+    try:
+        for k, bunch in enumerate(bunches):
+            st.reset()      # one handle serves every bunch, as one stacker object serves FocusStackBunch (stack.py:94-97)
+            for i in bunch:
+                st.push_frame(get_frame(i))
+                if check_running is not None and check_running() is False:
+                    from .errors import RunStopException
+                    raise RunStopException("bunches_then_stack")
+            if on_bunch is not None:
+                on_bunch(k, st)
+            st.finish_device(results.ptr + k * fb)
+        st.sync()
+    finally:
+        if not stacks:
+            st.close()
+    st2 = stacks[1] if stacks else _lib.Stack(height, width, in_dtype=dt, out_dtype=dt, device=device, **stack_kwargs)
+    try:
+        st2.reset()
+        st2.push_frames_device(results.ptr, len(bunches), fb)
+        if on_final is not None:
+            on_final(st2, results)
+        if out_dev is not None:
+            st2.finish_device(out_dev)
+            st2.sync()
+            out = None
+        else:
+            out = st2.finish()
+    finally:
+        if not stacks:
+            st2.close()
+        else:
+            st2.sync()      # `results` is freed below
+        results.free()
+    return out, bunches

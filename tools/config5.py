@@ -19,12 +19,53 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
+def two_stage(args):
+    from shinestacker_amd import _lib as L
+    from shinestacker_amd.pipeline import bunches_then_stack
+    N, H, W = args.frames, args.height, args.width
+    per = H * W * 3 * 2
+    ndist = 8   # distinct host frames, cycled (a real job decodes files here; 130 distinct 50 MP frames are 39 GB)
+    buf = L.DeviceBuffer(per * ndist)
+    L.synth_frames_device(buf.ptr, np.uint16, H, W, 0, ndist, ndist)
+    host = [buf.download((H, W, 3), np.uint16, offset=i * per) for i in range(ndist)]
+    buf.free()
+    out = L.DeviceBuffer(per)
+    marks = {}
+
+    def on_final(st2, _results):
+        L.check(L.load().mi_device_synchronize(0))
+        marks["stage1_done"] = time.perf_counter()
+
+    stacks = (L.Stack(H, W, in_dtype=np.uint16, out_dtype=np.uint16), L.Stack(H, W, in_dtype=np.uint16, out_dtype=np.uint16))
+
+    def run():
+        t0 = time.perf_counter()
+        _, bunches = bunches_then_stack(lambda i: host[i % ndist], N, H, W, np.uint16, out_dev=out.ptr, on_final=on_final,
+                                        stacks=stacks)
+        t1 = time.perf_counter()
+        return bunches, marks["stage1_done"] - t0, t1 - marks["stage1_done"]
+    run()
+    bunches, s1, s2 = run()
+    pushed = sum(len(b) for b in bunches)
+    print(json.dumps({"config": f"{N} x {W}x{H} u16 frames from host memory -> {len(bunches)} bunches of <= 10 (overlap 2) -> "
+                                f"one stack over the {len(bunches)} bunch results (resident, uint16), one GPU",
+                      "frames_pushed_stage1": pushed, "stage1_seconds": s1, "stage2_seconds": s2, "seconds": s1 + s2,
+                      "stage1_Mpixels_per_s": pushed * H * W / s1 / 1e6, "stage2_Mpixels_per_s": len(bunches) * H * W / s2 / 1e6,
+                      "host_to_device_GB_per_s": pushed * per / s1 / 1e9}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=64)
     ap.add_argument("--height", type=int, default=5792)
     ap.add_argument("--width", type=int, default=8640)
+    ap.add_argument("--two-stage", action="store_true",
+                    help="the whole config-5 flow on this GPU: bunches from host memory, then the bunch results -- kept on "
+                         "the device, truncated to uint16 as the reference's intermediate files are -- fused once more "
+                         "(pipeline.bunches_then_stack)")
     args = ap.parse_args()
+    if args.two_stage:
+        return two_stage(args)
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     dev = int(os.environ.get("MI_TOOL_DEVICE", os.environ.get("LOCAL_RANK", "0")))
     dist = None
