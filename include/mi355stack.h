@@ -49,7 +49,8 @@ enum {
     MI_ERR_HIP = 3,       /* a HIP runtime call failed        -> RuntimeError                    */
     MI_ERR_STATE = 4,     /* call order (finish before push)  -> RuntimeError                    */
     MI_ERR_NOMEM = 5,     /* device allocation failed         -> MemoryError                     */
-    MI_ERR_UNSUPPORTED = 6
+    MI_ERR_UNSUPPORTED = 6,
+    MI_ERR_ALIGNMENT = 7  /* a frame could not be registered    -> AlignmentError                  */
 };
 
 /* pixel / arithmetic types */
@@ -267,6 +268,36 @@ MI_API int mi_aligner_estimate(mi_aligner_t al, void* stream, const void* dev_mo
  * the method fails on (no overlap, constant image) gets cc = -2 and an identity matrix. */
 MI_API int mi_aligner_estimate_batch(mi_aligner_t al, void* stream, const void* const* dev_movs, int n, int max_iters,
                               double eps, double* M_out, double* cc_out, int* iters_out);
+
+/* ---- the resident align -> stack loop in ONE call (reference: CombinedActions.run_frame over AlignFrames with a fixed
+ * reference frame, stack_framework.py:191-232, :269-297, followed by FocusStack, stack.py:101-113; BASELINE config 4).
+ * Every frame of `dev_frames` (n_frames x H x W x 3, `frame_stride` bytes apart, the stack handle's in_dtype) except
+ * frame `ref_idx` is registered against frame `ref_idx` with the device estimator (`ecc_batch` <= 16 frames per batched
+ * Gauss-Newton), warped with align.py:230-251's border handling straight into the stacker's input batch and pushed
+ * (`batch_frames` warped frames per push; two batches alternate, so the next one fills while the last is fused); the
+ * reference frame passes through untouched (align.py:279-280).  The host-side sequencing that
+ * shinestacker_amd/pipeline.py does call by call (~25 library calls per frame) runs inside the library here -- same kernels
+ * in the same order on the same streams, same results.
+ *   dev_batches : 2 * batch_frames frames of scratch; dev_tmp: one frame, dev_mask: H x W bytes (border blur).
+ *   M_out       : n_frames x 9 doubles; row i holds the 2x3 (transform 0) or 3x3 (transform 1: the similarity applied through
+ *                 warpPerspective) matrix of frame i, zeros for the reference frame;  cc_out: n_frames correlation coefficients.
+ * A frame whose correlation stays below min_correlation stops the loop: MI_ERR_ALIGNMENT, *failed_frame = its index
+ * (-> AlignmentError); frames before it have been pushed. */
+typedef struct mi_align_stack_opts {
+    int transform;            /* 0: ALIGN_RIGID (warpAffine), 1: ALIGN_HOMOGRAPHY (warpPerspective) */
+    int border_mode;          /* as mi_warp_affine_device */
+    double border_value[4];
+    int blur_ksize;
+    double blur_sigma;
+    double min_correlation;
+    int max_iters;
+    double eps;
+    int ecc_batch;            /* 1..16 */
+    int batch_frames;         /* >= 1 */
+} mi_align_stack_opts_t;
+MI_API int mi_align_stack_device(mi_stack_t* st, mi_aligner_t al, const void* dev_frames, int n_frames, size_t frame_stride,
+                          int ref_idx, const mi_align_stack_opts_t* opts, void* dev_batches, void* dev_tmp, void* dev_mask,
+                          double* M_out, double* cc_out, int* failed_frame);
 
 /* ---- BalanceFrames device steps (reference algorithms/balance.py).
  * mi_histogram: histogram of an H x W x 3 uint8/uint16 BGR image as balance.py:158-180

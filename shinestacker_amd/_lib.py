@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("MI355STACK_LIB") or os.path.join(_HERE, "csrc", "libm
 
 # enums of mi355stack.h
 MI_OK, MI_ERR_INVALID, MI_ERR_NO_DEVICE, MI_ERR_HIP, MI_ERR_STATE, MI_ERR_NOMEM, \
-    MI_ERR_UNSUPPORTED = range(7)
+    MI_ERR_UNSUPPORTED, MI_ERR_ALIGNMENT = range(8)
 MI_U8, MI_U16, MI_F32, MI_F64 = range(4)
 (TAP_GAUSS, TAP_FUSED_LAP, TAP_ENERGY, TAP_INDEX, TAP_FUSED_BASE, TAP_BASE_IDX_E,
  TAP_BASE_IDX_D, TAP_COLLAPSED, TAP_BASE_ENT, TAP_BASE_DEV) = range(10)
@@ -37,6 +37,13 @@ class StackParams(C.Structure):
                 ("gen_kernel", C.c_double), ("float_type", C.c_int32), ("use_fma", C.c_int32),
                 ("device", C.c_int32), ("impl", C.c_int32), ("batch_frames", C.c_int32),
                 ("arith", C.c_int32), ("reserved", C.c_int32 * 4)]
+
+
+class AlignStackOpts(C.Structure):
+    """mi_align_stack_opts_t"""
+    _fields_ = [("transform", C.c_int), ("border_mode", C.c_int), ("border_value", C.c_double * 4),
+                ("blur_ksize", C.c_int), ("blur_sigma", C.c_double), ("min_correlation", C.c_double),
+                ("max_iters", C.c_int), ("eps", C.c_double), ("ecc_batch", C.c_int), ("batch_frames", C.c_int)]
 
 
 class DepthMapParams(C.Structure):
@@ -132,6 +139,9 @@ SIGNATURES = {
     "mi_aligner_estimate_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int,
                                             C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                             C.POINTER(C.c_int)]),
+    "mi_align_stack_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_int,
+                                        C.POINTER(AlignStackOpts), C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "mi_dmap_default_params": (None, [C.POINTER(DepthMapParams)]),
     "mi_dmap_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(DepthMapParams)]),
     "mi_dmap_destroy": (None, [C.c_void_p]),

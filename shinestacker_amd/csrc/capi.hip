@@ -1728,6 +1728,75 @@ int mi_aligner_estimate(mi_aligner_t al, void* stream, const void* dev_mov, int 
     return MI_OK;
 }
 
+int mi_align_stack_device(mi_stack_t* st, mi_aligner_t al, const void* dev_frames, int n_frames, size_t frame_stride,
+                          int ref_idx, const mi_align_stack_opts_t* o, void* dev_batches, void* dev_tmp, void* dev_mask,
+                          double* M_out, double* cc_out, int* failed_frame) {
+    int rc = check_handle(st);
+    if (rc) return rc;
+    if (!al || !dev_frames || !o || !dev_batches || !M_out || !cc_out) return fail(MI_ERR_INVALID, "null argument");
+    if (n_frames < 1 || ref_idx < 0 || ref_idx >= n_frames) return fail(MI_ERR_INVALID, "bad frame count / reference index");
+    if (o->ecc_batch < 1 || o->ecc_batch > ECC_MAXF || o->batch_frames < 1) return fail(MI_ERR_INVALID, "bad batch sizes");
+    if (al->height != st->p.height || al->width != st->p.width || al->dtype != st->p.in_dtype || al->device != st->p.device)
+        return fail(MI_ERR_INVALID, "the estimator and the stack handle are for different frames / devices");
+    if (failed_frame) *failed_frame = -1;
+    const int H = st->p.height, W = st->p.width, B = o->batch_frames;
+    const size_t fb = (size_t)H * W * 3 * dtype_size(st->p.in_dtype);
+    if (frame_stride == 0) frame_stride = fb;
+    const char* frames = (const char*)dev_frames;
+    MI_HIP(hipSetDevice(st->p.device));
+    if ((rc = mi_aligner_set_reference(al, nullptr, frames + (size_t)ref_idx * frame_stride))) return rc;
+    const bool persp = o->transform == 1;
+    std::vector<double> est((size_t)n_frames * 6, 0.0);
+    std::vector<char> have((size_t)n_frames, 0);
+    for (int i = 0; i < n_frames; ++i) {
+        for (int k = 0; k < 9; ++k) M_out[(size_t)i * 9 + k] = 0.0;
+        cc_out[i] = 1.0;
+    }
+    int cur = 0, filled = 0;
+    auto flush = [&]() -> int {
+        if (!filled) return MI_OK;
+        // no host synchronisation: the warps ran on the stacker's stream, where the level-0 kernels that read this batch
+        // are enqueued next, and the stacker joins its side streams into that stream after every push
+        int r = mi_stack_push_frames_device(st, (char*)dev_batches + (size_t)cur * B * fb, filled, fb);
+        cur ^= 1;
+        filled = 0;
+        return r;
+    };
+    for (int i = 0; i < n_frames; ++i) {
+        char* dst = (char*)dev_batches + ((size_t)cur * B + filled) * fb;
+        if (i == ref_idx) {
+            MI_HIP(hipMemcpyAsync(dst, frames + (size_t)i * frame_stride, fb, hipMemcpyDeviceToDevice, st->stream));
+        } else {
+            if (!have[i]) {   // the next ecc_batch moving frames in one batched Gauss-Newton (the estimator's own stream)
+                const void* ptrs[ECC_MAXF];
+                int idx[ECC_MAXF], nb = 0;
+                for (int k = i; k < n_frames && nb < o->ecc_batch; ++k)
+                    if (k != ref_idx) { idx[nb] = k; ptrs[nb++] = frames + (size_t)k * frame_stride; }
+                double Ms[ECC_MAXF * 6], ccs[ECC_MAXF];
+                int its[ECC_MAXF];
+                if ((rc = mi_aligner_estimate_batch(al, nullptr, ptrs, nb, o->max_iters, o->eps, Ms, ccs, its))) return rc;
+                for (int k = 0; k < nb; ++k) {
+                    for (int q = 0; q < 6; ++q) est[(size_t)idx[k] * 6 + q] = Ms[k * 6 + q];
+                    cc_out[idx[k]] = ccs[k];
+                    have[idx[k]] = 1;
+                }
+            }
+            if (!(cc_out[i] >= o->min_correlation)) {
+                if (failed_frame) *failed_frame = i;
+                return fail(MI_ERR_ALIGNMENT, "frame %d: correlation %.3f < %.3f", i, cc_out[i], o->min_correlation);
+            }
+            double* m = M_out + (size_t)i * 9;
+            for (int q = 0; q < 6; ++q) m[q] = est[(size_t)i * 6 + q];
+            if (persp) { m[6] = 0.0; m[7] = 0.0; m[8] = 1.0; }
+            if ((rc = warp_device_impl(st->p.device, st->stream, frames + (size_t)i * frame_stride, dst, dev_tmp, dev_mask, H, W,
+                                       st->p.in_dtype, m, persp, o->border_mode, o->border_value, o->blur_ksize, o->blur_sigma)))
+                return rc;
+        }
+        if (++filled == B && (rc = flush())) return rc;
+    }
+    return flush();
+}
+
 int mi_ecc_similarity(int device, const void* host_ref, const void* host_mov, int height, int width,
                       int dtype, int max_levels, int max_iters, double eps, double* M_out, double* cc_out,
                       int* iters_out) {

@@ -40,6 +40,15 @@ namespace mi {
 #ifndef MI_SEP_TH
 #define MI_SEP_TH 28
 #endif
+// threads per workgroup for fp32 input (all levels >= 1 and fp32 frames): 512 = one quad per lane; 576 adds a ninth wave so
+// that the 18 x 32 items of P2 fit one round (with 512 the last two rows are a second round on wave 0 alone)
+#ifndef MI_SEP_PF_SPLIT
+#define MI_SEP_PF_SPLIT 0
+#endif
+#ifndef MI_SEP_NT_F32
+#define MI_SEP_NT_F32 ((MI_SEP_TH / 2 + 2) * 32)
+#endif
+template <typename TIn> constexpr int sep_nt() { return sizeof(TIn) == 4 ? MI_SEP_NT_F32 : (MI_SEP_TH / 2 + 2) * 32; }
 // non-temporal G_{l+1} stores (written once, read by the next level's launch much later)
 #ifndef MI_SEP_NT_STORE
 #define MI_SEP_NT_STORE 1
@@ -66,7 +75,7 @@ struct SepGeom {
         return (interior && esize <= 2 ? GH * (GD / 4) * esize : GH * GS) + NH * VS + NH * XS;
     }
     static_assert(GD % 4 == 0 && NW == 32, "tile width is fixed by the 32-lane quad rows");
-    static_assert(QY * QL == NT, "one quad per lane");
+    static_assert(QY * QL <= NT, "one quad per lane (a ninth wave, if any, only stages, reduces and carries P2 items)");
     static_assert(HBH * HBS <= NH * VS, "HB aliases V");
     static_assert((NH / 2) * (GD / 4) <= NT && NH % 2 == 0 && NT % 64 == 0, "phase items");
 };
@@ -328,11 +337,13 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
         }
     }
     const uint32_t frame_bytes = (uint32_t)h * (uint32_t)w * 3u * (uint32_t)sizeof(TIn);
-    auto prefetch = [&](int b) {
+    // chunks [n0, n1) of frame b
+    auto prefetch = [&](int b, int n0 = 0, int n1 = G::NPRE) {
         const char* frb = src0 + (size_t)b * a.src_stride;
         const BufRsrc rs = make_rsrc(frb, frame_bytes);
 #pragma unroll
         for (int n = 0; n < G::NPRE; ++n) {
+            if (n < n0 || n >= n1) continue;
             const int id = tid + n * NT;
             if ((n + 1) * NT > G::NCH && id >= G::NCH) continue;
             if constexpr (INTERIOR) {
@@ -357,6 +368,9 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
         }
     };
     prefetch(0);
+#ifdef MI_PHASE_CLOCK
+    unsigned int pc_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pc_last = (unsigned int)clock64();
+#endif
 
     for (int b = 0; b < nfr; ++b) {
         int lt = tid;
@@ -395,8 +409,14 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
                 else *reinterpret_cast<v4f*>(sG + 4 * (lt + n * NT)) = pre[n].get();
             }
         }
+        MI_TICK(0);   // stage (waits for the prefetched loads)
         __syncthreads();
-        if (b + 1 < nfr && !MI_ABL(16)) prefetch(b + 1);
+        MI_TICK(1);   // barrier 1
+        // the next frame's loads: all here (0), or spread over the phases (MI_SEP_PF_SPLIT) so that the eight waves do
+        // not queue up at the texture-address unit together (an issue stalls while its queue is full)
+        constexpr int PF_A = MI_SEP_PF_SPLIT == 0 ? G::NPRE : MI_SEP_PF_SPLIT == 1 ? (G::NPRE + 1) / 2 : 1;
+        if (b + 1 < nfr && !MI_ABL(16)) prefetch(b + 1, 0, PF_A);
+        MI_TICK(2);   // prefetch issue
         const BufRsrc gn_rs = make_rsrc(gnext0 + (size_t)b * a.gnext_stride, (uint32_t)hn * (uint32_t)wn * 12u);
 
         // ---------------- P1: vertical reduce, 2 V rows x one float4 column group per lane
@@ -438,7 +458,11 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
             lds_store4(d, a0.x, a0.y, a1.x, a1.y);
             lds_store4(d + G::VS, b0.x, b0.y, b1.x, b1.y);
         }
+        if (MI_SEP_PF_SPLIT == 1 && b + 1 < nfr && !MI_ABL(16)) prefetch(b + 1, PF_A, G::NPRE);
+        if (MI_SEP_PF_SPLIT == 2 && b + 1 < nfr && !MI_ABL(16)) prefetch(b + 1, 1, 2);
+        MI_TICK(3);   // P1
         __syncthreads();
+        MI_TICK(4);   // barrier 2
 
         // ---------------- P2: horizontal reduce (one G_{l+1} pixel per lane, 32 lanes per patch row), G_{l+1} store, gray,
         // horizontal expand of the gray -> X.  18 rows x 32 = 576 items: the last two rows are a second round on wave 0.
@@ -490,10 +514,13 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
             const float gl = dpp_wave_prev(g), gr = dpp_wave_next(g);
             lds_store2(sX + mul24(r, G::XS) + 2 * jp, ex_even(gl, g, gr, ce, cc), ex_odd(g, gr, co));
         }
+        if (MI_SEP_PF_SPLIT == 2 && b + 1 < nfr && !MI_ABL(16)) prefetch(b + 1, 2, 3);
+        MI_TICK(5);   // P2
         __syncthreads();
+        MI_TICK(6);   // barrier 3
 
         // ---------------- P3: vertical expand of the gray, gray Laplacian, Q, row blur of Q -> HB
-        if (!MI_ABL(4)) {
+        if (lt < G::QY * G::QL && !MI_ABL(4)) {   // (uniform per wave)
             const int qy3 = lt >> 5, ql3 = lt & 31;
             float q[4];
             if constexpr (INTERIOR) {
@@ -542,7 +569,10 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
                 lds_store2(sHB + mul24(2 * qy3 + rr, G::HBS) + 2 * ql3, hb0, hb1);
             }
         }
+        if (MI_SEP_PF_SPLIT == 2 && b + 1 < nfr && !MI_ABL(16)) prefetch(b + 1, 3, G::NPRE);
+        MI_TICK(7);   // P3
         __syncthreads();
+        MI_TICK(8);   // barrier 4
 
         // ---------------- P4: column blur of HB for the own quad + running first-max
         if (own_tile && !MI_ABL(8)) {
@@ -562,9 +592,17 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
                 bI[p] = win ? fidx : bI[p];
             }
         }
+        MI_TICK(9);   // P4
         // no barrier here: sG is rewritten after P3's reads (barrier above), V/HB after the next frame's first
         // barrier, X after its second
     }
+#ifdef MI_PHASE_CLOCK
+    if (INTERIOR && a.dbg && (tid & 63) == 0 && blockIdx.y == 0) {
+#pragma unroll
+        for (int i = 0; i < 10; ++i) atomicAdd(a.dbg + (tid >> 6) * 16 + i, (unsigned long long)pc_acc[i]);
+        atomicAdd(a.dbg + (tid >> 6) * 16 + 15, 1ull);
+    }
+#endif
 
     // ---- write the running maxima back
 #pragma unroll
@@ -587,11 +625,11 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
 #define MI_SEP_BD_WAVES 1
 #endif
 template <typename TIn, bool INTERIOR, int TH, int NT>
-__global__ __launch_bounds__(NT, INTERIOR ? (sizeof(TIn) <= 2 ? 8 : 1) : MI_SEP_BD_WAVES) void level_sep(LevelArgs a) {
+__global__ __launch_bounds__(NT, INTERIOR ? (sizeof(TIn) <= 2 ? 8 : (NT > 512 ? 7 : 1)) : MI_SEP_BD_WAVES) void level_sep(LevelArgs a) {
     level_sep_body<TIn, INTERIOR, TH, NT>(a);
 }
 template <typename TIn, bool INTERIOR, int TH, int NT>
-__global__ __launch_bounds__(NT) void level_sep_coarse(LevelArgs a) {
+__global__ __launch_bounds__(NT, INTERIOR && NT > 512 ? 7 : 1) void level_sep_coarse(LevelArgs a) {
     level_sep_body<TIn, INTERIOR, TH, NT>(a);
 }
 

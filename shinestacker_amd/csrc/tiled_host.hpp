@@ -386,7 +386,7 @@ int launch_level(mi_stack* s, int l, int set, const void* src, size_t src_stride
 template <typename TIn, bool L0_NAME>
 int launch_level_sep(mi_stack* s, int l, int set, const void* src, size_t src_stride, int nb, hipStream_t st_in,
                      hipStream_t st_bd, hipEvent_t ev_bd) {
-    constexpr int TH = MI_SEP_TH, NT = (TH / 2 + 2) * 32;
+    constexpr int TH = MI_SEP_TH, NT = sep_nt<TIn>();
     using SG = SepGeom<TH, NT>;
     constexpr int TW = SG::TW;
     TiledState* t = tstate(s);
@@ -423,6 +423,32 @@ int launch_level_sep(mi_stack* s, int l, int set, const void* src, size_t src_st
     a.frame_idx0 = s->first_index + s->n_pushed;
     for (int i = 0; i < 3; ++i) a.k1d[i] = s->k1d[i];
     a.ablate = study_env("MI_ABLATE", 0);   // -DMI_STUDY builds only (results are wrong when set)
+#ifdef MI_PHASE_CLOCK
+    static unsigned long long* dbg_dev = nullptr;
+    if (l == 0) {
+        if (!dbg_dev) {
+            MI_HIP(hipMalloc(&dbg_dev, 16 * 16 * 8));
+            MI_HIP(hipMemset(dbg_dev, 0, 16 * 16 * 8));
+        } else {   // print the previous level-0 pass's numbers (cycles per wave and frame)
+            unsigned long long hbuf[16 * 16];
+            MI_HIP(hipMemcpy(hbuf, dbg_dev, sizeof hbuf, hipMemcpyDeviceToHost));
+            MI_HIP(hipMemset(dbg_dev, 0, 16 * 16 * 8));
+            static const char* nm[10] = {"stage", "bar1", "pfissue", "P1", "bar2", "P2", "bar3", "P3", "bar4", "P4"};
+            for (int wv = 0; wv < NT / 64; ++wv) {
+                if (!hbuf[wv * 16 + 15]) continue;
+                fprintf(stderr, "wave %d:", wv);
+                double tot = 0;
+                for (int i = 0; i < 10; ++i) {
+                    const double v = (double)hbuf[wv * 16 + i] / (double)hbuf[wv * 16 + 15] / std::min(nb, SEP_LAUNCH_FRAMES);
+                    tot += v;
+                    fprintf(stderr, " %s %.0f", nm[i], v);
+                }
+                fprintf(stderr, "  total %.0f (clock ticks per frame)\n", tot);
+            }
+        }
+        a.dbg = dbg_dev;
+    } else a.dbg = nullptr;
+#endif
     const size_t lds = (size_t)SG::LDS_FLOATS * sizeof(float);                                     // border tiles
     const size_t lds_in = (size_t)SG::lds_floats((int)sizeof(TIn), true) * sizeof(float);          // interior tiles
     auto kin = L0_NAME ? level_sep<TIn, true, TH, NT> : level_sep_coarse<TIn, true, TH, NT>;

@@ -188,7 +188,7 @@ def _make_correction(balance, device):
 
 def align_and_stack_device(dev_frames, n_frames, height, width, dtype, ref_idx=-1, alignment_config=None,
                            min_correlation=0.5, max_iters=60, device=0, batch_frames=16, out_dev=None,
-                           balance=None, ecc_batch=16, step_process=False, **stack_kwargs):
+                           balance=None, ecc_batch=16, step_process=False, native_loop=True, **stack_kwargs):
     """BASELINE config 4 with every frame resident in HBM: `dev_frames` is the device address of
     `n_frames` contiguous H x W x 3 frames.  Each frame is registered against frames[ref_idx] by
     the device ECC estimator (mi_aligner_*), warped with the blurred replicate border of
@@ -205,6 +205,9 @@ def align_and_stack_device(dev_frames, n_frames, height, width, dtype, ref_idx=-
     mask_size, intensity_interval): every aligned frame is then balanced against the reference frame
     (balance.py; the order of the reference's example projects: align, balance, stack) in place on the
     device -- histogram on the GPU, the 256/65536-entry table on the host, table apply on the GPU.
+
+    `native_loop` (default): without balancing the frame loop runs inside the library (`mi_align_stack_device`); False
+    keeps the call-by-call Python loop below (the two are tested equal).
 
     `step_process=True`: the reference's chained order (see `_align_chains_device`): every frame is registered against
     its already-aligned neighbour; the aligned frames are kept in one extra device buffer (n_frames frames) and fused in
@@ -253,6 +256,43 @@ def align_and_stack_device(dev_frames, n_frames, height, width, dtype, ref_idx=-
     aligner = _lib.Aligner(height, width, dt, subsample=max(1, int(cfg['subsample'])), device=device,
                                    fast=bool(cfg['fast_subsampling']))
     ecc_batch = max(1, min(int(ecc_batch), _lib.Aligner.MAX_BATCH))
+    if balance is None and native_loop:
+        # the whole loop below in ONE library call (mi_align_stack_device): same kernels in the same order on the same
+        # streams; the ~25 ctypes calls per frame of the Python loop made the pipeline's pace depend on how busy the host is
+        # (0.08 s on an idle box, 0.3 s on a shared one, for 128 x 24 MP)
+        batches = _lib.DeviceBuffer(2 * fb * batch_frames, device)
+        tmp = _lib.DeviceBuffer(fb, device)
+        mask = _lib.DeviceBuffer(height * width, device)
+        try:
+            opts = _lib.AlignStackOpts(transform=int(homography), border_mode=_BORDER_CODE[cfg['border_mode']],
+                                       border_value=(C.c_double * 4)(*(list(cfg['border_value']) + [0, 0, 0, 0])[:4]),
+                                       blur_ksize=21, blur_sigma=float(cfg['border_blur']),
+                                       min_correlation=float(min_correlation), max_iters=int(max_iters), eps=1e-9,
+                                       ecc_batch=ecc_batch, batch_frames=int(batch_frames))
+            M = (C.c_double * (9 * n_frames))()
+            cc = (C.c_double * n_frames)()
+            failed = C.c_int(-1)
+            rc = lib.mi_align_stack_device(stack._h, aligner._h, dev_frames, n_frames, fb, ref_idx, C.byref(opts), batches.ptr,
+                                           tmp.ptr, mask.ptr, M, cc, C.byref(failed))
+            if rc == _lib.MI_ERR_ALIGNMENT:
+                raise AlignmentError(failed.value, f"correlation {cc[failed.value]:.3f} < {min_correlation}")
+            _lib.check(rc)
+            ms = np.array(M, dtype=np.float64).reshape(n_frames, 9)
+            transforms = [None if i == ref_idx else (ms[i].reshape(3, 3).copy() if homography else ms[i, :6].reshape(2, 3).copy())
+                          for i in range(n_frames)]
+            ccs = [float(c) for c in cc]
+            if out_dev is not None:
+                stack.finish_device(out_dev)
+                stack.sync()
+                out = None
+            else:
+                out = stack.finish()
+        finally:
+            aligner.close()
+            stack.close()
+            for b in (batches, tmp, mask):
+                b.free()
+        return out, transforms, ccs
     tmp = _lib.DeviceBuffer(fb, device)
     mask = _lib.DeviceBuffer(height * width, device)
     # two batches of warped frames: one is being fused while the next is being filled

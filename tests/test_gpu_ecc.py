@@ -167,6 +167,44 @@ def test_align_and_stack_device_equals_host_pipeline(L, oracle):
     np.testing.assert_array_equal(out.download((h, w, 3), np.uint8), fused_dev)
 
 
+@pytest.mark.parametrize("transform", ["ALIGN_RIGID", "ALIGN_HOMOGRAPHY"])
+def test_native_align_stack_loop_equals_the_python_loop(L, oracle, transform):
+    """mi_align_stack_device (the frame loop inside the library) == the call-by-call loop of pipeline.py: same transforms,
+    same correlation coefficients, same fused image bit for bit; batches that do not divide the frame count, the reference
+    frame in the middle of a batch; a frame that cannot be registered raises AlignmentError with its index."""
+    from shinestacker_amd.errors import AlignmentError
+    from shinestacker_amd.pipeline import align_and_stack_device
+    h, w, n = 384, 512, 9
+    frames = []
+    for f in range(n):
+        d = f - n // 2
+        T = similarity(0.1 * d, 1 + 5e-4 * d, 1.7 * d, -1.1 * d, (w - 1) / 2, (h - 1) / 2)
+        ref, mov = make_pair(oracle, T, h=h, w=w, seed=19, noise=3.0)
+        frames.append(ref if d == 0 else mov)
+    fb = frames[0].nbytes
+    buf = L.DeviceBuffer(n * fb)
+    for f, fr in enumerate(frames):
+        buf.upload(fr, f * fb)
+    cfg = {'subsample': 2, 'fast_subsampling': True, 'transform': transform}
+    res = {}
+    for native in (True, False):
+        res[native] = align_and_stack_device(buf.ptr, n, h, w, np.uint8, alignment_config=cfg, batch_frames=4, ecc_batch=3,
+                                             native_loop=native)
+    (fa, ta, ca), (fb_, tb, cb) = res[True], res[False]
+    assert ta[n // 2] is None and tb[n // 2] is None
+    for i in range(n):
+        if i != n // 2:
+            assert ta[i].shape == ((3, 3) if transform == "ALIGN_HOMOGRAPHY" else (2, 3))
+            assert np.array_equal(ta[i], tb[i]), i
+    assert ca == cb and np.array_equal(fa, fb_)
+    # a flat frame cannot be registered: the loop stops there and names it
+    buf.upload(np.full_like(frames[0], 90), 6 * fb)
+    with pytest.raises(AlignmentError) as e:
+        align_and_stack_device(buf.ptr, n, h, w, np.uint8, alignment_config=cfg, batch_frames=4)
+    assert "6" in str(e.value)
+    buf.free()
+
+
 def test_batched_estimate_equals_single_estimates(L, oracle):
     """mi_aligner_estimate_batch: every frame gets exactly what a single estimate gives (the per-frame
     sums are reduced in the same order), including a frame the method fails on."""

@@ -55,6 +55,7 @@ def main():
     ap.add_argument("--batch", type=int, default=16, help="warped frames per push into the stacker (resident mode)")
     ap.add_argument("--step-process", action="store_true", help="the reference's chained order (resident mode)")
     ap.add_argument("--arith", default="exact", choices=["exact", "separable"], help="stacker arithmetic (resident mode)")
+    ap.add_argument("--python-loop", action="store_true", help="the call-by-call Python loop instead of mi_align_stack_device")
     args = ap.parse_args()
     from shinestacker_amd import _lib as L
     from shinestacker_amd.align import ecc_estimator
@@ -94,9 +95,9 @@ def main():
         out = L.DeviceBuffer(fb)
         bal = {'channel': 'LUMI', 'corr_map': 'LINEAR', 'subsample': 8} if args.balance else None
         acfg = {'transform': 'ALIGN_HOMOGRAPHY'} if args.homography else None
-        align_and_stack_device(buf.ptr, min(N, 4), H, W, np.uint8, out_dev=out.ptr, balance=bal, arith=args.arith, step_process=args.step_process, batch_frames=args.batch, alignment_config=acfg)   # warm-up
+        align_and_stack_device(buf.ptr, min(N, 4), H, W, np.uint8, out_dev=out.ptr, balance=bal, arith=args.arith, step_process=args.step_process, batch_frames=args.batch, alignment_config=acfg, native_loop=not args.python_loop)   # warm-up
         t0 = time.perf_counter()
-        _, tr, ccs = align_and_stack_device(buf.ptr, N, H, W, np.uint8, ref_idx=ref, out_dev=out.ptr, balance=bal, arith=args.arith, step_process=args.step_process, batch_frames=args.batch, alignment_config=acfg)
+        _, tr, ccs = align_and_stack_device(buf.ptr, N, H, W, np.uint8, ref_idx=ref, out_dev=out.ptr, balance=bal, arith=args.arith, step_process=args.step_process, batch_frames=args.batch, alignment_config=acfg, native_loop=not args.python_loop)
         dt = time.perf_counter() - t0
         recovered = {k: m.copy() for k, m in enumerate(t for t in tr if t is not None)}
         for m in recovered.values():
