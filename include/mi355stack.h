@@ -263,7 +263,7 @@ MI_API int mi_aligner_destroy(mi_aligner_t al);
 MI_API int mi_aligner_set_reference(mi_aligner_t al, void* stream, const void* dev_ref);
 MI_API int mi_aligner_estimate(mi_aligner_t al, void* stream, const void* dev_mov, int max_iters, double eps,
                         double* M_out, double* cc_out, int* iters_out);
-/* n <= 16 moving frames against the same reference in one batched Gauss-Newton: one launch and one host
+/* n <= 128 moving frames against the same reference in one batched Gauss-Newton: one launch and one host
  * round trip per iteration for the whole batch.  M_out: n x 6, cc_out / iters_out: n entries; a frame
  * the method fails on (no overlap, constant image) gets cc = -2 and an identity matrix. */
 MI_API int mi_aligner_estimate_batch(mi_aligner_t al, void* stream, const void* const* dev_movs, int n, int max_iters,
@@ -272,7 +272,7 @@ MI_API int mi_aligner_estimate_batch(mi_aligner_t al, void* stream, const void* 
 /* ---- the resident align -> stack loop in ONE call (reference: CombinedActions.run_frame over AlignFrames with a fixed
  * reference frame, stack_framework.py:191-232, :269-297, followed by FocusStack, stack.py:101-113; BASELINE config 4).
  * Every frame of `dev_frames` (n_frames x H x W x 3, `frame_stride` bytes apart, the stack handle's in_dtype) except
- * frame `ref_idx` is registered against frame `ref_idx` with the device estimator (`ecc_batch` <= 16 frames per batched
+ * frame `ref_idx` is registered against frame `ref_idx` with the device estimator (`ecc_batch` <= 128 frames per batched
  * Gauss-Newton), warped with align.py:230-251's border handling straight into the stacker's input batch and pushed
  * (`batch_frames` warped frames per push; two batches alternate, so the next one fills while the last is fused); the
  * reference frame passes through untouched (align.py:279-280).  The host-side sequencing that
@@ -292,7 +292,7 @@ typedef struct mi_align_stack_opts {
     double min_correlation;
     int max_iters;
     double eps;
-    int ecc_batch;            /* 1..16 */
+    int ecc_batch;            /* 1..128 */
     int batch_frames;         /* >= 1 */
 } mi_align_stack_opts_t;
 MI_API int mi_align_stack_device(mi_stack_t* st, mi_aligner_t al, const void* dev_frames, int n_frames, size_t frame_stride,

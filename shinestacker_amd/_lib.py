@@ -553,7 +553,7 @@ class Aligner:
                                          C.byref(cc), C.byref(it)))
         return np.array(list(m), dtype=np.float64).reshape(2, 3), cc.value, it.value
 
-    MAX_BATCH = 16
+    MAX_BATCH = 128
 
     def estimate_batch(self, dev_ptrs, max_iters=60, eps=1e-9, stream=None):
         """Up to 16 moving frames in one batched Gauss-Newton (mi_aligner_estimate_batch).

@@ -694,6 +694,7 @@ struct mi_aligner {
     double* partial = nullptr;       // [cap][ECC_MAX_BLOCKS][ECC_NSUM]
     unsigned int* ticket = nullptr;  // [cap]
     double* hsums = nullptr;         // pinned, device-visible [cap][ECC_NSUM]: written by each frame's last block
+    EccBatch* hbatch = nullptr;      // pinned, device-visible: the iteration's per-frame parameters and active flags
     std::vector<void*> bufs;         // template pyramid + gray scratch
     std::vector<void*> fbufs;        // per-frame buffers (re-allocated when the capacity grows)
     hipStream_t own = nullptr;       // used when the caller passes no stream: handles on different host
@@ -708,6 +709,8 @@ void aligner_free_frames(mi_aligner* al) {
     al->fbufs.clear();
     if (al->hsums) (void)hipHostFree(al->hsums);
     al->hsums = nullptr;
+    if (al->hbatch) (void)hipHostFree(al->hbatch);
+    al->hbatch = nullptr;
     al->cap = 0;
 }
 
@@ -741,6 +744,7 @@ int aligner_reserve(mi_aligner* al, int n) {
     ok = ok && al->partial && al->ticket;
     if (ok) ok = hipMemset(al->ticket, 0, sizeof(unsigned int) * n) == hipSuccess;
     if (ok) ok = hipHostMalloc((void**)&al->hsums, (size_t)n * ECC_NSUM * sizeof(double), hipHostMallocDefault) == hipSuccess;
+    if (ok) ok = hipHostMalloc((void**)&al->hbatch, sizeof(EccBatch), hipHostMallocDefault) == hipSuccess;
     if (!ok) {
         aligner_free_frames(al);
         return fail(MI_ERR_NOMEM, "out of device memory");
@@ -823,7 +827,7 @@ int aligner_solve(mi_aligner* al, hipStream_t st, int n, int max_iters, double e
             f.active = !f.failed;
         }
         for (int it = 0; it < max_iters; ++it) {
-            EccBatch pb{};
+            EccBatch& pb = *al->hbatch;   // (the previous launch was waited for: nobody reads it now)
             int nact = 0;
             for (int k = 0; k < n; ++k) {
                 pb.p[k] = EccParams{fr[k].a, fr[k].b, fr[k].tx, fr[k].ty};
@@ -832,7 +836,7 @@ int aligner_solve(mi_aligner* al, hipStream_t st, int n, int max_iters, double e
             }
             if (!nact) break;
             hipLaunchKernelGGL(ecc_accumulate, dim3(nblk, n), dim3(256), 0, st, L.tmpl, L.img, np, L.h, L.w,
-                               pb, step, al->partial, al->ticket, al->hsums);
+                               (const EccBatch*)al->hbatch, step, al->partial, al->ticket, al->hsums);
             MI_HIP(hipStreamSynchronize(st));
             for (int k = 0; k < n; ++k) {
                 EccFrame& f = fr[k];

@@ -199,7 +199,11 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 
 constexpr int ECC_MAX_BLOCKS = 1024;
-constexpr int ECC_MAXF = 16;  // moving frames per batched launch
+// Moving frames per batched launch.  Round 3: 128 (was 16): every Gauss-Newton iteration is one launch AND one host round
+// trip for the whole batch, and the round trips -- not the 11 ms of accumulation kernels -- were what an estimate of 128
+// frames spent its 58 ms on (8 batches x ~110 iterations x ~40 us).  The per-frame parameters moved from the kernel
+// arguments (4 KB limit) to device-visible pinned host memory.
+constexpr int ECC_MAXF = 128;
 
 struct EccBatch {
     EccParams p[ECC_MAXF];
@@ -217,11 +221,11 @@ struct EccBatch {
 // from the 4x4 neighbourhood of the sample point -- 12 loads from one array instead of 4 from each of
 // three, and no gradient images to build or keep.
 __global__ __launch_bounds__(256) void ecc_accumulate(const float* __restrict__ tmpl, const float* __restrict__ img,
-                               size_t fstride, int h, int w, EccBatch pb, int step, double* __restrict__ partial,
-                               unsigned int* __restrict__ ticket, double* __restrict__ sums) {
+                               size_t fstride, int h, int w, const EccBatch* __restrict__ pb, int step,
+                               double* __restrict__ partial, unsigned int* __restrict__ ticket, double* __restrict__ sums) {
     const int f = blockIdx.y;
-    if (!pb.active[f]) return;
-    const EccParams p = pb.p[f];
+    if (!pb->active[f]) return;
+    const EccParams p = pb->p[f];
     img += (size_t)f * fstride;
     partial += (size_t)f * ECC_MAX_BLOCKS * ECC_NSUM;
     ticket += f;

@@ -170,6 +170,15 @@ def _align_chains_device(lib, dev_frames, aligned, n_frames, height, width, dt, 
     return transforms, ccs
 
 
+def close_handles(handles):
+    """release what `align_and_stack_device(keep_handles=True)` returned"""
+    stack, aligner, batches, tmp, mask = handles
+    aligner.close()
+    stack.close()
+    for b in (batches, tmp, mask):
+        b.free()
+
+
 def _make_correction(balance, device):
     """The correction object of BalanceFrames for a dict of its options (balance.py:366-388: channel -> class; the
     sub-sampling default depends on the map)."""
@@ -188,7 +197,8 @@ def _make_correction(balance, device):
 
 def align_and_stack_device(dev_frames, n_frames, height, width, dtype, ref_idx=-1, alignment_config=None,
                            min_correlation=0.5, max_iters=60, device=0, batch_frames=16, out_dev=None,
-                           balance=None, ecc_batch=16, step_process=False, native_loop=True, **stack_kwargs):
+                           balance=None, ecc_batch=16, step_process=False, native_loop=True, handles=None,
+                           keep_handles=False, **stack_kwargs):
     """BASELINE config 4 with every frame resident in HBM: `dev_frames` is the device address of
     `n_frames` contiguous H x W x 3 frames.  Each frame is registered against frames[ref_idx] by
     the device ECC estimator (mi_aligner_*), warped with the blurred replicate border of
@@ -205,6 +215,11 @@ def align_and_stack_device(dev_frames, n_frames, height, width, dtype, ref_idx=-
     mask_size, intensity_interval): every aligned frame is then balanced against the reference frame
     (balance.py; the order of the reference's example projects: align, balance, stack) in place on the
     device -- histogram on the GPU, the 256/65536-entry table on the host, table apply on the GPU.
+
+    `keep_handles` / `handles`: a job that fuses many stacks of one geometry keeps the stacker, the estimator and the
+    scratch buffers between calls (`keep_handles=True` returns them as a fourth value, `handles=` takes them back; close them
+    with `close_handles`): creating them costs 10-35 ms -- pinned host buffers, several GB of device buffers -- beside a
+    128-frame job of 45-80 ms.
 
     `native_loop` (default): without balancing the frame loop runs inside the library (`mi_align_stack_device`); False
     keeps the call-by-call Python loop below (the two are tested equal).
@@ -251,18 +266,23 @@ def align_and_stack_device(dev_frames, n_frames, height, width, dtype, ref_idx=-
             stack.close()
             aligned.free()
         return out, transforms, ccs
-    stack = _lib.Stack(height, width, in_dtype=dt, out_dtype=dt, device=device, batch_frames=batch_frames,
-                       **stack_kwargs)
-    aligner = _lib.Aligner(height, width, dt, subsample=max(1, int(cfg['subsample'])), device=device,
-                                   fast=bool(cfg['fast_subsampling']))
     ecc_batch = max(1, min(int(ecc_batch), _lib.Aligner.MAX_BATCH))
+    if handles is not None:   # handles of an earlier call (a job of many stacks): nothing is allocated here
+        stack, aligner, batches, tmp, mask = handles
+        stack.reset()
+    else:
+        stack = _lib.Stack(height, width, in_dtype=dt, out_dtype=dt, device=device, batch_frames=batch_frames,
+                           **stack_kwargs)
+        aligner = _lib.Aligner(height, width, dt, subsample=max(1, int(cfg['subsample'])), device=device,
+                               fast=bool(cfg['fast_subsampling']))
     if balance is None and native_loop:
         # the whole loop below in ONE library call (mi_align_stack_device): same kernels in the same order on the same
         # streams; the ~25 ctypes calls per frame of the Python loop made the pipeline's pace depend on how busy the host is
         # (0.08 s on an idle box, 0.3 s on a shared one, for 128 x 24 MP)
-        batches = _lib.DeviceBuffer(2 * fb * batch_frames, device)
-        tmp = _lib.DeviceBuffer(fb, device)
-        mask = _lib.DeviceBuffer(height * width, device)
+        if handles is None:
+            batches = _lib.DeviceBuffer(2 * fb * batch_frames, device)
+            tmp = _lib.DeviceBuffer(fb, device)
+            mask = _lib.DeviceBuffer(height * width, device)
         try:
             opts = _lib.AlignStackOpts(transform=int(homography), border_mode=_BORDER_CODE[cfg['border_mode']],
                                        border_value=(C.c_double * 4)(*(list(cfg['border_value']) + [0, 0, 0, 0])[:4]),
@@ -288,11 +308,16 @@ def align_and_stack_device(dev_frames, n_frames, height, width, dtype, ref_idx=-
             else:
                 out = stack.finish()
         finally:
-            aligner.close()
-            stack.close()
-            for b in (batches, tmp, mask):
-                b.free()
+            if handles is None and not keep_handles:
+                aligner.close()
+                stack.close()
+                for b in (batches, tmp, mask):
+                    b.free()
+        if keep_handles:
+            return out, transforms, ccs, (stack, aligner, batches, tmp, mask)
         return out, transforms, ccs
+    if handles is not None or keep_handles:
+        raise InvalidOptionError("handles", "reuse", ": handle reuse is implemented for the native loop without balancing")
     tmp = _lib.DeviceBuffer(fb, device)
     mask = _lib.DeviceBuffer(height * width, device)
     # two batches of warped frames: one is being fused while the next is being filled
