@@ -220,7 +220,7 @@ def test_argument_errors(L):
         al.estimate(buf.ptr)                                                  # no reference yet
     al.set_reference(buf.ptr)
     with pytest.raises(ValueError):
-        al.estimate_batch([buf.ptr] * 17)                                     # more than 16 frames
+        al.estimate_batch([buf.ptr] * 129)                                    # more than 128 frames
     al.close()
 
 
