@@ -1673,6 +1673,22 @@ int mi_aligner_set_area_subsampling(mi_aligner_t al, int enable) {
     if (!al) return fail(MI_ERR_INVALID, "null handle");
     al->area = enable != 0;
     al->have_ref = false;   // the reference pyramid was built with the other rule
+    // cv2.resize(INTER_AREA) by 1/s keeps round-half-even(dim / s) pixels where img[::s, ::s] keeps ceil(dim / s): the
+    // sub-sampled grid, its centre and the pyramid geometry follow the rule in force (the buffers were allocated for the
+    // larger of the two sizes)
+    const int s = al->subsample;
+    const int h = al->area ? (int)std::nearbyint(al->height * (1.0 / s)) : (al->height + s - 1) / s;
+    const int w = al->area ? (int)std::nearbyint(al->width * (1.0 / s)) : (al->width + s - 1) / s;
+    if (h < 16 || w < 16) return fail(MI_ERR_INVALID, "image too small for ECC");
+    al->h = h;
+    al->w = w;
+    int lh = h, lw = w;
+    for (size_t l = 0; l < al->lv.size(); ++l) {
+        al->lv[l].h = lh;
+        al->lv[l].w = lw;
+        lh = (lh + 1) / 2;
+        lw = (lw + 1) / 2;
+    }
     return MI_OK;
 }
 

@@ -284,12 +284,13 @@ def test_align_and_stack_device_step_process_chains(L, oracle):
 
 @pytest.mark.parametrize("dtype", [np.uint8, np.uint16])
 @pytest.mark.parametrize("s", [2, 4, 8])
-def test_device_area_subsampling_equals_host_resize(L, oracle, dtype, s):
+@pytest.mark.parametrize("size", ["divisible", "ragged"])
+def test_device_area_subsampling_equals_host_resize(L, oracle, dtype, s, size):
     """fast_subsampling=False (the reference's default and the setting of its example projects, utils.py:79-86:
     cv2.resize(INTER_AREA) by an integer factor) folded into the device estimator's first kernel == the host-side
     img_subsample followed by the estimate on the small images (translation rescaled as align.py:223 does)."""
     from shinestacker_amd.align import img_subsample
-    h, w = 384, 512
+    h, w = (384, 512) if size == "divisible" else (387, 509)   # 387 / 4 = 96.75 -> 97 rows = ceil; 509 / 4 = 127.25 -> 127 < ceil
     T = similarity(0.3, 1.002, 6.0, -4.0, (w - 1) / 2, (h - 1) / 2)
     ref, mov = make_pair(oracle, T, h=h, w=w, seed=21, noise=2.0)
     if dtype == np.uint16:
