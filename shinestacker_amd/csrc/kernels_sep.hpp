@@ -506,7 +506,7 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
                                     __builtin_bit_cast(uint32_t, n[2])};
                     // one 12-byte buffer store, non-temporal (aux bit 1 = NT on gfx94x / gfx950): written once, read by
                     // the next level's launch much later
-                    __builtin_amdgcn_raw_buffer_store_b96(pv, gn_rs, (uint32_t)mul24(mul24(i, wn) + j, 12), 0, MI_SEP_NT_STORE ? 2 : 0);
+                    __builtin_amdgcn_raw_buffer_store_b96(pv, gn_rs, (uint32_t)(mul24(i, wn) + j) * 12u, 0, MI_SEP_NT_STORE ? 2 : 0);
                 }
             }
             // gray of the pixel, its neighbours along the row by DPP, expanded columns 2j' (even) and 2j'+1 (odd)

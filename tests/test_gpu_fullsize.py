@@ -236,3 +236,28 @@ def test_config5_two_stage_16_bunches_50mp_u16(L, oracle):
     gen.free()
     assert bunches == want and checked == list(range(16)) and final == {"lap": True, "idx": True}
     assert out.shape == (H, W, 3) and out.dtype == np.uint16 and 40 * 257 < out.mean() < 215 * 257
+
+
+@pytest.mark.parametrize("arith", ["separable", "exact"])
+def test_frames_beyond_67_megapixels_tiled_equals_simple(L, arith):
+    """In-frame offsets are 32-bit (frames up to 357 MP are accepted, mi_stack_create); products of pixel indices must not
+    be taken with the 24-bit multiplier once a LEVEL has more than 2^24 pixels -- 108 MP frames have 27 M of them at level 1.
+    Three 9000 x 12000 u8 frames: the LDS-tiled kernels against the one-thread-per-output implementation."""
+    H, W, N = 9000, 12000, 3
+    per = H * W * 3
+    buf = L.DeviceBuffer(per * N)
+    L.synth_frames_device(buf.ptr, np.uint8, H, W, 0, N, N)
+    outs, idx1 = {}, {}
+    for impl in (L.IMPL_SIMPLE, L.IMPL_TILED):
+        st = L.Stack(H, W, in_dtype=np.uint8, arith=arith, impl=impl)
+        if impl == L.IMPL_SIMPLE:
+            for f in range(N):
+                st.push_frames_device(buf.ptr + f * per, 1, per)
+        else:
+            st.push_frames_device(buf.ptr, N, per)
+        idx1[impl] = st.tap(L.TAP_INDEX, 1)
+        outs[impl] = st.finish()
+        st.close()
+    buf.free()
+    assert np.array_equal(idx1[L.IMPL_SIMPLE], idx1[L.IMPL_TILED])
+    assert np.array_equal(outs[L.IMPL_SIMPLE], outs[L.IMPL_TILED])
