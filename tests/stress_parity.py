@@ -30,14 +30,26 @@ def main():
               "kernel_size": int(rng.choice([3, 5, 7]))}
         batch = int(rng.integers(0, 5))
         frames = make_frames(rng, (h, w), dt, n)
-        so = oracle.StreamingOracle(h, w, dt, keep_gauss=False, **kw)
+        arith = ["exact", "separable"][case % 2]
+        if case % 5 == 0:   # long resident pushes: frame chunks + merges (duplicates: ties across chunks)
+            frames = [frames[int(k)] for k in rng.integers(0, len(frames), int(rng.integers(33, 80)))]
+        so = oracle.StreamingOracle(h, w, dt, keep_gauss=False, arith=arith, **kw)
         for f in frames:
             so.push_frame(f)
         want = so.finish()
         for impl in (L.IMPL_TILED,):
-            st = L.Stack(h, w, in_dtype=dt, impl=impl, batch_frames=batch, **kw)
-            for f in frames:
-                st.push_frame(f)
+            st = L.Stack(h, w, in_dtype=dt, impl=impl, batch_frames=batch, arith=arith, **kw)
+            if case % 5 == 0:
+                fbytes = frames[0].nbytes
+                buf = L.DeviceBuffer(fbytes * len(frames))
+                for i, f in enumerate(frames):
+                    buf.upload(f, i * fbytes)
+                st.push_frames_device(buf.ptr, len(frames), fbytes)
+                st.sync()
+                buf.free()
+            else:
+                for f in frames:
+                    st.push_frame(f)
             ok = all(np.array_equal(st.tap(L.TAP_ENERGY, lv), so.best_e[lv]) and
                      np.array_equal(st.tap(L.TAP_FUSED_LAP, lv), so.best_lap[lv]) for lv in range(st.levels))
             got = st.finish()
@@ -45,8 +57,8 @@ def main():
             st.close()
             if not ok:
                 bad += 1
-                print("MISMATCH", case, impl, h, w, dt.__name__, n, kw, batch)
-    print(f"{n_cases} cases x 2 implementations: {bad} mismatches")
+                print("MISMATCH", case, impl, arith, h, w, dt.__name__, len(frames), kw, batch)
+    print(f"{n_cases} cases (exact / separable alternating, every fifth a long resident push): {bad} mismatches")
     return 1 if bad else 0
 
 
