@@ -274,6 +274,12 @@ def main():
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     force_dist = os.environ.get("MI_BENCH_FORCE_COMBINE") == "1" or args.force_combine  # exercise the combine at world 1
     backend = os.environ.get("MI_BENCH_BACKEND", "nccl")
+    # MI_BENCH_ONE_GPU=1: every rank on device 0, collectives staged through the host over gloo (multigpu.HostStagedComm):
+    # the whole multi-rank flow -- sharding, device combine kernels, rank 0's collapse, verification -- on a box with ONE GPU
+    # (RCCL refuses two ranks on one device).  A functional run, not a scaling measurement.
+    one_gpu = os.environ.get("MI_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        backend, local_rank = "gloo", 0
     if world > 1 or force_dist:
         # torch ships its own HIP runtime: it must be loaded BEFORE libmi355stack.so pulls in
         # /opt/rocm's, otherwise the process holds two runtimes and torch sees no GPU
@@ -290,8 +296,10 @@ def main():
         torch.cuda.set_device(local_rank)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group(backend, rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     device = local_rank
 
     dt = {"u8": np.uint8, "u16": np.uint16, "f32": np.float32}[args.dtype]
@@ -326,7 +334,8 @@ def main():
         combiner = None
         if world > 1 or force_dist:
             from shinestacker_amd import multigpu
-            combiner = multigpu.Combiner(st, dist.group.WORLD, force=world == 1)
+            combiner = multigpu.Combiner(st, dist.group.WORLD, force=world == 1,
+                                         comm=multigpu.HostStagedComm(dist.group.WORLD) if backend != "nccl" and world > 1 else None)
         phase = {"compute": 0.0, "combine": 0.0, "collapse": 0.0}
         cphase = {}
 
@@ -370,7 +379,7 @@ def main():
         dt_s = time.perf_counter() - t0
         if world > 1 or force_dist:
             import torch
-            t = torch.tensor([dt_s], device=f"cuda:{local_rank}", dtype=torch.float64)
+            t = torch.tensor([dt_s], device=f"cuda:{local_rank}" if backend == "nccl" else "cpu", dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt_s = float(t.item())
         prof = {k: st.profile_get(v) for k, v in (("level0", L.PROF_LEVEL0), ("levels", L.PROF_LEVEL),
@@ -431,7 +440,9 @@ def main():
                        "frames_per_gpu": F, "source": args.source, "arith": args.arith,
                        "impl": args.impl if args.impl != "auto" else ["auto", "simple", "tiled"][st.params.impl],
                        "device": L.device_name(device),
-                       "parallelism": f"{total_frames} frames in contiguous blocks of {F} over {world} GPU(s)"},
+                       "parallelism": f"{total_frames} frames in contiguous blocks of {F} over {world} " +
+                                      ("rank(s) SHARING ONE GPU (functional run, collectives over gloo through the host)"
+                                       if one_gpu else "GPU(s)")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
                          "kernel": kernel[args.arith] if tiled else "simple impl: all level kernels of one frame",

@@ -172,3 +172,25 @@ def test_forced_combine_at_world_1_runs_the_kernels_and_changes_nothing():
     r = subprocess.run([sys.executable, "-c", FORCED], capture_output=True, text=True, timeout=600,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert "FORCED_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_flow_with_two_ranks_on_one_gpu(scaling):
+    """bench.py's multi-rank path end to end on ONE GPU (MI_BENCH_ONE_GPU=1: both ranks on device 0, collectives staged
+    through the host over gloo): frame sharding with global indices, the device combine kernels, rank 0's collapse, the
+    max-over-ranks timing and the verification of the result against the oracle fed ALL frames."""
+    import json
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MI_BENCH_ONE_GPU="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2", "--frames", "8", "--height", "600",
+                        "--width", "900", "--steps", "1", "--warmup", "1", "--scaling", scaling, "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert lines, r.stdout[-2000:] + r.stderr[-3000:]
+    d = json.loads(lines[-1])
+    assert d["n_gpus"] == 2 and d["scaling"] == scaling and d["verified"] is True, d
+    assert d["combine_ms"] > 0 and "SHARING ONE GPU" in d["config"]["parallelism"]
