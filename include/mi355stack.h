@@ -313,6 +313,12 @@ MI_API int mi_histogram(int device, const void* host_img, int height, int width,
 MI_API int mi_histogram_device(int device, void* stream, const void* dev_img, void* dev_scratch, int height,
                         int width, int dtype, int mode, int subsample, int fast, double mask_size,
                         int64_t* counts);
+/* the same for n frames with ONE host round trip: frame k's histogram lands in counts + k * nch * nbins; dev_scratch holds
+ * n * 3 * nbins uint32 (the resident pipeline balances a whole batch of warped frames behind one synchronisation instead
+ * of one per frame: balance.py:181-201 for the GAMMA / MATCH_HIST maps, whose tables SciPy builds on the host) */
+MI_API int mi_histogram_device_batch(int device, void* stream, const void* const* dev_imgs, int n, void* dev_scratch,
+                              int height, int width, int dtype, int mode, int subsample, int fast, double mask_size,
+                              int64_t* counts);
 /* mi_apply_lut: dst[p][c] = lut[nlut == 1 ? 0 : c][src[p][c]] -- cv2.LUT (uint8) / np.take (uint16)
  * as balance.py:30-50 applies them: one table for all channels (LUMI) or one per channel (RGB).
  * lut: nlut tables of nbins entries of the image dtype. */

@@ -127,6 +127,8 @@ SIGNATURES = {
                                C.c_double, C.c_void_p]),
     "mi_histogram_device": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                       C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p]),
+    "mi_histogram_device_batch": (C.c_int, [C.c_int, C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_int,
+                                            C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p]),
     "mi_apply_lut": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                C.c_int]),
     "mi_apply_lut_device": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int,

@@ -221,6 +221,47 @@ class Correction:
             self._corr_pending = []
         return self.corrections
 
+    def hist_device_batch(self, dev_imgs, stream=None):
+        """histograms of several device frames behind ONE synchronisation (mi_histogram_device_batch)"""
+        import ctypes as C
+        nbins, n = _pixel_range(self.dtype), len(dev_imgs)
+        if getattr(self, "_scratch_n", 1) < n:
+            _lib.check(_lib.load().mi_device_synchronize(self.device))   # nothing enqueued still uses the old buffer
+            self._scratch = _lib.DeviceBuffer(3 * nbins * 4 * n, self.device)
+            self._scratch_n = n
+        out = np.zeros((n, self.channels, nbins), np.int64)
+        ptrs = (C.c_void_p * n)(*dev_imgs)
+        _lib.check(_lib.load().mi_histogram_device_batch(
+            self.device, stream, ptrs, n, self._scratch.ptr, self._shape[0], self._shape[1], _lib.DTYPE_CODE[self.dtype],
+            self.hist_mode, int(self.subsample), int(bool(self.fast_subsampling)), C.c_double(float(self.mask_size)),
+            out.ctypes.data))
+        return [[out[k, c] for c in range(self.channels)] for k in range(n)]
+
+    def apply_correction_device_batch(self, indices, dev_imgs, stream=None):
+        """Balance several device frames in place with one host round trip for all of them (LINEAR: none at all): the
+        histograms of the whole batch come back together, the tables are built on the host as the reference builds them
+        (balance.py:53-120) and applied frame by frame on the stream."""
+        if isinstance(self.corr_map, LinearMap):
+            for i, p in zip(indices, dev_imgs):
+                self._linear_device(i, p, stream)
+            return
+        hists = self.hist_device_batch(list(dev_imgs), stream)
+        nb = _pixel_range(self.dtype)
+        if getattr(self, "_dev_lut_n", 1) < len(indices):   # (the batch histogram above synchronised the stream)
+            self._dev_lut = _lib.DeviceBuffer(3 * nb * self.dtype.itemsize * len(indices), self.device)
+            self._dev_lut_n = len(indices)
+        tabs = []
+        for i, h in zip(indices, hists):
+            correction = self.corr_map.correction(h)
+            tabs.append(np.ascontiguousarray(np.stack(self.tables(correction)).astype(self.dtype)))
+            self.corrections[i] = self.corr_map.correction_size(correction)
+        allt = np.ascontiguousarray(np.stack(tabs))
+        self._dev_lut.upload(allt)
+        per = allt[0].nbytes
+        for k, p in enumerate(dev_imgs):
+            _lib.check(_lib.load().mi_apply_lut_device(self.device, stream, p, p, self._shape[0] * self._shape[1],
+                                                       _lib.DTYPE_CODE[self.dtype], self._dev_lut.ptr + k * per, allt.shape[1]))
+
     def apply_correction_device(self, idx, dev_img, stream=None):
         """Balance the device frame in place."""
         if isinstance(self.corr_map, LinearMap):
@@ -294,6 +335,25 @@ class Ch2Correction(Correction):
             return Correction.hist_device(self, dev_img, stream)[1:]
         finally:
             self.channels = 2
+
+    def hist_device_batch(self, dev_imgs, stream=None):
+        self.channels = 3
+        try:
+            return [h[1:] for h in Correction.hist_device_batch(self, dev_imgs, stream)]
+        finally:
+            self.channels = 2
+
+    def apply_correction_device_batch(self, indices, dev_imgs, stream=None):
+        lib, n = _lib.load(), self._shape[0] * self._shape[1]
+        for p in dev_imgs:
+            _lib.check(lib.mi_cvt_color_device(self.device, stream, p, p, n, _lib.MI_U8, self.to_code))
+        if isinstance(self.corr_map, LinearMap):
+            for i, p in zip(indices, dev_imgs):
+                self._linear_device(i, p, stream, first_channel=1)
+        else:
+            Correction.apply_correction_device_batch(self, indices, dev_imgs, stream)
+        for p in dev_imgs:
+            _lib.check(lib.mi_cvt_color_device(self.device, stream, p, p, n, _lib.MI_U8, self.from_code))
 
     def apply_correction_device(self, idx, dev_img, stream=None):
         lib, n = _lib.load(), self._shape[0] * self._shape[1]

@@ -1892,6 +1892,25 @@ int mi_histogram_device(int device, void* stream, const void* dev_img, void* dev
     return MI_OK;
 }
 
+int mi_histogram_device_batch(int device, void* stream, const void* const* dev_imgs, int n, void* dev_scratch, int height,
+                              int width, int dtype, int mode, int subsample, int fast, double mask_size, int64_t* counts) {
+    if (!dev_imgs || !dev_scratch || !counts || n < 1) return fail(MI_ERR_INVALID, "bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    const int nbins = dtype == MI_U8 ? 256 : 65536, nch = mode == 0 ? 3 : 1;
+    const size_t per = (size_t)nch * nbins;
+    for (int k = 0; k < n; ++k) {
+        if (!dev_imgs[k]) return fail(MI_ERR_INVALID, "null frame %d", k);
+        int rc = hist_enqueue(device, st, dev_imgs[k], (uint32_t*)dev_scratch + (size_t)k * per, height, width, dtype, mode,
+                              subsample, fast, mask_size);
+        if (rc) return rc;
+    }
+    std::vector<uint32_t> tmp(per * n);   // one copy and ONE synchronisation for the whole batch
+    MI_HIP(hipMemcpyAsync(tmp.data(), dev_scratch, tmp.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    MI_HIP(hipStreamSynchronize(st));
+    for (size_t i = 0; i < tmp.size(); ++i) counts[i] = (int64_t)tmp[i];
+    return MI_OK;
+}
+
 int mi_histogram(int device, const void* host_img, int height, int width, int dtype, int mode,
                  int subsample, int fast, double mask_size, int64_t* counts) {
     if (!host_img || !counts) return fail(MI_ERR_INVALID, "null argument");

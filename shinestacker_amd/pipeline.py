@@ -342,8 +342,15 @@ def align_and_stack_device(dev_frames, n_frames, height, width, dtype, ref_idx=-
         corr = _make_correction(balance, device)
         corr.begin_device(dev_frames + ref_idx * fb, height, width, dt, n_frames)
 
+    to_balance = []   # (frame index, device address) of the warped frames of the batch being filled
+
     def flush():
         nonlocal cur, filled
+        if filled and corr is not None and to_balance:
+            # the whole batch behind ONE host round trip (GAMMA / MATCH_HIST: the histograms come back together, SciPy
+            # builds the tables, the table applies are enqueued; LINEAR: no round trip at all)
+            corr.apply_correction_device_batch([i for i, _ in to_balance], [p for _, p in to_balance], st)
+            to_balance.clear()
         if filled:
             # No host synchronisation here: the warps run on the stacker's stream, where the level-0 kernels that read
             # this batch are enqueued next, and the stacker joins its side streams into that stream after every push --
@@ -374,7 +381,7 @@ def align_and_stack_device(dev_frames, n_frames, height, width, dtype, ref_idx=-
                 _lib.check(warp(device, st, src, dst, tmp.ptr, mask.ptr, height, width, _lib.DTYPE_CODE[dt], mm, mode, bv, 21,
                                 float(cfg['border_blur'])))
                 if corr is not None:
-                    corr.apply_correction_device(i, dst, st)
+                    to_balance.append((i, dst))
                 transforms.append(m)
                 ccs.append(cc)
             filled += 1

@@ -113,36 +113,37 @@ def test_balance_frames_sub_action(L, oracle, tmp_path):
     assert bal.correction.corrections[0, 0] > 1.2 and bal.correction.corrections[2, 0] < 0.95
 
 
+@pytest.mark.parametrize("corr_map", ["LINEAR", "GAMMA", "MATCH_HIST"])
 @pytest.mark.parametrize("channel", ["LUMI", "HSV", "HLS"])
-def test_resident_pipeline_with_balance(L, oracle, channel):
+def test_resident_pipeline_with_balance(L, oracle, channel, corr_map):
     """align -> balance -> stack with every frame in HBM: the device balance equals the host-array
     sub-action applied to the same aligned frames (HSV / HLS: the colour conversions run in place on the device)."""
     from shinestacker_amd import balance as b
     from shinestacker_amd.pipeline import align_and_stack_device
     from test_gpu_ecc import make_pair, similarity
-    h, w, n = 256, 384, 3
+    h, w, n = 256, 384, 5     # batches of 2 warped frames + the reference frame: batched histograms of 2, 1 and 2 frames
     frames = []
     for f in range(n):
         d = f - 1
         T = similarity(0.1 * d, 1.0, 1.5 * d, -1.0 * d, (w - 1) / 2, (h - 1) / 2)
         ref, mov = make_pair(oracle, T, h=h, w=w, seed=21, noise=2.0)
         fr = ref if d == 0 else mov
-        frames.append(np.clip(fr.astype(np.float64) * (1.0 + 0.15 * d), 0, 255).astype(np.uint8))
+        frames.append(np.clip(fr.astype(np.float64) * (1.0 + 0.1 * d), 0, 255).astype(np.uint8))
     buf = L.DeviceBuffer(n * frames[0].nbytes)
     for f, fr in enumerate(frames):
         buf.upload(fr, f * fr.nbytes)
-    opts = {"channel": channel, "corr_map": "LINEAR", "subsample": 2, "fast_subsampling": True}
+    opts = {"channel": channel, "corr_map": corr_map, "subsample": 2, "fast_subsampling": True}
     cfg = {"subsample": 1}
-    fused_bal, tr, _ = align_and_stack_device(buf.ptr, n, h, w, np.uint8, alignment_config=cfg, batch_frames=2,
+    fused_bal, tr, _ = align_and_stack_device(buf.ptr, n, h, w, np.uint8, ref_idx=1, alignment_config=cfg, batch_frames=2,
                                               balance=opts)
-    fused_raw, _, _ = align_and_stack_device(buf.ptr, n, h, w, np.uint8, alignment_config=cfg, batch_frames=2)
+    fused_raw, _, _ = align_and_stack_device(buf.ptr, n, h, w, np.uint8, ref_idx=1, alignment_config=cfg, batch_frames=2)
     assert (fused_bal != fused_raw).mean() > 0.2   # balancing changed the stack
     # replay on host arrays: warp each frame with the recovered transform, balance with the sub-action's class,
     # stack in memory -> identical bytes
     from shinestacker_amd.pyramid import PyramidStack
     aligned = [frames[1] if t is None else L.warp_affine(fr, t) for fr, t in zip(frames, tr)]
     cls = {"LUMI": b.LumiCorrection, "HSV": b.SVCorrection, "HLS": b.LSCorrection}[channel]
-    c = cls(corr_map="LINEAR", subsample=2, fast_subsampling=True)
+    c = cls(corr_map=corr_map, subsample=2, fast_subsampling=True)
     c.begin(frames[1], n, 1)
     balanced = [a if i == 1 else c.apply_correction(i, a) for i, a in enumerate(aligned)]
     want = PyramidStack().focus_stack_arrays(balanced)
