@@ -295,9 +295,23 @@ typedef struct mi_align_stack_opts {
     int ecc_batch;            /* 1..128 */
     int batch_frames;         /* >= 1 */
 } mi_align_stack_opts_t;
+/* optional: every aligned frame (not the reference frame) is balanced in place with the LINEAR map before it is pushed
+ * (the example projects' order: align, balance, stack -- CombinedActions([AlignFrames, BalanceFrames])); the fields are
+ * mi_balance_linear_device's, plus the 8-bit colour conversions around it for the HSV / HLS channel modes (-1 = none) */
+typedef struct mi_balance_linear_opts {
+    int mode, subsample, fast;
+    double mask_size;
+    int lo, hi, first_channel;
+    int cvt_to, cvt_from;      /* MI_CVT_* codes applied before / after; -1 = stay in BGR */
+    double ref_means[3];
+    void* dev_hist_scratch;    /* 3 * nbins uint32 */
+    void* dev_lut;             /* 3 * nbins entries of the image dtype */
+    double* dev_corr_out;      /* NULL or device array of n_frames * ncorr doubles (row i = frame i) */
+    int ncorr;
+} mi_balance_linear_opts_t;
 MI_API int mi_align_stack_device(mi_stack_t* st, mi_aligner_t al, const void* dev_frames, int n_frames, size_t frame_stride,
-                          int ref_idx, const mi_align_stack_opts_t* opts, void* dev_batches, void* dev_tmp, void* dev_mask,
-                          double* M_out, double* cc_out, int* failed_frame);
+                          int ref_idx, const mi_align_stack_opts_t* opts, const mi_balance_linear_opts_t* balance,
+                          void* dev_batches, void* dev_tmp, void* dev_mask, double* M_out, double* cc_out, int* failed_frame);
 
 /* ---- BalanceFrames device steps (reference algorithms/balance.py).
  * mi_histogram: histogram of an H x W x 3 uint8/uint16 BGR image as balance.py:158-180

@@ -46,6 +46,14 @@ class AlignStackOpts(C.Structure):
                 ("max_iters", C.c_int), ("eps", C.c_double), ("ecc_batch", C.c_int), ("batch_frames", C.c_int)]
 
 
+class BalanceLinearOpts(C.Structure):
+    """mi_balance_linear_opts_t"""
+    _fields_ = [("mode", C.c_int), ("subsample", C.c_int), ("fast", C.c_int), ("mask_size", C.c_double),
+                ("lo", C.c_int), ("hi", C.c_int), ("first_channel", C.c_int), ("cvt_to", C.c_int), ("cvt_from", C.c_int),
+                ("ref_means", C.c_double * 3), ("dev_hist_scratch", C.c_void_p), ("dev_lut", C.c_void_p),
+                ("dev_corr_out", C.c_void_p), ("ncorr", C.c_int)]
+
+
 class DepthMapParams(C.Structure):
     _fields_ = [("height", C.c_int32), ("width", C.c_int32), ("dtype", C.c_int32), ("device", C.c_int32),
                 ("map_type", C.c_int32), ("energy", C.c_int32), ("kernel_size", C.c_int32),
@@ -142,7 +150,7 @@ SIGNATURES = {
                                             C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                             C.POINTER(C.c_int)]),
     "mi_align_stack_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_int,
-                                        C.POINTER(AlignStackOpts), C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.POINTER(AlignStackOpts), C.POINTER(BalanceLinearOpts), C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "mi_dmap_default_params": (None, [C.POINTER(DepthMapParams)]),
     "mi_dmap_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(DepthMapParams)]),

@@ -211,6 +211,25 @@ class Correction:
             self._dev_corr.ptr + 8 * idx * self.corrections.shape[1]))
         self._corr_pending.append(idx)
 
+    def native_linear_opts(self, first_channel=0, cvt_to=-1, cvt_from=-1):
+        """mi_balance_linear_opts_t for mi_align_stack_device (the LINEAR map only; None otherwise): the aligned frames are
+        balanced inside the library's frame loop, the correction factors land in the device array `fetch_corrections` reads."""
+        import ctypes as C
+        if not isinstance(self.corr_map, LinearMap):
+            return None
+        m = self.corr_map
+        ncorr = len(m.reference)
+        if getattr(self, "_dev_corr", None) is None:
+            self._dev_corr = _lib.DeviceBuffer(8 * self.corrections.size, self.device)
+            self._corr_pending = []
+        o = _lib.BalanceLinearOpts(mode=self.hist_mode, subsample=int(self.subsample), fast=int(bool(self.fast_subsampling)),
+                                   mask_size=float(self.mask_size), lo=int(m.lo), hi=int(min(m.hi, m.n)),
+                                   first_channel=int(first_channel), cvt_to=int(cvt_to), cvt_from=int(cvt_from),
+                                   ref_means=(C.c_double * 3)(*([float(r) for r in m.reference] + [0.0] * (3 - ncorr))),
+                                   dev_hist_scratch=self._scratch.ptr, dev_lut=self._dev_lut.ptr,
+                                   dev_corr_out=self._dev_corr.ptr, ncorr=int(self.corrections.shape[1]))
+        return o
+
     def fetch_corrections(self):
         """Correction factors of the frames balanced by the device-only LINEAR path (synchronises the device)."""
         if getattr(self, "_corr_pending", None):
@@ -335,6 +354,9 @@ class Ch2Correction(Correction):
             return Correction.hist_device(self, dev_img, stream)[1:]
         finally:
             self.channels = 2
+
+    def native_linear_opts(self, first_channel=1, cvt_to=-1, cvt_from=-1):
+        return Correction.native_linear_opts(self, 1, self.to_code, self.from_code)
 
     def hist_device_batch(self, dev_imgs, stream=None):
         self.channels = 3

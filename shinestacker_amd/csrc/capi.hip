@@ -1749,8 +1749,8 @@ int mi_aligner_estimate(mi_aligner_t al, void* stream, const void* dev_mov, int 
 }
 
 int mi_align_stack_device(mi_stack_t* st, mi_aligner_t al, const void* dev_frames, int n_frames, size_t frame_stride,
-                          int ref_idx, const mi_align_stack_opts_t* o, void* dev_batches, void* dev_tmp, void* dev_mask,
-                          double* M_out, double* cc_out, int* failed_frame) {
+                          int ref_idx, const mi_align_stack_opts_t* o, const mi_balance_linear_opts_t* bal, void* dev_batches,
+                          void* dev_tmp, void* dev_mask, double* M_out, double* cc_out, int* failed_frame) {
     int rc = check_handle(st);
     if (rc) return rc;
     if (!al || !dev_frames || !o || !dev_batches || !M_out || !cc_out) return fail(MI_ERR_INVALID, "null argument");
@@ -1811,6 +1811,16 @@ int mi_align_stack_device(mi_stack_t* st, mi_aligner_t al, const void* dev_frame
             if ((rc = warp_device_impl(st->p.device, st->stream, frames + (size_t)i * frame_stride, dst, dev_tmp, dev_mask, H, W,
                                        st->p.in_dtype, m, persp, o->border_mode, o->border_value, o->blur_ksize, o->blur_sigma)))
                 return rc;
+            if (bal) {   // LINEAR balance of the aligned frame, in place, no host round trip
+                const size_t npx = (size_t)H * W;
+                if (bal->cvt_to >= 0 && (rc = mi_cvt_color_device(st->p.device, st->stream, dst, dst, npx, st->p.in_dtype, bal->cvt_to))) return rc;
+                if ((rc = mi_balance_linear_device(st->p.device, st->stream, dst, bal->dev_hist_scratch, bal->dev_lut, H, W,
+                                                   st->p.in_dtype, bal->mode, bal->subsample, bal->fast, bal->mask_size, bal->lo,
+                                                   bal->hi, bal->first_channel, bal->ref_means,
+                                                   bal->dev_corr_out ? bal->dev_corr_out + (size_t)i * bal->ncorr : nullptr)))
+                    return rc;
+                if (bal->cvt_from >= 0 && (rc = mi_cvt_color_device(st->p.device, st->stream, dst, dst, npx, st->p.in_dtype, bal->cvt_from))) return rc;
+            }
         }
         if (++filled == B && (rc = flush())) return rc;
     }

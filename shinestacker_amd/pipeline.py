@@ -275,7 +275,12 @@ def align_and_stack_device(dev_frames, n_frames, height, width, dtype, ref_idx=-
                            **stack_kwargs)
         aligner = _lib.Aligner(height, width, dt, subsample=max(1, int(cfg['subsample'])), device=device,
                                fast=bool(cfg['fast_subsampling']))
-    if balance is None and native_loop:
+    corr = bal_opts = None
+    if balance is not None:
+        corr = _make_correction(balance, device)
+        corr.begin_device(dev_frames + ref_idx * fb, height, width, dt, n_frames)
+        bal_opts = corr.native_linear_opts() if native_loop else None
+    if native_loop and (balance is None or bal_opts is not None):
         # the whole loop below in ONE library call (mi_align_stack_device): same kernels in the same order on the same
         # streams; the ~25 ctypes calls per frame of the Python loop made the pipeline's pace depend on how busy the host is
         # (0.08 s on an idle box, 0.3 s on a shared one, for 128 x 24 MP)
@@ -292,8 +297,11 @@ def align_and_stack_device(dev_frames, n_frames, height, width, dtype, ref_idx=-
             M = (C.c_double * (9 * n_frames))()
             cc = (C.c_double * n_frames)()
             failed = C.c_int(-1)
-            rc = lib.mi_align_stack_device(stack._h, aligner._h, dev_frames, n_frames, fb, ref_idx, C.byref(opts), batches.ptr,
+            rc = lib.mi_align_stack_device(stack._h, aligner._h, dev_frames, n_frames, fb, ref_idx, C.byref(opts),
+                                           C.byref(bal_opts) if bal_opts is not None else None, batches.ptr,
                                            tmp.ptr, mask.ptr, M, cc, C.byref(failed))
+            if bal_opts is not None:
+                corr._corr_pending.extend(i for i in range(n_frames) if i != ref_idx)
             if rc == _lib.MI_ERR_ALIGNMENT:
                 raise AlignmentError(failed.value, f"correlation {cc[failed.value]:.3f} < {min_correlation}")
             _lib.check(rc)
@@ -336,11 +344,6 @@ def align_and_stack_device(dev_frames, n_frames, height, width, dtype, ref_idx=-
         ms, cs, _ = aligner.estimate_batch([dev_frames + k * fb for k in idx], max_iters=max_iters)
         for k, m, c in zip(idx, ms, cs):
             estimates[k] = (m, float(c))
-
-    corr = None
-    if balance is not None:
-        corr = _make_correction(balance, device)
-        corr.begin_device(dev_frames + ref_idx * fb, height, width, dt, n_frames)
 
     to_balance = []   # (frame index, device address) of the warped frames of the batch being filled
 

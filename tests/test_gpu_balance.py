@@ -148,6 +148,12 @@ def test_resident_pipeline_with_balance(L, oracle, channel, corr_map):
     balanced = [a if i == 1 else c.apply_correction(i, a) for i, a in enumerate(aligned)]
     want = PyramidStack().focus_stack_arrays(balanced)
     assert np.array_equal(fused_bal, want)
+    # LINEAR runs inside the library's frame loop (mi_align_stack_device with mi_balance_linear_opts_t); the call-by-call
+    # Python loop must give the same bytes
+    if corr_map == "LINEAR":
+        fused_py, _, _ = align_and_stack_device(buf.ptr, n, h, w, np.uint8, ref_idx=1, alignment_config=cfg, batch_frames=2,
+                                                balance=opts, native_loop=False)
+        assert np.array_equal(fused_py, fused_bal)
 
 
 @pytest.mark.parametrize("dtype", [np.uint8, np.uint16])
