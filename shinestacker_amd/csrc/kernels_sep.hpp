@@ -100,6 +100,30 @@ __device__ __forceinline__ float ex_even(float l, float c, float r, float ce, fl
 __device__ __forceinline__ float ex_odd(float c, float r, float co) { return co * (c + r); }
 __device__ __forceinline__ v2f ex_even(v2f l, v2f c, v2f r, float ce, float cc) { return pk_fma((v2f)ce, l + r, c * cc); }
 __device__ __forceinline__ v2f ex_odd(v2f c, v2f r, float co) { return (c + r) * co; }
+// two grays at once, each component in gray_of<true>'s order
+__device__ __forceinline__ v2f gray_of2(v2f b, v2f g, v2f r) {
+    return pk_fma(r, (v2f)0.299f, pk_fma(g, (v2f)0.587f, b * 0.114f));
+}
+
+// n / D for 0 <= n < LIM with one 24-bit multiply and a shift (the compiler's n / 51 is a 32-bit mul_hi plus a 64-bit
+// mad, both quarter rate); the magic is checked at compile time over the whole range
+template <int D, int LIM>
+struct SmallDiv {
+    static constexpr uint32_t M = 65536 / D + 1;
+    static constexpr bool ok() {
+        for (int n = 0; n < LIM; ++n)
+            if ((int)(((uint32_t)n * M) >> 16) != n / D) return false;
+        return (uint64_t)LIM * M < (1u << 24);
+    }
+    static_assert(ok(), "magic does not cover the range");
+    static __device__ __forceinline__ int div(int n) { return (int)(__umul24((uint32_t)n, M) >> 16); }
+};
+// 12 x: shift-and-add (the compiler picks the quarter-rate v_mul_lo_u32 for the constant)
+__device__ __forceinline__ uint32_t times12(uint32_t x) {
+    uint32_t x3;
+    asm("v_lshl_add_u32 %0, %1, 1, %1" : "=v"(x3) : "v"(x));
+    return x3 << 2;
+}
 
 // 8-byte LDS load that stays a ds_read_b64 (2 LDS cycles per wave): the machine load/store optimiser otherwise pairs
 // neighbouring ones into ds_read2_b64, which moves the same 16 bytes per lane in 8 cycles
@@ -148,14 +172,15 @@ template <> struct PreChunk<uint8_t> {
         const uint32_t w = *(const volatile uint32_t __attribute__((address_space(3)))*)(uint32_t)(uintptr_t)q;
         return v4f{(float)(w & 0xffu), (float)((w >> 8) & 0xffu), (float)((w >> 16) & 0xffu), (float)(w >> 24)};
     }
-    // six consecutive elements starting at element `e0` (even) of the row at `row`
+    // six consecutive elements (two pixels) starting at element `e0` (even) of the row at `row`, channel by channel:
+    // out[c] = (pixel 0, pixel 1) of channel c.  v_alignbyte takes the byte offset from the low two bits of e0.
     static __device__ __forceinline__ void unpack6(const uint32_t* row, int e0, v2f* out) {
         const uint32_t* q = row + (e0 >> 2);
-        const uint64_t w = ((uint64_t)q[1] << 32 | q[0]) >> (8 * (e0 & 3));
-        const uint32_t lo = (uint32_t)w, hi = (uint32_t)(w >> 32);
-        out[0] = v2f{(float)(lo & 0xffu), (float)((lo >> 8) & 0xffu)};
-        out[1] = v2f{(float)((lo >> 16) & 0xffu), (float)(lo >> 24)};
-        out[2] = v2f{(float)(hi & 0xffu), (float)((hi >> 8) & 0xffu)};
+        const uint32_t q0 = q[0], q1 = q[1];
+        const uint32_t lo = __builtin_amdgcn_alignbyte(q1, q0, (uint32_t)e0), hi = __builtin_amdgcn_alignbyte(0u, q1, (uint32_t)e0);
+        out[0] = v2f{(float)(lo & 0xffu), (float)(lo >> 24)};
+        out[1] = v2f{(float)((lo >> 8) & 0xffu), (float)(hi & 0xffu)};
+        out[2] = v2f{(float)((lo >> 16) & 0xffu), (float)((hi >> 8) & 0xffu)};
     }
     __device__ __forceinline__ void load(const char* p) { __builtin_memcpy(&v, p, 4); }
     __device__ __forceinline__ void load(BufRsrc r, uint32_t off) { v = __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0); }
@@ -175,14 +200,13 @@ template <> struct PreChunk<uint16_t> {
         const v2u w = *(const volatile v2u __attribute__((address_space(3)))*)(uint32_t)(uintptr_t)q;
         return v4f{(float)(w.x & 0xffffu), (float)(w.x >> 16), (float)(w.y & 0xffffu), (float)(w.y >> 16)};
     }
-    // six consecutive elements starting at element `e0` (even) of the row at `row`
+    // six consecutive elements (two pixels) starting at element `e0` (even) of the row at `row`, channel by channel
     static __device__ __forceinline__ void unpack6(const uint32_t* row, int e0, v2f* out) {
         const uint32_t* q = row + (e0 >> 1);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const uint32_t w = q[k];
-            out[k] = v2f{(float)(w & 0xffffu), (float)(w >> 16)};
-        }
+        const uint32_t q0 = q[0], q1 = q[1], q2 = q[2];
+        out[0] = v2f{(float)(q0 & 0xffffu), (float)(q1 >> 16)};
+        out[1] = v2f{(float)(q0 >> 16), (float)(q2 & 0xffffu)};
+        out[2] = v2f{(float)(q1 & 0xffffu), (float)(q2 >> 16)};
     }
     __device__ __forceinline__ void load(const char* p) {
         uint64_t t;
@@ -421,7 +445,7 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
 
         // ---------------- P1: vertical reduce, 2 V rows x one float4 column group per lane
         if (lt < (G::NH / 2) * CPR && !MI_ABL(1)) {
-            const int rp = lt / CPR, g = lt - rp * CPR;
+            const int rp = SmallDiv<CPR, NT>::div(lt), g = lt - mul24(rp, CPR);
             v2f a0, a1, b0, b1;   // (row 2rp | 2rp+1) x (floats 4g, 4g+1 | 4g+2, 4g+3)
             if constexpr (INTERIOR) {
                 v4f r[7];
@@ -506,7 +530,7 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
                                     __builtin_bit_cast(uint32_t, n[2])};
                     // one 12-byte buffer store, non-temporal (aux bit 1 = NT on gfx94x / gfx950): written once, read by
                     // the next level's launch much later
-                    __builtin_amdgcn_raw_buffer_store_b96(pv, gn_rs, (uint32_t)(mul24(i, wn) + j) * 12u, 0, MI_SEP_NT_STORE ? 2 : 0);
+                    __builtin_amdgcn_raw_buffer_store_b96(pv, gn_rs, times12((uint32_t)(mul24(i, wn) + j)), 0, MI_SEP_NT_STORE ? 2 : 0);
                 }
             }
             // gray of the pixel, its neighbours along the row by DPP, expanded columns 2j' (even) and 2j'+1 (odd)
@@ -526,22 +550,30 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
             if constexpr (INTERIOR) {
                 const float* xr = sX + mul24(qy3, G::XS) + 2 * ql3;           // X rows qy, qy+1, qy+2
                 const v2f xa = lds_load2s(xr), xb = lds_load2s(xr + G::XS), xc = lds_load2s(xr + 2 * G::XS);
-                v2f ge[3], go[3];   // patch rows 2qy+4, +5; columns 2ql+2, +3: six elements per row
+                const v2f ev = ex_even(xa, xb, xc, ce, cc), od = ex_odd(xb, xc, co);
+                v2f gge, ggo;   // gray of patch rows 2qy+4, +5; columns 2ql+2, +3
                 if constexpr (RAW) {
+                    // unpacked channel by channel ((pixel, pixel) pairs: the conversions write where they like), so the
+                    // two grays of a row are one packed chain
+                    v2f ge[3], go[3];
                     const uint32_t* rowp = sGr + mul24(2 * qy3 + 4, RD * CPR);
                     PreChunk<TIn>::unpack6(rowp, 6 * ql3 + 6, ge);
                     PreChunk<TIn>::unpack6(rowp + RD * CPR, 6 * ql3 + 6, go);
+                    gge = gray_of2(ge[0], ge[1], ge[2]);
+                    ggo = gray_of2(go[0], go[1], go[2]);
                 } else {
+                    // fp32 arrives as three 8-byte loads per row (pairs in memory order; regrouping them by channel
+                    // costs more moves than the packed chain saves)
+                    v2f ge[3], go[3];
                     const float* gp = sG + mul24(2 * qy3 + 4, G::GS) + 6 * ql3 + 6;
 #pragma unroll
                     for (int t = 0; t < 3; ++t) {
                         ge[t] = lds_load2s(gp + 2 * t);
                         go[t] = lds_load2s(gp + G::GS + 2 * t);
                     }
+                    gge = v2f{gray_of<true>(ge[0].x, ge[0].y, ge[1].x), gray_of<true>(ge[1].y, ge[2].x, ge[2].y)};
+                    ggo = v2f{gray_of<true>(go[0].x, go[0].y, go[1].x), gray_of<true>(go[1].y, go[2].x, go[2].y)};
                 }
-                const v2f ev = ex_even(xa, xb, xc, ce, cc), od = ex_odd(xb, xc, co);
-                const v2f gge = {gray_of<true>(ge[0].x, ge[0].y, ge[1].x), gray_of<true>(ge[1].y, ge[2].x, ge[2].y)};
-                const v2f ggo = {gray_of<true>(go[0].x, go[0].y, go[1].x), gray_of<true>(go[1].y, go[2].x, go[2].y)};
                 const v2f le = gge - ev, lo = ggo - od;
                 const v2f qe = le * le, qo = lo * lo;
                 q[0] = qe.x; q[1] = qe.y; q[2] = qo.x; q[3] = qo.y;
