@@ -560,6 +560,27 @@ int warp_scratch(int device, hipStream_t st, size_t ntiles, uint32_t** cnt, uint
     return MI_OK;
 }
 
+// the coordinate tables of one warp (warp_coord_tables): one buffer per (device, stream), as above
+int warp_coord_scratch(int device, hipStream_t st, size_t n_ints, int** tab) {
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, WarpScratch> cache;
+    const size_t need = n_ints * sizeof(int);
+    std::lock_guard<std::mutex> lk(mu);
+    WarpScratch& w = cache[{device, st}];
+    if (w.bytes < need) {
+        if (w.ptr) {
+            MI_HIP(hipStreamSynchronize(st));
+            (void)hipFree(w.ptr);
+            w.ptr = nullptr;
+            w.bytes = 0;
+        }
+        MI_HIP(hipMalloc(&w.ptr, need));
+        w.bytes = need;
+    }
+    *tab = (int*)w.ptr;
+    return MI_OK;
+}
+
 // the blurred-border composite behind a warp (align.py:245-251): passes over the tiles that hold a masked pixel
 template <typename T>
 int blur_launch(int device, hipStream_t st, void* side, void* out, uint8_t* valid, int h, int w, const GaussArgs& g,
@@ -614,8 +635,15 @@ int warp_launch(int device, hipStream_t st, const void* src, void* side, void* o
         }
         // LDS-staged tiles of 256 x 32 (16) destination pixels, four pixels x 8 (4) rows per thread; whole-dword stores
         // when every row starts 4-byte aligned
+        int* tab = nullptr;
+        {
+            int rc = warp_coord_scratch(device, st, 2 * ((size_t)w + h), &tab);
+            if (rc) return rc;
+        }
+        hipLaunchKernelGGL(warp_coord_tables, dim3(cdiv(std::max(w, h), 256)), dim3(256), 0, st, a, tab);
         const bool vec = (w % 4) == 0 && ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(valid)) & 3) == 0;
-        const dim3 grid(cdiv(w, WT_W), cdiv(h, WarpTile<T>::TH));
+        const int gx = cdiv(w, WT_W), gy = cdiv(h, WarpTile<T>::TH);   // tiles; the kernel's header has the block order
+        const dim3 grid(gx >= 3 && gy >= 3 ? (2 * gx + 2 * (gy - 2)) * WT_SPLIT + gx * (gy - 2) : gx * gy);
         const size_t lds = (size_t)WT_LDS_DWORDS * 4;
         auto kv = warp_affine_tiled<T, true>;
         auto ks = warp_affine_tiled<T, false>;
@@ -625,8 +653,8 @@ int warp_launch(int device, hipStream_t st, const void* src, void* side, void* o
             MI_HIP(hipFuncSetAttribute((const void*)ks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             attr_set = true;
         }
-        if (vec) hipLaunchKernelGGL(kv, grid, dim3(256), lds, st, (const T*)src, (T*)out, valid, a, bitmap, blur_tiles_x);
-        else hipLaunchKernelGGL(ks, grid, dim3(256), lds, st, (const T*)src, (T*)out, valid, a, bitmap, blur_tiles_x);
+        if (vec) hipLaunchKernelGGL(kv, grid, dim3(256), lds, st, (const T*)src, (T*)out, valid, a, bitmap, blur_tiles_x, (const int*)tab, gx, gy);
+        else hipLaunchKernelGGL(ks, grid, dim3(256), lds, st, (const T*)src, (T*)out, valid, a, bitmap, blur_tiles_x, (const int*)tab, gx, gy);
     }
     MI_HIP(hipGetLastError());
     // the warped image went straight to `out`; the few pixels outside the source frame are blurred from it into `side`

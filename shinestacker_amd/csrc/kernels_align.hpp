@@ -16,10 +16,34 @@ struct AffineArgs {
     int border[3];     // constant border value per channel, already rounded / saturated
 };
 
+// lane value x uniform value as ONE 24-bit multiply (left to itself the compiler re-associates the row offset into
+// v_mul_lo_u32, a quarter-rate instruction).  Only for operands that ordinary VALU instructions produced: the hazard
+// recogniser does not look inside inline asm, and a v_dot* result needs three wait states before a VALU may read it.
+__device__ __forceinline__ int mul24_vs(int v, int s) {
+    int d;
+    asm("v_mul_i32_i24 %0, %1, %2" : "=v"(d) : "s"(s), "v"(v));
+    return d;
+}
+
 __device__ __forceinline__ int cv_round_d(double v) {
     if (v >= 2147483647.0) return 2147483647;
     if (v <= -2147483648.0) return (-2147483647 - 1);
     return (int)rint(v);  // round half to even, as cvRound / lrint
+}
+
+// OpenCV's warpAffine rounds its coordinate terms in double ONCE per column (adelta / bdelta) and once per row; so does
+// this kernel, into a table the warp kernel reads: [ad: w][bd: w][X0: h][Y0: h] -- no double arithmetic per tile and row
+// in the warp itself (it was a third of the tiled kernel's instruction time).
+__global__ __launch_bounds__(256) void warp_coord_tables(AffineArgs a, int* __restrict__ tab) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < a.w) {
+        tab[i] = cv_round_d(a.iM[0] * i * 1024.0);
+        tab[a.w + i] = cv_round_d(a.iM[3] * i * 1024.0);
+    }
+    if (i < a.h) {
+        tab[2 * a.w + i] = cv_round_d((a.iM[1] * i + a.iM[2]) * 1024.0) + 16;
+        tab[2 * a.w + a.h + i] = cv_round_d((a.iM[4] * i + a.iM[5]) * 1024.0) + 16;
+    }
 }
 
 // one destination pixel: the 3 channel values and the mask bit
@@ -100,11 +124,11 @@ __device__ __forceinline__ void warp_pixel_xy(const T* __restrict__ src, const A
 // pixel; an affine map keeps the ones between them between): no clamping, no per-tap in-image flags, mask = 1 -- the
 // kernel is instruction-bound, and that bookkeeping was a third of its instructions.  Same arithmetic, same results.
 template <typename T>
-__device__ __forceinline__ void warp_pixel_inside(const T* __restrict__ src, const AffineArgs& a, int x, int X0, int Y0,
+__device__ __forceinline__ void warp_pixel_inside(const T* __restrict__ src, const AffineArgs& a, int adx, int bdx, int X0, int Y0,
                                                   int out[3]) {
     const int w = a.w;
-    const int X = (X0 + cv_round_d(a.iM[0] * x * 1024.0)) >> 5;
-    const int Y = (Y0 + cv_round_d(a.iM[3] * x * 1024.0)) >> 5;
+    const int X = (X0 + adx) >> 5;
+    const int Y = (Y0 + bdx) >> 5;
     const int sx = X >> 5, sy = Y >> 5, fx = X & 31, fy = Y & 31;
     int iw0 = (32 - fy) * (32 - fx) * 32, iw1 = (32 - fy) * fx * 32, iw2 = fy * (32 - fx) * 32, iw3 = fy * fx * 32;
     if (fx == 0 && fy == 0) { iw0 = 32767; iw3 = 1; }
@@ -188,24 +212,67 @@ __global__ __launch_bounds__(256) void warp_perspective_kernel(const T* __restri
 // path.
 constexpr int WT_W = 256;
 template <typename T> struct WarpTile { static constexpr int TH = sizeof(T) == 1 ? 32 : 16; };
-constexpr int WT_LDS_DWORDS = 10240;   // 40 KB: four workgroups per CU
+constexpr int WT_SPLIT = 4;   // workgroups per outer-ring tile (divides the rows per thread: 8 / 4)
+#ifndef MI_WT_LDS_DWORDS
+#define MI_WT_LDS_DWORDS 10240
+#endif
+constexpr int WT_LDS_DWORDS = MI_WT_LDS_DWORDS;   // 40 KB: four workgroups per CU
 
 template <typename T, bool VEC>
 __global__ __launch_bounds__(256) void warp_affine_tiled(const T* __restrict__ src, T* __restrict__ dst,
                                                          uint8_t* __restrict__ valid, AffineArgs a,
-                                                         uint32_t* __restrict__ tile_bitmap, int blur_tiles_x) {
+                                                         uint32_t* __restrict__ tile_bitmap, int blur_tiles_x,
+                                                         const int* __restrict__ tab, int gx, int gy) {
     extern __shared__ uint32_t s_src[];
     constexpr int BPP = 3 * (int)sizeof(T), TH = WarpTile<T>::TH, RPT = TH / 4;   // rows per thread
     const int h = a.h, w = a.w;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int x_t = blockIdx.x * WT_W, y_t = blockIdx.y * TH;
+    const int wvu = __builtin_amdgcn_readfirstlane(wv);   // the wave index as a scalar: row terms come in through scalar loads
+    // Which tile, which of its rows?  The grid is one-dimensional: the OUTER RING of tiles first, each as WT_SPLIT
+    // workgroups that take a quarter of every thread's rows, then the inner tiles one workgroup each.  A ring tile's source
+    // window usually leaves the image, so it takes the per-pixel path below -- dependent gathers, ten times an inner
+    // tile's duration: dispatched last and whole (the raster order's bottom row) they ran on alone for half the kernel's
+    // time (75 us per 24 MP frame, of which 35 us with the GPU nearly empty).
+    static_assert(RPT % WT_SPLIT == 0, "ring tiles split their rows evenly");
+    int tx, ty, k_lo = 0, k_hi = RPT;
+    {
+        const bool ring = gx >= 3 && gy >= 3;
+        const int nring = ring ? 2 * gx + 2 * (gy - 2) : 0;
+        int id = blockIdx.x;
+        if (id < nring * WT_SPLIT) {
+            int r = id / WT_SPLIT;
+            const int sub = id - r * WT_SPLIT;
+            k_lo = sub * (RPT / WT_SPLIT);
+            k_hi = k_lo + RPT / WT_SPLIT;
+            if (r < gx) { ty = 0; tx = r; }
+            else if (r < 2 * gx) { ty = gy - 1; tx = r - gx; }
+            else { r -= 2 * gx; ty = 1 + (r >> 1); tx = (r & 1) ? gx - 1 : 0; }
+        } else if (ring) {
+            // inner rows in raster order over the FULL width (their two ring tiles are done above: those workgroups leave):
+            // workgroup -> XCD stays `tile column mod 8` when the tile columns are a multiple of 8 (6000 px: 24), so an
+            // XCD's L2 sees vertical stripes of tiles, whose source rows overlap
+            id -= nring * WT_SPLIT;
+            ty = id / gx;
+            tx = id - ty * gx;
+            ty += 1;
+            if (tx == 0 || tx == gx - 1) return;
+        } else {
+            ty = id / gx;
+            tx = id - ty * gx;
+        }
+    }
+    const int x_t = tx * WT_W, y_t = ty * TH;
     const int xq = x_t + 4 * lane;
+    const int* const tad = tab;           // column terms (warp_coord_tables)
+    const int* const tbd = tab + w;
+    const int* const tx0 = tab + 2 * w;   // row terms, + 16
+    const int* const ty0 = tab + 2 * w + h;
     int ad[4], bd[4];
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const int x = min(xq + p, w - 1);
-        ad[p] = cv_round_d(a.iM[0] * x * 1024.0);
-        bd[p] = cv_round_d(a.iM[3] * x * 1024.0);
+        ad[p] = tad[x];
+        bd[p] = tbd[x];
     }
     // source bounding box of the tile (first taps; the +1 taps are added below)
     int sxmin = 0x7fffffff, sxmax = -0x7fffffff, symin = 0x7fffffff, symax = -0x7fffffff;
@@ -213,12 +280,11 @@ __global__ __launch_bounds__(256) void warp_affine_tiled(const T* __restrict__ s
         const int cxs[2] = {x_t, min(x_t + WT_W, w) - 1}, cys[2] = {y_t, min(y_t + TH, h) - 1};
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int X0 = cv_round_d((a.iM[1] * cys[i] + a.iM[2]) * 1024.0) + 16;
-            const int Y0 = cv_round_d((a.iM[4] * cys[i] + a.iM[5]) * 1024.0) + 16;
+            const int X0 = tx0[cys[i]], Y0 = ty0[cys[i]];   // (uniform: scalar loads)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const int sx = ((X0 + cv_round_d(a.iM[0] * cxs[j] * 1024.0)) >> 5) >> 5;
-                const int sy = ((Y0 + cv_round_d(a.iM[3] * cxs[j] * 1024.0)) >> 5) >> 5;
+                const int sx = ((X0 + tad[cxs[j]]) >> 5) >> 5;
+                const int sy = ((Y0 + tbd[cxs[j]]) >> 5) >> 5;
                 sxmin = min(sxmin, sx); sxmax = max(sxmax, sx);
                 symin = min(symin, sy); symax = max(symax, sy);
             }
@@ -229,16 +295,14 @@ __global__ __launch_bounds__(256) void warp_affine_tiled(const T* __restrict__ s
     const int pitch = (((nc * BPP + 3 + 3) >> 2) + 3) & ~3;
     const size_t row_bytes = (size_t)w * BPP;
     const size_t start0 = ((size_t)max(symin, 0) * w + max(sxmin, 0)) * BPP;
-    bool tiled = sxmin >= 0 && symin >= 0 && sxmax + 1 < w && symax + 1 < h && (long long)nr * pitch <= WT_LDS_DWORDS &&
-                 (reinterpret_cast<uintptr_t>(src) & 3) == 0;
-    if (tiled) {   // the 16-byte reads of the last staged row must end inside the buffer
-        const size_t st = start0 + (size_t)(nr - 1) * row_bytes;
-        tiled = (st & ~(size_t)3) + (size_t)pitch * 4 <= (size_t)h * w * BPP;
-    }
+    bool tiled = sxmin >= 0 && symin >= 0 && sxmax + 1 < w && symax + 1 < h && (long long)nr * pitch <= WT_LDS_DWORDS;
+    if (tiled)   // the 16-byte reads of the last staged row must end inside the buffer
+        tiled = start0 + (size_t)(nr - 1) * row_bytes + (size_t)pitch * 4 <= (size_t)h * w * BPP;
     if (tiled) {   // uniform over the workgroup
-        // staging: wave wv takes rows wv, wv+4, ...; a lane one 16-byte chunk of a row (global accesses need no
-        // alignment beyond the element's).  All loads of a pass are issued before the first LDS store: one pass of
-        // latency per 12 rows instead of one per load.
+        // staging: wave wv takes rows wv, wv+4, ...; a lane one 16-byte chunk of a row, read from the row's first BYTE on
+        // (global loads need no alignment here), so that byte b of every staged row is byte b of the source window and
+        // the taps' LDS addresses need no per-row alignment term.  All loads of a pass are issued before the first LDS
+        // store: one pass of latency per 12 rows instead of one per load.
         const char* g8 = reinterpret_cast<const char*>(src);
         const int cpr = pitch >> 2;
         constexpr int PASS = 12;
@@ -249,8 +313,7 @@ __global__ __launch_bounds__(256) void warp_affine_tiled(const T* __restrict__ s
                 for (int i = 0; i < PASS; ++i) {
                     const int r = rb + 4 * i;
                     if (r < nr) {
-                        const size_t st = start0 + (size_t)r * row_bytes;
-                        __builtin_memcpy(&buf[i], g8 + (st & ~(size_t)3) + 16 * (size_t)j, 16);
+                        __builtin_memcpy(&buf[i], g8 + start0 + (size_t)r * row_bytes + 16 * (size_t)j, 16);
                     }
                 }
 #pragma unroll
@@ -261,57 +324,69 @@ __global__ __launch_bounds__(256) void warp_affine_tiled(const T* __restrict__ s
             }
         }
         __syncthreads();
-        const uint32_t sh0 = (uint32_t)(start0 & 3), rb3 = (uint32_t)(row_bytes & 3);
+        const int pitch4 = pitch * 4;
 #pragma unroll 2
-        for (int k = 0; k < RPT; ++k) {
-            const int y = y_t + wv * RPT + k;
+        for (int k = k_lo; k < k_hi; ++k) {
+            const int y = y_t + wvu * RPT + k;
             if (y >= h) break;
-            const int X0 = cv_round_d((a.iM[1] * y + a.iM[2]) * 1024.0) + 16;
-            const int Y0 = cv_round_d((a.iM[4] * y + a.iM[5]) * 1024.0) + 16;
+            const int X0 = tx0[y], Y0 = ty0[y];   // (uniform per wave: scalar loads)
             int v[4][3];
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 const int X = (X0 + ad[p]) >> 5, Y = (Y0 + bd[p]) >> 5;
                 const int sx = X >> 5, sy = Y >> 5, fx = X & 31, fy = Y & 31;
                 const int r0 = sy - symin;
-                int q[4][3];
+                if constexpr (sizeof(T) == 1) {
+                    // 8-bit: cv2's weights are iw = wy * wx * 32 (wy, wx in 0..32), so
+                    //   (sum q * iw + 16384) >> 15  ==  (sum q * wy * wx + 512) >> 10
+                    // exactly (the fx = fy = 0 table entry 32767 / 1 gives q00 either way), and the sum splits into a row
+                    // step and a column step in integers.  Row step: the pixel pair of a source row is 6 bytes q0c0 q0c1
+                    // q0c2 q1c0 q1c1 q1c2; shifted by c bytes, channel c's two taps sit in bytes 0 and 3 of a dword and one
+                    // v_dot4_u32_u8 with the weight bytes (32 - fx, 0, 0, fx) is q0 * wx0 + q1 * wx1 -- no unpacking.
+                    const uint32_t Wx = (uint32_t)(32 - fx) | ((uint32_t)fx << 24);
+                    uint32_t hrow[2][3];
+                    const uint32_t cb = (uint32_t)(3 * (sx - sxmin));   // byte column inside the staged row
+                    const char* sp0 = reinterpret_cast<const char*>(s_src) + mul24_vs(r0, pitch4) + (cb & ~3u);
 #pragma unroll
-                for (int rr = 0; rr < 2; ++rr) {
-                    // byte position inside the staged row: the row's alignment shift (start0 + r * row_bytes) mod 4
-                    const uint32_t A = ((sh0 + (uint32_t)((r0 + rr) & 3) * rb3) & 3u) + (uint32_t)mul24(sx - sxmin, BPP);
-                    const uint32_t* sp = s_src + mul24(r0 + rr, pitch) + (A >> 2);
-                    const uint32_t sh = A & 3;
-                    if constexpr (sizeof(T) == 1) {
+                    for (int rr = 0; rr < 2; ++rr) {
+                        const uint32_t* sp = reinterpret_cast<const uint32_t*>(sp0 + rr * pitch4);
                         const uint32_t d0 = sp[0], d1 = sp[1], d2 = sp[2];
-                        const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, sh), hi = __builtin_amdgcn_alignbyte(d2, d1, sh);
-                        q[2 * rr][0] = lo & 255u; q[2 * rr][1] = (lo >> 8) & 255u; q[2 * rr][2] = (lo >> 16) & 255u;
-                        q[2 * rr + 1][0] = lo >> 24; q[2 * rr + 1][1] = hi & 255u; q[2 * rr + 1][2] = (hi >> 8) & 255u;
-                    } else {
+                        const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, cb), hi = __builtin_amdgcn_alignbyte(d2, d1, cb);
+                        const uint32_t l1 = __builtin_amdgcn_alignbyte(hi, lo, 1u), l2 = __builtin_amdgcn_alignbyte(hi, lo, 2u);
+                        hrow[rr][0] = __builtin_amdgcn_udot4(lo, Wx, 0u, false);
+                        hrow[rr][1] = __builtin_amdgcn_udot4(l1, Wx, 0u, false);
+                        hrow[rr][2] = __builtin_amdgcn_udot4(l2, Wx, 0u, false);
+                    }
+                    const uint32_t wy0 = (uint32_t)(32 - fy), wy1 = (uint32_t)fy;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        uint32_t S = __umul24(hrow[1][c], wy1) + (__umul24(hrow[0][c], wy0) + 512u);
+                        asm("" : "+v"(S));   // keeps the two 24-bit multiply-adds apart from the byte packing below
+                        v[p][c] = (int)(S >> 10);   // <= 255
+                    }
+                } else {
+                    // 16-bit: cv2 interpolates in float (weights from the 1/32 table); six elements per source row
+                    int q[4][3];
+#pragma unroll
+                    for (int rr = 0; rr < 2; ++rr) {
+                        const uint32_t A = (uint32_t)(BPP * (sx - sxmin));   // byte column inside the staged row
+                        const uint32_t* sp = s_src + mul24_vs(r0 + rr, pitch) + (A >> 2);
                         const uint32_t d0 = sp[0], d1 = sp[1], d2 = sp[2], d3 = sp[3];
-                        const uint32_t w0 = __builtin_amdgcn_alignbyte(d1, d0, sh), w1 = __builtin_amdgcn_alignbyte(d2, d1, sh),
-                                       w2 = __builtin_amdgcn_alignbyte(d3, d2, sh);
+                        const uint32_t w0 = __builtin_amdgcn_alignbyte(d1, d0, A), w1 = __builtin_amdgcn_alignbyte(d2, d1, A),
+                                       w2 = __builtin_amdgcn_alignbyte(d3, d2, A);
                         q[2 * rr][0] = w0 & 65535u; q[2 * rr][1] = w0 >> 16; q[2 * rr][2] = w1 & 65535u;
                         q[2 * rr + 1][0] = w1 >> 16; q[2 * rr + 1][1] = w2 & 65535u; q[2 * rr + 1][2] = w2 >> 16;
                     }
-                }
-                int iw0 = (32 - fy) * (32 - fx) * 32, iw1 = (32 - fy) * fx * 32, iw2 = fy * (32 - fx) * 32, iw3 = fy * fx * 32;
-                if (fx == 0 && fy == 0) { iw0 = 32767; iw3 = 1; }
+                    const float wx1 = fx * (1.0f / 32), wx0 = 1.0f - wx1, wy1 = fy * (1.0f / 32), wy0 = 1.0f - wy1;
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    int r;
-                    if constexpr (sizeof(T) == 1) {
-                        r = (q[0][c] * iw0 + q[1][c] * iw1 + q[2][c] * iw2 + q[3][c] * iw3 + 16384) >> 15;
-                        r = min(max(r, 0), 255);
-                    } else {
-                        const float wx1 = fx * (1.0f / 32), wx0 = 1.0f - wx1, wy1 = fy * (1.0f / 32), wy0 = 1.0f - wy1;
+                    for (int c = 0; c < 3; ++c) {
                         const float q0 = (float)q[0][c] * (wy0 * wx0), q1 = (float)q[1][c] * (wy0 * wx1);
                         const float q2 = (float)q[2][c] * (wy1 * wx0), q3 = (float)q[3][c] * (wy1 * wx1);
                         float sacc = q0 + q1;
                         sacc = sacc + q2;
                         sacc = sacc + q3;
-                        r = min(max((int)rintf(sacc), 0), 65535);
+                        v[p][c] = min(max((int)rintf(sacc), 0), 65535);
                     }
-                    v[p][c] = r;
                 }
             }
             const size_t px = (size_t)y * w + xq;
@@ -348,11 +423,10 @@ __global__ __launch_bounds__(256) void warp_affine_tiled(const T* __restrict__ s
     }
     // ---- per-pixel path (border tiles, large rotations): gathers from global memory, in-image flags per tap
     bool bad = false;   // some pixel of this thread has no full in-image footprint: its blur tile goes on the list
-    for (int k = 0; k < RPT; ++k) {
-        const int y = y_t + wv * RPT + k;
-        if (y >= h || xq >= w) break;
-        const int X0 = cv_round_d((a.iM[1] * y + a.iM[2]) * 1024.0) + 16;
-        const int Y0 = cv_round_d((a.iM[4] * y + a.iM[5]) * 1024.0) + 16;
+    auto row = [&](int k) __attribute__((always_inline)) {
+        const int y = y_t + wvu * RPT + k;
+        if (y >= h || xq >= w) return;
+        const int X0 = tx0[y], Y0 = ty0[y];
         int v[4][3], ok[4];
         bool inside = xq + 3 < w;
         if (inside) {
@@ -367,7 +441,7 @@ __global__ __launch_bounds__(256) void warp_affine_tiled(const T* __restrict__ s
             ok[p] = 0;
             v[p][0] = v[p][1] = v[p][2] = 0;
             if (inside) {
-                warp_pixel_inside<T>(src, a, xq + p, X0, Y0, v[p]);
+                warp_pixel_inside<T>(src, a, ad[p], bd[p], X0, Y0, v[p]);
                 ok[p] = 1;
             } else if (xq + p < w) {
                 warp_pixel_xy<T>(src, a, (X0 + ad[p]) >> 5, (Y0 + bd[p]) >> 5, v[p], ok[p]);
@@ -383,13 +457,26 @@ __global__ __launch_bounds__(256) void warp_affine_tiled(const T* __restrict__ s
                 if (valid) valid[px + p] = (uint8_t)ok[p];
                 bad = bad || !ok[p];
             }
+    };
+    // constant trip counts (the compiler overlaps the rows' gathers): all of a thread's rows, or a ring workgroup's share
+    if (k_hi - k_lo == RPT) {
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) row(k);
+    } else {
+#pragma unroll
+        for (int k = 0; k < RPT / WT_SPLIT; ++k) row(k_lo + k);
     }
     // the border-blur pass works on 32 x 64 tiles that hold masked pixels: the warp marks them here (fire-and-forget
     // atomics from the few threads concerned) instead of a separate scan of the whole mask (38 us per 24 MP frame).
     // A thread's rows lie in one blur-tile row (TH divides BT_H = 32), its four pixels in one blur-tile column.
-    if (tile_bitmap && bad) {
-        const int bit = (y_t / 32) * blur_tiles_x + (xq >> 6);
-        atomicOr(&tile_bitmap[bit >> 5], 1u << (bit & 31));
+    // One atomic per 16 lanes (= one blur-tile column), not per thread: same-address atomics serialise in the L2, and a
+    // ring tile under a rotation has hundreds of threads with masked pixels.
+    if (tile_bitmap) {
+        const unsigned long long b = __ballot(bad);
+        if ((lane & 15) == 0 && ((b >> (lane & 48)) & 0xffffull) != 0) {
+            const int bit = (y_t / 32) * blur_tiles_x + (xq >> 6);
+            atomicOr(&tile_bitmap[bit >> 5], 1u << (bit & 31));
+        }
     }
 }
 

@@ -14,6 +14,8 @@ from shinestacker_amd import _lib as L  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--dtype", default="u8")
 ap.add_argument("--reps", type=int, default=50)
+ap.add_argument("--only", default="", help="run only the transform whose name contains this")
+ap.add_argument("--no-blur", action="store_true")
 a = ap.parse_args()
 dt = np.uint8 if a.dtype == "u8" else np.uint16
 H, W = 4000, 6000
@@ -25,10 +27,12 @@ bv = (C.c_double * 4)(0, 0, 0, 0)
 cx, cy = (W - 1) / 2, (H - 1) / 2
 for name, (deg, s, tx, ty) in {"shift 3.4/-2.2": (0, 1, 3.4, -2.2), "0.2 deg": (0.2, 1.001, 5, -3), "1.3 deg": (1.3, 1.006, 24, -13),
                                "5 deg": (5, 1.0, 0, 0), "30 deg": (30, 1.0, 0, 0)}.items():
+    if a.only and a.only not in name:
+        continue
     t = np.deg2rad(deg)
     ca, sa = s * np.cos(t), s * np.sin(t)
     M = (C.c_double * 6)(ca, -sa, cx - ca * cx + sa * cy + tx, sa, ca, cy - sa * cx - ca * cy + ty)
-    for mode, mname in ((1, "replicate"), (2, "replicate+blur")):
+    for mode, mname in ((1, "replicate"), (2, "replicate+blur"))[:1 if a.no_blur else 2]:
         def run():
             L.check(lib.mi_warp_affine_device(0, None, src.ptr, dst.ptr, tmp.ptr, mask.ptr, H, W, L.DTYPE_CODE[np.dtype(dt)], M, mode,
                                               bv, 21, 50.0))
