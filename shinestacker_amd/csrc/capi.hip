@@ -721,8 +721,8 @@ struct mi_aligner {
     int cap = 0;                     // moving frames the per-frame buffers hold
     double* partial = nullptr;       // [cap][ECC_MAX_BLOCKS][ECC_NSUM]
     unsigned int* ticket = nullptr;  // [cap]
-    double* hsums = nullptr;         // pinned, device-visible [cap][ECC_NSUM]: written by each frame's last block
-    EccBatch* hbatch = nullptr;      // pinned, device-visible: the iteration's per-frame parameters and active flags
+    EccState* dstate = nullptr;      // [cap] the frames' Gauss-Newton state (device memory: the kernels iterate on it)
+    EccState* hstate = nullptr;      // pinned host copy: initial values up, `active` flags and results down
     std::vector<void*> bufs;         // template pyramid + gray scratch
     std::vector<void*> fbufs;        // per-frame buffers (re-allocated when the capacity grows)
     hipStream_t own = nullptr;       // used when the caller passes no stream: handles on different host
@@ -735,10 +735,8 @@ namespace {
 void aligner_free_frames(mi_aligner* al) {
     for (void* b : al->fbufs) (void)hipFree(b);
     al->fbufs.clear();
-    if (al->hsums) (void)hipHostFree(al->hsums);
-    al->hsums = nullptr;
-    if (al->hbatch) (void)hipHostFree(al->hbatch);
-    al->hbatch = nullptr;
+    if (al->hstate) (void)hipHostFree(al->hstate);
+    al->hstate = nullptr;
     al->cap = 0;
 }
 
@@ -771,8 +769,9 @@ int aligner_reserve(mi_aligner* al, int n) {
     al->ticket = (unsigned int*)dalloc(sizeof(unsigned int) * n);
     ok = ok && al->partial && al->ticket;
     if (ok) ok = hipMemset(al->ticket, 0, sizeof(unsigned int) * n) == hipSuccess;
-    if (ok) ok = hipHostMalloc((void**)&al->hsums, (size_t)n * ECC_NSUM * sizeof(double), hipHostMallocDefault) == hipSuccess;
-    if (ok) ok = hipHostMalloc((void**)&al->hbatch, sizeof(EccBatch), hipHostMallocDefault) == hipSuccess;
+    al->dstate = (EccState*)dalloc(sizeof(EccState) * n);
+    ok = ok && al->dstate;
+    if (ok) ok = hipHostMalloc((void**)&al->hstate, sizeof(EccState) * n, hipHostMallocDefault) == hipSuccess;
     if (!ok) {
         aligner_free_frames(al);
         return fail(MI_ERR_NOMEM, "out of device memory");
@@ -819,19 +818,23 @@ int aligner_build(mi_aligner* al, hipStream_t st, const void* dev_img, bool is_t
 // batch; frames that converged on a level sit out the rest of it.  M_out[f] in FULL-resolution pixel
 // coordinates (translation scaled by the sub-sampling factor, as align.py:224-231 does).  A frame
 // the method fails on (no overlap, constant image, degenerate transform) gets cc = -2.
-struct EccFrame {
-    double a = 1.0, b = 0.0, T0 = 0.0, T1 = 0.0, rho = -1.0;
-    double tx = 0.0, ty = 0.0, last_rho = -2.0;
-    int iters = 0;
-    bool failed = false, active = false;
-};
+// iterations enqueued between two looks at the frames' `active` flags: the first look of a level comes late (a level
+// rarely converges in fewer), the following ones sooner
+constexpr int ECC_CHUNK_FIRST = 8, ECC_CHUNK_NEXT = 4;
 
 int aligner_solve(mi_aligner* al, hipStream_t st, int n, int max_iters, double eps, double* M_out, double* cc_out,
                   int* iters_out) {
     if (max_iters < 1) max_iters = 50;
     if (!(eps > 0)) eps = 1e-8;
     auto& lv = al->lv;
-    std::vector<EccFrame> fr(n);
+    EccState* const hs = al->hstate;
+    for (int k = 0; k < n; ++k) {
+        hs[k] = EccState{};
+        hs[k].a = 1.0;
+        hs[k].rho = -1.0;
+        hs[k].last_rho = -2.0;
+    }
+    MI_HIP(hipMemcpyAsync(al->dstate, hs, sizeof(EccState) * n, hipMemcpyHostToDevice, st));
     for (int l = (int)lv.size() - 1; l >= 0; --l) {
         const EccLevel& L = lv[l];
         const double cx = 0.5 * (L.w - 1), cy = 0.5 * (L.h - 1);
@@ -842,75 +845,35 @@ int aligner_solve(mi_aligner* al, hipStream_t st, int n, int max_iters, double e
         int step = 1;
         while ((size_t)(step + 1) * (step + 1) * 500000 <= np) ++step;
         if (ecc_step > 0) step = ecc_step;
-        // ~24 samples per thread (the 28 double sums cost a thread ~500 instructions to reduce, as much as 5 samples),
-        // at most ECC_MAX_BLOCKS blocks (4 per CU)
-        static const size_t per_blk = (size_t)study_env("MI_ECC_PER_BLOCK", 6144);   // study knob
+        // ~48 samples per thread (the 28 double sums cost a thread ~500 instructions to reduce, as much as 5 samples),
+        // at most ECC_MAX_BLOCKS blocks (4 per CU).  Measured (round 3, config 4 / the estimate of a 16-frame batch alone):
+        // 3072 -> 0.054 s / 6.6 ms, 6144 -> 0.047 / 5.5, 12288 -> 0.042 / 5.5, 24576 -> 0.041 / 6.7: fewer, longer
+        // workgroups leave more of the GPU to the warps and the fuse that run beside the estimate
+        static const size_t per_blk = (size_t)study_env("MI_ECC_PER_BLOCK", 12288);   // study knob
         const size_t work = (np / ((size_t)step * step) + per_blk - 1) / per_blk;
         const unsigned nblk = (unsigned)(work < 1 ? 1 : (work > (size_t)ECC_MAX_BLOCKS ? ECC_MAX_BLOCKS : work));
-        for (auto& f : fr) {
-            // W in origin coordinates u = A x + T, A = [a -b; b a]; centred parameters t = T - c + A c
-            f.tx = f.T0 - cx + (f.a * cx - f.b * cy);
-            f.ty = f.T1 - cy + (f.b * cx + f.a * cy);
-            f.last_rho = -2.0;
-            f.active = !f.failed;
-        }
-        for (int it = 0; it < max_iters; ++it) {
-            EccBatch& pb = *al->hbatch;   // (the previous launch was waited for: nobody reads it now)
-            int nact = 0;
-            for (int k = 0; k < n; ++k) {
-                pb.p[k] = EccParams{fr[k].a, fr[k].b, fr[k].tx, fr[k].ty};
-                pb.active[k] = fr[k].active ? 1 : 0;
-                nact += pb.active[k];
-            }
-            if (!nact) break;
-            hipLaunchKernelGGL(ecc_accumulate, dim3(nblk, n), dim3(256), 0, st, L.tmpl, L.img, np, L.h, L.w,
-                               (const EccBatch*)al->hbatch, step, al->partial, al->ticket, al->hsums);
+        hipLaunchKernelGGL(ecc_level_begin, dim3(cdiv(n, 64)), dim3(64), 0, st, al->dstate, n, cx, cy);
+        const double reach = std::hypot(cx, cy);
+        for (int it = 0; it < max_iters;) {
+            const int chunk = std::min(it == 0 ? ECC_CHUNK_FIRST : ECC_CHUNK_NEXT, max_iters - it);
+            for (int j = 0; j < chunk; ++j)   // frames that have stopped leave at once
+                hipLaunchKernelGGL(ecc_accumulate, dim3(nblk, n), dim3(256), 0, st, L.tmpl, L.img, np, L.h, L.w, al->dstate, step,
+                                   al->partial, al->ticket, reach, eps);
+            it += chunk;
+            MI_HIP(hipMemcpyAsync(hs, al->dstate, sizeof(EccState) * n, hipMemcpyDeviceToHost, st));
             MI_HIP(hipStreamSynchronize(st));
-            for (int k = 0; k < n; ++k) {
-                EccFrame& f = fr[k];
-                if (!f.active) continue;
-                double S[ECC_NSUM];
-                for (int q = 0; q < ECC_NSUM; ++q) S[q] = ((volatile double*)al->hsums)[(size_t)k * ECC_NSUM + q];
-                ++f.iters;
-                const double cnt = S[0];
-                if (cnt < 64) { f.failed = true; f.active = false; continue; }   // the images do not overlap
-                const double mw = S[1] / cnt, mr = S[2] / cnt;
-                const double wn2 = S[3] - cnt * mw * mw, rn2 = S[4] - cnt * mr * mr, corr = S[5] - cnt * mw * mr;
-                if (!(wn2 > 0) || !(rn2 > 0)) { f.failed = true; f.active = false; continue; }   // constant image
-                f.rho = corr / std::sqrt(wn2 * rn2);
-                double ip[4], tp[4], Hi_ip[4];
-                for (int q = 0; q < 4; ++q) {
-                    ip[q] = S[10 + q] - mw * S[6 + q];
-                    tp[q] = S[14 + q] - mr * S[6 + q];
-                }
-                if (!solve4(&S[18], ip, Hi_ip)) { f.active = false; continue; }
-                double ipH = 0, tpH = 0;
-                for (int q = 0; q < 4; ++q) { ipH += ip[q] * Hi_ip[q]; tpH += tp[q] * Hi_ip[q]; }
-                const double lam_n = wn2 - ipH, lam_d = corr - tpH;
-                if (!(lam_d > 0)) { f.active = false; continue; }  // the algorithm stopped before its convergence
-                const double lam = lam_n / lam_d;
-                double ep[4], dp[4];
-                for (int q = 0; q < 4; ++q) ep[q] = lam * tp[q] - ip[q];
-                if (!solve4(&S[18], ep, dp)) { f.active = false; continue; }
-                f.a += dp[0]; f.b += dp[1]; f.tx += dp[2]; f.ty += dp[3];
-                // converged when the update moves no pixel of this level by more than 0.002 px
-                // (the image corners move the most), or when rho stalls
-                const double move = (std::fabs(dp[0]) + std::fabs(dp[1])) * std::hypot(cx, cy) +
-                                    std::fabs(dp[2]) + std::fabs(dp[3]);
-                if (move < 2e-3 || std::fabs(f.rho - f.last_rho) < eps) f.active = false;
-                f.last_rho = f.rho;
-            }
+            int nact = 0;
+            for (int k = 0; k < n; ++k) nact += hs[k].active;
+            if (!nact) break;
         }
-        for (auto& f : fr) {
-            // back to origin coordinates, then up to the next finer level (u_f = 2 u_c, x_f = 2 x_c)
-            f.T0 = f.tx + cx - (f.a * cx - f.b * cy);
-            f.T1 = f.ty + cy - (f.b * cx + f.a * cy);
-            if (l > 0) { f.T0 *= 2.0; f.T1 *= 2.0; }
-        }
+        // back to origin coordinates, then up to the next finer level (u_f = 2 u_c, x_f = 2 x_c)
+        hipLaunchKernelGGL(ecc_level_end, dim3(cdiv(n, 64)), dim3(64), 0, st, al->dstate, n, cx, cy, l > 0 ? 1 : 0);
     }
+    MI_HIP(hipMemcpyAsync(hs, al->dstate, sizeof(EccState) * n, hipMemcpyDeviceToHost, st));
+    MI_HIP(hipStreamSynchronize(st));
     const double s = (double)al->subsample;
     for (int k = 0; k < n; ++k) {
-        const EccFrame& f = fr[k];
+        const EccState& f = hs[k];
         double* M = M_out + 6 * k;
         // M (moving -> reference) = W^-1, translation back to full-resolution pixels
         const double det = f.a * f.a + f.b * f.b;

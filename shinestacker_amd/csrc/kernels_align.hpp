@@ -213,10 +213,7 @@ __global__ __launch_bounds__(256) void warp_perspective_kernel(const T* __restri
 constexpr int WT_W = 256;
 template <typename T> struct WarpTile { static constexpr int TH = sizeof(T) == 1 ? 32 : 16; };
 constexpr int WT_SPLIT = 4;   // workgroups per outer-ring tile (divides the rows per thread: 8 / 4)
-#ifndef MI_WT_LDS_DWORDS
-#define MI_WT_LDS_DWORDS 10240
-#endif
-constexpr int WT_LDS_DWORDS = MI_WT_LDS_DWORDS;   // 40 KB: four workgroups per CU
+constexpr int WT_LDS_DWORDS = 10240;   // 40 KB: four workgroups per CU
 
 template <typename T, bool VEC>
 __global__ __launch_bounds__(256) void warp_affine_tiled(const T* __restrict__ src, T* __restrict__ dst,
@@ -325,10 +322,9 @@ __global__ __launch_bounds__(256) void warp_affine_tiled(const T* __restrict__ s
         }
         __syncthreads();
         const int pitch4 = pitch * 4;
-#pragma unroll 2
-        for (int k = k_lo; k < k_hi; ++k) {
+        auto trow = [&](int k) __attribute__((always_inline)) {
             const int y = y_t + wvu * RPT + k;
-            if (y >= h) break;
+            if (y >= h) return;
             const int X0 = tx0[y], Y0 = ty0[y];   // (uniform per wave: scalar loads)
             int v[4][3];
 #pragma unroll
@@ -418,6 +414,13 @@ __global__ __launch_bounds__(256) void warp_affine_tiled(const T* __restrict__ s
                         if (valid) valid[px + p] = 1;
                     }
             }
+        };
+        if (k_hi - k_lo == RPT) {
+#pragma unroll 2
+            for (int k = 0; k < RPT; ++k) trow(k);
+        } else {
+#pragma unroll
+            for (int k = 0; k < RPT / WT_SPLIT; ++k) trow(k_lo + k);
         }
         return;
     }

@@ -199,37 +199,125 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 
 constexpr int ECC_MAX_BLOCKS = 1024;
-// Moving frames per batched launch.  Round 3: 128 (was 16): every Gauss-Newton iteration is one launch AND one host round
-// trip for the whole batch, and the round trips -- not the 11 ms of accumulation kernels -- were what an estimate of 128
-// frames spent its 58 ms on (8 batches x ~110 iterations x ~40 us).  The per-frame parameters moved from the kernel
-// arguments (4 KB limit) to device-visible pinned host memory.
-constexpr int ECC_MAXF = 128;
+constexpr int ECC_MAXF = 128;   // moving frames per batched launch (blockIdx.y)
 
-struct EccBatch {
-    EccParams p[ECC_MAXF];
-    int active[ECC_MAXF];
+// The Gauss-Newton state of one moving frame, resident in device memory: the accumulation kernel reads the parameters
+// from it and the block that finishes the frame's reduction UPDATES it (the 4 x 4 solves, the step, the convergence test)
+// -- an iteration is one launch and no host round trip; the host enqueues a few iterations at a time and looks at the
+// `active` flags only then.  (Round 2 solved on the host: ~110 synchronisations per batch were what an estimate of 128
+// frames spent most of its 58 ms on.)
+struct EccState {
+    double a, b, tx, ty;     // similarity about the image centre of the current level
+    double T0, T1;           // translation in origin coordinates (carried from level to level)
+    double rho, last_rho;
+    int iters, failed, active, pad_;
 };
 
-// One Gauss-Newton accumulation pass for up to ECC_MAXF moving frames against one template
-// (blockIdx.y = frame; frames whose `active` flag is 0 return at once): every reference pixel
-// samples the moving image (and its gradients) at W(x) and adds its terms to 28 sums (double).
-// `step`: pixel stride (sub-sampling of the sum at the finest levels).  Deterministic two-stage
-// reduction in one launch: each block writes its 28 partial sums to partial[frame][block][28];
-// the block that draws the frame's last ticket adds the partials in block order and writes
-// sums[frame][28] (host-visible memory), then re-arms the ticket.
+// H d = r for the symmetric 4 x 4 H (10 values, row-major upper triangle): column-scaled Gaussian elimination with
+// partial pivoting, in double.  false: not positive on the diagonal / singular.
+__device__ inline bool ecc_solve4(const double Hs[10], const double r[4], double d[4]) {
+    double A[4][5], Hm[4][4], sc[4];
+    int k = 0;
+    for (int i = 0; i < 4; ++i)
+        for (int j = i; j < 4; ++j) Hm[i][j] = Hm[j][i] = Hs[k++];
+    for (int i = 0; i < 4; ++i) {
+        if (!(Hm[i][i] > 0)) return false;
+        sc[i] = 1.0 / sqrt(Hm[i][i]);
+    }
+    for (int i = 0; i < 4; ++i) {
+        for (int j = 0; j < 4; ++j) A[i][j] = Hm[i][j] * sc[i] * sc[j];
+        A[i][4] = r[i] * sc[i];
+    }
+    for (int c = 0; c < 4; ++c) {
+        int piv = c;
+        for (int i = c + 1; i < 4; ++i)
+            if (fabs(A[i][c]) > fabs(A[piv][c])) piv = i;
+        if (fabs(A[piv][c]) < 1e-12) return false;
+        if (piv != c)
+            for (int j = 0; j < 5; ++j) { const double t = A[c][j]; A[c][j] = A[piv][j]; A[piv][j] = t; }
+        for (int i = c + 1; i < 4; ++i) {
+            const double f = A[i][c] / A[c][c];
+            for (int j = c; j < 5; ++j) A[i][j] -= f * A[c][j];
+        }
+    }
+    for (int i = 3; i >= 0; --i) {
+        double v = A[i][4];
+        for (int j = i + 1; j < 4; ++j) v -= A[i][j] * d[j];
+        d[i] = v / A[i][i];
+    }
+    for (int i = 0; i < 4; ++i) d[i] *= sc[i];
+    return true;
+}
+
+// One forward-additive ECC step from the 28 sums of a frame (Evangelidis & Psarakis; the same arithmetic the host ran in
+// round 2): correlation, the two projections, lambda, the parameter update, the stopping rule.
+// `reach`: distance of the level's corners from its centre (a rotation / scale step moves them the most).
+__device__ inline void ecc_update(EccState& f, const double* S, double reach, double eps) {
+    ++f.iters;
+    const double cnt = S[0];
+    if (cnt < 64) { f.failed = 1; f.active = 0; return; }   // the images do not overlap
+    const double mw = S[1] / cnt, mr = S[2] / cnt;
+    const double wn2 = S[3] - cnt * mw * mw, rn2 = S[4] - cnt * mr * mr, corr = S[5] - cnt * mw * mr;
+    if (!(wn2 > 0) || !(rn2 > 0)) { f.failed = 1; f.active = 0; return; }   // constant image
+    f.rho = corr / sqrt(wn2 * rn2);
+    double ip[4], tp[4], Hi_ip[4];
+    for (int q = 0; q < 4; ++q) {
+        ip[q] = S[10 + q] - mw * S[6 + q];
+        tp[q] = S[14 + q] - mr * S[6 + q];
+    }
+    if (!ecc_solve4(&S[18], ip, Hi_ip)) { f.active = 0; return; }
+    double ipH = 0, tpH = 0;
+    for (int q = 0; q < 4; ++q) { ipH += ip[q] * Hi_ip[q]; tpH += tp[q] * Hi_ip[q]; }
+    const double lam_n = wn2 - ipH, lam_d = corr - tpH;
+    if (!(lam_d > 0)) { f.active = 0; return; }   // the algorithm stopped before its convergence
+    const double lam = lam_n / lam_d;
+    double ep[4], dp[4];
+    for (int q = 0; q < 4; ++q) ep[q] = lam * tp[q] - ip[q];
+    if (!ecc_solve4(&S[18], ep, dp)) { f.active = 0; return; }
+    f.a += dp[0]; f.b += dp[1]; f.tx += dp[2]; f.ty += dp[3];
+    // converged when the update moves no pixel of this level by more than 0.002 px, or when rho stalls
+    const double move = (fabs(dp[0]) + fabs(dp[1])) * reach + fabs(dp[2]) + fabs(dp[3]);
+    if (move < 2e-3 || fabs(f.rho - f.last_rho) < eps) f.active = 0;
+    f.last_rho = f.rho;
+}
+
+// level transitions of the whole batch: origin coordinates u = A x + T with A = [a -b; b a]  <->  centred parameters
+// t = T - c + A c of the level about to be solved; T doubles on the way to the next finer level
+__global__ void ecc_level_begin(EccState* __restrict__ st, int n, double cx, double cy) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    EccState& f = st[k];
+    f.tx = f.T0 - cx + (f.a * cx - f.b * cy);
+    f.ty = f.T1 - cy + (f.b * cx + f.a * cy);
+    f.last_rho = -2.0;
+    f.active = !f.failed;
+}
+__global__ void ecc_level_end(EccState* __restrict__ st, int n, double cx, double cy, int finer) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    EccState& f = st[k];
+    f.T0 = f.tx + cx - (f.a * cx - f.b * cy);
+    f.T1 = f.ty + cy - (f.b * cx + f.a * cy);
+    if (finer) { f.T0 *= 2.0; f.T1 *= 2.0; }
+}
+
+// One Gauss-Newton iteration for up to ECC_MAXF moving frames against one template (blockIdx.y = frame; frames whose
+// `active` flag is 0 return at once): every reference pixel samples the moving image (and its gradients) at W(x) and adds
+// its terms to 28 sums (double).  `step`: pixel stride (sub-sampling of the sum at the finest levels).  Deterministic
+// two-stage reduction in one launch: each block writes its 28 partial sums to partial[frame][block][28]; the block that
+// draws the frame's last ticket adds the partials in a fixed order, takes the step (ecc_update) and re-arms the ticket.
 // img: frame f at base + f * fstride.  The image gradients (central differences) are taken on the fly
 // from the 4x4 neighbourhood of the sample point -- 12 loads from one array instead of 4 from each of
 // three, and no gradient images to build or keep.
 __global__ __launch_bounds__(256) void ecc_accumulate(const float* __restrict__ tmpl, const float* __restrict__ img,
-                               size_t fstride, int h, int w, const EccBatch* __restrict__ pb, int step,
-                               double* __restrict__ partial, unsigned int* __restrict__ ticket, double* __restrict__ sums) {
+                               size_t fstride, int h, int w, EccState* __restrict__ state, int step,
+                               double* __restrict__ partial, unsigned int* __restrict__ ticket, double reach, double eps) {
     const int f = blockIdx.y;
-    if (!pb->active[f]) return;
-    const EccParams p = pb->p[f];
+    if (!state[f].active) return;
+    const EccParams p = {state[f].a, state[f].b, state[f].tx, state[f].ty};
     img += (size_t)f * fstride;
     partial += (size_t)f * ECC_MAX_BLOCKS * ECC_NSUM;
     ticket += f;
-    sums += (size_t)f * ECC_NSUM;
     double acc[ECC_NSUM];
 #pragma unroll
     for (int i = 0; i < ECC_NSUM; ++i) acc[i] = 0.0;
@@ -310,13 +398,21 @@ __global__ __launch_bounds__(256) void ecc_accumulate(const float* __restrict__ 
         slice[part][sidx] = t;
     }
     __syncthreads();
+    __shared__ double tot28[ECC_NSUM];
     if (threadIdx.x < ECC_NSUM) {
         double t = 0.0;
 #pragma unroll
         for (int part = 0; part < SLICES; ++part) t += slice[part][threadIdx.x];
-        sums[threadIdx.x] = t;
+        tot28[threadIdx.x] = t;
     }
-    if (threadIdx.x == 0) *ticket = 0;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // every block of this frame has read the parameters (they all drew their tickets): the step may overwrite them
+        EccState fs = state[f];
+        ecc_update(fs, tot28, reach, eps);
+        state[f] = fs;
+        *ticket = 0;
+    }
 }
 
 }  // namespace mi
