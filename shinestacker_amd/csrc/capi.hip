@@ -784,7 +784,23 @@ int aligner_reserve(mi_aligner* al, int n) {
 // `upto`: build levels 0 .. upto-1 only (the batch builds the small levels of all its frames with one launch each)
 int aligner_build(mi_aligner* al, hipStream_t st, const void* dev_img, bool is_tmpl, int slot, int upto = 1 << 30) {
     const dim3 blk(64, 4), g0(cdiv(al->w, 64), cdiv(al->h, 4));
-    if (al->subsample == 2) {   // the common factor: four outputs per thread from 8-byte loads
+    auto& lv = al->lv;
+    auto at = [&](float* base, size_t l) { return base + (size_t)slot * lv[l].h * lv[l].w; };
+    size_t first = 0;   // first level the loop below still has to build
+    if (al->subsample == 2 && lv.size() >= 2 && upto >= 2) {
+        // the common factor: gray, level 0 and level 1 in one pass over the frame (ecc_pyramid2)
+        float* d0 = is_tmpl ? lv[0].tmpl : at(lv[0].img, 0);
+        float* d1 = is_tmpl ? lv[1].tmpl : at(lv[1].img, 1);
+        const dim3 gp(cdiv(al->w, 64), cdiv(al->h, 32));
+        if (al->dtype == MI_U8) {
+            if (al->area) hipLaunchKernelGGL((ecc_pyramid2<uint8_t, true>), gp, dim3(256), 0, st, (const uint8_t*)dev_img, al->height, al->width, al->h, al->w, d0, lv[1].h, lv[1].w, d1);
+            else hipLaunchKernelGGL((ecc_pyramid2<uint8_t, false>), gp, dim3(256), 0, st, (const uint8_t*)dev_img, al->height, al->width, al->h, al->w, d0, lv[1].h, lv[1].w, d1);
+        } else {
+            if (al->area) hipLaunchKernelGGL((ecc_pyramid2<uint16_t, true>), gp, dim3(256), 0, st, (const uint16_t*)dev_img, al->height, al->width, al->h, al->w, d0, lv[1].h, lv[1].w, d1);
+            else hipLaunchKernelGGL((ecc_pyramid2<uint16_t, false>), gp, dim3(256), 0, st, (const uint16_t*)dev_img, al->height, al->width, al->h, al->w, d0, lv[1].h, lv[1].w, d1);
+        }
+        first = 2;
+    } else if (al->subsample == 2) {   // the common factor: four outputs per thread from 8-byte loads
         const dim3 g2(cdiv(cdiv(al->w, 4), 64), cdiv(al->h, 4));
         if (al->dtype == MI_U8) {
             if (al->area) hipLaunchKernelGGL((ecc_gray_s2<uint8_t, true>), g2, blk, 0, st, (const uint8_t*)dev_img, al->height, al->width, al->h, al->w, al->gray);
@@ -799,9 +815,7 @@ int aligner_build(mi_aligner* al, hipStream_t st, const void* dev_img, bool is_t
     else
         hipLaunchKernelGGL((ecc_gray<uint16_t>), g0, blk, 0, st, (const uint16_t*)dev_img, al->height, al->width, al->h, al->w,
                            al->subsample, al->area, al->gray);
-    auto& lv = al->lv;
-    auto at = [&](float* base, size_t l) { return base + (size_t)slot * lv[l].h * lv[l].w; };
-    for (size_t l = 0; l < lv.size() && (int)l < upto; ++l) {
+    for (size_t l = first; l < lv.size() && (int)l < upto; ++l) {
         float* dst = is_tmpl ? lv[l].tmpl : at(lv[l].img, l);
         const float* src = l == 0 ? al->gray : (is_tmpl ? lv[l - 1].tmpl : at(lv[l - 1].img, l - 1));
         const int sh = l == 0 ? al->h : lv[l - 1].h, sw = l == 0 ? al->w : lv[l - 1].w;

@@ -77,11 +77,9 @@ __global__ void ecc_blur_down(const float* __restrict__ src, int h, int w, float
 // pixels (24 / 48 bytes, loaded as three / six 8-byte words) of one row (fast) or two rows (area), instead of
 // byte-wide loads per channel and output.  The launch covers ceil(w / 4) x h threads; threads whose 8 source pixels
 // are not all inside the row use the scalar form.
+// four consecutive gray values (x0 .. x0+3 of row y) into o[]; entries at x >= w are left alone
 template <typename T, bool AREA>
-__global__ __launch_bounds__(256) void ecc_gray_s2(const T* __restrict__ img, int src_h, int src_w, int h, int w,
-                                                   float* __restrict__ out) {
-    const int x0 = 4 * (blockIdx.x * blockDim.x + threadIdx.x), y = blockIdx.y * blockDim.y + threadIdx.y;
-    if (x0 >= w || y >= h) return;
+__device__ __forceinline__ void ecc_gray4(const T* __restrict__ img, int src_h, int src_w, int w, int x0, int y, float o[4]) {
     const bool rows_ok = !AREA || 2 * y + 1 < src_h;
     if (x0 + 3 < w && 2 * x0 + 7 < src_w && rows_ok) {
         constexpr int NW = 24 * (int)sizeof(T) / 8;   // 8-byte words per row segment
@@ -98,7 +96,6 @@ __global__ __launch_bounds__(256) void ecc_gray_s2(const T* __restrict__ img, in
             constexpr int PER = 8 / (int)sizeof(T);
             return (uint32_t)(r[e / PER] >> (8 * (int)sizeof(T) * (e % PER))) & (sizeof(T) == 1 ? 0xffu : 0xffffu);
         };
-        float o[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             float c[3];
@@ -113,9 +110,6 @@ __global__ __launch_bounds__(256) void ecc_gray_s2(const T* __restrict__ img, in
             }
             o[q] = 0.114f * c[0] + 0.587f * c[1] + 0.299f * c[2];
         }
-        float* d = out + (size_t)y * w + x0;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) d[q] = o[q];
         return;
     }
     for (int x = x0; x < min(x0 + 4, w); ++x) {   // row / image ends: the scalar form of ecc_gray
@@ -133,7 +127,95 @@ __global__ __launch_bounds__(256) void ecc_gray_s2(const T* __restrict__ img, in
             for (int k = 0; k < 3; ++k)
                 c[k] = n == 4 ? (float)((sum[k] + 2u) >> 2) : (float)__float2int_rn((float)sum[k] / (float)n);
         }
-        out[(size_t)y * w + x] = 0.114f * c[0] + 0.587f * c[1] + 0.299f * c[2];
+        o[x - x0] = 0.114f * c[0] + 0.587f * c[1] + 0.299f * c[2];
+    }
+}
+
+template <typename T, bool AREA>
+__global__ __launch_bounds__(256) void ecc_gray_s2(const T* __restrict__ img, int src_h, int src_w, int h, int w,
+                                                   float* __restrict__ out) {
+    const int x0 = 4 * (blockIdx.x * blockDim.x + threadIdx.x), y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x0 >= w || y >= h) return;
+    float o[4];
+    ecc_gray4<T, AREA>(img, src_h, src_w, w, x0, y, o);
+    float* d = out + (size_t)y * w + x0;
+    for (int q = 0; q < min(4, w - x0); ++q) d[q] = o[q];
+}
+
+// ecc_pyramid2: sub-sampled gray, level 0 (= 5 x 5 binomial blur of it) and level 1 (= blur + 2x decimation of level 0) of
+// one frame in ONE pass over it: the three kernels above / below read and wrote the gray image and level 0 twice each
+// (100 us per 24 MP frame for what is one 72 MB read and 30 MB of writes).  A workgroup owns a 64 x 32 tile of level 0 and
+// the 32 x 16 tile of level 1 under it: gray patch (halo 4) -> row pass -> level-0 patch (halo 2: what level 1's taps
+// reach) -> row pass -> level-1 tile, all through LDS.  Replicate borders = clamped reads of in-image patch entries, the
+// sums in ecc_blur_tile's order: the pyramids are bit-identical to the separate kernels' (GPU test).
+template <typename T, bool AREA>
+__global__ __launch_bounds__(256) void ecc_pyramid2(const T* __restrict__ img, int src_h, int src_w, int h, int w,
+                                                    float* __restrict__ L0, int h1, int w1, float* __restrict__ L1) {
+    constexpr int TW = 64, TH = 32;
+    constexpr int GW = TW + 8, GH = TH + 8, GS = GW + 1;      // gray patch: level coordinates x0-4 .., y0-4 ..
+    constexpr int PW = TW + 4, PH = TH + 4, PS = PW + 1;      // level-0 patch: x0-2 .., y0-2 ..
+    __shared__ float sG[GH * GS];      // later: level 1's row pass [PH][TW / 2 + 1]
+    __shared__ float sR[GH * PS];      // level 0's row pass
+    __shared__ float sP[PH * PS];      // level-0 patch
+    static_assert(PH * (TW / 2 + 1) <= GH * GS, "level 1's row pass aliases the gray patch");
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH, tid = threadIdx.x;
+    const float k[5] = {1.f / 16, 4.f / 16, 6.f / 16, 4.f / 16, 1.f / 16};
+    // ---- gray patch, four entries per thread and step (the patch starts on a multiple of 4)
+    for (int g = tid; g < GH * (GW / 4); g += 256) {
+        const int r = g / (GW / 4), c = 4 * (g - r * (GW / 4));
+        const int y = y0 - 4 + r, x = x0 - 4 + c;
+        if (y < 0 || y >= h || x < 0 || x >= w) continue;
+        float o[4] = {0.f, 0.f, 0.f, 0.f};
+        ecc_gray4<T, AREA>(img, src_h, src_w, w, x, y, o);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sG[r * GS + c + q] = o[q];
+    }
+    __syncthreads();
+    // ---- level 0, row pass: the in-image rows of the gray patch x the in-image columns of the level-0 patch
+    for (int i = tid; i < GH * PW; i += 256) {
+        const int r = i / PW, c = i - r * PW;
+        const int y = y0 - 4 + r, xx = x0 - 2 + c;
+        if (y < 0 || y >= h || xx < 0 || xx >= w) continue;
+        float row = 0.f;
+#pragma unroll
+        for (int t = 0; t < 5; ++t) row += k[t] * sG[r * GS + (min(max(xx - 2 + t, 0), w - 1) - (x0 - 4))];
+        sR[r * PS + c] = row;
+    }
+    __syncthreads();
+    // ---- level 0, column pass -> patch; the tile itself also goes to memory
+    for (int i = tid; i < PH * PW; i += 256) {
+        const int r = i / PW, c = i - r * PW;
+        const int yy = y0 - 2 + r, xx = x0 - 2 + c;
+        if (yy < 0 || yy >= h || xx < 0 || xx >= w) continue;
+        float acc = 0.f;
+#pragma unroll
+        for (int t = 0; t < 5; ++t) acc += k[t] * sR[(min(max(yy - 2 + t, 0), h - 1) - (y0 - 4)) * PS + c];
+        sP[r * PS + c] = acc;
+        if (r >= 2 && r < PH - 2 && c >= 2 && c < PW - 2) L0[(size_t)yy * w + xx] = acc;
+    }
+    __syncthreads();
+    // ---- level 1, row pass (decimating): every in-image row of the level-0 patch x the tile's 32 columns
+    float* sR1 = sG;
+    constexpr int R1S = TW / 2 + 1;
+    for (int i = tid; i < PH * (TW / 2); i += 256) {
+        const int r = i / (TW / 2), j = i - r * (TW / 2);
+        const int yy = y0 - 2 + r, xj = x0 / 2 + j;
+        if (yy < 0 || yy >= h || xj >= w1) continue;
+        float row = 0.f;
+#pragma unroll
+        for (int t = 0; t < 5; ++t) row += k[t] * sP[r * PS + (min(max(2 * xj - 2 + t, 0), w - 1) - (x0 - 2))];
+        sR1[r * R1S + j] = row;
+    }
+    __syncthreads();
+    // ---- level 1, column pass
+    for (int i = tid; i < (TH / 2) * (TW / 2); i += 256) {
+        const int yl = i / (TW / 2), j = i - yl * (TW / 2);
+        const int yi = y0 / 2 + yl, xj = x0 / 2 + j;
+        if (yi >= h1 || xj >= w1) continue;
+        float acc = 0.f;
+#pragma unroll
+        for (int t = 0; t < 5; ++t) acc += k[t] * sR1[(min(max(2 * yi - 2 + t, 0), h - 1) - (y0 - 2)) * R1S + j];
+        L1[(size_t)yi * w1 + xj] = acc;
     }
 }
 
