@@ -46,6 +46,26 @@ def test_warp_matches_oracle(L, oracle, dtype, mode, ti):
     assert got.dtype == img.dtype and np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16])
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("shape", [(100, 800), (131, 1030), (70, 777)])
+@pytest.mark.parametrize("tr", [(0.0, 1.0, 3.4, -2.2), (0.4, 1.002, 5.0, -3.0), (-1.1, 0.997, -9.5, 6.25), (4.0, 1.0, 0.0, 0.0)])
+def test_warp_with_an_outer_ring_of_tiles(L, oracle, dtype, mode, shape, tr):
+    """Images of three and more 256 x 32 (16) tiles each way: the kernel runs the outer ring of tiles first, each as four
+    workgroups, and the inner tiles through LDS (8-bit: the dot-product form of cv2's fixed-point weights); widths that
+    are and are not a multiple of four (dword / byte stores); a rotation whose source window no longer fits the LDS
+    budget (all tiles per pixel).  Bit-equal to the oracle, mask included."""
+    h, w = shape
+    rng = np.random.default_rng(h * 7 + w)
+    hi = 256 if dtype == np.uint8 else 65536
+    img = rng.integers(0, hi, (h, w, 3)).astype(dtype)
+    M = np.array(rot(tr[0], tr[1], tr[2], tr[3], (w - 1) / 2, (h - 1) / 2), dtype=np.float64)
+    want, wmask = oracle.warp_affine(img, M, border_mode=mode, border_value=(0, 0, 0, 0), want_mask=True)
+    got, gmask = L.warp_affine(img, M, border_mode=mode, border_value=(0, 0, 0, 0), want_mask=True)
+    assert np.array_equal(gmask, wmask)
+    assert np.array_equal(got, want)
+
+
 def test_float32_matrix_as_the_reference_passes_it(L, oracle):
     """After sub-sampling the reference hands cv2 a float32 matrix (align.py:220-223)."""
     rng = np.random.default_rng(5)
