@@ -283,6 +283,29 @@ def test_align_and_stack_device_step_process_chains(L, oracle):
 
 
 @pytest.mark.parametrize("dtype", [np.uint8, np.uint16])
+@pytest.mark.parametrize("size", [(384, 512), (387, 509), (130, 1031)])
+def test_one_pass_pyramid_equals_the_separate_kernels(L, oracle, dtype, size):
+    """Sub-sample 2 builds gray, level 0 and level 1 in one pass over the frame (ecc_pyramid2); the estimate on the strided
+    image itself (sub-sample 1: ecc_gray + ecc_blur_tile<0> + <1>) must see the same pyramids: same transform to 1e-9."""
+    h, w = size
+    T = similarity(0.25, 1.001, 5.0, -3.0, (w - 1) / 2, (h - 1) / 2)
+    ref, mov = make_pair(oracle, T, h=h, w=w, seed=33, noise=2.0)
+    if dtype == np.uint16:
+        ref, mov = ref.astype(np.uint16) * 257, mov.astype(np.uint16) * 257
+    buf = L.DeviceBuffer(2 * ref.nbytes)
+    buf.upload(ref)
+    buf.upload(mov, ref.nbytes)
+    al = L.Aligner(h, w, dtype, subsample=2, fast=True)
+    al.set_reference(buf.ptr)
+    m_dev, cc_dev, _ = al.estimate(buf.ptr + ref.nbytes)
+    al.close()
+    m_host, cc_host, _ = L.ecc_similarity(np.ascontiguousarray(ref[::2, ::2]), np.ascontiguousarray(mov[::2, ::2]))
+    m_host = m_host.copy()
+    m_host[:, 2] *= 2
+    assert np.allclose(m_dev, m_host, rtol=0, atol=1e-9) and abs(cc_dev - cc_host) < 1e-12
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16])
 @pytest.mark.parametrize("s", [2, 4, 8])
 @pytest.mark.parametrize("size", ["divisible", "ragged"])
 def test_device_area_subsampling_equals_host_resize(L, oracle, dtype, s, size):
