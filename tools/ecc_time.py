@@ -6,7 +6,7 @@ fb = H*W*3
 buf = L.DeviceBuffer(N*fb)
 L.synth_frames_device(buf.ptr, np.uint8, H, W, 0, N, N)
 # smooth-ish content: reuse frame 0 for all (identity transforms) - timing only
-al = L.Aligner(H, W, np.uint8, subsample=2)
+al = L.Aligner(H, W, np.uint8, subsample=2, fast=("--area" not in sys.argv))
 al.set_reference(buf.ptr)
 ptrs = [buf.ptr + (k+1)*fb for k in range(32)]
 for nb in (1, 4, 16):
