@@ -129,7 +129,7 @@ __device__ __forceinline__ uint32_t times12(uint32_t x) {
 // neighbouring ones into ds_read2_b64, which moves the same 16 bytes per lane in 8 cycles
 __device__ __forceinline__ v2f lds_load2s(const float* p) {
     typedef const volatile v2f __attribute__((address_space(3))) * lds_ptr;   // volatile accesses are never paired
-    return *(lds_ptr)(uint32_t)(uintptr_t)p;                                 // generic LDS address: low 32 bits = offset
+    return *(lds_ptr)(size_t)(uint32_t)(uintptr_t)p;                                 // generic LDS address: low 32 bits = offset
 }
 
 // value of lane-1 / lane+1 across the wave; lanes without a source get 0
@@ -169,7 +169,7 @@ template <> struct PreChunk<uint8_t> {
     // raw LDS form: one dword = four elements
     __device__ __forceinline__ void store_raw(uint32_t* q) const { *q = v; }
     static __device__ __forceinline__ v4f unpack_raw(const uint32_t* q) {
-        const uint32_t w = *(const volatile uint32_t __attribute__((address_space(3)))*)(uint32_t)(uintptr_t)q;
+        const uint32_t w = *(const volatile uint32_t __attribute__((address_space(3)))*)(size_t)(uint32_t)(uintptr_t)q;
         return v4f{(float)(w & 0xffu), (float)((w >> 8) & 0xffu), (float)((w >> 16) & 0xffu), (float)(w >> 24)};
     }
     // six consecutive elements (two pixels) starting at element `e0` (even) of the row at `row`, channel by channel:
@@ -197,7 +197,7 @@ template <> struct PreChunk<uint16_t> {
     // raw LDS form: two dwords = four elements
     __device__ __forceinline__ void store_raw(uint32_t* q) const { *reinterpret_cast<v2u*>(q) = v2u{v0, v1}; }
     static __device__ __forceinline__ v4f unpack_raw(const uint32_t* q) {
-        const v2u w = *(const volatile v2u __attribute__((address_space(3)))*)(uint32_t)(uintptr_t)q;
+        const v2u w = *(const volatile v2u __attribute__((address_space(3)))*)(size_t)(uint32_t)(uintptr_t)q;
         return v4f{(float)(w.x & 0xffffu), (float)(w.x >> 16), (float)(w.y & 0xffffu), (float)(w.y >> 16)};
     }
     // six consecutive elements (two pixels) starting at element `e0` (even) of the row at `row`, channel by channel
@@ -252,7 +252,12 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
         // frame chunks (blockIdx.y) rotate the XCD a super-block runs on: a small level has fewer super-blocks than
         // the GPU has XCDs, and its chunks would otherwise all queue up on the same few
         const int xcd = (blockIdx.x + 8 - (blockIdx.y & 7)) & 7, slot = blockIdx.x >> 3;
-        const int S = (slot >> 6) * 8 + xcd, within = slot & 63;
+        int S = (slot >> 6) * 8 + xcd;
+        const int within = slot & 63;
+        if (a.sb_order) {
+            S = a.sb_order[S];
+            if (S == 0xFFFF) return;
+        }
         const int sby = S / sb_x, sbx = S - sby * sb_x;
         const int tyi = sby * SB + (within >> 3), txi = sbx * SB + (within & 7);
         if (tyi >= nty || txi >= ntx) return;

@@ -25,6 +25,8 @@ struct TiledState {
     std::vector<float*> partE;      // [l] frame-chunk partial maxima / arg-maxima of level l (launch_level_sep)
     std::vector<int32_t*> partI;
     std::vector<size_t> part_cap;   // elements allocated in partE[l] / partI[l]
+    std::vector<uint16_t*> sbOrder; // [l] super-block order of the level's interior launch (LevelArgs::sb_order), device
+    std::vector<int> sbGroups;      // [l] entries of sbOrder[l] (a multiple of 8)
     std::vector<size_t> gstride;    // floats between frames in Gb[.][l]
     void* ring = nullptr;           // staging ring for host-pushed frames (bcap frames, in_dtype)
     size_t frame_bytes = 0;
@@ -235,6 +237,46 @@ inline int level_chunk_frames(int nb, int tiles, bool* parallel) {
     *parallel = on && c > 1 && nb >= 32;
     if (!*parallel) return std::min(nb, lf);
     return std::min(lf, std::max(16, cdiv(cdiv(nb, c), 4) * 4));
+}
+
+// Super-block order of an interior launch: longest-processing-time-first assignment of the super-blocks (weight = tiles
+// inside the interior rectangle) to the eight XCDs; group g = 8 * round + XCD of the launch takes order[g].
+inline int build_sb_order(mi_stack* s, int l, int nty, int ntx) {
+    TiledState* t = tstate(s);
+    if ((int)t->sbOrder.size() <= l) { t->sbOrder.resize(l + 1, nullptr); t->sbGroups.resize(l + 1, 0); }
+    if (t->sbOrder[l]) return MI_OK;
+    const int sbx = cdiv(ntx, SB), sby = cdiv(nty, SB), nsb = sbx * sby;
+    if (nsb >= 0xFFFF) return MI_OK;   // (never: 65 535 super-blocks are 4 M tiles) keep the plain order
+    std::vector<std::pair<int, int>> sb(nsb);   // (tiles, index)
+    for (int S = 0; S < nsb; ++S) {
+        const int y = S / sbx, x = S - y * sbx;
+        sb[S] = {std::min(SB, nty - y * SB) * std::min(SB, ntx - x * SB), S};
+    }
+    std::stable_sort(sb.begin(), sb.end(), [](const std::pair<int, int>& a, const std::pair<int, int>& b) { return a.first > b.first; });
+    std::vector<int> lists[8];
+    long load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (const auto& e : sb) {
+        int best = 0;
+        for (int x = 1; x < 8; ++x)
+            if (load[x] < load[best]) best = x;
+        lists[best].push_back(e.second);
+        load[best] += e.first;
+    }
+    size_t rounds = 0;
+    for (auto& v : lists) {
+        std::sort(v.begin(), v.end());   // an XCD walks its super-blocks in raster order
+        rounds = std::max(rounds, v.size());
+    }
+    std::vector<uint16_t> order(rounds * 8, (uint16_t)0xFFFF);
+    for (int x = 0; x < 8; ++x)
+        for (size_t r = 0; r < lists[x].size(); ++r) order[r * 8 + x] = (uint16_t)lists[x][r];
+    uint16_t* d = nullptr;
+    int rc = dev_alloc_t(s, &d, order.size());
+    if (rc) return rc;
+    MI_HIP(hipMemcpy(d, order.data(), order.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    t->sbOrder[l] = d;
+    t->sbGroups[l] = (int)order.size();
+    return MI_OK;
 }
 
 // Launch the interior and border kernels of level l for `nb` frames.
@@ -488,6 +530,12 @@ int launch_level_sep(mi_stack* s, int l, int set, const void* src, size_t src_st
     // border launches of a level touch disjoint pixels, so each sequence only has to keep its own order)
     const int nborder = ntiles - nyi * nxi;
     const int nsb = cdiv(nxi, SB) * cdiv(nyi, SB);
+    int ngroups = cdiv(nsb, 8) * 8;   // 64-workgroup groups of the interior launch
+    if (nyi > 0 && !MI_ABL(4096)) {
+        int rc = build_sb_order(s, l, nyi, nxi);
+        if (rc) return rc;
+        if (t->sbOrder[l]) { a.sb_order = t->sbOrder[l]; ngroups = t->sbGroups[l]; }
+    }
     const int first = a.first, idx0 = a.frame_idx0;
     const int step = parallel ? nb : fc, nlaunch = cdiv(nb, step);
     auto frames_of = [&](int f0) {
@@ -514,7 +562,7 @@ int launch_level_sep(mi_stack* s, int l, int set, const void* src, size_t src_st
         ps.r.launches = nlaunch;
         for (int f0 = 0; f0 < nb; f0 += step) {
             frames_of(f0);
-            hipLaunchKernelGGL(kin, dim3(cdiv(nsb, 8) * 8 * SB * SB, nchunks), dim3(NT), lds_in, st_in, a);
+            hipLaunchKernelGGL(kin, dim3(ngroups * SB * SB, nchunks), dim3(NT), lds_in, st_in, a);
         }
     }
     if (nchunks > 1) {
