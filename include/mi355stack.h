@@ -252,7 +252,8 @@ MI_API int mi_ecc_similarity(int device, const void* host_ref, const void* host_
  * dev_ref / dev_mov: H x W x 3 device images of the handle's dtype.  The kernels run on `stream`, or on
  * a stream the handle owns when `stream` is NULL (handles driven from different host threads then
  * run side by side);
- * mi_aligner_estimate returns after the last iteration (it reads 28 sums back per iteration). */
+ * mi_aligner_estimate returns after the last iteration (the Gauss-Newton steps run on the device; the host reads the frames'
+ * `active` flags back every few iterations). */
 typedef struct mi_aligner* mi_aligner_t;
 MI_API int mi_aligner_create(mi_aligner_t* out, int device, int height, int width, int dtype, int subsample,
                       int max_levels);
@@ -263,8 +264,8 @@ MI_API int mi_aligner_destroy(mi_aligner_t al);
 MI_API int mi_aligner_set_reference(mi_aligner_t al, void* stream, const void* dev_ref);
 MI_API int mi_aligner_estimate(mi_aligner_t al, void* stream, const void* dev_mov, int max_iters, double eps,
                         double* M_out, double* cc_out, int* iters_out);
-/* n <= 128 moving frames against the same reference in one batched Gauss-Newton: one launch and one host
- * round trip per iteration for the whole batch.  M_out: n x 6, cc_out / iters_out: n entries; a frame
+/* n <= 128 moving frames against the same reference in one batched Gauss-Newton: one launch per iteration for the
+ * whole batch, the step itself on the device.  M_out: n x 6, cc_out / iters_out: n entries; a frame
  * the method fails on (no overlap, constant image) gets cc = -2 and an identity matrix. */
 MI_API int mi_aligner_estimate_batch(mi_aligner_t al, void* stream, const void* const* dev_movs, int n, int max_iters,
                               double eps, double* M_out, double* cc_out, int* iters_out);
