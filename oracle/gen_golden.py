@@ -415,10 +415,93 @@ def depth_map_case():
         json.dump(meta, fh, indent=1)
 
 
+ALIGN_CASES = [
+    # name, dtype, (h, w), true transform, scene kwargs, alignment_config, feature_config, matching_config
+    ("rigid_sub2_area_blur_u8", np.uint8, (120, 160), [[0.9995, 0.0314, 3.0], [-0.0314, 0.9995, -5.0]],
+     {"block": 2}, {"min_good_matches": 10}, None, None),                                   # the defaults of align.py
+    ("rigid_sub2_fast_replicate_u8", np.uint8, (121, 163), [[1.002, -0.01, -4.0], [0.01, 1.002, 6.0]],
+     {"block": 1}, {"min_good_matches": 10, "fast_subsampling": True, "border_mode": "BORDER_REPLICATE"}, None, None),
+    ("rigid_sub1_constant_u8", np.uint8, (96, 130), [[1.0, 0.02, 7.0], [-0.02, 1.0, 2.0]],
+     {"block": 1}, {"subsample": 1, "border_mode": "BORDER_CONSTANT", "border_value": [10, 200, 30, 0]}, None, None),
+    ("rigid_sub2_area_blur_u16", np.uint16, (100, 140), [[0.998, 0.02, -6.0], [-0.02, 0.998, 4.0]],
+     {"block": 2}, {"min_good_matches": 10, "border_blur": 20}, None, None),
+    ("homography_sub1_blur_u8", np.uint8, (110, 150), [[1.0, 0.02, 4.0], [-0.015, 1.0, 2.0], [4e-5, -2e-5, 1.0]],
+     {"block": 1}, {"subsample": 1, "transform": "ALIGN_HOMOGRAPHY"}, None, None),
+    ("homography_sub2_area_replicate_u8", np.uint8, (120, 160), [[1.01, 0.0, -3.0], [0.01, 0.99, 5.0], [-3e-5, 2e-5, 1.0]],
+     {"block": 2}, {"min_good_matches": 10, "transform": "ALIGN_HOMOGRAPHY", "border_mode": "BORDER_REPLICATE"}, None, None),
+    ("homography_sub2_fast_constant_u16", np.uint16, (101, 141), [[1.0, 0.01, 5.0], [-0.01, 1.0, -3.0], [2e-5, 1e-5, 1.0]],
+     {"block": 1}, {"min_good_matches": 10, "transform": "ALIGN_HOMOGRAPHY", "fast_subsampling": True,
+                    "border_mode": "BORDER_CONSTANT", "border_value": [1000, 60000, 3, 0]}, None, None),
+    ("rigid_retry_without_subsampling_u8", np.uint8, (120, 160), [[1.0, 0.0, 4.0], [0.0, 1.0, -6.0]],
+     {"block": 1, "parity": (1, 1)}, {"min_good_matches": 10, "fast_subsampling": True}, None, None),
+    ("rigid_too_few_matches_u8", np.uint8, (64, 80), [[1.0, 0.0, 2.0], [0.0, 1.0, 2.0]],
+     {"block": 2, "n": 2}, {"min_good_matches": 1}, None, None),
+    ("homography_three_matches_u8", np.uint8, (64, 80), [[1.0, 0.0, 2.0], [0.0, 1.0, 2.0], [0.0, 0.0, 1.0]],
+     {"block": 2, "n": 3}, {"min_good_matches": 1, "transform": "ALIGN_HOMOGRAPHY"}, None, None),
+    ("rigid_sub4_area_ragged_blur_u8", np.uint8, (123, 162), [[1.0, 0.01, 8.0], [-0.01, 1.0, -4.0]],
+     {"block": 4, "grid": 4}, {"min_good_matches": 5, "subsample": 4}, None, None),
+    ("rigid_orb_hamming_lmeds_u8", np.uint8, (96, 128), [[1.0, 0.0, -3.0], [0.0, 1.0, 5.0]],
+     {"block": 2}, {"min_good_matches": 10, "align_method": "LMEDS", "border_mode": "BORDER_REPLICATE"},
+     {"detector": "ORB", "descriptor": "ORB"}, {"match_method": "NORM_HAMMING"}),
+]
+
+
+def align_case():
+    """The reference's OWN `align_images` (align.py:154-252) run here through ref_import.load_align_module: estimator
+    calls on the stand-in (oracle/cv2_standin.py), numeric cv2 calls on oracle.py's raw primitives.  Asserts, before
+    freezing anything, that the restatements the GPU tests compare with -- oracle.warp_affine / warp_perspective
+    (warp + `valid` rule + composite in one call) -- reproduce what the reference's own lines (mask warp, cvtColor,
+    `mask == 0`, GaussianBlur, argument order, float32 cast of the rescaled rigid matrix, getPerspectiveTransform
+    conjugation) produced, bit for bit."""
+    from . import cv2_standin as cs
+    arrays, meta = {}, []
+    for name, dtype, (h, w), m_true, skw, acfg, fcfg, mcfg in ALIGN_CASES:
+        log = []
+        al = ri.load_align_module(log)
+        mov, ref, src, _dst = cs.marker_scene(m_true, h=h, w=w, dtype=dtype, texture=True, seed=len(meta) + 5,
+                                              **{"n": 30, **skw})
+        trace = []
+        callbacks = {k: (lambda *a, _k=k: trace.append([_k] + [str(x) for x in a]))
+                     for k in ("message", "matches_message", "align_message", "ecc_message", "blur_message", "warning",
+                               "save_plot")}
+        n_good, m, img_warp = al.align_images(ref, mov.copy(), feature_config=fcfg, matching_config=mcfg,
+                                              alignment_config=acfg, callbacks=callbacks)
+        cfg = {**al._DEFAULT_ALIGNMENT_CONFIG, **(acfg or {})}
+        calls = [e[0] for e in log]
+        entry = {"name": name, "alignment_config": acfg, "feature_config": fcfg, "matching_config": mcfg,
+                 "n_good_matches": int(n_good), "callbacks": trace,
+                 "standin_calls": [c for c in calls if c in ("detectAndCompute", "detect", "flann", "bf",
+                                                             "estimateAffinePartial2D", "findHomography")],
+                 "fit_args": [[str(x) for x in e[1:]] for e in log if e[0] in ("estimateAffinePartial2D", "findHomography")]}
+        arrays[f"{name}_mov"], arrays[f"{name}_ref"] = mov, ref
+        if m is None:
+            assert img_warp is None
+            entry["aligned"] = False
+        else:
+            entry["aligned"] = True
+            entry["m_dtype"] = str(m.dtype)
+            mode = {"BORDER_CONSTANT": orc.BORDER_CONSTANT, "BORDER_REPLICATE": orc.BORDER_REPLICATE,
+                    "BORDER_REPLICATE_BLUR": orc.BORDER_REPLICATE_BLUR}[cfg["border_mode"]]
+            fn = orc.warp_perspective if m.shape == (3, 3) else orc.warp_affine
+            mine = fn(mov, m, mode, cfg["border_value"], 21, cfg["border_blur"])
+            assert np.array_equal(mine, img_warp), f"{name}: oracle apply restatement != the reference's align_images"
+            arrays[f"{name}_m"], arrays[f"{name}_warp"] = m, img_warp
+            filled = int((orc.warp_affine(mov, m, want_mask=True)[1] == 0).sum()) if m.shape == (2, 3) else \
+                int((orc.warp_perspective(mov, m, want_mask=True)[1] == 0).sum())
+            entry["out_of_frame_pixels"] = filled
+        meta.append(entry)
+        print("  ", name, "n_good", n_good, "aligned" if m is not None else "not aligned", entry["standin_calls"])
+    arrays["meta"] = np.array(json.dumps(meta))
+    _save("align", **arrays)
+
+
 def main():
     assert ri.available(), "needs /root/reference"
     os.makedirs(OUT, exist_ok=True)
     orc.build()
+    if "--only-align" in sys.argv:
+        align_case()
+        return
     if "--only-depth-map" in sys.argv:
         depth_map_case()
         return
@@ -462,6 +545,8 @@ def main():
     balance_case()
     print("depth map stacker")
     depth_map_case()
+    print("alignment (the reference's align_images)")
+    align_case()
     print("G5 primitives")
     primitive_cases()
     print("G7 base")

@@ -508,6 +508,26 @@ def warp_affine(img, M, border_mode=BORDER_REPLICATE_BLUR, border_value=(0, 0, 0
     return (out, valid) if want_mask else out
 
 
+def _warp_raw(fn, img, M, n, mode, border_value):
+    img = np.ascontiguousarray(img)
+    h, w = img.shape[:2]
+    M = np.ascontiguousarray(np.asarray(M, dtype=np.float64).reshape(n))
+    bv = np.ascontiguousarray(np.asarray(list(border_value) + [0, 0, 0, 0], dtype=np.float64)[:4])
+    warp = np.empty_like(img)
+    fn(img.ctypes.data, warp.ctypes.data, None, h, w, 0 if img.dtype == np.uint8 else 1, M,
+       0 if mode == BORDER_CONSTANT else 1, bv)
+    return warp
+
+
+def warp_affine_raw(img, M, mode, border_value=(0, 0, 0, 0)):
+    """cv2.warpAffine alone (no mask, no composite): the primitive oracle/ref_import.py hands the reference's align.py."""
+    return _warp_raw(lib().orc_warp_affine, img, M, 6, mode, border_value)
+
+
+def warp_perspective_raw(img, M, mode, border_value=(0, 0, 0, 0)):
+    return _warp_raw(lib().orc_warp_perspective, img, M, 9, mode, border_value)
+
+
 def gaussian_blur_fixed(img, ksize=21, sigma=50.0):
     """cv2.GaussianBlur(img, (ksize, ksize), sigmaX=sigma) of an HxWx3 uint8 / uint16 image: OpenCV's bit-exact fixed-point
     path as align_oracle.c restates it [from memory, parity unpinned] (the blur behind align.py:249)."""

@@ -91,9 +91,34 @@ def make_cv2_shim(use_fma=True):
         kx, ky = dmo.sobel_kernels(dx, dy, ksize)
         return dmo.filter2d_f64(img, np.outer(ky, kx))
 
-    def GaussianBlur(img, ksize, sigma):
-        assert sigma == 0 and ksize[0] == ksize[1] and img.dtype in (np.float32, np.float64)
+    def GaussianBlur(img, ksize, sigma=None, sigmaX=None):
+        sigma = sigmaX if sigma is None else sigma
+        assert ksize[0] == ksize[1]
+        if img.dtype in (np.uint8, np.uint16):      # align.py:249 (the blurred border): cv2's fixed-point path
+            return orc.gaussian_blur_fixed(img, ksize[0], sigma)
+        assert sigma == 0 and img.dtype in (np.float32, np.float64)
         return dmo.gaussian_blur(img, ksize[0])
+
+    # the alignment apply step (align.py:231-247): the RAW remap primitives of oracle/align_oracle.c -- no mask, no
+    # composite; those are the reference's own lines and this shim must not pre-empt them
+    def _border(mode, value):
+        assert mode in (cv2.BORDER_CONSTANT, cv2.BORDER_REPLICATE)
+        return (orc.BORDER_CONSTANT if mode == cv2.BORDER_CONSTANT else orc.BORDER_REPLICATE), \
+            (0, 0, 0, 0) if value is None or np.isscalar(value) and value == 0 else value
+
+    def warpAffine(img, m, dsize, borderMode=None, borderValue=None):
+        assert dsize == (img.shape[1], img.shape[0]) and np.asarray(m).shape == (2, 3)
+        mode, bv = _border(borderMode, borderValue)
+        return orc.warp_affine_raw(img, np.asarray(m, np.float64), mode, bv)
+
+    def warpPerspective(img, m, dsize, borderMode=None, borderValue=None):
+        assert dsize == (img.shape[1], img.shape[0]) and np.asarray(m).shape == (3, 3)
+        mode, bv = _border(borderMode, borderValue)
+        return orc.warp_perspective_raw(img, np.asarray(m, np.float64), mode, bv)
+
+    def getPerspectiveTransform(src, dst):
+        from . import cv2_standin
+        return cv2_standin.get_perspective_transform(src, dst)
 
     def Laplacian(img, ddepth, ksize=1):
         assert ddepth == cv2.CV_64F and img.dtype in (np.float32, np.float64)
@@ -118,10 +143,11 @@ def make_cv2_shim(use_fma=True):
     cv2.copyMakeBorder = copyMakeBorder
     cv2.LUT, cv2.split, cv2.merge, cv2.resize = LUT, split, merge, resize
     cv2.GaussianBlur = GaussianBlur
-    for name in ("imread", "imwrite", "warpAffine", "warpPerspective",
+    cv2.warpAffine, cv2.warpPerspective, cv2.getPerspectiveTransform = warpAffine, warpPerspective, getPerspectiveTransform
+    for name in ("imread", "imwrite",
                  "SIFT_create", "ORB_create", "AKAZE_create", "BRISK_create",
                  "FastFeatureDetector_create", "FlannBasedMatcher", "BFMatcher",
-                 "findHomography", "estimateAffinePartial2D", "getPerspectiveTransform",
+                 "findHomography", "estimateAffinePartial2D",
                  "drawMatches", "fastNlMeansDenoisingColored"):
         setattr(cv2, name, _unavailable)
     return cv2
@@ -218,6 +244,24 @@ def load_balance_module():
     except Exception:  # noqa: BLE001
         pass
     return importlib.import_module("shinestacker.algorithms.balance")
+
+
+def load_align_module(log=None):
+    """The reference's shinestacker.algorithms.align (align.py:1-353), importable here: the numeric cv2 calls of its
+    APPLY step (warpAffine / warpPerspective / GaussianBlur / cvtColor / resize / getPerspectiveTransform) are the raw
+    primitives of oracle.py / align_oracle.c, the calls of its ESTIMATE step (feature detectors, matchers,
+    estimateAffinePartial2D / findHomography) are oracle/cv2_standin.py.  Everything between those calls -- sub-sampling
+    and the retry without it, the min-matches rules, the rescale of the transform, the float32 cast, the mask warp,
+    `mask == 0` composite, the argument order -- is the reference's own code.  `log` collects the stand-in's calls."""
+    load_balance_module()            # pyramid + stubs for exif / denoise / matplotlib + config
+    from . import cv2_standin
+    cv2 = sys.modules["cv2"]
+    cv2_standin.install_features(cv2, [] if log is None else log)
+    plt = sys.modules["matplotlib.pyplot"]
+    for name in ("figure", "imshow", "savefig", "plot", "close"):
+        if not hasattr(plt, name):
+            setattr(plt, name, lambda *a, **k: None)
+    return importlib.import_module("shinestacker.algorithms.align")
 
 
 class _NumpyWithExactExp:

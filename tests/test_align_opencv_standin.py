@@ -8,134 +8,19 @@ picks this path when `cv2` is importable, including cv2.resize(INTER_AREA) for t
 
 The stand-in's "images" carry their keypoints: a pixel of value 200 + k is keypoint k.  Detectors find those pixels,
 descriptors encode k (a one-hot float vector for SIFT, a bit pattern for the binary descriptors), the matchers are brute
-force, the model fits are plain least squares (similarity) / DLT (homography)."""
+force, the model fits are plain least squares (similarity / homography with h22 = 1) -- `oracle/cv2_standin.py`, shared
+with `oracle/ref_import.load_align_module`, which runs the REFERENCE's own align.py over the same stand-in
+(tests/test_align_golden.py holds the comparison)."""
 import sys
 import types
 
 import numpy as np
 import pytest
 
+from oracle.cv2_standin import make_cv2
 from shinestacker_amd import align as A
 from shinestacker_amd.defaults import constants as c
 from shinestacker_amd.errors import InvalidOptionError
-
-
-class KeyPoint:
-    def __init__(self, x, y, k):
-        self.pt, self.k = (float(x), float(y)), k
-
-
-class DMatch:
-    def __init__(self, q, t, d):
-        self.queryIdx, self.trainIdx, self.distance = q, t, float(d)
-
-
-def make_cv2(log):
-    cv2 = types.ModuleType("cv2")
-    cv2.COLOR_BGR2GRAY, cv2.RANSAC, cv2.LMEDS, cv2.NORM_HAMMING, cv2.INTER_AREA = 6, 8, 4, 6, 3
-
-    def cvtColor(im, code):
-        assert code == cv2.COLOR_BGR2GRAY and im.dtype == np.uint8 and im.ndim == 3
-        log.append(("cvtColor", im.shape))
-        return im.max(axis=2)          # the marker pixels are gray (equal in B, G, R)
-    cv2.cvtColor = cvtColor
-
-    def resize(img, dsize, fx=None, fy=None, interpolation=None):
-        log.append(("resize", fx, fy, interpolation))
-        s = int(round(1 / fx))
-        return img[::s, ::s]           # the marker pixels sit on the even grid
-    cv2.resize = resize
-
-    class Feature2D:
-        binary = False
-
-        def __init__(self, name):
-            self.name = name
-            log.append(("create", name))
-
-        def detect(self, img, mask):
-            assert img.dtype == np.uint8 and img.ndim == 2 and mask is None
-            log.append(("detect", self.name))
-            ys, xs = np.nonzero(img >= 200)
-            return [KeyPoint(x, y, int(img[y, x]) - 200) for y, x in zip(ys, xs)]
-
-        def compute(self, img, kps):
-            log.append(("compute", self.name))
-            if self.binary:
-                d = np.zeros((len(kps), 32), np.uint8)
-                for i, kp in enumerate(kps):
-                    d[i] = np.unpackbits(np.array([kp.k * 37 + 11], np.uint32).view(np.uint8)).repeat(8)[:256].reshape(32, 8) \
-                        .dot(1 << np.arange(8)[::-1]).astype(np.uint8)
-            else:
-                d = np.zeros((len(kps), 128), np.float32)
-                for i, kp in enumerate(kps):
-                    d[i, kp.k % 128] = 1.0
-                    d[i, (kp.k * 7 + 3) % 128] += 0.25 * (kp.k // 128)
-            return kps, d
-
-        def detectAndCompute(self, img, mask):
-            log.append(("detectAndCompute", self.name))
-            return self.compute(img, self.detect(img, mask))
-
-    def factory(name, binary):
-        def create():
-            f = Feature2D(name)
-            f.binary = binary
-            return f
-        return create
-    cv2.SIFT_create = factory("SIFT", False)
-    cv2.ORB_create = factory("ORB", True)
-    cv2.AKAZE_create = factory("AKAZE", True)
-    cv2.BRISK_create = factory("BRISK", True)
-    cv2.FastFeatureDetector_create = factory("FAST", True)
-
-    class FlannBasedMatcher:
-        def __init__(self, index_params, search_params):
-            log.append(("flann", dict(index_params), dict(search_params)))
-
-        def knnMatch(self, d0, d1, k):
-            assert k == 2
-            out = []
-            for q in range(len(d0)):
-                dist = np.sqrt(((d1.astype(np.float64) - d0[q]) ** 2).sum(axis=1))
-                order = np.argsort(dist, kind="stable")[:2]
-                out.append((DMatch(q, order[0], dist[order[0]]), DMatch(q, order[1], dist[order[1]])))
-            return out
-    cv2.FlannBasedMatcher = FlannBasedMatcher
-
-    class BFMatcher:
-        def __init__(self, norm, crossCheck=False):
-            log.append(("bf", norm, crossCheck))
-            assert norm == cv2.NORM_HAMMING and crossCheck is True
-
-        def match(self, d0, d1):
-            ham = np.unpackbits(d0[:, None, :] ^ d1[None, :, :], axis=2).sum(axis=2)
-            fwd, bwd = ham.argmin(axis=1), ham.argmin(axis=0)
-            return [DMatch(q, t, ham[q, t]) for q, t in enumerate(fwd) if bwd[t] == q][::-1]   # unsorted on purpose
-    cv2.BFMatcher = BFMatcher
-
-    def estimateAffinePartial2D(src, dst, method=None, ransacReprojThreshold=None, confidence=None, refineIters=None):
-        log.append(("estimateAffinePartial2D", src.shape, src.dtype, method, ransacReprojThreshold, confidence, refineIters))
-        s, d = src.reshape(-1, 2).astype(np.float64), dst.reshape(-1, 2).astype(np.float64)
-        # x' = a x - b y + tx ; y' = b x + a y + ty
-        rows = np.zeros((2 * len(s), 4))
-        rows[0::2] = np.c_[s[:, 0], -s[:, 1], np.ones(len(s)), np.zeros(len(s))]
-        rows[1::2] = np.c_[s[:, 1], s[:, 0], np.zeros(len(s)), np.ones(len(s))]
-        a, b, tx, ty = np.linalg.lstsq(rows, d.reshape(-1), rcond=None)[0]
-        return np.array([[a, -b, tx], [b, a, ty]]), np.ones((len(s), 1), np.uint8)
-    cv2.estimateAffinePartial2D = estimateAffinePartial2D
-
-    def findHomography(src, dst, method=None, ransacReprojThreshold=None, maxIters=None):
-        log.append(("findHomography", src.shape, src.dtype, method, ransacReprojThreshold, maxIters))
-        s, d = src.reshape(-1, 2).astype(np.float64), dst.reshape(-1, 2).astype(np.float64)
-        rows = []
-        for (x, y), (u, v) in zip(s, d):
-            rows.append([-x, -y, -1, 0, 0, 0, u * x, u * y, u])
-            rows.append([0, 0, 0, -x, -y, -1, v * x, v * y, v])
-        h = np.linalg.svd(np.array(rows))[2][-1].reshape(3, 3)
-        return h / h[2, 2], np.ones((len(s), 1), np.uint8)
-    cv2.findHomography = findHomography
-    return cv2
 
 
 @pytest.fixture
