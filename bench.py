@@ -32,7 +32,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
-CORNER, CORNER_OK = 128, 120   # crop fed to the oracle / part of it that does not feel the crop's own borders
+CROP, CROP_LEVELS, CROP_MARGIN = 512, 3, 40   # verify(): crop side, pyramid levels compared, level-0 pixels a crop border can reach
 
 
 def parse():
@@ -148,22 +148,66 @@ def verify(L, st, args, total_frames, world):
         band = (np.arange(H, dtype=np.int64) * total_frames // H)[:, None]
         res["band_match"] = float((idx == band).mean())
         ok &= res["band_match"] > 0.9
-    c = min(CORNER, H, W)
-    good = c - (CORNER - CORNER_OK)
-    so = orc.StreamingOracle(c, c, np.uint16 if args.dtype == "u16" else np.uint8, levels=1, arith=args.arith)
-    for f in range(total_frames):
-        crop = orc.synth_crop_u8(H, W, f, total_frames, 0, 0, c, c)
-        so.push_frame(crop.astype(np.uint16) * 257 if args.dtype == "u16" else crop)
-    lap = st.tap(L.TAP_FUSED_LAP, 0)
-    eq = bool(np.array_equal(lap[:good, :good], so.best_lap[0][:good, :good]))
-    if world == 1:
-        eq &= bool(np.array_equal(st.tap(L.TAP_ENERGY, 0)[:good, :good], so.best_e[0][:good, :good]))
-        eq &= bool(np.array_equal(idx[:good, :good], so.best_idx[0][:good, :good]))
-    res["corner_equal"] = eq
-    res["corner"] = (f"level-0 fused Laplacian{' / energy / arg-max' if world == 1 else ''} of the top-left "
-                     f"{good}x{good} pixels == oracle.StreamingOracle(arith={args.arith}) fed the {total_frames} "
-                     f"generator frames cropped to {c}x{c}")
-    ok &= eq
+    # SURVEY 8(d) at full size: crops at the four image corners, the centre and a super-block seam of the level-0 tile
+    # grid; the oracle is fed the generator frames cropped to each window and must reproduce the running state of
+    # levels 0..CROP_LEVELS-1 wherever the crop's own (artificial) borders cannot reach.  A crop side that coincides
+    # with an image edge is exact up to that edge (same REFLECT101, same parities: origins are multiples of 2^levels).
+    taps = {}
+
+    def tap(kind, lv):
+        if (kind, lv) not in taps:
+            taps[(kind, lv)] = st.tap(kind, lv)
+        return taps[(kind, lv)]
+    crops = []
+    all_eq = True
+    c = min(CROP, H // 8 * 8, W // 8 * 8)
+    nlev = min(CROP_LEVELS, st.levels)
+    while nlev > 1 and (c >> nlev) < 8:
+        nlev -= 1
+    al = 1 << nlev
+
+    def origin(pos, n):                      # (origin, touches the near edge, touches the far edge)
+        o = max(0, min(pos, n - c)) // al * al
+        return o, o == 0, o + c == n
+    seam_y, seam_x = (H // 2) // (8 * 28) * (8 * 28), (W // 2) // (8 * 56) * (8 * 56)   # corner of four 8x8-tile super-blocks
+    wanted = [("top-left", 0, 0), ("top-right", 0, W), ("bottom-left", H, 0), ("bottom-right", H, W),
+              ("centre", H // 2 - c // 2, W // 2 - c // 2), ("super-block seam", seam_y - c // 2 + 120, seam_x - c // 2 - 88)]
+    seen = set()
+    for name, py, px in wanted:
+        (y0, top, bot), (x0, left, right) = origin(py, H), origin(px, W)
+        if (y0, x0) in seen:
+            continue
+        seen.add((y0, x0))
+        so = orc.StreamingOracle(c, c, np.uint16 if args.dtype == "u16" else np.uint8, levels=nlev, arith=args.arith)
+        for f in range(total_frames):
+            crop = orc.synth_crop_u8(H, W, f, total_frames, y0, x0, c, c)
+            so.push_frame(crop.astype(np.uint16) * 257 if args.dtype == "u16" else crop)
+        entry = {"name": name, "origin": [int(y0), int(x0)], "size": int(c), "levels": {}}
+        eq_all = True
+        for lv in range(nlev):
+            m = -(-CROP_MARGIN // (1 << lv)) + 2          # level-lv pixels a crop border can reach
+            cl = c >> lv
+            ys = slice(0 if top else m, cl if bot else cl - m)
+            xs = slice(0 if left else m, cl if right else cl - m)
+            gy = slice((y0 >> lv) + ys.start, (y0 >> lv) + ys.stop)
+            gx = slice((x0 >> lv) + xs.start, (x0 >> lv) + xs.stop)
+            eq = bool(np.array_equal(tap(L.TAP_FUSED_LAP, lv)[gy, gx], so.best_lap[lv][ys, xs]))
+            if world == 1:
+                eq &= bool(np.array_equal(tap(L.TAP_ENERGY, lv)[gy, gx], so.best_e[lv][ys, xs]))
+                eq &= bool(np.array_equal(tap(L.TAP_INDEX, lv)[gy, gx], so.best_idx[lv][ys, xs]))
+            entry["levels"][str(lv)] = {"equal": eq, "pixels": int((ys.stop - ys.start) * (xs.stop - xs.start))}
+            eq_all &= eq
+        entry["equal"] = eq_all
+        all_eq &= eq_all
+        crops.append(entry)
+    res["crops"] = crops
+    res["crops_equal"] = bool(all_eq)
+    res["corner_equal"] = bool(crops[0]["equal"])     # (the round 1-3 name of the first crop's verdict)
+    res["corner"] = (f"fused Laplacian{' / energy / arg-max' if world == 1 else ''} of levels 0..{nlev - 1} inside "
+                     f"{len(crops)} crops of {c}x{c} (image corners, centre, a super-block seam; {CROP_MARGIN} px in from "
+                     f"every artificial crop border) == oracle.StreamingOracle(arith={args.arith}, levels={nlev}) fed the "
+                     f"{total_frames} generator frames cropped to each window")
+    ok &= all_eq
     res["ok"] = bool(ok)
     return res
 

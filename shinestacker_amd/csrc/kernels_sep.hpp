@@ -54,6 +54,13 @@ template <typename TIn> constexpr int sep_nt() { return sizeof(TIn) == 4 ? MI_SE
 #define MI_SEP_NT_STORE 1
 #endif
 
+// fp32 interior tiles: stage the G_l patch by LDS-DMA (`buffer_load_dwordx4 ... lds`: HBM -> LDS without a VGPR round trip,
+// 1 KB per wave instruction) instead of prefetching into registers and writing them out.  The lane's quad takes its gray
+// of G_l in P1 (registers), so the staged patch is dead after P1 and the next frame's DMA runs beside P2-P4.
+#ifndef MI_SEP_DMA
+#define MI_SEP_DMA 1
+#endif
+
 template <int TH_, int NT_>
 struct SepGeom {
     static constexpr int TH = TH_, TW = 56, NT = NT_;
@@ -131,6 +138,21 @@ __device__ __forceinline__ v2f lds_load2s(const float* p) {
     typedef const volatile v2f __attribute__((address_space(3))) * lds_ptr;   // volatile accesses are never paired
     return *(lds_ptr)(size_t)(uint32_t)(uintptr_t)p;                                 // generic LDS address: low 32 bits = offset
 }
+
+// ---- LDS-DMA (gfx950: 16 bytes per lane).  Inline assembly on purpose: with the builtin the compiler drains vmcnt at every
+// workgroup barrier behind it (it cannot tell which LDS reads the transfer feeds); here the kernel places the wait itself.
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ v4u make_rsrc_words(const void* base, uint32_t bytes) {   // raw buffer, as make_rsrc
+    const uint64_t ad = (uint64_t)(uintptr_t)base;
+    return v4u{(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ad),
+               (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(ad >> 32)) & 0xffffu, bytes, 0x00020000u};
+}
+// lane i of the wave: 16 bytes from buffer offset `voff` to LDS byte address lds_base + 16 i (lds_base wave-uniform)
+__device__ __forceinline__ void lds_dma16(v4u rsrc, uint32_t voff, uint32_t lds_base) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+                 :: "s"(lds_base), "v"(voff), "s"(rsrc) : "memory");
+}
+__device__ __forceinline__ void wait_vmem_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // value of lane-1 / lane+1 across the wave; lanes without a source get 0
 __device__ __forceinline__ float dpp_wave_prev(float v) {
@@ -235,6 +257,7 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
     constexpr int TW = G::TW;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr bool RAW = INTERIOR && sizeof(TIn) <= 2;   // staged patch kept in the input type (see SepGeom::lds_floats)
+    constexpr bool DMA = MI_SEP_DMA && INTERIOR && sizeof(TIn) == 4;   // patch staged by LDS-DMA (see MI_SEP_DMA)
     constexpr int RD = (int)sizeof(TIn);                 // dwords per 4-element chunk in that form
     float* sG = smem;
     uint32_t* sGr = reinterpret_cast<uint32_t*>(smem);
@@ -396,7 +419,21 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
             }
         }
     };
-    prefetch(0);
+    // LDS-DMA form of the same: chunk id = tid + n * NT lands at sG + 4 * id, i.e. wave-uniform base + 16 * lane
+    const uint32_t dma_base = (uint32_t)(uintptr_t)sG + 1024u * (uint32_t)__builtin_amdgcn_readfirstlane(tid >> 6);
+    auto dma_issue = [&](int b) {
+        if constexpr (DMA) {
+            const v4u rs = make_rsrc_words(src0 + (size_t)b * a.src_stride, frame_bytes);
+#pragma unroll
+            for (int n = 0; n < G::NPRE; ++n) {
+                if ((n + 1) * NT > G::NCH && tid + n * NT >= G::NCH) continue;
+                lds_dma16(rs, goff[n], dma_base + 16u * (uint32_t)(n * NT));
+            }
+        }
+    };
+    if constexpr (DMA) dma_issue(0);
+    else prefetch(0);
+    v2f gq_e = {0.f, 0.f}, gq_o = {0.f, 0.f};   // DMA: gray of the lane's quad (rows 2qy+4, +5 of the patch), taken in P1
 #ifdef MI_PHASE_CLOCK
     unsigned int pc_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pc_last = (unsigned int)clock64();
 #endif
@@ -405,7 +442,30 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
         int lt = tid;
         asm volatile("" : "+v"(lt));   // per-frame addresses are rebuilt from this, not hoisted out of the loop
         // ---------------- P0: stage
-        if (INTERIOR && edge) {
+        if constexpr (DMA) {
+            wait_vmem_all();   // this wave's share of the patch has landed (and the previous frame's G_{l+1} stores)
+            if (edge) {
+                // the chunk that straddles an image edge was fetched 2 elements further in: rotate it in place, then the
+                // mirrored columns as below
+#pragma unroll
+                for (int n = 0; n < G::NPRE; ++n) {
+                    const int id = lt + n * NT;
+                    if ((n + 1) * NT > G::NCH && id >= G::NCH) continue;
+                    const int col = id - (id / CPR) * CPR;
+                    if (col == colL || col == colR) {
+                        const v4f c = lds_load4(sG + 4 * id);
+                        lds_store4(sG + 4 * id, c.z, c.w, c.x, c.y);
+                    }
+                }
+                __syncthreads();
+                for (int e = lt; e < G::GH * 18; e += NT) {
+                    const int r = e / 18, k = e - r * 18, pc = k / 3, c = k - pc * 3;
+                    float* rowp = sG + mul24(r, G::GS);
+                    if (colL >= 0) rowp[3 * pc + c] = rowp[3 * (12 - pc) + c];
+                    if (peR >= 0 && peR + 1 + pc < G::GW) rowp[3 * (peR + 1 + pc) + c] = rowp[3 * (peR - 1 - pc) + c];
+                }
+            }
+        } else if (INTERIOR && edge) {
 #pragma unroll
             for (int n = 0; n < G::NPRE; ++n) {
                 const int id = lt + n * NT;
@@ -444,7 +504,7 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
         // the next frame's loads: all here (0), or spread over the phases (MI_SEP_PF_SPLIT) so that the eight waves do
         // not queue up at the texture-address unit together (an issue stalls while its queue is full)
         constexpr int PF_A = MI_SEP_PF_SPLIT == 0 ? G::NPRE : MI_SEP_PF_SPLIT == 1 ? (G::NPRE + 1) / 2 : 1;
-        if (b + 1 < nfr && !MI_ABL(16)) prefetch(b + 1, 0, PF_A);
+        if (!DMA && b + 1 < nfr && !MI_ABL(16)) prefetch(b + 1, 0, PF_A);
         MI_TICK(2);   // prefetch issue
         const BufRsrc gn_rs = make_rsrc(gnext0 + (size_t)b * a.gnext_stride, (uint32_t)hn * (uint32_t)wn * 12u);
 
@@ -487,11 +547,26 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
             lds_store4(d, a0.x, a0.y, a1.x, a1.y);
             lds_store4(d + G::VS, b0.x, b0.y, b1.x, b1.y);
         }
-        if (MI_SEP_PF_SPLIT == 1 && b + 1 < nfr && !MI_ABL(16)) prefetch(b + 1, PF_A, G::NPRE);
-        if (MI_SEP_PF_SPLIT == 2 && b + 1 < nfr && !MI_ABL(16)) prefetch(b + 1, 1, 2);
+        if constexpr (DMA) {
+            // gray of the lane's quad of G_l (what P3 subtracts the expanded gray from): the last read of the staged patch
+            if (lt < G::QY * G::QL) {
+                const float* gp = sG + mul24(2 * (lt >> 5) + 4, G::GS) + 6 * (lt & 31) + 6;
+                v2f ge[3], go[3];
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    ge[t] = lds_load2s(gp + 2 * t);
+                    go[t] = lds_load2s(gp + G::GS + 2 * t);
+                }
+                gq_e = v2f{gray_of<true>(ge[0].x, ge[0].y, ge[1].x), gray_of<true>(ge[1].y, ge[2].x, ge[2].y)};
+                gq_o = v2f{gray_of<true>(go[0].x, go[0].y, go[1].x), gray_of<true>(go[1].y, go[2].x, go[2].y)};
+            }
+        }
+        if (!DMA && MI_SEP_PF_SPLIT == 1 && b + 1 < nfr && !MI_ABL(16)) prefetch(b + 1, PF_A, G::NPRE);
+        if (!DMA && MI_SEP_PF_SPLIT == 2 && b + 1 < nfr && !MI_ABL(16)) prefetch(b + 1, 1, 2);
         MI_TICK(3);   // P1
         __syncthreads();
         MI_TICK(4);   // barrier 2
+        if (DMA && b + 1 < nfr && !MI_ABL(16)) dma_issue(b + 1);   // the patch is dead: the next frame streams in beside P2-P4
 
         // ---------------- P2: horizontal reduce (one G_{l+1} pixel per lane, 32 lanes per patch row), G_{l+1} store, gray,
         // horizontal expand of the gray -> X.  18 rows x 32 = 576 items: the last two rows are a second round on wave 0.
@@ -543,7 +618,7 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
             const float gl = dpp_wave_prev(g), gr = dpp_wave_next(g);
             lds_store2(sX + mul24(r, G::XS) + 2 * jp, ex_even(gl, g, gr, ce, cc), ex_odd(g, gr, co));
         }
-        if (MI_SEP_PF_SPLIT == 2 && b + 1 < nfr && !MI_ABL(16)) prefetch(b + 1, 2, 3);
+        if (!DMA && MI_SEP_PF_SPLIT == 2 && b + 1 < nfr && !MI_ABL(16)) prefetch(b + 1, 2, 3);
         MI_TICK(5);   // P2
         __syncthreads();
         MI_TICK(6);   // barrier 3
@@ -557,7 +632,10 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
                 const v2f xa = lds_load2s(xr), xb = lds_load2s(xr + G::XS), xc = lds_load2s(xr + 2 * G::XS);
                 const v2f ev = ex_even(xa, xb, xc, ce, cc), od = ex_odd(xb, xc, co);
                 v2f gge, ggo;   // gray of patch rows 2qy+4, +5; columns 2ql+2, +3
-                if constexpr (RAW) {
+                if constexpr (DMA) {
+                    gge = gq_e;
+                    ggo = gq_o;
+                } else if constexpr (RAW) {
                     // unpacked channel by channel ((pixel, pixel) pairs: the conversions write where they like), so the
                     // two grays of a row are one packed chain
                     v2f ge[3], go[3];
@@ -606,7 +684,7 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
                 lds_store2(sHB + mul24(2 * qy3 + rr, G::HBS) + 2 * ql3, hb0, hb1);
             }
         }
-        if (MI_SEP_PF_SPLIT == 2 && b + 1 < nfr && !MI_ABL(16)) prefetch(b + 1, 3, G::NPRE);
+        if (!DMA && MI_SEP_PF_SPLIT == 2 && b + 1 < nfr && !MI_ABL(16)) prefetch(b + 1, 3, G::NPRE);
         MI_TICK(7);   // P3
         __syncthreads();
         MI_TICK(8);   // barrier 4

@@ -44,7 +44,10 @@ def test_config2_256_frames_24mp_fp32(L, oracle, arith):
     out = st.finish()
     args = types.SimpleNamespace(height=H, width=W, dtype="f32", arith=arith)
     v = bench.verify(L, st, args, N, 1)
-    assert v["band_match"] > 0.9 and v["corner_equal"], v
+    # six 512 x 512 windows (image corners, centre, a super-block seam), levels 0-2: energy / arg-max / fused Laplacian ==
+    # the oracle fed the cropped frames (tests/test_verify_crops.py proves the windows on the CPU)
+    assert v["band_match"] > 0.9 and v["crops_equal"] and len(v["crops"]) == 6, v
+    assert all(sorted(c["levels"]) == ["0", "1", "2"] for c in v["crops"]), v
     # the fused image: every frame is sharp in its own band around the same 64..191 ramp, so the result stays in range
     assert out.shape == (H, W, 3) and out.dtype == np.uint8 and 40 < out.mean() < 215
     _FUSED[arith] = out
@@ -82,6 +85,52 @@ def test_config2_parity_report_between_the_arithmetics_at_full_size(L):
     assert hist[1] < 5e-3 and hist[2] < 1e-5 and hist[3] < 1e-5, hist
     assert rep["final_pixels_off_by_2plus_outside_a_flip_footprint"] == 0 and rep["flip_footprint_fraction_of_image"] < 0.01, rep
     assert rep["base"]["fused_base_abs_diff_max_lsb"] < 0.9, rep["base"]
+
+
+def _parity_tools():
+    tools = os.path.join(ROOT, "tools")
+    if tools not in sys.path:
+        sys.path.insert(0, tools)
+    import parity_report
+    return parity_report
+
+
+def _assert_parity(rep, npx3):
+    assert rep["ok"], rep
+    for row in rep["levels"]:
+        assert row["energy_diff_over_bound_max"] <= 1.0, row
+        if row["level"] >= 1:
+            assert row["gauss_abs_diff_max_lsb"] <= row["gauss_bound_lsb"], row
+    nt = rep["near_tie"]
+    assert nt["checked"] == nt["pixels"] and nt.get("not_a_near_tie", 0) == 0 and nt.get("winner_energy_reproduced", True), nt
+    assert rep["final_pixels_off_by_2plus_outside_a_flip_footprint"] == 0, rep
+    hist = np.array(rep["final_abs_diff_counts_0_1_2_3plus"], float) / npx3
+    return hist
+
+
+def test_parity_report_on_real_frames(L):
+    """The same report on NON-synthetic content: the six frames of tests/golden/img_jpg_crop (crops of the reference's own
+    example stack, 256 x 384, three levels).  Real frames differ in their low-pass content, so here the base-level rule
+    (pyramid.py:95-111) decides visible values: the report's base rows and the final-image histogram are what to read."""
+    pr = _parity_tools()
+    frames = pr.real_crop_frames()
+    rep = pr.report_host_frames(L, frames)
+    print("\n[parity, real frames]", {k: rep[k] for k in ("base", "final_abs_diff_counts_0_1_2_3plus", "final_max_abs_diff", "near_tie")},
+          [(r["level"], r["selection_mismatches"]) for r in rep["levels"]])
+    hist = _assert_parity(rep, frames[0].size)
+    assert hist[1] < 5e-3 and hist[2:].sum() < 1e-4, hist
+
+
+def test_parity_report_on_frames_with_an_exposure_ramp(L, oracle):
+    """... and on the generator with a per-frame exposure ramp (gain 0.70 .. 1.30): the frames' base images differ by tens of
+    counts, so a base-selection flip between the arithmetics would show in the fused image."""
+    pr = _parity_tools()
+    H, W, N = 2000, 3000, 24
+    rep = pr.report_host_frames(L, pr.ramp_frames(H, W, N, oracle))
+    print("\n[parity, exposure ramp]", {k: rep[k] for k in ("base", "final_abs_diff_counts_0_1_2_3plus", "final_max_abs_diff", "near_tie")},
+          [(r["level"], r["selection_mismatches"]) for r in rep["levels"]])
+    hist = _assert_parity(rep, H * W * 3)
+    assert hist[1] < 5e-3 and hist[2:].sum() < 1e-4, hist
 
 
 def test_config5_two_bunches_50mp_u16_from_host(L, oracle):

@@ -178,6 +178,45 @@ def report(L, dev_ptr, n, H, W, dtype, device=0, max_proof_pixels=2_000_000, log
     return rep
 
 
+def real_crop_frames():
+    """the six frames of tests/golden/img_jpg_crop (crops of the reference's examples/input/img-jpg), BGR uint8"""
+    import os
+    from PIL import Image
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "img_jpg_crop")
+    return [np.ascontiguousarray(np.array(Image.open(os.path.join(d, n)))[:, :, ::-1]) for n in sorted(os.listdir(d))]
+
+
+def ramp_frames(H, W, n, orc=None):
+    """the config-2 generator with a per-frame exposure ramp (gain 0.70 .. 1.30 and an offset), so that the frames' LOW-PASS
+    content differs and the base-level winners (pyramid.py:95-111) matter to the result"""
+    if orc is None:
+        import os
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from oracle import oracle as orc
+    out = []
+    for f in range(n):
+        v = orc.synth_frame_numpy(H, W, f, n).astype(np.float64)
+        gain = 0.70 + 0.60 * f / max(n - 1, 1)
+        out.append(np.clip(np.rint(v * gain + 3.0 * ((f * 5) % 7)), 0, 255).astype(np.uint8))
+    return out
+
+
+def report_host_frames(L, frames, **kw):
+    """report() on frames given as host arrays (uploaded into one device buffer)"""
+    n = len(frames)
+    H, W = frames[0].shape[:2]
+    dt = frames[0].dtype
+    fb = H * W * 3 * dt.itemsize
+    buf = L.DeviceBuffer(fb * n)
+    for i, f in enumerate(frames):
+        buf.upload(np.ascontiguousarray(f), offset=i * fb)
+    try:
+        return report(L, buf.ptr, n, H, W, dt, **kw)
+    finally:
+        buf.free()
+
+
 if __name__ == "__main__":
     import argparse
     import json
@@ -190,9 +229,17 @@ if __name__ == "__main__":
     ap.add_argument("--height", type=int, default=4000)
     ap.add_argument("--width", type=int, default=6000)
     ap.add_argument("--dtype", default="f32", choices=["u8", "u16", "f32"])
+    ap.add_argument("--source", default="generator", choices=["generator", "crops", "ramp"],
+                    help="crops: the six real frames of tests/golden/img_jpg_crop; ramp: the generator with an exposure ramp")
     a = ap.parse_args()
     dt = {"u8": np.uint8, "u16": np.uint16, "f32": np.float32}[a.dtype]
     L.require_device()
-    buf = L.DeviceBuffer(a.height * a.width * 3 * np.dtype(dt).itemsize * a.frames)
-    L.synth_frames_device(buf.ptr, dt, a.height, a.width, 0, a.frames, a.frames)
-    print(json.dumps(report(L, buf.ptr, a.frames, a.height, a.width, dt, log=lambda s: print(s, file=sys.stderr))))
+    log = lambda s: print(s, file=sys.stderr)   # noqa: E731
+    if a.source == "crops":
+        print(json.dumps(report_host_frames(L, real_crop_frames(), log=log)))
+    elif a.source == "ramp":
+        print(json.dumps(report_host_frames(L, ramp_frames(a.height, a.width, a.frames), log=log)))
+    else:
+        buf = L.DeviceBuffer(a.height * a.width * 3 * np.dtype(dt).itemsize * a.frames)
+        L.synth_frames_device(buf.ptr, dt, a.height, a.width, 0, a.frames, a.frames)
+        print(json.dumps(report(L, buf.ptr, a.frames, a.height, a.width, dt, log=log)))

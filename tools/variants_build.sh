@@ -1,9 +1,12 @@
 #!/bin/bash
-# Build variants of the library locally (one .so per flag set) for A/B runs on ONE GPU box:
-#   tools/variants_build.sh name1 "-DFLAG.." name2 "-DFLAG.."   ->  shinestacker_amd/csrc/libmi355stack_<name>.so
+# Build named variants of the library HERE (hipcc cross-compiles; the .so files travel to the GPU box with gpurun):
+#   tools/variants_build.sh base "" dma "-DMI_SEP_DMA=1" th44 "-DMI_SEP_TH=44"
+# -> shinestacker_amd/csrc/variants/libmi355stack_<name>.so ; run them with tools/variants_run.sh
 cd "$(dirname "$0")/.."
+mkdir -p shinestacker_amd/csrc/variants
 while [ $# -ge 2 ]; do
-  export MI355STACK_LIB="$PWD/shinestacker_amd/csrc/libmi355stack_$1.so"
-  MI_EXTRA_FLAGS="-DMI_STUDY $2" python -m shinestacker_amd.build --force > /dev/null 2>&1 && echo "$MI355STACK_LIB" || echo "build failed: $1"
-  shift 2
+  name=$1; flags=$2; shift 2
+  ( MI355STACK_LIB="$PWD/shinestacker_amd/csrc/variants/libmi355stack_$name.so" MI_EXTRA_FLAGS="$flags" \
+      python -m shinestacker_amd.build --force > /dev/null 2>&1 && echo "built $name [$flags]" || echo "FAILED $name [$flags]" ) &
 done
+wait
