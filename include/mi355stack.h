@@ -123,6 +123,8 @@ MI_API int mi_memcpy_d2h(int device, void* host_dst, const void* dev_src, size_t
 MI_API int mi_memcpy_d2d(int device, void* dev_dst, const void* dev_src, size_t bytes);
 MI_API int mi_memcpy_d2d_async(int device, void* stream, void* dev_dst, const void* dev_src, size_t bytes);
 MI_API int mi_device_synchronize(int device);
+/* free / total device memory in bytes (hipMemGetInfo): callers size resident stacks and batches with it */
+MI_API int mi_device_mem_info(int device, size_t* free_bytes, size_t* total_bytes);
 
 /* ---- stacker handle ---- */
 MI_API int mi_stack_create(mi_stack_t** out, const mi_stack_params_t* params);
@@ -283,7 +285,9 @@ MI_API int mi_aligner_estimate_batch(mi_aligner_t al, void* stream, const void* 
  *   M_out       : n_frames x 9 doubles; row i holds the 2x3 (transform 0) or 3x3 (transform 1: the similarity applied through
  *                 warpPerspective) matrix of frame i, zeros for the reference frame;  cc_out: n_frames correlation coefficients.
  * A frame whose correlation stays below min_correlation stops the loop: MI_ERR_ALIGNMENT, *failed_frame = its index
- * (-> AlignmentError); frames before it have been pushed. */
+ * (-> AlignmentError).  Only COMPLETE batches of `batch_frames` warped frames before it have been pushed: the frames
+ * already warped into the partially filled batch are not flushed, so the stack holds a prefix of the frames and must be
+ * reset (mi_stack_reset) before it is used again. */
 typedef struct mi_align_stack_opts {
     int transform;            /* 0: ALIGN_RIGID (warpAffine), 1: ALIGN_HOMOGRAPHY (warpPerspective) */
     int border_mode;          /* as mi_warp_affine_device */

@@ -78,6 +78,7 @@ SIGNATURES = {
     "mi_memcpy_d2d": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]),
     "mi_memcpy_d2d_async": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "mi_device_synchronize": (C.c_int, [C.c_int]),
+    "mi_device_mem_info": (C.c_int, [C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "mi_stack_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(StackParams)]),
     "mi_stack_destroy": (None, [C.c_void_p]),
     "mi_stack_reset": (C.c_int, [C.c_void_p]),
@@ -223,6 +224,13 @@ def require_device():
     if device_count() < 1:
         raise DeviceError("no HIP device visible: the MI355X path cannot run "
                           "(there is no CPU fallback)")
+
+
+def mem_info(device=0):
+    """(free, total) device memory in bytes"""
+    f, t = C.c_size_t(), C.c_size_t()
+    check(load().mi_device_mem_info(device, C.byref(f), C.byref(t)))
+    return int(f.value), int(t.value)
 
 
 def device_name(device=0):
@@ -566,7 +574,7 @@ class Aligner:
     MAX_BATCH = 128
 
     def estimate_batch(self, dev_ptrs, max_iters=60, eps=1e-9, stream=None):
-        """Up to 16 moving frames in one batched Gauss-Newton (mi_aligner_estimate_batch).
+        """Up to MAX_BATCH (128) moving frames in one batched Gauss-Newton (mi_aligner_estimate_batch).
         -> (M n x 2 x 3 float64, cc n float64 [-2 where the method failed], iterations n int32)"""
         n = len(dev_ptrs)
         ptrs = (C.c_void_p * n)(*dev_ptrs)

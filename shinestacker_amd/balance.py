@@ -211,6 +211,10 @@ class Correction:
             self._dev_corr.ptr + 8 * idx * self.corrections.shape[1]))
         self._corr_pending.append(idx)
 
+    def supports_native_linear(self):
+        """True when the map is LINEAR (before or after begin): the only one mi_align_stack_device balances itself"""
+        return self.corr_map == constants.BALANCE_LINEAR or isinstance(self.corr_map, LinearMap)
+
     def native_linear_opts(self, first_channel=0, cvt_to=-1, cvt_from=-1):
         """mi_balance_linear_opts_t for mi_align_stack_device (the LINEAR map only; None otherwise): the aligned frames are
         balanced inside the library's frame loop, the correction factors land in the device array `fetch_corrections` reads."""
@@ -246,6 +250,7 @@ class Correction:
         nbins, n = _pixel_range(self.dtype), len(dev_imgs)
         if getattr(self, "_scratch_n", 1) < n:
             _lib.check(_lib.load().mi_device_synchronize(self.device))   # nothing enqueued still uses the old buffer
+            self._scratch.free()
             self._scratch = _lib.DeviceBuffer(3 * nbins * 4 * n, self.device)
             self._scratch_n = n
         out = np.zeros((n, self.channels, nbins), np.int64)
@@ -267,6 +272,7 @@ class Correction:
         hists = self.hist_device_batch(list(dev_imgs), stream)
         nb = _pixel_range(self.dtype)
         if getattr(self, "_dev_lut_n", 1) < len(indices):   # (the batch histogram above synchronised the stream)
+            self._dev_lut.free()
             self._dev_lut = _lib.DeviceBuffer(3 * nb * self.dtype.itemsize * len(indices), self.device)
             self._dev_lut_n = len(indices)
         tabs = []

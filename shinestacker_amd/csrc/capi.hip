@@ -7,6 +7,7 @@
 #include <cstring>
 #include <algorithm>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -985,6 +986,13 @@ int mi_device_synchronize(int device) {
     return MI_OK;
 }
 
+int mi_device_mem_info(int device, size_t* free_bytes, size_t* total_bytes) {
+    if (!free_bytes || !total_bytes) return fail(MI_ERR_INVALID, "null argument");
+    MI_HIP(hipSetDevice(device));
+    MI_HIP(hipMemGetInfo(free_bytes, total_bytes));
+    return MI_OK;
+}
+
 int mi_stack_create(mi_stack_t** out, const mi_stack_params_t* params) {
     if (!out || !params) return fail(MI_ERR_INVALID, "null argument");
     *out = nullptr;
@@ -1449,8 +1457,12 @@ int mi_combine_plan(int device, void* stream, const void* win, size_t npix, int 
     unsigned long long* tot = (unsigned long long*)(counts + nblocks * n_ranks);
     hipStream_t st = (hipStream_t)stream;
     if (nblocks) {
-        hipLaunchKernelGGL(combine_count, dim3((unsigned)nblocks), dim3(256), 0, st, (const uint8_t*)win, npix, n_ranks, counts);
-        hipLaunchKernelGGL(combine_scan, dim3(1), dim3(1024), 0, st, counts, (int)nblocks, n_ranks, tot);
+        switch ((n_ranks + 3) / 4) {
+            case 1: hipLaunchKernelGGL(combine_count<1>, dim3((unsigned)nblocks), dim3(256), 0, st, (const uint8_t*)win, npix, n_ranks, counts); break;
+            case 2: hipLaunchKernelGGL(combine_count<2>, dim3((unsigned)nblocks), dim3(256), 0, st, (const uint8_t*)win, npix, n_ranks, counts); break;
+            default: hipLaunchKernelGGL(combine_count<CB_WORDS>, dim3((unsigned)nblocks), dim3(256), 0, st, (const uint8_t*)win, npix, n_ranks, counts); break;
+        }
+        hipLaunchKernelGGL(combine_scan, dim3(n_ranks), dim3(1024), 0, st, counts, (int)nblocks, n_ranks, tot);
         MI_HIP(hipGetLastError());
         unsigned long long h[CB_MAXR];
         MI_HIP(hipMemcpyAsync(h, tot, sizeof(unsigned long long) * n_ranks, hipMemcpyDeviceToHost, st));
@@ -1468,9 +1480,15 @@ int mi_combine_pack(int device, void* stream, const void* win, size_t npix, int 
     if (n_ranks < 1 || n_ranks > CB_MAXR || rank < 0 || rank >= n_ranks || !win || !plan || !src || !out || width < 1)
         return fail(MI_ERR_INVALID, "bad argument");
     MI_HIP(hipSetDevice(device));
-    hipLaunchKernelGGL((combine_move<true>), dim3((unsigned)((npix + CB_PX - 1) / CB_PX)), dim3(256), 0, (hipStream_t)stream,
-                       (const uint8_t*)win, npix, n_ranks, rank, (const uint32_t*)plan, (const float*)src,
-                       (const float* const*)nullptr, width, (float*)out);
+    const dim3 grd((unsigned)((npix + CB_PX - 1) / CB_PX));
+#define MI_CB_PACK(NW) hipLaunchKernelGGL((combine_move<true, NW>), grd, dim3(256), 0, (hipStream_t)stream, (const uint8_t*)win, npix, \
+                                          n_ranks, rank, (const uint32_t*)plan, (const float*)src, (const float* const*)nullptr, width, (float*)out)
+    switch ((n_ranks + 3) / 4) {
+        case 1: MI_CB_PACK(1); break;
+        case 2: MI_CB_PACK(2); break;
+        default: MI_CB_PACK(CB_WORDS); break;
+    }
+#undef MI_CB_PACK
     MI_HIP(hipGetLastError());
     return MI_OK;
 }
@@ -1481,9 +1499,15 @@ int mi_combine_unpack(int device, void* stream, const void* win, size_t npix, in
     if (n_ranks < 1 || n_ranks > CB_MAXR || rank < 0 || rank >= n_ranks || !win || !plan || !dev_bufs || !dst || width < 1)
         return fail(MI_ERR_INVALID, "bad argument");
     MI_HIP(hipSetDevice(device));
-    hipLaunchKernelGGL((combine_move<false>), dim3((unsigned)((npix + CB_PX - 1) / CB_PX)), dim3(256), 0, (hipStream_t)stream,
-                       (const uint8_t*)win, npix, n_ranks, rank, (const uint32_t*)plan, (const float*)nullptr,
-                       (const float* const*)dev_bufs, width, (float*)dst);
+    const dim3 grd((unsigned)((npix + CB_PX - 1) / CB_PX));
+#define MI_CB_UNPACK(NW) hipLaunchKernelGGL((combine_move<false, NW>), grd, dim3(256), 0, (hipStream_t)stream, (const uint8_t*)win, npix, \
+                                            n_ranks, rank, (const uint32_t*)plan, (const float*)nullptr, (const float* const*)dev_bufs, width, (float*)dst)
+    switch ((n_ranks + 3) / 4) {
+        case 1: MI_CB_UNPACK(1); break;
+        case 2: MI_CB_UNPACK(2); break;
+        default: MI_CB_UNPACK(CB_WORDS); break;
+    }
+#undef MI_CB_UNPACK
     MI_HIP(hipGetLastError());
     return MI_OK;
 }
@@ -1553,8 +1577,18 @@ int warp_device_impl(int device, void* stream, const void* dev_src, void* dev_ds
     // stream -- the two step_process chains of pipeline._align_chains_device on the default stream -- must not interleave
     // their enqueue sequences (memset, warp marks tiles, bitmap -> list, blur, scatter), or one warp's memset lands between
     // the other's marks and its list.  One lock across the whole sequence; the stream then runs the sequences in order.
-    static std::mutex enqueue_mu;
-    std::lock_guard<std::mutex> lk(enqueue_mu);
+    // The lock is per (device, stream) -- the key of the scratch cache: warps on other GPUs or streams of the same process
+    // (the threads of a multi-GPU job) neither serialise here nor wait behind another device's scratch re-allocation.
+    static std::mutex map_mu;
+    static std::map<std::pair<int, void*>, std::unique_ptr<std::mutex>> enqueue_mus;
+    std::mutex* enqueue_mu;
+    {
+        std::lock_guard<std::mutex> lk(map_mu);
+        auto& slot = enqueue_mus[{device, stream}];
+        if (!slot) slot.reset(new std::mutex);
+        enqueue_mu = slot.get();
+    }
+    std::lock_guard<std::mutex> lk(*enqueue_mu);
     if (dtype == MI_U8)
         return warp_launch<uint8_t>(device, (hipStream_t)stream, dev_src, dev_tmp, dev_dst, (uint8_t*)dev_mask, height, width, a,
                                     blur, g, persp ? &pa : nullptr);

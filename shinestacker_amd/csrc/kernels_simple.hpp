@@ -371,93 +371,141 @@ __global__ void combine_winner(int n, const float* __restrict__ cand_e, size_t n
     win[p] = (uint8_t)bi;
 }
 
-// per block and rank: number of pixels that rank won.  One workgroup of 256 threads per block of CB_PX pixels.
-__global__ void combine_count(const uint8_t* __restrict__ win, size_t npix, int n_ranks, uint32_t* __restrict__ counts) {
-    __shared__ uint32_t c[CB_MAXR];
-    if (threadIdx.x < CB_MAXR) c[threadIdx.x] = 0;
-    __syncthreads();
-    const size_t base = (size_t)blockIdx.x * CB_PX;
-    for (int k = threadIdx.x; k < CB_PX; k += blockDim.x) {
-        const size_t p = base + k;
-        const int r = p < npix ? win[p] : -1;
-        for (int s = 0; s < n_ranks; ++s) {
-            const unsigned long long m = __ballot(r == s);
-            if ((threadIdx.x & 63) == 0 && m) atomicAdd(&c[s], (uint32_t)__popcll(m));
+// Blocks of CB_PX = 1024 pixels, one workgroup of 256 threads each, a thread = 4 consecutive pixels (one 32-bit load of the
+// winner map).  Inside a block the position of a pixel among the pixels of ITS rank comes from one packed prefix scan:
+// the thread's per-rank counts (0..4) sit in 16-bit fields of 64-bit words (4 ranks per word), scanned across the wave by
+// shuffles and across the four waves through LDS -- one barrier per block, no per-rank ballot loops (round 3: four passes
+// of 256 pixels with three barriers and 2 x n_ranks ballots each; 1.7 ms of kernels per combine at 32 Mpx).
+constexpr int CB_WORDS = CB_MAXR / 4;
+struct CbCounts { unsigned long long w[CB_WORDS]; };
+
+__device__ __forceinline__ unsigned long long shfl_up64(unsigned long long v, int d) {
+    const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)v, d), hi = (uint32_t)__shfl_up((int)(uint32_t)(v >> 32), d);
+    return ((unsigned long long)hi << 32) | lo;
+}
+// per-thread winner bytes (r[4], -1 = outside the image) -> exclusive prefix (over the threads of the block, in pixel
+// order) and block totals of the per-rank counts; NW = words in use = ceil(n_ranks / 4)
+template <int NW>
+__device__ __forceinline__ void cb_block_scan(const int* r, CbCounts& excl, CbCounts& total, unsigned long long (*sh)[CB_WORDS]) {
+    CbCounts c{};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (r[j] >= 0) c.w[r[j] >> 2] += 1ull << (16 * (r[j] & 3));
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    CbCounts inc = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+            const unsigned long long up = shfl_up64(inc.w[k], d);
+            if (lane >= d) inc.w[k] += up;
         }
     }
+    if (lane == 63)
+#pragma unroll
+        for (int k = 0; k < NW; ++k) sh[wv][k] = inc.w[k];
     __syncthreads();
-    if ((int)threadIdx.x < n_ranks) counts[(size_t)blockIdx.x * n_ranks + threadIdx.x] = c[threadIdx.x];
+#pragma unroll
+    for (int k = 0; k < NW; ++k) {
+        unsigned long long before = 0, all = 0;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const unsigned long long t = sh[v][k];
+            if (v < wv) before += t;
+            all += t;
+        }
+        excl.w[k] = before + inc.w[k] - c.w[k];
+        total.w[k] = all;
+    }
+}
+__device__ __forceinline__ uint32_t cb_field(const CbCounts& c, int r) { return (uint32_t)(c.w[r >> 2] >> (16 * (r & 3))) & 0xffffu; }
+__device__ __forceinline__ void cb_load4(const uint8_t* __restrict__ win, size_t npix, size_t p0, int* r) {
+    if (p0 + 3 < npix && (p0 & 3) == 0) {
+        const uint32_t v = *reinterpret_cast<const uint32_t*>(win + p0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[j] = (int)((v >> (8 * j)) & 0xffu);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[j] = p0 + j < npix ? (int)win[p0 + j] : -1;
+    }
 }
 
-// exclusive scan of every rank column down the blocks (one workgroup; in place: counts -> offsets), totals per rank
-__global__ void combine_scan(uint32_t* __restrict__ counts, int nblocks, int n_ranks, unsigned long long* __restrict__ totals) {
+// per block and rank: number of pixels that rank won
+template <int NW>
+__global__ __launch_bounds__(256) void combine_count(const uint8_t* __restrict__ win, size_t npix, int n_ranks, uint32_t* __restrict__ counts) {
+    __shared__ unsigned long long sh[4][CB_WORDS];
+    int r[4];
+    cb_load4(win, npix, (size_t)blockIdx.x * CB_PX + 4 * threadIdx.x, r);
+    CbCounts excl, total;
+    cb_block_scan<NW>(r, excl, total, sh);
+    if ((int)threadIdx.x < n_ranks) counts[(size_t)blockIdx.x * n_ranks + threadIdx.x] = cb_field(total, threadIdx.x);
+}
+
+// exclusive scan of one rank's column down the blocks (in place: counts -> offsets) + its total; one workgroup PER RANK
+__global__ __launch_bounds__(1024) void combine_scan(uint32_t* __restrict__ counts, int nblocks, int n_ranks, unsigned long long* __restrict__ totals) {
     __shared__ unsigned long long part[1024];
-    const int t = threadIdx.x, nt = blockDim.x;
+    const int t = threadIdx.x, nt = blockDim.x, s = blockIdx.x;
     const int per = (nblocks + nt - 1) / nt;
-    for (int s = 0; s < n_ranks; ++s) {
-        unsigned long long sum = 0;
-        for (int k = 0; k < per; ++k) {
-            const int b = t * per + k;
-            if (b < nblocks) sum += counts[(size_t)b * n_ranks + s];
-        }
-        part[t] = sum;
+    unsigned long long sum = 0;
+    for (int k = 0; k < per; ++k) {
+        const int b = t * per + k;
+        if (b < nblocks) sum += counts[(size_t)b * n_ranks + s];
+    }
+    part[t] = sum;
+    __syncthreads();
+    // Hillis-Steele inclusive scan over the 1024 partial sums
+    for (int d = 1; d < nt; d <<= 1) {
+        const unsigned long long v = t >= d ? part[t - d] : 0;
         __syncthreads();
-        if (t == 0) {
-            unsigned long long run = 0;
-            for (int i = 0; i < nt; ++i) { const unsigned long long v = part[i]; part[i] = run; run += v; }
-            totals[s] = run;
-        }
+        part[t] += v;
         __syncthreads();
-        unsigned long long run = part[t];
-        for (int k = 0; k < per; ++k) {
-            const int b = t * per + k;
-            if (b < nblocks) {
-                const uint32_t v = counts[(size_t)b * n_ranks + s];
-                counts[(size_t)b * n_ranks + s] = (uint32_t)run;
-                run += v;
-            }
+    }
+    if (t == nt - 1) totals[s] = part[t];
+    unsigned long long run = part[t] - sum;
+    for (int k = 0; k < per; ++k) {
+        const int b = t * per + k;
+        if (b < nblocks) {
+            const uint32_t v = counts[(size_t)b * n_ranks + s];
+            counts[(size_t)b * n_ranks + s] = (uint32_t)run;
+            run += v;
         }
-        __syncthreads();
     }
 }
 
 // PACK: out[pos(p)] = src[p] for the pixels `rank` won; !PACK: dst[p] = bufs[rank of p][pos(p)] for every pixel `rank`
-// (the receiver) did NOT win itself.  Rows of `width` floats.  One workgroup of 256 threads per block of CB_PX pixels,
-// pixels visited in order, 256 at a time: the running per-rank position lives in LDS.
-template <bool PACK>
-__global__ void combine_move(const uint8_t* __restrict__ win, size_t npix, int n_ranks, int rank,
-                             const uint32_t* __restrict__ offsets, const float* __restrict__ src,
-                             const float* const* __restrict__ bufs, int width, float* __restrict__ dst) {
-    __shared__ uint32_t run[CB_MAXR];
-    __shared__ uint32_t wave_cnt[4][CB_MAXR];
-    if ((int)threadIdx.x < n_ranks) run[threadIdx.x] = offsets[(size_t)blockIdx.x * n_ranks + threadIdx.x];
-    __syncthreads();
-    const size_t base = (size_t)blockIdx.x * CB_PX;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (int k0 = 0; k0 < CB_PX; k0 += 256) {
-        const size_t p = base + k0 + threadIdx.x;
-        const int r = p < npix ? win[p] : -1;
-        uint32_t before = 0;
-        for (int s = 0; s < n_ranks; ++s) {
-            const unsigned long long m = __ballot(r == s);
-            if (r == s) before = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-            if (lane == 0) wave_cnt[wv][s] = (uint32_t)__popcll(m);
+// (the receiver) did NOT win itself.  Rows of `width` floats (12-byte moves for width 3).
+template <bool PACK, int NW>
+__global__ __launch_bounds__(256) void combine_move(const uint8_t* __restrict__ win, size_t npix, int n_ranks, int rank,
+                                                    const uint32_t* __restrict__ offsets, const float* __restrict__ src,
+                                                    const float* const* __restrict__ bufs, int width, float* __restrict__ dst) {
+    __shared__ unsigned long long sh[4][CB_WORDS];
+    __shared__ uint32_t base[CB_MAXR];
+    if ((int)threadIdx.x < n_ranks) base[threadIdx.x] = offsets[(size_t)blockIdx.x * n_ranks + threadIdx.x];
+    const size_t p0 = (size_t)blockIdx.x * CB_PX + 4 * threadIdx.x;
+    int r[4];
+    cb_load4(win, npix, p0, r);
+    CbCounts excl, total;
+    cb_block_scan<NW>(r, excl, total, sh);     // (its barrier also publishes `base`)
+    uint32_t seen[4] = {0, 0, 0, 0};           // pixels of the same rank earlier in this thread's four
+#pragma unroll
+    for (int j = 1; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < j; ++i) seen[j] += (r[i] == r[j]) ? 1u : 0u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int rr = r[j];
+        if (rr < 0 || (PACK ? rr != rank : rr == rank)) continue;
+        const size_t pos = (size_t)base[rr] + cb_field(excl, rr) + seen[j], p = p0 + j;
+        if (width == 3) {
+            struct __attribute__((packed, aligned(4))) Row3 { float v[3]; };
+            if (PACK) *reinterpret_cast<Row3*>(dst + pos * 3) = *reinterpret_cast<const Row3*>(src + p * 3);
+            else *reinterpret_cast<Row3*>(dst + p * 3) = *reinterpret_cast<const Row3*>(bufs[rr] + pos * 3);
+        } else if (PACK) {
+            for (int c = 0; c < width; ++c) dst[pos * width + c] = src[p * width + c];
+        } else {
+            const float* b = bufs[rr];
+            for (int c = 0; c < width; ++c) dst[p * width + c] = b[pos * width + c];
         }
-        __syncthreads();
-        if (r >= 0 && (PACK ? r == rank : r != rank)) {
-            uint32_t pos = run[r] + before;
-            for (int v = 0; v < wv; ++v) pos += wave_cnt[v][r];
-            if (PACK) {
-                for (int c = 0; c < width; ++c) dst[(size_t)pos * width + c] = src[p * width + c];
-            } else {
-                const float* b = bufs[r];
-                for (int c = 0; c < width; ++c) dst[p * width + c] = b[(size_t)pos * width + c];
-            }
-        }
-        __syncthreads();
-        if ((int)threadIdx.x < n_ranks) run[threadIdx.x] += wave_cnt[0][threadIdx.x] + wave_cnt[1][threadIdx.x] +
-                                                           wave_cnt[2][threadIdx.x] + wave_cnt[3][threadIdx.x];
-        __syncthreads();
     }
 }
 

@@ -719,7 +719,7 @@ int tiled_push(mi_stack* s, const void* dev_frames, int n, size_t stride) {
     const bool fma = s->p.use_fma != 0;
     // MI_ARITH_SEPARABLE: the whole push is one batch when its per-batch buffers fit (level after level over all the
     // frames: every kernel has the GPU to itself, a pixel's winning Laplacian is filled in once, and the small levels run
-    // in frame chunks); longer pushes are cut into equal batches.  MI_ARITH_EXACT keeps batches of `bcap` frames.
+    // in frame chunks); longer pushes are cut into equal batches.  MI_ARITH_EXACT runs on the same schedule since round 3.
     int sep_nb = 0;
     if (n > 0) {
         if (t->dev_cap == 0) {

@@ -9,6 +9,11 @@ constants = SimpleNamespace(
     FLOAT_32="float-32", FLOAT_64="float-64",
     DEFAULT_PY_FLOAT="float-32", DEFAULT_PY_MIN_SIZE=32, DEFAULT_PY_KERNEL_SIZE=5,
     DEFAULT_PY_GEN_KERNEL=0.4,
+    # evaluation order of the pyramid stencils -- an option the reference does not have:
+    # "separable" (5 + 5 tap form, within the stated float-32 tolerance of the reference's float-64 mode; the default of
+    # PyramidStack()) or "exact" (the reference's own row-major 25-tap order, bit-identical to its restatement: the audit
+    # mode).  The environment variable SHINESTACKER_AMD_ARITH overrides the default without a code change.
+    DEFAULT_PY_ARITH="separable",
     DEFAULT_FRAMES=10, DEFAULT_OVERLAP=2, DEFAULT_STACK_PREFIX="stack_",
     DEFAULT_PLOT_STACK=True, DEFAULT_PLOTS_PATH="plots", DEFAULT_FILE_REVERSE_ORDER=False,
     ALIGN_RIGID="ALIGN_RIGID", ALIGN_HOMOGRAPHY="ALIGN_HOMOGRAPHY",

@@ -170,13 +170,32 @@ def _align_chains_device(lib, dev_frames, aligned, n_frames, height, width, dt, 
     return transforms, ccs
 
 
+class StackHandles:
+    """What `align_and_stack_device(keep_handles=True)` returns and `handles=` takes back: the stacker, the estimator and
+    the scratch buffers of ONE geometry.  The library never sees the sizes of `batches` / `tmp` / `mask`, so the geometry
+    they were made for travels with them and a later call is checked against it (`matches`)."""
+
+    def __init__(self, stack, aligner, batches, tmp, mask, **geometry):
+        self.stack, self.aligner, self.batches, self.tmp, self.mask = stack, aligner, batches, tmp, mask
+        self.geometry = geometry
+
+    def __iter__(self):    # (stack, aligner, batches, tmp, mask), as rounds 2-3 returned them
+        return iter((self.stack, self.aligner, self.batches, self.tmp, self.mask))
+
+    def mismatch(self, **geometry):
+        """names of the geometry items that differ from what the handles were created for"""
+        return [k for k, v in geometry.items() if self.geometry.get(k) != v]
+
+    def close(self):
+        self.aligner.close()
+        self.stack.close()
+        for b in (self.batches, self.tmp, self.mask):
+            b.free()
+
+
 def close_handles(handles):
     """release what `align_and_stack_device(keep_handles=True)` returned"""
-    stack, aligner, batches, tmp, mask = handles
-    aligner.close()
-    stack.close()
-    for b in (batches, tmp, mask):
-        b.free()
+    handles.close()
 
 
 def _make_correction(balance, device):
@@ -198,7 +217,7 @@ def _make_correction(balance, device):
 def align_and_stack_device(dev_frames, n_frames, height, width, dtype, ref_idx=-1, alignment_config=None,
                            min_correlation=0.5, max_iters=60, device=0, batch_frames=16, out_dev=None,
                            balance=None, ecc_batch=16, step_process=False, native_loop=True, handles=None,
-                           keep_handles=False, **stack_kwargs):
+                           keep_handles=False, info=None, **stack_kwargs):
     """BASELINE config 4 with every frame resident in HBM: `dev_frames` is the device address of
     `n_frames` contiguous H x W x 3 frames.  Each frame is registered against frames[ref_idx] by
     the device ECC estimator (mi_aligner_*), warped with the blurred replicate border of
@@ -223,6 +242,9 @@ def align_and_stack_device(dev_frames, n_frames, height, width, dtype, ref_idx=-
 
     `native_loop` (default): without balancing the frame loop runs inside the library (`mi_align_stack_device`); False
     keeps the call-by-call Python loop below (the two are tested equal).
+
+    `info`: an optional dict; with `balance` it receives `info["corrections"]` = the per-frame correction factors the
+    reference's sub-action records (balance.py: `self.corrections`), for the frames that were processed.
 
     `step_process=True`: the reference's chained order (see `_align_chains_device`): every frame is registered against
     its already-aligned neighbour; the aligned frames are kept in one extra device buffer (n_frames frames) and fused in
@@ -267,28 +289,47 @@ def align_and_stack_device(dev_frames, n_frames, height, width, dtype, ref_idx=-
             aligned.free()
         return out, transforms, ccs
     ecc_batch = max(1, min(int(ecc_batch), _lib.Aligner.MAX_BATCH))
+    geometry = dict(height=int(height), width=int(width), dtype=dt.name, batch_frames=int(batch_frames),
+                    subsample=max(1, int(cfg['subsample'])), fast=bool(cfg['fast_subsampling']), device=int(device))
+    # everything that can be refused is refused BEFORE anything is allocated
+    corr = bal_opts = None
+    if balance is not None:
+        corr = _make_correction(balance, device)
+    native = native_loop and (balance is None or corr.supports_native_linear())
+    if (handles is not None or keep_handles) and not native:
+        raise InvalidOptionError("handles", "reuse", ": handle reuse is implemented for the native loop (no balancing, or the "
+                                 "LINEAR map)")
     if handles is not None:   # handles of an earlier call (a job of many stacks): nothing is allocated here
+        bad = handles.mismatch(**geometry)
+        if bad:
+            raise InvalidOptionError("handles", {k: geometry[k] for k in bad},
+                                     f": these handles were created for {({k: handles.geometry.get(k) for k in bad})}; the "
+                                     "scratch buffers are sized for that geometry (close them and let the call allocate)")
         stack, aligner, batches, tmp, mask = handles
         stack.reset()
+        created = None
     else:
         stack = _lib.Stack(height, width, in_dtype=dt, out_dtype=dt, device=device, batch_frames=batch_frames,
                            **stack_kwargs)
         aligner = _lib.Aligner(height, width, dt, subsample=max(1, int(cfg['subsample'])), device=device,
                                fast=bool(cfg['fast_subsampling']))
-    corr = bal_opts = None
-    if balance is not None:
-        corr = _make_correction(balance, device)
+        created = [stack, aligner]     # released here whenever an exception leaves this call
+    if corr is not None:
         corr.begin_device(dev_frames + ref_idx * fb, height, width, dt, n_frames)
-        bal_opts = corr.native_linear_opts() if native_loop else None
-    if native_loop and (balance is None or bal_opts is not None):
+        bal_opts = corr.native_linear_opts() if native else None
+    if native:
         # the whole loop below in ONE library call (mi_align_stack_device): same kernels in the same order on the same
         # streams; the ~25 ctypes calls per frame of the Python loop made the pipeline's pace depend on how busy the host is
         # (0.08 s on an idle box, 0.3 s on a shared one, for 128 x 24 MP)
-        if handles is None:
-            batches = _lib.DeviceBuffer(2 * fb * batch_frames, device)
-            tmp = _lib.DeviceBuffer(fb, device)
-            mask = _lib.DeviceBuffer(height * width, device)
+        done = False
         try:
+            if handles is None:
+                batches = _lib.DeviceBuffer(2 * fb * batch_frames, device)
+                created.append(batches)
+                tmp = _lib.DeviceBuffer(fb, device)
+                created.append(tmp)
+                mask = _lib.DeviceBuffer(height * width, device)
+                created.append(mask)
             opts = _lib.AlignStackOpts(transform=int(homography), border_mode=_BORDER_CODE[cfg['border_mode']],
                                        border_value=(C.c_double * 4)(*(list(cfg['border_value']) + [0, 0, 0, 0])[:4]),
                                        blur_ksize=21, blur_sigma=float(cfg['border_blur']),
@@ -301,7 +342,12 @@ def align_and_stack_device(dev_frames, n_frames, height, width, dtype, ref_idx=-
                                            C.byref(bal_opts) if bal_opts is not None else None, batches.ptr,
                                            tmp.ptr, mask.ptr, M, cc, C.byref(failed))
             if bal_opts is not None:
-                corr._corr_pending.extend(i for i in range(n_frames) if i != ref_idx)
+                # only the frames the library got to have a correction row on the device (it stops at the first
+                # frame whose correlation is too low: those from `failed` on were never balanced)
+                stop = failed.value if rc == _lib.MI_ERR_ALIGNMENT and failed.value >= 0 else n_frames
+                corr._corr_pending.extend(i for i in range(stop) if i != ref_idx)
+                if info is not None:
+                    info["corrections"] = corr.fetch_corrections()
             if rc == _lib.MI_ERR_ALIGNMENT:
                 raise AlignmentError(failed.value, f"correlation {cc[failed.value]:.3f} < {min_correlation}")
             _lib.check(rc)
@@ -315,17 +361,15 @@ def align_and_stack_device(dev_frames, n_frames, height, width, dtype, ref_idx=-
                 out = None
             else:
                 out = stack.finish()
+            done = True
         finally:
-            if handles is None and not keep_handles:
-                aligner.close()
-                stack.close()
-                for b in (batches, tmp, mask):
-                    b.free()
+            if created is not None and not (keep_handles and done):
+                for obj in created:
+                    obj.close() if hasattr(obj, "close") else obj.free()
         if keep_handles:
-            return out, transforms, ccs, (stack, aligner, batches, tmp, mask)
+            return out, transforms, ccs, (handles if handles is not None else
+                                          StackHandles(stack, aligner, batches, tmp, mask, **geometry))
         return out, transforms, ccs
-    if handles is not None or keep_handles:
-        raise InvalidOptionError("handles", "reuse", ": handle reuse is implemented for the native loop without balancing")
     tmp = _lib.DeviceBuffer(fb, device)
     mask = _lib.DeviceBuffer(height * width, device)
     # two batches of warped frames: one is being fused while the next is being filled
@@ -397,9 +441,13 @@ def align_and_stack_device(dev_frames, n_frames, height, width, dtype, ref_idx=-
             out = None
         else:
             out = stack.finish()
+        if corr is not None and info is not None:
+            info["corrections"] = corr.fetch_corrections()
     finally:
         aligner.close()
         stack.close()
+        for b in [tmp, mask] + batches:
+            b.free()
     return out, transforms, ccs
 
 
@@ -446,9 +494,15 @@ def bunches_then_stack(get_frame, n_frames, height, width, dtype, frames=constan
                 on_bunch(k, st)
             st.finish_device(results.ptr + k * fb)
         st.sync()
-    finally:
-        if not stacks:
+    except BaseException:
+        if stacks:
+            st.sync()       # the reused handle may still be writing into `results`
+        else:
             st.close()
+        results.free()
+        raise
+    if not stacks:
+        st.close()
     st2 = stacks[1] if stacks else _lib.Stack(height, width, in_dtype=dt, out_dtype=dt, device=device, **stack_kwargs)
     try:
         st2.reset()

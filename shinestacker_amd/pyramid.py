@@ -4,6 +4,7 @@ Drop-in for the reference's `PyramidStack` (algorithms/pyramid.py:114-179) and i
 `BaseStackAlgo` protocol (algorithms/base_stack_algo.py:9-42):
 
 * constructor  PyramidStack(min_size=32, kernel_size=5, gen_kernel=0.4, float_type='float-32')
+  (+ keyword-only extensions; `arith="separable"|"exact"`: the evaluation order of the stencils, see __init__)
 * set by the owning action: ``.process`` (stack.py:23), ``.do_step_callback`` (stack.py:103 / :76)
 * name() -> 'pyramid', steps_per_frame() -> 2, print_message(), focus_stack(filenames) -> H x W x 3
   array of the input dtype, BGR, C-contiguous, host memory
@@ -107,10 +108,19 @@ class PyramidStack(BaseStackAlgo):
                  kernel_size=constants.DEFAULT_PY_KERNEL_SIZE,
                  gen_kernel=constants.DEFAULT_PY_GEN_KERNEL,
                  float_type=constants.DEFAULT_PY_FLOAT, *, device=0, use_fma=True,
-                 impl=_lib.IMPL_AUTO, batch_frames=0, decode_threads=8, arith="exact"):
+                 impl=_lib.IMPL_AUTO, batch_frames=0, decode_threads=8, arith=None):
         super().__init__("pyramid", 2, float_type)
-        # arith (keyword-only extension): "exact" = the reference's own evaluation order, bit-identical results (default);
-        # "separable" = MI_ARITH_SEPARABLE, the 5 + 5 tap form within the stated float32 tolerance, ~1.35x the throughput
+        # arith (keyword-only extension; the reference has one evaluation order):
+        #   "separable" = MI_ARITH_SEPARABLE, the 5 + 5 tap form of the same stencils: within the stated float-32 tolerance
+        #                 of the reference's float-64 mode, ~1.3x the throughput -- the default since round 4
+        #                 (constants.DEFAULT_PY_ARITH; float-64 stacks always run "exact")
+        #   "exact"     = the reference's own row-major 25-tap order: bit-identical to its restatement, the audit mode
+        # None -> $SHINESTACKER_AMD_ARITH, else the default.
+        if arith is None:
+            import os
+            arith = os.environ.get("SHINESTACKER_AMD_ARITH") or constants.DEFAULT_PY_ARITH
+            if float_type == constants.FLOAT_64:
+                arith = "exact"
         if arith not in _lib.ARITH_CODE:
             raise InvalidOptionError("arith", arith, details=" valid values are 'exact' and 'separable'")
         if arith == "separable" and float_type == constants.FLOAT_64:

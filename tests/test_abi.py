@@ -9,6 +9,8 @@ import pytest
 
 from conftest import ROOT
 
+HEADER = os.path.join(ROOT, "include", "mi355stack.h")
+
 
 def header_symbols():
     text = open(os.path.join(ROOT, "include", "mi355stack.h")).read()
@@ -35,12 +37,47 @@ def test_python_binding_covers_header(hiplib):
     assert hiplib.load().mi_abi_version() == 1
 
 
+def _header_params_fields():
+    """(name, ctype, count) of every member of mi_stack_params_t, parsed from include/mi355stack.h"""
+    import re
+    text = open(HEADER).read()
+    body = text[text.index("typedef struct mi_stack_params {"):text.index("} mi_stack_params_t;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for decl in body.split("{", 1)[1].split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        ctype, names = decl.split(None, 1)
+        for nm in names.split(","):
+            m = re.match(r"\s*(\w+)(?:\[(\d+)\])?\s*$", nm)
+            fields.append((m.group(1), ctype, int(m.group(2) or 1)))
+    return fields
+
+
 def test_params_struct_layout(hiplib):
-    # int32 x6, double, int32 x5, reserved[5]  -> 24 + 8 + 20 + 20 = 72 bytes
-    assert ctypes.sizeof(hiplib.StackParams) == 72
+    """mi_stack_params_t as the header declares it == the ctypes mirror (names, order, OFFSETS, size) == the stub shown
+    in INTEGRATION.md: int32 x6, double, int32 x5 (float_type .. batch_frames), arith, reserved[4] -> 72 bytes."""
+    ct = {"int32_t": ctypes.c_int32, "double": ctypes.c_double}
+    fields = _header_params_fields()
+
+    class FromHeader(ctypes.Structure):
+        _fields_ = [(n, ct[t] * k if k > 1 else ct[t]) for n, t, k in fields]
+    mine = hiplib.StackParams
+    assert [f[0] for f in mine._fields_] == [n for n, _, _ in fields]
+    for n, _, _ in fields:
+        assert getattr(mine, n).offset == getattr(FromHeader, n).offset, n
+        assert getattr(mine, n).size == getattr(FromHeader, n).size, n
+    assert ctypes.sizeof(mine) == ctypes.sizeof(FromHeader) == 72
+    assert mine.arith.offset == 52 and mine.reserved.offset == 56 and mine.gen_kernel.offset == 24
+    # the reference-side stub of INTEGRATION.md lists the same members in the same order
+    import re
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    stub = doc[doc.index("class _Params(C.Structure):"):doc.index("_lib.mi_last_error.restype")]
+    assert re.findall(r'\("(\w+)", C\.', stub) == [n for n, _, _ in fields]
     p = hiplib.StackParams()
     hiplib.load().mi_stack_default_params(ctypes.byref(p))
-    assert (p.min_size, p.kernel_size, p.gen_kernel, p.use_fma) == (32, 5, 0.4, 1)
+    assert (p.min_size, p.kernel_size, p.gen_kernel, p.use_fma, p.arith) == (32, 5, 0.4, 1, 0)
 
 
 def test_argument_validation_without_gpu(hiplib):

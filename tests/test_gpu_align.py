@@ -177,7 +177,7 @@ def test_project_align_balance_stack_on_files(hiplib, oracle, tmp_path):
         job.add_action(CombinedActions(f"align-{tag}", [AlignFrames(estimator=ecc_estimator(), subsample=1),
                                                         BalanceFrames(subsample=1)],
                                        output_path=f"aligned-{tag}", io_threads=io_threads))
-        job.add_action(FocusStack(f"stack-{tag}", PyramidStack(decode_threads=dec), input_path=f"aligned-{tag}",
+        job.add_action(FocusStack(f"stack-{tag}", PyramidStack(decode_threads=dec, arith="exact"), input_path=f"aligned-{tag}",
                                   output_path=f"stack-{tag}"))
         job.run()
         aligned = [read_img(os.path.join(work, f"aligned-{tag}", n))

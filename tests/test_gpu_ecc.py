@@ -235,7 +235,7 @@ def test_batched_estimate_equals_single_estimates(L, oracle):
 
 
 def test_align_and_stack_device_step_process_chains(L, oracle):
-    """step_process=True (the reference's documented default, stack_framework.py:214-232): every frame is registered
+    """step_process=True (the chained order of stack_framework.py:214-232; the class default is False, :192): every frame is registered
     against its already ALIGNED neighbour, in two chains away from the reference frame.  The resident pipeline must give
     what the same procedure gives step by step through the single-frame entry points, fused in file order; and the
     chained transforms still bring every frame onto the reference frame."""
@@ -376,3 +376,61 @@ def test_step_process_chains_balance_before_the_next_reference(L, oracle):
         so.push_frame(out[i])
     assert np.array_equal(fused, so.finish())
     buf.free()
+
+
+def test_handles_of_one_stack_serve_the_next_and_are_checked_against_its_geometry(L, oracle):
+    """A job of many stacks keeps the stacker, the estimator and the scratch buffers (`keep_handles` / `handles=`): a second,
+    DIFFERENT stack through the same handles equals a fresh call; a call whose geometry the scratch buffers were not made
+    for (more frames per batch, another frame size, another sub-sampling) is refused before the library could write past
+    them; an alignment failure releases what the failing call itself created; the LINEAR balance factors are returned."""
+    from shinestacker_amd.errors import AlignmentError, InvalidOptionError
+    from shinestacker_amd.pipeline import StackHandles, align_and_stack_device, close_handles
+    h, w, n = 256, 384, 6
+
+    def stack_frames(seed):
+        frames = []
+        for f in range(n):
+            d = f - n // 2
+            T = similarity(0.1 * d, 1 + 3e-4 * d, 1.1 * d, -0.7 * d, (w - 1) / 2, (h - 1) / 2)
+            ref, mov = make_pair(oracle, T, h=h, w=w, seed=seed, noise=2.0)
+            frames.append(np.clip((ref if d == 0 else mov) * (1.0 + 0.05 * d), 0, 255).astype(np.uint8))
+        buf = L.DeviceBuffer(n * frames[0].nbytes)
+        for f, fr in enumerate(frames):
+            buf.upload(fr, f * fr.nbytes)
+        return buf
+    a, b = stack_frames(41), stack_frames(42)
+    cfg = {'subsample': 1}
+    kw = dict(alignment_config=cfg, batch_frames=4)
+    fresh_a, tr_a, _ = align_and_stack_device(a.ptr, n, h, w, np.uint8, **kw)
+    fresh_b, tr_b, _ = align_and_stack_device(b.ptr, n, h, w, np.uint8, **kw)
+    out, tr, _, hd = align_and_stack_device(a.ptr, n, h, w, np.uint8, keep_handles=True, **kw)
+    assert isinstance(hd, StackHandles) and np.array_equal(out, fresh_a)
+    out, tr, _ = align_and_stack_device(b.ptr, n, h, w, np.uint8, handles=hd, **kw)          # another stack, same handles
+    assert np.array_equal(out, fresh_b) and all(np.array_equal(x, y) for x, y in zip(tr[:n // 2], tr_b[:n // 2]))
+    out, _, _, hd2 = align_and_stack_device(a.ptr, n, h, w, np.uint8, handles=hd, keep_handles=True, **kw)
+    assert hd2 is hd and np.array_equal(out, fresh_a)
+    for bad_kw, bad_shape in ((dict(alignment_config=cfg, batch_frames=8), (h, w)),
+                              (dict(alignment_config={'subsample': 2}, batch_frames=4), (h, w)),
+                              (kw, (h // 2, w))):
+        with pytest.raises(InvalidOptionError, match="handles"):
+            align_and_stack_device(a.ptr, n, bad_shape[0], bad_shape[1], np.uint8, handles=hd, **bad_kw)
+    with pytest.raises(InvalidOptionError, match="handles"):                                  # refused before any allocation
+        align_and_stack_device(a.ptr, n, h, w, np.uint8, keep_handles=True, native_loop=False, **kw)
+    # the handles survive the refusals
+    out, _, _ = align_and_stack_device(b.ptr, n, h, w, np.uint8, handles=hd, **kw)
+    assert np.array_equal(out, fresh_b)
+    # an alignment failure with keep_handles: AlignmentError, nothing returned, nothing left behind by that call
+    free0 = L.mem_info()[0] if hasattr(L, "mem_info") else None
+    with pytest.raises(AlignmentError):
+        align_and_stack_device(a.ptr, n, h, w, np.uint8, keep_handles=True, min_correlation=2.0, **kw)
+    if free0 is not None:
+        assert L.mem_info()[0] >= free0 - (1 << 20)
+    # LINEAR balance inside the native loop: the correction factors come back, one row per processed frame
+    info = {}
+    align_and_stack_device(a.ptr, n, h, w, np.uint8, balance={'channel': 'LUMI', 'corr_map': 'LINEAR', 'subsample': 2},
+                           info=info, **kw)
+    c = info["corrections"]
+    assert c.shape == (n, 1) and c[n // 2, 0] == 1.0 and np.all(c > 0.5) and np.all(c < 2.0) and np.ptp(c) > 0.05
+    close_handles(hd)
+    a.free()
+    b.free()

@@ -230,9 +230,9 @@ def test_stack_job_on_gpu_matches_reference_outputs(L, tmp_path):
     keys = ("before_action", "after_action", "step_counts", "begin_steps", "end_steps",
             "after_step", "save_plot", "check_running")
     job = StackJob("job", work, input_path="input", callbacks={k: cb(k) for k in keys})
-    job.add_action(FocusStack("stack-pyramid", PyramidStack(), output_path="out-stack",
+    job.add_action(FocusStack("stack-pyramid", PyramidStack(arith="exact"), output_path="out-stack",
                               prefix="pyr_"))
-    job.add_action(FocusStackBunch("bunches", PyramidStack(), input_path="input",
+    job.add_action(FocusStackBunch("bunches", PyramidStack(arith="exact"), input_path="input",
                                    output_path="out-bunch", frames=3))
     job.run()
     outs = load_golden("plumbing_outputs")
@@ -246,6 +246,36 @@ def test_stack_job_on_gpu_matches_reference_outputs(L, tmp_path):
                         if isinstance(x, str) else x for x in t] for t in tr]
     n_stack = len(gold["trace_stack"]) - 1  # golden ends with the job's own after_action
     assert norm(trace[:n_stack]) == norm(gold["trace_stack"][:n_stack])
+
+
+def test_default_arithmetic_on_the_reference_example_job(L, tmp_path):
+    """The one-import swap as a user gets it: `PyramidStack()` with no arguments (constants.DEFAULT_PY_ARITH = "separable")
+    in the same StackJob, against the files the reference's own job wrote (tests/golden/plumbing_outputs.npz: real image
+    content, crops of examples/input/img-jpg).  Same files, same callback trace; pixel values within the stated
+    tolerance: a value differs from the recording by at most ONE count, and fewer than 0.05 % of the values do (the
+    truncating cast at an integer boundary, pyramid.py:179) -- measured: 18 of 294 912 in the full stack."""
+    from shinestacker_amd import FocusStack, FocusStackBunch, PyramidStack, StackJob
+    from shinestacker_amd.imageio import read_img
+    with open(os.path.join(GOLDEN, "plumbing.json")) as fh:
+        gold = json.load(fh)
+    work = str(tmp_path)
+    os.makedirs(os.path.join(work, "input"))
+    for n in gold["input_names"]:
+        shutil.copy(os.path.join(GOLDEN, "img_jpg_crop", n), os.path.join(work, "input", n))
+    assert PyramidStack().arith == "separable"
+    job = StackJob("job", work, input_path="input")
+    job.add_action(FocusStack("stack-pyramid", PyramidStack(), output_path="out-stack", prefix="pyr_"))
+    job.add_action(FocusStackBunch("bunches", PyramidStack(), input_path="input", output_path="out-bunch", frames=3))
+    job.run()
+    outs = load_golden("plumbing_outputs")
+    pairs = [(read_img(os.path.join(work, "out-stack", gold["stack_out_files"][0])), outs["stack"])]
+    files = sorted(os.listdir(os.path.join(work, "out-bunch")))
+    assert files == gold["bunch_out_files"]
+    pairs += [(read_img(os.path.join(work, "out-bunch", f)), outs[f"bunch_{i}"]) for i, f in enumerate(files)]
+    for got, want in pairs:
+        assert got.dtype == want.dtype and got.shape == want.shape
+        d = np.abs(got.astype(np.int32) - want.astype(np.int32))
+        assert d.max() <= 1 and (d != 0).mean() < 5e-4, (int(d.max()), float((d != 0).mean()))
 
 
 def test_large_frame_properties(L, oracle):
@@ -390,7 +420,7 @@ def test_bunches_of_16bit_tiff_frames(L, oracle, tmp_path):
         write_img(os.path.join(work, "in16", names[-1]), fr)
         assert np.array_equal(read_img(os.path.join(work, "in16", names[-1])), fr)   # lossless 16-bit round trip
     job = StackJob("job", work, input_path="in16")
-    job.add_action(FocusStackBunch("bunches", PyramidStack(min_size=16, batch_frames=4), output_path="out16",
+    job.add_action(FocusStackBunch("bunches", PyramidStack(min_size=16, batch_frames=4, arith="exact"), output_path="out16",
                                    frames=5, overlap=2))
     job.run()
     outs = sorted(os.listdir(os.path.join(work, "out16")))

@@ -205,7 +205,9 @@ def test_separable_tiled_equals_simple_on_random_shapes(L, seed):
 
 def test_pyramid_stack_arith_option(L, oracle):
     """PyramidStack(arith="separable") -- the keyword the drop-in class adds -- fuses with the separable arithmetic
-    (== its oracle), the default stays the reference's evaluation order, and bad combinations are refused."""
+    (== its oracle) and is what PyramidStack() gives (constants.DEFAULT_PY_ARITH, round 4); arith="exact" is the reference's
+    evaluation order (== the exact oracle); $SHINESTACKER_AMD_ARITH overrides the default; float-64 stacks stay exact; bad
+    combinations are refused."""
     from shinestacker_amd.errors import InvalidOptionError
     from shinestacker_amd.pyramid import PyramidStack
     h, w, n = 300, 452, 5
@@ -215,7 +217,17 @@ def test_pyramid_stack_arith_option(L, oracle):
     se = oracle.StreamingOracle(h, w, np.uint8)
     for f in frames:
         se.push_frame(f)
-    assert np.array_equal(PyramidStack().focus_stack_arrays(frames), se.finish())
+    want_exact = se.finish()
+    assert np.array_equal(PyramidStack(arith="exact").focus_stack_arrays(frames), want_exact)
+    assert PyramidStack().arith == "separable" and PyramidStack(float_type="float-64").arith == "exact"
+    assert np.array_equal(PyramidStack().focus_stack_arrays(frames), so.finish())
+    import os
+    os.environ["SHINESTACKER_AMD_ARITH"] = "exact"
+    try:
+        assert PyramidStack().arith == "exact"
+        assert np.array_equal(PyramidStack().focus_stack_arrays(frames), want_exact)
+    finally:
+        del os.environ["SHINESTACKER_AMD_ARITH"]
     with pytest.raises(InvalidOptionError):
         PyramidStack(arith="fast")
     with pytest.raises(InvalidOptionError):

@@ -99,6 +99,9 @@ def main():
         acfg = {'transform': 'ALIGN_HOMOGRAPHY'} if args.homography else None
         align_and_stack_device(buf.ptr, min(N, 4), H, W, np.uint8, out_dev=out.ptr, balance=bal, arith=args.arith, step_process=args.step_process, batch_frames=args.batch, alignment_config=acfg, native_loop=not args.python_loop, **({'ecc_batch': args.ecc_batch} if args.ecc_batch else {}))   # warm-up
         if args.reuse_handles:   # what a job of many stacks pays per stack: the handles exist already
+            if args.step_process or args.python_loop:
+                # (round 3 dropped these flags silently here and wrote a non-chained run into config4_resident_step.json)
+                raise SystemExit("--reuse-handles times the native non-chained loop; it cannot be combined with --step-process / --python-loop")
             kw = dict(balance=bal, arith=args.arith, batch_frames=args.batch, alignment_config=acfg, **({'ecc_batch': args.ecc_batch} if args.ecc_batch else {}))
             from shinestacker_amd.pipeline import close_handles
             *_, hd = align_and_stack_device(buf.ptr, N, H, W, np.uint8, ref_idx=ref, out_dev=out.ptr, keep_handles=True, **kw)
@@ -117,7 +120,7 @@ def main():
         recovered = {k: m.copy() for k, m in enumerate(t for t in tr if t is not None)}
         for m in recovered.values():
             m[:, 2] /= 2    # compare at the sub-sampled scale like the host path below
-        report(N, H, W, dt, recovered, truth, ref, cx, cy, "resident + balance" if args.balance else "resident", list(out.download((H, W, 3), np.uint8).shape))
+        report(N, H, W, dt, recovered, truth, ref, cx, cy, ("resident, step_process (chained)" if args.step_process else "resident") + (" + balance" if args.balance else ""), list(out.download((H, W, 3), np.uint8).shape))
         return
     est = ecc_estimator()
     recovered = {}
