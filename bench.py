@@ -55,6 +55,11 @@ def parse():
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-other-mode", action="store_true", help="do not also measure the other arithmetic mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-dtypes", action="store_true",
+                    help="do not also time the same stack held as uint8 / uint16 frames (the reference's real input types)")
+    ap.add_argument("--no-projection", action="store_true",
+                    help="do not add the PROJECTED 2 / 4 / 8-GPU lines (measured single-GPU compute at 256/N frames + measured "
+                         "local combine kernels + the xGMI link rate; labelled 'projected', never a measurement)")
     ap.add_argument("--cpu-frames", type=int, default=64,
                     help="frames of the CPU-baseline sample (about 10 s of CPU work at 24 MP on 16 cores)")
     ap.add_argument("--cpu-refshaped", type=int, default=4,
@@ -210,6 +215,82 @@ def verify(L, st, args, total_frames, world):
     ok &= all_eq
     res["ok"] = bool(ok)
     return res
+
+
+XGMI_LINK_GBS = 153.0      # per link and direction; 7 links per GPU, point to point (the task's hardware notes)
+XGMI_EFFICIENCY = 0.8      # assumed achievable fraction of the link rate for multi-megabyte RCCL transfers
+
+
+def project_scaling(L, measure, args, H, W, total_frames, t1_s, device):
+    """PROJECTED strong scaling of this job over N = 2, 4, 8 GPUs of one node -- NOT a measurement (no multi-GPU node was
+    available to any round).  Built from two things measured here and one taken from the hardware notes:
+      compute   the single-GPU step on total/N frames (the rank's block), timed like the headline;
+      local     the per-rank kernels of the winners-only exchange (winner map over the rank's pixel chunk, plan over the
+                whole map, pack of the rows the rank won, unpack of the other ranks' rows at rank 0), timed on this GPU on a
+                synthetic winner map in which rank r wins the r-th horizontal band of every level;
+      link      bytes that cross rank 0's busiest xGMI link once: 4 (energies, all-to-all) + 1 (winner map, all-gather) +
+                12 (winners' Laplacians to rank 0) bytes per state pixel, divided by N (one peer's share), at
+                XGMI_LINK_GBS x XGMI_EFFICIENCY.
+    step(N) = compute + local + link with no overlap credited (the implementation exchanges level 0 while the rank's
+    coarser levels still run; that saving is listed as `hidden_behind_coarse_levels_ms` and NOT subtracted)."""
+    import ctypes as C
+    out = {"label": "projected", "basis": "measured compute at total/N frames + measured local combine kernels + "
+           f"{XGMI_LINK_GBS:.0f} GB/s x {XGMI_EFFICIENCY} per xGMI link; strong scaling of the {total_frames}-frame job",
+           "measured_n1": {"ms_per_step": t1_s * 1e3}, "lines": []}
+    lib = L.load()
+    for n in (2, 4, 8):
+        if total_frames % n:
+            continue
+        fn = total_frames // n
+        st, dt_s, prof, _ = measure(args.arith, max(2, args.steps // 2), 1, F=fn)
+        k = max(2, args.steps // 2)
+        compute_ms = dt_s / k * 1e3
+        coarse_ms = prof["levels"][0] / k
+        e_ptr, l_ptr, _i_ptr, npx = st.state_ptrs(-1)
+        # synthetic winner map: rank r wins the r-th band of every level (what frame-sharded focus stacks look like)
+        win_h = np.concatenate([np.repeat((np.arange(h, dtype=np.int64) * n // max(h, 1)).astype(np.uint8), w)
+                                for (h, w) in list(st.shapes[:-1]) + [st.shapes[-1], st.shapes[-1]]])
+        win_h = np.concatenate([win_h, np.zeros(max(0, npx - win_h.size), np.uint8)])[:npx]
+        win = L.DeviceBuffer(npx, device)
+        win.upload(win_h)
+        chunk = -(-npx // n)
+        cand = L.DeviceBuffer(4 * chunk * n, device)
+        wchunk = L.DeviceBuffer(chunk, device)
+        plan = L.DeviceBuffer(lib.mi_combine_plan_bytes(npx, n), device)
+        rows = L.DeviceBuffer(12 * npx, device)
+        totals = (C.c_int64 * n)()
+        ptrs_h = np.array([0] + [rows.ptr] * (n - 1), np.int64)   # (offsets are per rank: one shared buffer serves the timing)
+        ptrs = L.DeviceBuffer(8 * n, device)
+        ptrs.upload(ptrs_h)
+
+        def local(rank):
+            L.check(lib.mi_combine_winner(device, None, n, cand.ptr, chunk, wchunk.ptr))
+            L.check(lib.mi_combine_plan(device, None, win.ptr, npx, n, plan.ptr, totals))
+            if rank:
+                L.check(lib.mi_combine_pack(device, None, win.ptr, npx, n, rank, plan.ptr, l_ptr, 3, rows.ptr))
+            else:
+                L.check(lib.mi_combine_unpack(device, None, win.ptr, npx, n, 0, plan.ptr, ptrs.ptr, 3, l_ptr))
+            L.check(lib.mi_device_synchronize(device))
+        t_local = {}
+        for rank in (0, 1):
+            local(rank)
+            t0 = time.perf_counter()
+            for _ in range(5):
+                local(rank)
+            t_local[rank] = (time.perf_counter() - t0) / 5 * 1e3
+        for b in (win, cand, wchunk, plan, rows, ptrs):
+            b.free()
+        st.close()
+        local_ms = max(t_local.values())      # rank 0 unpacks, the others pack: the slower of the two bounds the step
+        link_ms = 17.0 * npx / n / (XGMI_LINK_GBS * XGMI_EFFICIENCY * 1e9) * 1e3
+        step_ms = compute_ms + local_ms + link_ms
+        out["lines"].append({"n_gpus": n, "label": "projected", "frames_per_gpu": fn,
+                             "value": total_frames * H * W / step_ms / 1e3, "unit": "Mpixels/s", "ms_per_step": step_ms,
+                             "compute_ms": compute_ms, "local_combine_ms": local_ms,
+                             "local_combine_ms_by_role": {"root_unpack": t_local[0], "sender_pack": t_local[1]},
+                             "link_ms": link_ms, "hidden_behind_coarse_levels_ms": min(coarse_ms, link_ms * 0.75),
+                             "scaling_efficiency_vs_measured_n1": (t1_s * 1e3 / step_ms) / n})
+    return out
 
 
 def dry_run(args, rank, world):
@@ -372,7 +453,7 @@ def main():
             torch.cuda.synchronize()
         st.sync()
 
-    def measure(arith, steps, warmup):
+    def measure(arith, steps, warmup, buf=buf, dt=dt, out_dt=out_dt, F=F):
         st = L.Stack(H, W, in_dtype=dt, out_dtype=out_dt, device=device, impl=impl, batch_frames=args.batch, arith=arith)
         st.set_first_index(rank * F)
         combiner = None
@@ -538,6 +619,32 @@ def main():
             line["other_mode"]["fused_image_max_abs_diff"] = pr["final_max_abs_diff"]
         if st2 is not None:
             st2.close()
+    extras = world == 1 and not force_dist and args.source == "device" and args.impl != "simple"
+    if extras and not args.no_projection and total_frames >= 16:
+        line["projected_scaling"] = project_scaling(L, measure, args, H, W, total_frames, dt_s / args.steps, device)
+    if extras and not args.no_other_dtypes:
+        # the reference's real input types (pyramid.py:159-164: uint8 / uint16 files): the same stack, same values, held as
+        # integer frames -- 3 / 6 bytes per pixel cross HBM instead of 12, and the level-0 kernel converts on the fly
+        line["other_dtypes"] = {}
+        buf.free()
+        buf = None
+        for name, d2 in (("u8", np.uint8), ("u16", np.uint16), ("f32", np.float32)):
+            if name == args.dtype:
+                continue
+            per2 = H * W * 3 * np.dtype(d2).itemsize
+            b2 = L.DeviceBuffer(per2 * F, device)
+            L.synth_frames_device(b2.ptr, d2, H, W, 0, F, total_frames, device=device)
+            st3, dt3, prof3, _ = measure(args.arith, args.steps, max(1, args.warmup), buf=b2, dt=d2,
+                                         out_dt=np.uint16 if name == "u16" else np.uint8)
+            ms3, n3, by3 = prof3["level0"] if prof3["level0"][1] > 0 else prof3["levels"]
+            jb = float(np.dtype(d2).itemsize * 3 * H * W + 36 * sum(h * w for (h, w) in st3.shapes[1:]))
+            line["other_dtypes"][name] = {
+                "value": total_frames * H * W * args.steps / dt3 / 1e6, "unit": "Mpixels/s", "ms_per_step": dt3 / args.steps * 1e3,
+                "job_roofline_frac": (jb * total_frames * args.steps / dt3) / (HBM_PEAK_GBS * 1e9),
+                "roofline_frac": roofline(ms3, n3, by3) / HBM_PEAK_GBS, "avg_launch_ms": ms3 / max(n3, 1),
+                "algorithmic_bytes_per_launch": by3 / max(n3, 1), "arith": args.arith}
+            st3.close()
+            b2.free()
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, total_frames)

@@ -139,6 +139,20 @@ MI_API int mi_stack_set_first_index(mi_stack_t* s, int first_global_index);
 /* One frame from host memory (H rows of row_stride_bytes; 0 = tightly packed).
  * Returns after the work is enqueued; the host buffer may be reused on return. */
 MI_API int mi_stack_push_frame(mi_stack_t* s, const void* host_bgr, size_t row_stride_bytes);
+/* The same for a frame that already lies in PINNED host memory with contiguous rows (mi_host_alloc, or any buffer pinned
+ * with mi_host_register -- e.g. the array an image decoder writes into): the upload reads the caller's buffer directly, no
+ * bounce copy (the reference's frames come from cv2.imread, stack.py:61-97 -> utils.py:10-19; config 5 is upload-bound).
+ * The buffer must stay untouched until mi_stack_wait_uploads reports the upload done.  MI_ERR_INVALID when the memory is
+ * not pinned. */
+MI_API int mi_stack_push_frame_pinned(mi_stack_t* st, const void* host_bgr, size_t row_stride_bytes);
+/* blocks until at most `max_outstanding` of the frames pushed with mi_stack_push_frame_pinned are still being uploaded
+ * (0: all of them are on the device; a decoder that cycles k pinned buffers calls it with k - 1 before it reuses one) */
+MI_API int mi_stack_wait_uploads(mi_stack_t* st, int max_outstanding);
+/* pinned host memory: allocate / free, or pin / unpin memory the caller owns */
+MI_API int mi_host_alloc(void** ptr, size_t bytes);
+MI_API int mi_host_free(void* ptr);
+MI_API int mi_host_register(void* ptr, size_t bytes);
+MI_API int mi_host_unregister(void* ptr);
 /* n frames already resident in device memory (tightly packed rows, frames
  * frame_stride_bytes apart), dtype = params.in_dtype.  The frames must be complete either on the host's
  * timeline (a finished copy / kernel) or in the order of the handle's stream (mi_stack_stream): work the

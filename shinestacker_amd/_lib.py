@@ -88,6 +88,12 @@ SIGNATURES = {
     "mi_stack_frames_pushed": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "mi_stack_set_first_index": (C.c_int, [C.c_void_p, C.c_int]),
     "mi_stack_push_frame": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "mi_stack_push_frame_pinned": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "mi_stack_wait_uploads": (C.c_int, [C.c_void_p, C.c_int]),
+    "mi_host_alloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
+    "mi_host_free": (C.c_int, [C.c_void_p]),
+    "mi_host_register": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "mi_host_unregister": (C.c_int, [C.c_void_p]),
     "mi_stack_push_frames_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t]),
     "mi_stack_sync": (C.c_int, [C.c_void_p]),
     "mi_stack_sync_level": (C.c_int, [C.c_void_p, C.c_int]),
@@ -226,6 +232,52 @@ def require_device():
                           "(there is no CPU fallback)")
 
 
+# ---- pinned host memory (zero-copy uploads: Stack.push_frame sends an array that lies in it straight over PCIe)
+_PINNED = {}    # base address -> bytes, of every live pinned range this module knows about
+
+
+def host_alloc(shape, dtype):
+    """An ndarray in pinned host memory (mi_host_alloc): decode / generate into it, then `Stack.push_frame` uploads it
+    without the bounce copy.  Freed when the array (and every view of it) is garbage collected."""
+    import weakref
+    dt = np.dtype(dtype)
+    nbytes = int(np.prod(shape)) * dt.itemsize
+    p = C.c_void_p()
+    check(load().mi_host_alloc(C.byref(p), nbytes))
+    addr = p.value
+    raw = (C.c_char * nbytes).from_address(addr)
+    arr = np.frombuffer(raw, dtype=dt).reshape(shape)
+    _PINNED[addr] = nbytes
+
+    def release(a=addr):
+        _PINNED.pop(a, None)
+        load().mi_host_free(a)
+    weakref.finalize(raw, release)
+    return arr
+
+
+def host_register(arr):
+    """Pin the memory of an existing C-contiguous array in place (mi_host_register); undo with host_unregister."""
+    a = np.asarray(arr)
+    if not a.flags.c_contiguous:
+        raise ValueError("only C-contiguous arrays can be pinned")
+    check(load().mi_host_register(a.ctypes.data, a.nbytes))
+    _PINNED[a.ctypes.data] = a.nbytes
+
+
+def host_unregister(arr):
+    a = np.asarray(arr)
+    if _PINNED.pop(a.ctypes.data, None) is not None:
+        check(load().mi_host_unregister(a.ctypes.data))
+
+
+def is_pinned(arr):
+    """does the array lie inside a pinned range made by host_alloc / host_register?"""
+    a0 = arr.ctypes.data
+    a1 = a0 + arr.nbytes
+    return any(b <= a0 and a1 <= b + n for b, n in _PINNED.items())
+
+
 def mem_info(device=0):
     """(free, total) device memory in bytes"""
     f, t = C.c_size_t(), C.c_size_t()
@@ -353,7 +405,24 @@ class Stack:
                 check(load().mi_stack_push_frame(self._h, a.ctypes.data, a.strides[0]))
                 return
             a = np.ascontiguousarray(a)
+        if _PINNED and is_pinned(a):
+            # zero-copy: the upload reads the caller's pinned array; it is kept alive here and must not be modified
+            # until wait_uploads() (or any sync / finish of the handle) has returned
+            check(load().mi_stack_push_frame_pinned(self._h, a.ctypes.data, 0))
+            self._inflight = getattr(self, "_inflight", [])
+            self._inflight.append(a)
+            if len(self._inflight) > 64:
+                self.wait_uploads(32)
+            return
         check(load().mi_stack_push_frame(self._h, a.ctypes.data, 0))
+
+    def wait_uploads(self, max_outstanding=0):
+        """block until at most `max_outstanding` of the pinned frames pushed so far are still being uploaded: a producer that
+        cycles k pinned buffers calls wait_uploads(k - 1) before it overwrites the oldest"""
+        check(load().mi_stack_wait_uploads(self._h, int(max_outstanding)))
+        fl = getattr(self, "_inflight", None)
+        if fl:
+            del fl[:max(0, len(fl) - int(max_outstanding))]
 
     def push_frames_device(self, dev_ptr, n, frame_stride_bytes=0):
         check(load().mi_stack_push_frames_device(self._h, dev_ptr, int(n),
@@ -361,6 +430,7 @@ class Stack:
 
     def sync(self):
         check(load().mi_stack_sync(self._h))
+        self._inflight = []
 
     def sync_level(self, level):
         """wait until the state of `level` covers every pushed frame (level 0: before the coarser levels finish)"""
@@ -369,6 +439,7 @@ class Stack:
     def finish(self):
         out = np.empty((self.height, self.width, 3), self.out_dtype)
         check(load().mi_stack_finish(self._h, out.ctypes.data, 0))
+        self._inflight = []      # the result is on the host: every upload it depends on has completed
         return out
 
     def finish_device(self, dev_ptr=None):

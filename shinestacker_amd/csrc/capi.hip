@@ -6,6 +6,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <condition_variable>
+#include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -32,7 +34,8 @@ void tiled_destroy(mi_stack* s);
 int tiled_reset(mi_stack* s);
 int tiled_pending(const mi_stack* s);
 int tiled_push(mi_stack* s, const void* dev_frames, int n, size_t stride);
-int tiled_push_host(mi_stack* s, const void* host_bgr, size_t row_stride_bytes);
+int tiled_push_host(mi_stack* s, const void* host_bgr, size_t row_stride_bytes, bool pinned = false);
+int tiled_wait_uploads(mi_stack* s, int max_outstanding);
 int tiled_flush(mi_stack* s);
 int tiled_sync_all(mi_stack* s);
 int tiled_sync_level0(mi_stack* s);
@@ -1226,6 +1229,50 @@ int mi_stack_push_frame(mi_stack_t* s, const void* host_bgr, size_t row_stride_b
     if (s->finished) return fail(MI_ERR_STATE, "push after finish; call mi_stack_reset first");
     MI_HIP(hipSetDevice(s->p.device));
     return tiled_push_host(s, host_bgr, row_stride_bytes);
+}
+
+int mi_stack_push_frame_pinned(mi_stack_t* s, const void* host_bgr, size_t row_stride_bytes) {
+    int rc = check_handle(s);
+    if (rc) return rc;
+    if (!host_bgr) return fail(MI_ERR_INVALID, "null frame");
+    if (s->finished) return fail(MI_ERR_STATE, "push after finish; call mi_stack_reset first");
+    if (s->p.impl != MI_IMPL_TILED || s->f64) return mi_stack_push_frame(s, host_bgr, row_stride_bytes);   // synchronous paths
+    MI_HIP(hipSetDevice(s->p.device));
+    hipPointerAttribute_t at{};
+    if (hipPointerGetAttributes(&at, host_bgr) != hipSuccess || at.type != hipMemoryTypeHost) {
+        (void)hipGetLastError();
+        return fail(MI_ERR_INVALID, "mi_stack_push_frame_pinned: the frame is not in pinned host memory (mi_host_alloc / mi_host_register)");
+    }
+    return tiled_push_host(s, host_bgr, row_stride_bytes, true);
+}
+
+int mi_stack_wait_uploads(mi_stack_t* s, int max_outstanding) {
+    int rc = check_handle(s);
+    if (rc) return rc;
+    MI_HIP(hipSetDevice(s->p.device));
+    return tiled_wait_uploads(s, max_outstanding);
+}
+
+int mi_host_alloc(void** ptr, size_t bytes) {
+    if (!ptr || !bytes) return fail(MI_ERR_INVALID, "bad argument");
+    MI_HIP(hipHostMalloc(ptr, bytes, hipHostMallocPortable));
+    return MI_OK;
+}
+
+int mi_host_free(void* ptr) {
+    if (ptr) MI_HIP(hipHostFree(ptr));
+    return MI_OK;
+}
+
+int mi_host_register(void* ptr, size_t bytes) {
+    if (!ptr || !bytes) return fail(MI_ERR_INVALID, "bad argument");
+    MI_HIP(hipHostRegister(ptr, bytes, hipHostRegisterPortable));
+    return MI_OK;
+}
+
+int mi_host_unregister(void* ptr) {
+    if (ptr) MI_HIP(hipHostUnregister(ptr));
+    return MI_OK;
 }
 
 int mi_stack_sync(mi_stack_t* s) {

@@ -53,6 +53,10 @@ struct TiledState {
     hipEvent_t evRingFree = nullptr;                        // level-0 kernels finished reading the ring
     hipEvent_t evInput = nullptr;                           // device pushes: the frames are complete in s->stream order
     long pin_no = 0;
+    // zero-copy uploads (mi_stack_push_frame_pinned): one event per upload in a ring, for mi_stack_wait_uploads
+    static constexpr int NUP = 64;
+    hipEvent_t evUp[NUP] = {};
+    long up_no = 0;
 };
 
 inline TiledState*& tstate(mi_stack* s) { return *reinterpret_cast<TiledState**>(&s->tiled); }
@@ -176,6 +180,8 @@ void tiled_destroy(mi_stack* s) {
         if (t->evL0done[set]) (void)hipEventDestroy(t->evL0done[set]);
     }
     for (auto e : t->evLvl) (void)hipEventDestroy(e);
+    for (int i = 0; i < TiledState::NUP; ++i)
+        if (t->evUp[i]) (void)hipEventDestroy(t->evUp[i]);
     for (int i = 0; i < TiledState::NPIN; ++i) {
         if (t->pin[i]) (void)hipHostFree(t->pin[i]);
         if (t->evPin[i]) (void)hipEventDestroy(t->evPin[i]);
@@ -781,9 +787,72 @@ int tiled_flush(mi_stack* s) {
     return MI_OK;
 }
 
+// Persistent helper threads for the bounce copy of big frames (round 3 spawned three std::threads per frame): workers
+// sleep on a condition variable and take the row bands of ONE copy at a time.
+class CopyPool {
+public:
+    static CopyPool& get() {
+        static CopyPool p;
+        return p;
+    }
+    // runs fn(k) for k = 0 .. parts-1: k = 0 on the caller, the others on the workers; returns when all are done
+    void run(int parts, const std::function<void(int)>& fn) {
+        std::lock_guard<std::mutex> serial(call_mu_);   // one copy at a time (several stacks may push from several threads)
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            fn_ = &fn;
+            next_ = 1;
+            parts_ = parts;
+            pending_ = parts - 1;
+            ++gen_;
+        }
+        cv_.notify_all();
+        fn(0);
+        std::unique_lock<std::mutex> lk(mu_);
+        done_.wait(lk, [&] { return pending_ == 0; });
+        fn_ = nullptr;
+    }
+
+private:
+    CopyPool() {
+        for (int i = 0; i < NW; ++i) th_[i] = std::thread([this] { loop(); });
+    }
+    ~CopyPool() {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto& t : th_) t.join();
+    }
+    void loop() {
+        std::unique_lock<std::mutex> lk(mu_);
+        for (;;) {
+            cv_.wait(lk, [&] { return stop_ || (fn_ && next_ < parts_); });
+            if (stop_) return;
+            const int k = next_++;
+            const auto* fn = fn_;
+            lk.unlock();
+            (*fn)(k);
+            lk.lock();
+            if (--pending_ == 0) done_.notify_all();
+        }
+    }
+    static constexpr int NW = 3;
+    std::thread th_[NW];
+    std::mutex mu_, call_mu_;
+    std::condition_variable cv_, done_;
+    const std::function<void(int)>* fn_ = nullptr;
+    int next_ = 0, parts_ = 0, pending_ = 0;
+    long gen_ = 0;
+    bool stop_ = false;
+};
+
 // One host frame: copy it into a pinned bounce buffer, start the asynchronous upload into the
 // device ring and return (the caller's buffer is free again); a full ring triggers a fused batch.
-int tiled_push_host(mi_stack* s, const void* host_bgr, size_t row_stride_bytes) {
+// `pinned`: the caller's buffer IS pinned memory (mi_host_alloc / mi_host_register) with contiguous rows: the upload
+// reads it directly -- no bounce copy -- and the caller must leave it alone until mi_stack_wait_uploads says so.
+int tiled_push_host(mi_stack* s, const void* host_bgr, size_t row_stride_bytes, bool pinned) {
     TiledState* t = tstate(s);
     const size_t rb = (size_t)s->p.width * 3 * dtype_size(s->p.in_dtype);
     if (row_stride_bytes == 0) row_stride_bytes = rb;
@@ -806,40 +875,58 @@ int tiled_push_host(mi_stack* s, const void* host_bgr, size_t row_stride_bytes) 
             MI_HIP(hipStreamCreateWithFlags(&t->stc, hipStreamNonBlocking));
             MI_HIP(hipEventCreateWithFlags(&t->evCopied, hipEventDisableTiming));
             MI_HIP(hipEventCreateWithFlags(&t->evRingFree, hipEventDisableTiming));
+        }
+        if (!pinned && !t->pin[0])
             for (int i = 0; i < TiledState::NPIN; ++i) {
                 MI_HIP(hipHostMalloc(&t->pin[i], t->frame_bytes, hipHostMallocDefault));
                 MI_HIP(hipEventCreateWithFlags(&t->evPin[i], hipEventDisableTiming));
             }
-        }
-        const int slot = (int)(t->pin_no % TiledState::NPIN);
-        MI_HIP(hipEventSynchronize(t->evPin[slot]));  // bounce buffer free again? (no-op when unused)
-        char* pb = (char*)t->pin[slot];
-        // One thread copies ~25 GB/s into pinned memory -- half of what the PCIe link then moves; big
-        // frames are copied by a few threads, in row bands.
-        {
+        if (pinned) {
+            if (row_stride_bytes != rb) return fail(MI_ERR_INVALID, "a pinned frame must have contiguous rows");
+            hipEvent_t& ev = t->evUp[t->up_no % TiledState::NUP];
+            if (!ev) MI_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            else MI_HIP(hipEventSynchronize(ev));   // (only when more than NUP uploads are in flight)
+            MI_HIP(hipMemcpyAsync(dst, host_bgr, t->frame_bytes, hipMemcpyHostToDevice, t->stc));
+            MI_HIP(hipEventRecord(ev, t->stc));
+            t->up_no++;
+        } else {
+            const int slot = (int)(t->pin_no % TiledState::NPIN);
+            MI_HIP(hipEventSynchronize(t->evPin[slot]));  // bounce buffer free again? (no-op when unused)
+            char* pb = (char*)t->pin[slot];
+            // One thread copies ~25 GB/s into pinned memory -- half of what the PCIe link then moves; big
+            // frames are copied by four threads (the caller + the pool's three), in row bands.
             const int H = s->p.height;
             const size_t total = rb * (size_t)H;
             const int nthr = total >= ((size_t)32 << 20) ? 4 : 1;
-            auto band = [&](int y0, int y1) {
+            const std::function<void(int)> band = [&](int k) {
+                const int y0 = (int)((long)H * k / nthr), y1 = (int)((long)H * (k + 1) / nthr);
                 if (row_stride_bytes == rb) memcpy(pb + (size_t)y0 * rb, (const char*)host_bgr + (size_t)y0 * rb, rb * (size_t)(y1 - y0));
                 else
                     for (int y = y0; y < y1; ++y)
                         memcpy(pb + (size_t)y * rb, (const char*)host_bgr + (size_t)y * row_stride_bytes, rb);
             };
-            if (nthr == 1) band(0, H);
-            else {
-                std::thread th[3];
-                for (int k = 1; k < nthr; ++k) th[k - 1] = std::thread(band, H * k / nthr, H * (k + 1) / nthr);
-                band(0, H / nthr);
-                for (int k = 1; k < nthr; ++k) th[k - 1].join();
-            }
+            if (nthr == 1) band(0);
+            else CopyPool::get().run(nthr, band);
+            MI_HIP(hipMemcpyAsync(dst, pb, t->frame_bytes, hipMemcpyHostToDevice, t->stc));
+            MI_HIP(hipEventRecord(t->evPin[slot], t->stc));
+            t->pin_no++;
         }
-        MI_HIP(hipMemcpyAsync(dst, pb, t->frame_bytes, hipMemcpyHostToDevice, t->stc));
-        MI_HIP(hipEventRecord(t->evPin[slot], t->stc));
-        t->pin_no++;
     }
     t->pending++;
     if (t->pending == t->bcap) return tiled_flush(s);
+    return MI_OK;
+}
+
+// host blocks until at most `max_outstanding` of the zero-copy uploads pushed so far are still in flight
+int tiled_wait_uploads(mi_stack* s, int max_outstanding) {
+    TiledState* t = tstate(s);
+    if (!t || t->up_no == 0) return MI_OK;
+    if (max_outstanding < 0) max_outstanding = 0;
+    const long upto = t->up_no - max_outstanding;          // uploads 0 .. upto-1 must be complete
+    if (upto <= 0) return MI_OK;
+    if (max_outstanding >= TiledState::NUP) return MI_OK;   // (older ones were waited for when their event slot was reused)
+    hipEvent_t ev = t->evUp[(upto - 1) % TiledState::NUP];
+    if (ev) MI_HIP(hipEventSynchronize(ev));
     return MI_OK;
 }
 

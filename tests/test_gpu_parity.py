@@ -543,3 +543,50 @@ def test_large_coarse_levels_on_the_wide_tile(L, oracle, shape, dtype):
         assert np.array_equal(st.tap(L.TAP_FUSED_LAP, lv), so.best_lap[lv]), lv
     assert np.array_equal(st.finish(), want)
     st.close()
+
+
+def test_pinned_frames_are_uploaded_without_the_bounce_copy_and_give_the_same_stack(L, oracle):
+    """mi_stack_push_frame_pinned (BASELINE config 5 is upload-bound): frames that lie in pinned host memory -- `host_alloc`
+    arrays or arrays pinned in place with `host_register` -- go to the device straight from the caller's buffer; the
+    fused image equals the bounce-copy path's and the oracle's; pageable memory is refused by the pinned entry point; a
+    producer cycling two pinned buffers throttles itself with wait_uploads."""
+    import ctypes as C
+    H, W, N = 300, 452, 7
+    frames = [oracle.synth_frame_numpy(H, W, f, N) for f in range(N)]
+    so = oracle.StreamingOracle(H, W, np.uint8)
+    for f in frames:
+        so.push_frame(f)
+    want = so.finish()
+    st = L.Stack(H, W, in_dtype=np.uint8, batch_frames=4)
+    pinned = [L.host_alloc((H, W, 3), np.uint8) for _ in range(N)]
+    for p, f in zip(pinned, frames):
+        p[...] = f
+        assert L.is_pinned(p) and not L.is_pinned(f)
+        st.push_frame(p)
+    assert len(st._inflight) == N
+    st.wait_uploads(0)
+    assert st._inflight == []
+    assert np.array_equal(st.finish(), want)
+    # pageable memory through the pinned entry point: refused, nothing pushed
+    st.reset()
+    rc = L.load().mi_stack_push_frame_pinned(st._h, frames[0].ctypes.data, 0)
+    assert rc == L.MI_ERR_INVALID and b"pinned" in L.load().mi_last_error()
+    # an ordinary array pinned in place
+    reg = [f.copy() for f in frames]
+    for r in reg:
+        L.host_register(r)
+        st.push_frame(r)
+    assert np.array_equal(st.finish(), want)
+    for r in reg:
+        L.host_unregister(r)
+        assert not L.is_pinned(r)
+    # two pinned buffers cycled by a "decoder"
+    st.reset()
+    ring = pinned[:2]
+    for i, f in enumerate(frames):
+        st.wait_uploads(1)          # the buffer about to be overwritten (pushed two frames ago) is on the device
+        ring[i % 2][...] = f
+        st.push_frame(ring[i % 2])
+    assert np.array_equal(st.finish(), want)
+    st.close()
+    del pinned, ring
