@@ -164,8 +164,8 @@ def test_chunk_bounds_cover_everything():
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("scaling", ["strong", "weak"])
-def test_bench_dry_run_under_torch_distributed_run(scaling):
+@pytest.mark.parametrize("scaling,nproc", [("strong", 2), ("weak", 2), ("strong", 8)])
+def test_bench_dry_run_under_torch_distributed_run(scaling, nproc):
     """bench.py's distributed skeleton the way the driver starts it (python -m torch.distributed.run, one process per
     rank), on CPU: --dry-run replaces the HIP path by the oracle and RCCL by gloo; the strong split (BASELINE configs[2]:
     the SAME stack, frames / N per rank), the winners-only combine and the JSON contract are the real ones."""
@@ -173,15 +173,15 @@ def test_bench_dry_run_under_torch_distributed_run(scaling):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--frames", "6", "--scaling", scaling, "--dry-run"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", str(nproc), "--steps", "2", "--warmup", "1",
+           "--frames", "6" if nproc == 2 else "16", "--scaling", scaling, "--dry-run"]   # 8 ranks: the driver's configs[2] launch
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=280, cwd=root)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert r.returncode == 0 and lines, r.stdout[-1500:] + r.stderr[-3000:]
     d = json.loads(lines[-1])
-    assert d["n_gpus"] == 2 and d["scaling"] == scaling and d["verified"] is True and d["steps"] == 2
-    assert d["config"]["frames_per_gpu"] == (3 if scaling == "strong" else 6)
+    assert d["n_gpus"] == nproc and d["scaling"] == scaling and d["verified"] is True and d["steps"] == 2
+    assert d["config"]["frames_per_gpu"] == ((3 if scaling == "strong" else 6) if nproc == 2 else 2)
     assert {"compute_ms_host", "combine_ms_host", "collapse_ms_host"} <= set(d["breakdown_ms_per_step"])
     for k in ("metric", "value", "unit", "ms_per_step", "higher_is_better", "vs_baseline", "dtype", "data"):
         assert k in d

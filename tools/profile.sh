@@ -8,7 +8,7 @@ TAG=${1:-r01}; shift || true
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-ARGS="--no-cpu-baseline --no-other-mode --steps 2 --warmup 1 $*"
+ARGS="--no-cpu-baseline --no-other-mode --no-other-dtypes --no-projection --steps 2 --warmup 1 $*"
 # 1) kernel trace + stats (no counters)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o trace -- python bench.py $ARGS > $OUT/bench_stats.json 2> $OUT/stats.log
 # 2) PMC passes, each in its own run (kernel-trace only)
