@@ -276,6 +276,16 @@ MI_API int mi_aligner_create(mi_aligner_t* out, int device, int height, int widt
 /* sub-sample like the reference's default (fast_subsampling = False: cv2.resize(INTER_AREA), the mean of every s x s
  * block, utils.py:83) instead of img[::s, ::s]; call before mi_aligner_set_reference */
 MI_API int mi_aligner_set_area_subsampling(mi_aligner_t al, int enable);
+/* Coarse initialiser (north_star: "ECC/phase-correlation"): before the Gauss-Newton iteration every estimate takes the
+ * TRANSLATION that phase correlation finds on the finest pyramid level of at most 512 pixels per side (Hann window, DFT,
+ * normalised cross-power spectrum, inverse DFT, 5 x 5 centroid around the peak -- cv2.phaseCorrelate's recipe) as the
+ * starting point; a peak with a response below 0.02 is ignored.  Extends the capture range from a few pixels of the
+ * coarsest level to half the frame.  Off by default. */
+MI_API int mi_aligner_set_phase_init(mi_aligner_t al, int enable);
+/* The correlation alone, for two float32 planes (height x width, at most 1024 pixels per side) on the device:
+ * out3 = (dx, dy, response) with mov(x + dx, y + dy) ~ ref(x, y). */
+MI_API int mi_phase_correlate_device(int device, void* stream, const void* dev_ref, const void* dev_mov, int height, int width,
+                              double* out3);
 MI_API int mi_aligner_destroy(mi_aligner_t al);
 MI_API int mi_aligner_set_reference(mi_aligner_t al, void* stream, const void* dev_ref);
 MI_API int mi_aligner_estimate(mi_aligner_t al, void* stream, const void* dev_mov, int max_iters, double eps,

@@ -134,6 +134,9 @@ SIGNATURES = {
     "mi_aligner_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                     C.c_int]),
     "mi_aligner_set_area_subsampling": (C.c_int, [C.c_void_p, C.c_int]),
+    "mi_aligner_set_phase_init": (C.c_int, [C.c_void_p, C.c_int]),
+    "mi_phase_correlate_device": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                            C.POINTER(C.c_double)]),
     "mi_aligner_destroy": (C.c_int, [C.c_void_p]),
     "mi_aligner_set_reference": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "mi_aligner_estimate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double,
@@ -618,11 +621,28 @@ def ecc_similarity(ref, mov, max_levels=0, max_iters=60, eps=1e-9, device=0):
     return np.array(list(m), dtype=np.float64).reshape(2, 3), cc.value, it.value
 
 
+def phase_correlate(ref, mov, device=0):
+    """(dx, dy, response) with mov(x + dx, y + dy) ~ ref(x, y) for two float32 planes (mi_phase_correlate_device)"""
+    require_device()
+    a, b = np.ascontiguousarray(ref, np.float32), np.ascontiguousarray(mov, np.float32)
+    if a.ndim != 2 or a.shape != b.shape:
+        raise ValueError("phase_correlate expects two H x W planes of the same shape")
+    buf = DeviceBuffer(2 * a.nbytes, device)
+    try:
+        buf.upload(a)
+        buf.upload(b, a.nbytes)
+        out = (C.c_double * 3)()
+        check(load().mi_phase_correlate_device(device, None, buf.ptr, buf.ptr + a.nbytes, a.shape[0], a.shape[1], out))
+    finally:
+        buf.free()
+    return out[0], out[1], out[2]
+
+
 class Aligner:
     """Device-resident ECC estimator (mi_aligner_t): frames stay in HBM, the pyramids are allocated
     once, `subsample` is the reference's fast sub-sampling factor (align.py default 2)."""
 
-    def __init__(self, height, width, dtype=np.uint8, subsample=1, max_levels=0, device=0, fast=True):
+    def __init__(self, height, width, dtype=np.uint8, subsample=1, max_levels=0, device=0, fast=True, phase_init=False):
         require_device()
         self._h = C.c_void_p()
         self.device = device
@@ -630,6 +650,8 @@ class Aligner:
                                        DTYPE_CODE[np.dtype(dtype)], int(subsample), int(max_levels)))
         if not fast and subsample > 1:   # the reference's default: cv2.resize(INTER_AREA) (utils.py:83)
             check(load().mi_aligner_set_area_subsampling(self._h, 1))
+        if phase_init:                   # translation by phase correlation as the starting point (mi_aligner_set_phase_init)
+            check(load().mi_aligner_set_phase_init(self._h, 1))
 
     def set_reference(self, dev_ptr, stream=None):
         check(load().mi_aligner_set_reference(self._h, stream, dev_ptr))

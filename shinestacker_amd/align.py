@@ -178,13 +178,31 @@ def resolve_estimator(estimator, device=0):
     raise InvalidOptionError("estimator", estimator, ". Valid options are: 'auto', 'opencv', 'ecc' or a callable")
 
 
-def ecc_estimator(min_correlation=0.5, max_iters=60, device=0):
+def ecc_estimator(min_correlation=0.5, max_iters=60, device=0, phase_init=False):
     """Estimator for `align_images` that runs on the GPU (mi_ecc_similarity): ECC maximisation of
     a 4-DoF similarity, coarse to fine.  It needs no feature matches; to satisfy the protocol it
     reports 1000 "good matches" when the final correlation coefficient reaches `min_correlation`
-    and 0 otherwise (which makes align_images / AlignFrames raise AlignmentError as usual)."""
+    and 0 otherwise (which makes align_images / AlignFrames raise AlignmentError as usual).
+    `phase_init`: start every estimate from the translation found by phase correlation (mi_aligner_set_phase_init):
+    shifts far beyond the ECC pyramid's capture range (tens of per cent of the frame) are then recovered too."""
     def estimate(img_0_sub, img_1_sub, _feature_config, _matching_config, alignment_config):
-        m, cc, _iters = _lib.ecc_similarity(img_1_sub, img_0_sub, max_iters=max_iters, device=device)
+        if phase_init:
+            ref, mov = np.ascontiguousarray(img_1_sub), np.ascontiguousarray(img_0_sub)
+            al = _lib.Aligner(ref.shape[0], ref.shape[1], ref.dtype, subsample=1, device=device, phase_init=True)
+            buf = _lib.DeviceBuffer(2 * ref.nbytes, device)
+            try:
+                buf.upload(ref)
+                buf.upload(mov, ref.nbytes)
+                al.set_reference(buf.ptr)
+                try:
+                    m, cc, _iters = al.estimate(buf.ptr + ref.nbytes, max_iters=max_iters)
+                except Exception:   # noqa: BLE001  (no overlap / constant image: "no matches")
+                    return 0, None
+            finally:
+                al.close()
+                buf.free()
+        else:
+            m, cc, _iters = _lib.ecc_similarity(img_1_sub, img_0_sub, max_iters=max_iters, device=device)
         if cc < min_correlation:
             return 0, None
         if (alignment_config or {}).get('transform') == constants.ALIGN_HOMOGRAPHY:

@@ -20,6 +20,7 @@
 #include "kernels_sep.hpp"
 #include "kernels_align.hpp"
 #include "kernels_ecc.hpp"
+#include "kernels_phase.hpp"
 #include "kernels_balance.hpp"
 #include "kernels_f64.hpp"
 
@@ -732,9 +733,38 @@ struct mi_aligner {
     hipStream_t own = nullptr;       // used when the caller passes no stream: handles on different host
                                      // threads then run side by side instead of serialising on stream 0
     bool have_ref = false;
+    // optional coarse initialiser (mi_aligner_set_phase_init): phase correlation on pyramid level `pc_level`
+    bool phase_init = false;
+    int pc_level = 0, pc_P = 0, pc_Q = 0;
+    float2 *pc_ref = nullptr, *pc_mov = nullptr;   // P x Q spectra: the template's (kept per reference) and a frame's
+    double* pc_out = nullptr;                      // [cap][3] (dx, dy, response) on the device
+    bool pc_ref_valid = false;
 };
 
 namespace {
+
+int pc_log2(int n) { int l = 0; while ((1 << l) < n) ++l; return l; }
+
+// 2-D DFT of a P x Q complex plane in place (rows, then columns)
+template <bool INVERSE>
+void pc_fft2(hipStream_t st, float2* d, int P, int Q) {
+    hipLaunchKernelGGL((pc_fft_lines<INVERSE>), dim3(P), dim3(std::max(Q / 2, 1)), 0, st, d, Q, pc_log2(Q), (size_t)1, (size_t)Q);
+    hipLaunchKernelGGL((pc_fft_lines<INVERSE>), dim3(Q), dim3(std::max(P / 2, 1)), 0, st, d, P, pc_log2(P), (size_t)Q, (size_t)1);
+}
+
+// spectrum of one windowed, padded plane
+void pc_spectrum(hipStream_t st, const float* plane, int h, int w, float2* out, int P, int Q) {
+    hipLaunchKernelGGL(pc_prepare, dim3(cdiv(Q, 64), cdiv(P, 4)), dim3(64, 4), 0, st, plane, h, w, out, P, Q);
+    pc_fft2<false>(st, out, P, Q);
+}
+
+// mov's spectrum (in `fm`, destroyed) against the reference's `fr`: (dx, dy, response) -> dev_out3
+void pc_correlate(hipStream_t st, const float2* fr, float2* fm, int P, int Q, double* dev_out3) {
+    const size_t n = (size_t)P * Q;
+    hipLaunchKernelGGL(pc_cross_power, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, fm, fr, n);
+    pc_fft2<true>(st, fm, P, Q);
+    hipLaunchKernelGGL(pc_peak, dim3(1), dim3(1024), 0, st, (const float2*)fm, P, Q, dev_out3);
+}
 
 void aligner_free_frames(mi_aligner* al) {
     for (void* b : al->fbufs) (void)hipFree(b);
@@ -775,6 +805,8 @@ int aligner_reserve(mi_aligner* al, int n) {
     if (ok) ok = hipMemset(al->ticket, 0, sizeof(unsigned int) * n) == hipSuccess;
     al->dstate = (EccState*)dalloc(sizeof(EccState) * n);
     ok = ok && al->dstate;
+    al->pc_out = (double*)dalloc(sizeof(double) * 3 * n);
+    ok = ok && al->pc_out;
     if (ok) ok = hipHostMalloc((void**)&al->hstate, sizeof(EccState) * n, hipHostMallocDefault) == hipSuccess;
     if (!ok) {
         aligner_free_frames(al);
@@ -851,6 +883,42 @@ int aligner_solve(mi_aligner* al, hipStream_t st, int n, int max_iters, double e
         hs[k].a = 1.0;
         hs[k].rho = -1.0;
         hs[k].last_rho = -2.0;
+    }
+    if (al->phase_init) {
+        // coarse initialiser: the translation phase correlation finds on level pc_level (<= 512 pixels per side) becomes
+        // the starting translation of the Gauss-Newton iteration at the coarsest level
+        const EccLevel& PL = lv[al->pc_level];
+        const int P = al->pc_P, Q = al->pc_Q;
+        if (!al->pc_ref) {
+            void *a = nullptr, *b = nullptr;
+            if (hipMalloc(&a, sizeof(float2) * P * Q) != hipSuccess || hipMalloc(&b, sizeof(float2) * P * Q) != hipSuccess)
+                return fail(MI_ERR_NOMEM, "out of device memory");
+            al->bufs.push_back(a);
+            al->bufs.push_back(b);
+            al->pc_ref = (float2*)a;
+            al->pc_mov = (float2*)b;
+        }
+        if (!al->pc_ref_valid) {
+            pc_spectrum(st, PL.tmpl, PL.h, PL.w, al->pc_ref, P, Q);
+            al->pc_ref_valid = true;
+        }
+        for (int k = 0; k < n; ++k) {
+            pc_spectrum(st, PL.img + (size_t)k * PL.h * PL.w, PL.h, PL.w, al->pc_mov, P, Q);
+            pc_correlate(st, al->pc_ref, al->pc_mov, P, Q, al->pc_out + 3 * k);
+        }
+        MI_HIP(hipGetLastError());
+        std::vector<double> o3((size_t)3 * n);
+        MI_HIP(hipMemcpyAsync(o3.data(), al->pc_out, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, st));
+        MI_HIP(hipStreamSynchronize(st));
+        const double down = std::ldexp(1.0, al->pc_level - ((int)lv.size() - 1));   // level pc_level -> the coarsest level
+        for (int k = 0; k < n; ++k) {
+            // R = Mov conj(Ref): the peak sits at d with mov(x) = ref(x - d), i.e. ref(x) ~ mov(x + d) -- exactly the
+            // translation of W (kernels_ecc.hpp); a weak peak (flat or unrelated content) is not used
+            if (o3[3 * k + 2] > 0.02) {
+                hs[k].T0 = o3[3 * k] * down;
+                hs[k].T1 = o3[3 * k + 1] * down;
+            }
+        }
     }
     MI_HIP(hipMemcpyAsync(al->dstate, hs, sizeof(EccState) * n, hipMemcpyHostToDevice, st));
     for (int l = (int)lv.size() - 1; l >= 0; --l) {
@@ -1793,6 +1861,56 @@ int mi_aligner_set_reference(mi_aligner_t al, void* stream, const void* dev_ref)
     int rc = aligner_build(al, stream ? (hipStream_t)stream : al->own, dev_ref, true, 0);
     if (rc) return rc;
     al->have_ref = true;
+    al->pc_ref_valid = false;
+    return MI_OK;
+}
+
+int mi_aligner_set_phase_init(mi_aligner_t al, int enable) {
+    if (!al) return fail(MI_ERR_INVALID, "null argument");
+    al->phase_init = enable != 0;
+    if (al->phase_init && al->pc_P == 0) {
+        // the finest pyramid level with at most 512 pixels per side (the coarsest one if every level is larger)
+        int lp = (int)al->lv.size() - 1;
+        for (int l = 0; l < (int)al->lv.size(); ++l)
+            if (std::max(al->lv[l].h, al->lv[l].w) <= 512) { lp = l; break; }
+        al->pc_level = lp;
+        al->pc_P = 1 << pc_log2(al->lv[lp].h);
+        al->pc_Q = 1 << pc_log2(al->lv[lp].w);
+        if (al->pc_P > PC_MAX_N || al->pc_Q > PC_MAX_N || al->pc_P < 2 || al->pc_Q < 2) {
+            al->phase_init = false;
+            al->pc_P = al->pc_Q = 0;
+            return fail(MI_ERR_UNSUPPORTED, "phase correlation: no pyramid level between 2 and %d pixels per side", PC_MAX_N);
+        }
+    }
+    return MI_OK;
+}
+
+int mi_phase_correlate_device(int device, void* stream, const void* dev_ref, const void* dev_mov, int height, int width,
+                              double* out3) {
+    if (!dev_ref || !dev_mov || !out3) return fail(MI_ERR_INVALID, "null argument");
+    if (height < 2 || width < 2) return fail(MI_ERR_INVALID, "plane too small");
+    const int P = 1 << pc_log2(height), Q = 1 << pc_log2(width);
+    if (P > PC_MAX_N || Q > PC_MAX_N) return fail(MI_ERR_UNSUPPORTED, "phase correlation takes planes of at most %d pixels per side", PC_MAX_N);
+    MI_HIP(hipSetDevice(device));
+    hipStream_t st = (hipStream_t)stream;
+    float2 *a = nullptr, *b = nullptr;
+    double* o = nullptr;
+    MI_HIP(hipMalloc((void**)&a, sizeof(float2) * P * Q));
+    if (hipMalloc((void**)&b, sizeof(float2) * P * Q) != hipSuccess || hipMalloc((void**)&o, 3 * sizeof(double)) != hipSuccess) {
+        (void)hipFree(a);
+        if (b) (void)hipFree(b);
+        return fail(MI_ERR_NOMEM, "out of device memory");
+    }
+    pc_spectrum(st, (const float*)dev_ref, height, width, a, P, Q);
+    pc_spectrum(st, (const float*)dev_mov, height, width, b, P, Q);
+    pc_correlate(st, a, b, P, Q, o);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(out3, o, 3 * sizeof(double), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(a);
+    (void)hipFree(b);
+    (void)hipFree(o);
+    if (e != hipSuccess) return fail(MI_ERR_HIP, "phase correlation: %s", hipGetErrorString(e));
     return MI_OK;
 }
 

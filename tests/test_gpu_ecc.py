@@ -419,12 +419,14 @@ def test_handles_of_one_stack_serve_the_next_and_are_checked_against_its_geometr
     # the handles survive the refusals
     out, _, _ = align_and_stack_device(b.ptr, n, h, w, np.uint8, handles=hd, **kw)
     assert np.array_equal(out, fresh_b)
-    # an alignment failure with keep_handles: AlignmentError, nothing returned, nothing left behind by that call
-    free0 = L.mem_info()[0] if hasattr(L, "mem_info") else None
-    with pytest.raises(AlignmentError):
-        align_and_stack_device(a.ptr, n, h, w, np.uint8, keep_handles=True, min_correlation=2.0, **kw)
-    if free0 is not None:
-        assert L.mem_info()[0] >= free0 - (1 << 20)
+    # an alignment failure with keep_handles: AlignmentError, nothing returned, and what the failing call created is released
+    # (free device memory is the same after a second failing call as after the first: nothing accumulates)
+    free = []
+    for _ in range(3):
+        with pytest.raises(AlignmentError):
+            align_and_stack_device(a.ptr, n, h, w, np.uint8, keep_handles=True, min_correlation=2.0, **kw)
+        free.append(L.mem_info()[0])
+    assert free[2] >= free[1] - (1 << 20), free
     # LINEAR balance inside the native loop: the correction factors come back, one row per processed frame
     info = {}
     align_and_stack_device(a.ptr, n, h, w, np.uint8, balance={'channel': 'LUMI', 'corr_map': 'LINEAR', 'subsample': 2},
@@ -434,3 +436,77 @@ def test_handles_of_one_stack_serve_the_next_and_are_checked_against_its_geometr
     close_handles(hd)
     a.free()
     b.free()
+
+
+def _phase_correlate_numpy(ref, mov):
+    """cv2.phaseCorrelate's recipe [from memory] in float64: Hann window, zero-padding to powers of two, R = Mov conj(Ref)
+    normalised, inverse DFT, first arg-max, 5 x 5 weighted centroid (wrapping), response = window sum / (P Q)."""
+    h, w = ref.shape
+    P, Q = 1 << int(np.ceil(np.log2(h))), 1 << int(np.ceil(np.log2(w)))
+    wy = 0.5 * (1 - np.cos(2 * np.pi * np.arange(h) / (h - 1)))
+    wx = 0.5 * (1 - np.cos(2 * np.pi * np.arange(w) / (w - 1)))
+    win = np.outer(wy, wx)
+    a, b = np.zeros((P, Q)), np.zeros((P, Q))
+    a[:h, :w], b[:h, :w] = ref * win, mov * win
+    R = np.fft.fft2(b) * np.conj(np.fft.fft2(a))
+    mag = np.abs(R)
+    R = np.where(mag > 1e-20, R / np.maximum(mag, 1e-300), 0)
+    c = np.fft.ifft2(R).real * (P * Q)
+    py, px = np.unravel_index(np.argmax(c), c.shape)
+    m = mx = my = 0.0
+    for dy in range(-2, 3):
+        for dx in range(-2, 3):
+            v = c[(py + dy) % P, (px + dx) % Q]
+            m, mx, my = m + v, mx + v * (px + dx), my + v * (py + dy)
+    cx, cy = mx / m, my / m
+    return (cx - Q if cx > Q / 2 else cx), (cy - P if cy > P / 2 else cy), m / (P * Q)
+
+
+@pytest.mark.parametrize("shape,shift", [((250, 375), (17.0, -9.0)), ((256, 512), (-40.0, 31.0)), ((125, 188), (3.4, 7.7)),
+                                         ((300, 300), (0.0, 0.0))])
+def test_phase_correlation_equals_its_float64_statement_and_finds_the_shift(L, shape, shift):
+    """mi_phase_correlate_device (hand-written LDS radix-2 DFT, cross-power spectrum, peak + centroid) against the NumPy
+    float64 statement of the same recipe, and against the shift the second plane was made with:
+    mov(x + dx, y + dy) ~ ref(x, y)."""
+    from scipy import ndimage
+    h, w = shape
+    big = texture(h + 200, w + 200, seed=7).astype(np.float64)
+    big = ndimage.gaussian_filter(big, 1.0)
+    dx, dy = shift
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    ref = ndimage.map_coordinates(big, [yy + 100, xx + 100], order=3)
+    mov = ndimage.map_coordinates(big, [yy + 100 - dy, xx + 100 - dx], order=3)      # mov(x) = ref(x - d)
+    gx, gy, gr = L.phase_correlate(ref.astype(np.float32), mov.astype(np.float32))
+    wx, wy, wr = _phase_correlate_numpy(ref.astype(np.float32).astype(np.float64), mov.astype(np.float32).astype(np.float64))
+    assert abs(gx - wx) < 2e-3 and abs(gy - wy) < 2e-3 and abs(gr - wr) < 2e-3 * max(1.0, wr), (gx, gy, gr, wx, wy, wr)
+    assert abs(gx - dx) < 0.35 and abs(gy - dy) < 0.35 and gr > 0.1, (gx, gy, gr)
+
+
+def test_phase_correlation_extends_the_capture_range_of_the_ecc_estimator(L, oracle):
+    """A frame displaced by a fifth of its width (beyond what the coarsest ECC level can pull in) plus a small rotation and
+    scale: the plain estimator fails or lands elsewhere, the one that starts from the phase-correlation translation recovers
+    the transform to the reference's precision-test tolerances (tests/test_0031_align_precision.py:62-65)."""
+    h, w = 768, 1024
+    T = similarity(0.3, 1.002, 205.0, -118.0, (w - 1) / 2, (h - 1) / 2)
+    ref, mov = make_pair(oracle, T, h=h, w=w, seed=21, noise=2.0)
+    buf = L.DeviceBuffer(2 * ref.nbytes)
+    buf.upload(ref)
+    buf.upload(mov, ref.nbytes)
+    want = invert(T)                                   # moving -> reference, what the estimator returns
+    out = {}
+    for phase in (False, True):
+        al = L.Aligner(h, w, np.uint8, subsample=1, phase_init=phase)
+        al.set_reference(buf.ptr)
+        try:
+            m, cc, _ = al.estimate(buf.ptr + ref.nbytes)
+            ang, sc = decompose(m)[:2]
+            wang, wsc = decompose(want)[:2]
+            ctr = np.array([(w - 1) / 2, (h - 1) / 2, 1.0])
+            out[phase] = (abs(ang - wang), abs(sc - wsc), np.abs(m @ ctr - want @ ctr).max(), cc)
+        except Exception:   # noqa: BLE001
+            out[phase] = None
+        al.close()
+    buf.free()
+    good = out[True]
+    assert good is not None and good[0] < 0.005 and good[1] < 1e-4 and good[2] < 0.2 and good[3] > 0.9, out
+    assert out[False] is None or out[False][2] > 5.0 or out[False][3] < 0.5, out    # the plain estimator does not get there
