@@ -267,6 +267,9 @@ def align_and_stack_device(dev_frames, n_frames, height, width, dtype, ref_idx=-
     dt = np.dtype(dtype)
     fb = height * width * 3 * dt.itemsize
     lib = _lib.load()
+    if step_process and (handles is not None or keep_handles):
+        raise InvalidOptionError("handles", "reuse", ": handle reuse is implemented for the non-chained native loop, not for "
+                                 "step_process")
     if step_process:
         aligned = _lib.DeviceBuffer(fb * n_frames, device)
         corr = None

@@ -23,9 +23,11 @@ dev = torch.device("cuda", 0)
 st = L.Stack(200, 296)
 hip, ref = Combiner(st), TorchWinnerOps()
 g = torch.Generator(device="cpu").manual_seed(3)
-for n in (1, 1023, 1024, 1025, 300007):
-    world = 3
+# worlds 3 / 5 / 8 use one / two 64-bit words of packed per-rank counts in the block scan, 13 / 16 all four
+for n, world in ((1, 3), (1023, 3), (1024, 3), (1025, 3), (300007, 3), (70001, 5), (262144, 8), (99999, 13), (131077, 16), (4099, 2)):
     cand = torch.randint(0, 50, (world, n), generator=g).float().to(dev)     # many exact ties
+    if world == 8:
+        cand[5] = 100.0 + torch.arange(n, device=dev) % 7                     # one rank wins whole 1024-pixel blocks
     win = hip.winner(cand)
     assert torch.equal(win, first_max_rank(cand)), n
     plan, totals = hip.plan(win, world)
