@@ -242,8 +242,8 @@ def project_scaling(L, measure, args, H, W, total_frames, t1_s, device):
         if total_frames % n:
             continue
         fn = total_frames // n
-        st, dt_s, prof, _ = measure(args.arith, max(2, args.steps // 2), 1, F=fn)
-        k = max(2, args.steps // 2)
+        k = max(3, args.steps)
+        st, dt_s, prof, _ = measure(args.arith, k, 1, F=fn)
         compute_ms = dt_s / k * 1e3
         coarse_ms = prof["levels"][0] / k
         e_ptr, l_ptr, _i_ptr, npx = st.state_ptrs(-1)
