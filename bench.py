@@ -567,6 +567,13 @@ def main():
                                    f"{st.levels}-level Laplacian pyramid fusion "
                                    f"(BASELINE.json configs[{1 if world == 1 or args.scaling == 'weak' else 2}])",
                        "frames_per_gpu": F, "source": args.source, "arith": args.arith,
+                       "arith_parity": ("separable: bit-identical to oracle/separable_oracle.c (its specification); against the "
+                                        "reference's evaluation order the stated bound is 32 u maxv per convolution (u = 2^-24; "
+                                        "SURVEY 7), not north_star's 1 ULP: measured Gaussian / energy differences <= 8 % / 1.5 % of "
+                                        "it, arg-max flips only at proven near ties (other_mode.parity)"
+                                        if args.arith == "separable" else
+                                        "exact: the reference's row-major 25-tap order, bit-identical to the restatement the "
+                                        "reference's own recordings pin (cv2.filter2D's real order: unpinned third party)"),
                        "impl": args.impl if args.impl != "auto" else ["auto", "simple", "tiled"][st.params.impl],
                        "device": L.device_name(device),
                        "parallelism": f"{total_frames} frames in contiguous blocks of {F} over {world} " +
