@@ -431,9 +431,11 @@ int launch_level(mi_stack* s, int l, int set, const void* src, size_t src_stride
 }
 
 // `ev_bd`: recorded on st_bd behind the border kernel when the level ran in chunks (the merge on st_in waits for it).
+// `f_begin`, `f_end`: launch the frames [f_begin, f_end) of the batch only (levels that run as consecutive launches; the
+// interleaved level-0 / level-1 schedule of run_batch) -- the whole batch by default.
 template <typename TIn, bool L0_NAME>
 int launch_level_sep(mi_stack* s, int l, int set, const void* src, size_t src_stride, int nb, hipStream_t st_in,
-                     hipStream_t st_bd, hipEvent_t ev_bd) {
+                     hipStream_t st_bd, hipEvent_t ev_bd, int f_begin = 0, int f_end = -1) {
     constexpr int TH = MI_SEP_TH, NT = sep_nt<TIn>();
     using SG = SepGeom<TH, NT>;
     constexpr int TW = SG::TW;
@@ -543,9 +545,11 @@ int launch_level_sep(mi_stack* s, int l, int set, const void* src, size_t src_st
         if (t->sbOrder[l]) { a.sb_order = t->sbOrder[l]; ngroups = t->sbGroups[l]; }
     }
     const int first = a.first, idx0 = a.frame_idx0;
-    const int step = parallel ? nb : fc, nlaunch = cdiv(nb, step);
+    if (f_end < 0 || parallel) { f_begin = 0; f_end = nb; }
+    const int step = parallel ? nb : fc, nlaunch = cdiv(f_end - f_begin, step);
+    const double part = (double)(f_end - f_begin) / (double)nb;   // share of the batch's bytes this call launches
     auto frames_of = [&](int f0) {
-        const int nf = parallel ? nb : std::min(fc, nb - f0);
+        const int nf = parallel ? nb : std::min(fc, f_end - f0);
         a.src = (const char*)src + (size_t)f0 * src_stride;
         a.gnext = t->Gb[set][l + 1] + (size_t)f0 * a.gnext_stride;
         a.nframes = nf;
@@ -556,17 +560,17 @@ int launch_level_sep(mi_stack* s, int l, int set, const void* src, size_t src_st
     // one timing-event pair around each stream's sequence of launches (an event record between two kernels of a stream
     // costs a few microseconds of idle GPU: 30 launches per level pass)
     if (nborder > 0 && !MI_ABL(256)) {
-        ProfScope ps(s, MI_PROF_LEVEL, bytes * (1.0 - frac_in), st_bd);
+        ProfScope ps(s, MI_PROF_LEVEL, bytes * (1.0 - frac_in) * part, st_bd);
         ps.r.launches = nlaunch;
-        for (int f0 = 0; f0 < nb; f0 += step) {
+        for (int f0 = f_begin; f0 < f_end; f0 += step) {
             frames_of(f0);
             hipLaunchKernelGGL(kbd, dim3(nborder, nchunks), dim3(NT), lds, st_bd, a);
         }
     }
     if (nyi > 0) {
-        ProfScope ps(s, l == 0 ? MI_PROF_LEVEL0 : MI_PROF_LEVEL, bytes * frac_in, st_in);
+        ProfScope ps(s, l == 0 ? MI_PROF_LEVEL0 : MI_PROF_LEVEL, bytes * frac_in * part, st_in);
         ps.r.launches = nlaunch;
-        for (int f0 = 0; f0 < nb; f0 += step) {
+        for (int f0 = f_begin; f0 < f_end; f0 += step) {
             frames_of(f0);
             hipLaunchKernelGGL(kin, dim3(ngroups * SB * SB, nchunks), dim3(NT), lds_in, st_in, a);
         }
@@ -626,7 +630,26 @@ int run_batch(mi_stack* s, const void* frames, size_t stride, int nb) {
     // before the level-0 interior kernel by the stream itself; the border kernel runs on st1 and needs the event
     MI_HIP(hipEventRecord(t->evInput, st0));
     MI_HIP(hipStreamWaitEvent(st1, t->evInput, 0));
-    if (s->sep) rc = launch_level_sep<TIn, true>(s, 0, set, frames, stride, nb, st0, st1, t->evL0b[set]);
+    // -DMI_STUDY, MI_INTERLEAVE01=1: level 1 of frame group g right behind level 0 of the same group, on the same stream (the
+    // G_1 images level 0 just wrote are the freshest lines of the 256 MB Infinity Cache when level 1 reads them), instead of
+    // all of level 0, then all of level 1.  Only when both levels run as consecutive launches without border tiles.
+    static const int interleave01 = study_env("MI_INTERLEAVE01", 0);
+    bool il = false;
+    if (s->sep && interleave01 && L >= 2 && nb > SEP_LAUNCH_FRAMES) {
+        bool p0 = false, p1 = false;
+        const int nt0 = cdiv(s->lw[0], 56) * cdiv(s->lh[0], MI_SEP_TH), nt1 = cdiv(s->lw[1], 56) * cdiv(s->lh[1], MI_SEP_TH);
+        level_chunk_frames(nb, nt0, &p0);
+        level_chunk_frames(nb, nt1, &p1);
+        il = !p0 && !p1 && !(s->lh[0] & 1) && !(s->lw[0] & 1) && !(s->lh[1] & 1) && !(s->lw[1] & 1);
+    }
+    if (il) {
+        for (int f0 = 0; f0 < nb && !rc; f0 += SEP_LAUNCH_FRAMES) {
+            const int f1 = std::min(nb, f0 + SEP_LAUNCH_FRAMES);
+            rc = launch_level_sep<TIn, true>(s, 0, set, frames, stride, nb, st0, st1, t->evL0b[set], f0, f1);
+            if (!rc) rc = launch_level_sep<float, false>(s, 1, set, t->Gb[set][1], t->gstride[1] * sizeof(float), nb, st0, st1,
+                                                         t->evLvl[(set * (L + 1) + 1) * 2 + 1], f0, f1);
+        }
+    } else if (s->sep) rc = launch_level_sep<TIn, true>(s, 0, set, frames, stride, nb, st0, st1, t->evL0b[set]);
     else
         rc = launch_level<TIn, FMA, MI_TILE0_H, MI_TILE0_W, MI_TILE0_NT, MI_TILE_PAD != 0, MI_TILE_H, MI_TILE_W, MI_TILE_NT>(
             s, 0, set, frames, stride, nb, st0, st1, t->evL0b[set]);
@@ -648,7 +671,9 @@ int run_batch(mi_stack* s, const void* frames, size_t stride, int nb) {
         // level 0's tile configuration -- less halo per tile: +2 % on the 256 x 24 MP job; MI_WIDE_LEVELS overrides
         static const int wide_levels = study_env("MI_WIDE_LEVELS", -1);
         const bool wide = wide_levels >= 0 ? l <= wide_levels : (size_t)s->lh[l] * s->lw[l] >= ((size_t)4 << 20);
-        if (s->sep)
+        if (s->sep && il && l == 1)
+            rc = MI_OK;   // level 1 ran interleaved with level 0 on st0 (st2 waited for evL0i, recorded behind both)
+        else if (s->sep)
             rc = launch_level_sep<float, false>(s, l, set, t->Gb[set][l], t->gstride[l] * sizeof(float), nb, st2, st1,
                                                 t->evLvl[(set * (L + 1) + l) * 2 + 1]);
         else if (wide)
