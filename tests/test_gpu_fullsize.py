@@ -310,3 +310,31 @@ def test_frames_beyond_67_megapixels_tiled_equals_simple(L, arith):
     buf.free()
     assert np.array_equal(idx1[L.IMPL_SIMPLE], idx1[L.IMPL_TILED])
     assert np.array_equal(outs[L.IMPL_SIMPLE], outs[L.IMPL_TILED])
+
+
+def test_config5_second_stage_over_128_resident_results_50mp_u16(L, oracle):
+    """BASELINE config 5's SECOND stage at its full length: 1024 frames in bunches of 10 with overlap 2 leave 128 bunch
+    results, each a 5760 x 8640 uint16 image that stays on the device (37 GB), and `FocusStack` fuses those once more
+    (stack.py:101-113).  Here 128 resident uint16 frames of that size stand in for the results (the generator's frames:
+    the stage only sees size, type and count) and are fused in one resident push -- 7 levels, one batch; verified like
+    the benchmark verifies config 2 (six windows x three levels == the oracle on the cropped frames)."""
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    import bench
+    H, W, N = 5760, 8640, 128
+    free, _total = L.mem_info()
+    per = H * W * 3 * 2
+    if free < per * N + (90 << 30):
+        pytest.skip("needs ~130 GB of free device memory")
+    buf = L.DeviceBuffer(per * N)
+    L.synth_frames_device(buf.ptr, np.uint16, H, W, 0, N, N)
+    st = L.Stack(H, W, in_dtype=np.uint16, out_dtype=np.uint16, arith="separable")
+    assert st.levels == 7
+    st.push_frames_device(buf.ptr, N)
+    out = st.finish()
+    args = types.SimpleNamespace(height=H, width=W, dtype="u16", arith="separable")
+    v = bench.verify(L, st, args, N, 1)
+    assert v["band_match"] > 0.9 and v["crops_equal"] and len(v["crops"]) == 6, v
+    assert out.shape == (H, W, 3) and out.dtype == np.uint16 and 40 * 257 < out.mean() < 215 * 257
+    st.close()
+    buf.free()
