@@ -829,7 +829,6 @@ public:
             next_ = 1;
             parts_ = parts;
             pending_ = parts - 1;
-            ++gen_;
         }
         cv_.notify_all();
         fn(0);
@@ -869,7 +868,6 @@ private:
     std::condition_variable cv_, done_;
     const std::function<void(int)>* fn_ = nullptr;
     int next_ = 0, parts_ = 0, pending_ = 0;
-    long gen_ = 0;
     bool stop_ = false;
 };
 
