@@ -57,8 +57,11 @@ template <typename TIn> constexpr int sep_nt() { return sizeof(TIn) == 4 ? MI_SE
 // fp32 interior tiles: stage the G_l patch by LDS-DMA (`buffer_load_dwordx4 ... lds`: HBM -> LDS without a VGPR round trip,
 // 1 KB per wave instruction) instead of prefetching into registers and writing them out.  The lane's quad takes its gray
 // of G_l in P1 (registers), so the staged patch is dead after P1 and the next frame's DMA runs beside P2-P4.
+// Bit-identical (all parity tests pass with it), 60 instead of 73 VGPRs -- and NOT faster: interleaved A/B on three boxes
+// gave +1.0 %, -1.1 %, -1.4 % on the job (docs/studies.md, round 4): the kernel moves its bytes at the fabric's rate
+// either way.  Off by default; -DMI_SEP_DMA=1 builds it.
 #ifndef MI_SEP_DMA
-#define MI_SEP_DMA 1
+#define MI_SEP_DMA 0
 #endif
 
 template <int TH_, int NT_>
