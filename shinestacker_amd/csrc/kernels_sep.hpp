@@ -60,6 +60,15 @@ template <typename TIn> constexpr int sep_nt() { return sizeof(TIn) == 4 ? MI_SE
 // Bit-identical (all parity tests pass with it), 60 instead of 73 VGPRs -- and NOT faster: interleaved A/B on three boxes
 // gave +1.0 %, -1.1 %, -1.4 % on the job (docs/studies.md, round 4): the kernel moves its bytes at the fabric's rate
 // either way.  Off by default; -DMI_SEP_DMA=1 builds it.
+// study knobs for the 8 / 16-bit instantiations (VALU-bound): waves per SIMD the compiler must leave room for (8 = 64
+// VGPRs, 4 workgroups per CU; 6 = 85 VGPRs, 3 workgroups) and whether the per-frame addresses are laundered (rebuilt every
+// frame) or may be hoisted into registers
+#ifndef MI_SEP_INT_WAVES
+#define MI_SEP_INT_WAVES 8
+#endif
+#ifndef MI_SEP_LAUNDER
+#define MI_SEP_LAUNDER 1
+#endif
 #ifndef MI_SEP_DMA
 #define MI_SEP_DMA 0
 #endif
@@ -443,7 +452,9 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
 
     for (int b = 0; b < nfr; ++b) {
         int lt = tid;
+#if MI_SEP_LAUNDER
         asm volatile("" : "+v"(lt));   // per-frame addresses are rebuilt from this, not hoisted out of the loop
+#endif
         // ---------------- P0: stage
         if constexpr (DMA) {
             wait_vmem_all();   // this wave's share of the patch has landed (and the previous frame's G_{l+1} stores)
@@ -743,7 +754,7 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
 #define MI_SEP_BD_WAVES 1
 #endif
 template <typename TIn, bool INTERIOR, int TH, int NT>
-__global__ __launch_bounds__(NT, INTERIOR ? (sizeof(TIn) <= 2 ? 8 : (NT > 512 ? 7 : 1)) : MI_SEP_BD_WAVES) void level_sep(LevelArgs a) {
+__global__ __launch_bounds__(NT, INTERIOR ? (sizeof(TIn) <= 2 ? MI_SEP_INT_WAVES : (NT > 512 ? 7 : 1)) : MI_SEP_BD_WAVES) void level_sep(LevelArgs a) {
     level_sep_body<TIn, INTERIOR, TH, NT>(a);
 }
 template <typename TIn, bool INTERIOR, int TH, int NT>
