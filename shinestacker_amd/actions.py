@@ -105,7 +105,8 @@ class StackJob(ActionBase):
         self._actions = []
         if logger_name is not None:
             self.logger = logging.getLogger(logger_name)
-        self.callbacks = callbacks
+        # 'tqdm' selects the reference's progress-bar callbacks (core/framework.py:158): bars are out of scope, the job runs
+        self.callbacks = None if callbacks == 'tqdm' else callbacks
 
     def add_action(self, a):
         a.id = self.action_counter
