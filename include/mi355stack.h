@@ -296,6 +296,13 @@ MI_API int mi_aligner_estimate(mi_aligner_t al, void* stream, const void* dev_mo
 MI_API int mi_aligner_estimate_batch(mi_aligner_t al, void* stream, const void* const* dev_movs, int n, int max_iters,
                               double eps, double* M_out, double* cc_out, int* iters_out);
 
+/* ALIGN_HOMOGRAPHY (align.py:138-140, cv2.findHomography): the same estimate refined to 8 degrees of freedom -- the
+ * forward-additive ECC iteration in cv2.findTransformECC's MOTION_HOMOGRAPHY form, on the finest level, from the
+ * converged similarity.  M9_out: n x 9 doubles, row-major 3 x 3 (moving -> reference, full-resolution pixels, M[8] = 1),
+ * ready for mi_warp_perspective; a frame whose refinement fails or does not raise the correlation keeps its similarity. */
+MI_API int mi_aligner_estimate_homography_batch(mi_aligner_t al, void* stream, const void* const* dev_movs, int n, int max_iters,
+                                         double eps, double* M9_out, double* cc_out, int* iters_out);
+
 /* ---- the resident align -> stack loop in ONE call (reference: CombinedActions.run_frame over AlignFrames with a fixed
  * reference frame, stack_framework.py:191-232, :269-297, followed by FocusStack, stack.py:101-113; BASELINE config 4).
  * Every frame of `dev_frames` (n_frames x H x W x 3, `frame_stride` bytes apart, the stack handle's in_dtype) except

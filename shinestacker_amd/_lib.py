@@ -135,6 +135,9 @@ SIGNATURES = {
                                     C.c_int]),
     "mi_aligner_set_area_subsampling": (C.c_int, [C.c_void_p, C.c_int]),
     "mi_aligner_set_phase_init": (C.c_int, [C.c_void_p, C.c_int]),
+    "mi_aligner_estimate_homography_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int,
+                                                       C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                                       C.POINTER(C.c_int)]),
     "mi_phase_correlate_device": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                             C.POINTER(C.c_double)]),
     "mi_aligner_destroy": (C.c_int, [C.c_void_p]),
@@ -676,6 +679,18 @@ class Aligner:
         it = (C.c_int * n)()
         check(load().mi_aligner_estimate_batch(self._h, stream, ptrs, n, int(max_iters), float(eps), m, cc, it))
         return (np.array(list(m), dtype=np.float64).reshape(n, 2, 3), np.array(list(cc), dtype=np.float64),
+                np.array(list(it), dtype=np.int32))
+
+    def estimate_homography_batch(self, dev_ptrs, max_iters=60, eps=1e-9, stream=None):
+        """ALIGN_HOMOGRAPHY: the same estimate refined to 8 degrees of freedom (mi_aligner_estimate_homography_batch).
+        -> (M n x 3 x 3 float64 with M[2, 2] = 1, cc n float64 [-2 where the method failed], iterations n int32)"""
+        n = len(dev_ptrs)
+        ptrs = (C.c_void_p * n)(*dev_ptrs)
+        m = (C.c_double * (9 * n))()
+        cc = (C.c_double * n)()
+        it = (C.c_int * n)()
+        check(load().mi_aligner_estimate_homography_batch(self._h, stream, ptrs, n, int(max_iters), float(eps), m, cc, it))
+        return (np.array(list(m), dtype=np.float64).reshape(n, 3, 3), np.array(list(cc), dtype=np.float64),
                 np.array(list(it), dtype=np.int32))
 
     def close(self):

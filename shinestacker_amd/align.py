@@ -186,27 +186,30 @@ def ecc_estimator(min_correlation=0.5, max_iters=60, device=0, phase_init=False)
     `phase_init`: start every estimate from the translation found by phase correlation (mi_aligner_set_phase_init):
     shifts far beyond the ECC pyramid's capture range (tens of per cent of the frame) are then recovered too."""
     def estimate(img_0_sub, img_1_sub, _feature_config, _matching_config, alignment_config):
-        if phase_init:
+        homography = (alignment_config or {}).get('transform') == constants.ALIGN_HOMOGRAPHY
+        if phase_init or homography:
             ref, mov = np.ascontiguousarray(img_1_sub), np.ascontiguousarray(img_0_sub)
-            al = _lib.Aligner(ref.shape[0], ref.shape[1], ref.dtype, subsample=1, device=device, phase_init=True)
+            al = _lib.Aligner(ref.shape[0], ref.shape[1], ref.dtype, subsample=1, device=device, phase_init=phase_init)
             buf = _lib.DeviceBuffer(2 * ref.nbytes, device)
             try:
                 buf.upload(ref)
                 buf.upload(mov, ref.nbytes)
                 al.set_reference(buf.ptr)
-                try:
-                    m, cc, _iters = al.estimate(buf.ptr + ref.nbytes, max_iters=max_iters)
-                except Exception:   # noqa: BLE001  (no overlap / constant image: "no matches")
-                    return 0, None
+                if homography:   # the similarity refined to 8 degrees of freedom (cv2.findHomography's role, align.py:138-140)
+                    ms, ccs, _ = al.estimate_homography_batch([buf.ptr + ref.nbytes], max_iters=max_iters)
+                    m, cc = ms[0], float(ccs[0])
+                else:
+                    try:
+                        m, cc, _iters = al.estimate(buf.ptr + ref.nbytes, max_iters=max_iters)
+                    except Exception:   # noqa: BLE001  (no overlap / constant image: "no matches")
+                        return 0, None
             finally:
                 al.close()
                 buf.free()
         else:
             m, cc, _iters = _lib.ecc_similarity(img_1_sub, img_0_sub, max_iters=max_iters, device=device)
-        if cc < min_correlation:
+        if not cc >= min_correlation:
             return 0, None
-        if (alignment_config or {}).get('transform') == constants.ALIGN_HOMOGRAPHY:
-            m = np.vstack([m, [0.0, 0.0, 1.0]])   # the similarity, in the shape the homography apply takes
         return 1000, m
     return estimate
 

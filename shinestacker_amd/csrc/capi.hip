@@ -728,6 +728,8 @@ struct mi_aligner {
     unsigned int* ticket = nullptr;  // [cap]
     EccState* dstate = nullptr;      // [cap] the frames' Gauss-Newton state (device memory: the kernels iterate on it)
     EccState* hstate = nullptr;      // pinned host copy: initial values up, `active` flags and results down
+    EccStateH* dstate_h = nullptr;   // [cap] state of the 8-DoF refinement (ALIGN_HOMOGRAPHY)
+    EccStateH* hstate_h = nullptr;   // pinned host copy
     std::vector<void*> bufs;         // template pyramid + gray scratch
     std::vector<void*> fbufs;        // per-frame buffers (re-allocated when the capacity grows)
     hipStream_t own = nullptr;       // used when the caller passes no stream: handles on different host
@@ -771,6 +773,8 @@ void aligner_free_frames(mi_aligner* al) {
     al->fbufs.clear();
     if (al->hstate) (void)hipHostFree(al->hstate);
     al->hstate = nullptr;
+    if (al->hstate_h) (void)hipHostFree(al->hstate_h);
+    al->hstate_h = nullptr;
     al->cap = 0;
 }
 
@@ -799,7 +803,7 @@ int aligner_reserve(mi_aligner* al, int n) {
         L.img = (float*)dalloc(nb);
         ok = ok && L.img;
     }
-    al->partial = (double*)dalloc((size_t)n * ECC_MAX_BLOCKS * ECC_NSUM * sizeof(double));
+    al->partial = (double*)dalloc((size_t)n * ECC_MAX_BLOCKS * (ECC_NSUM_H > ECC_NSUM ? ECC_NSUM_H : ECC_NSUM) * sizeof(double));
     al->ticket = (unsigned int*)dalloc(sizeof(unsigned int) * n);
     ok = ok && al->partial && al->ticket;
     if (ok) ok = hipMemset(al->ticket, 0, sizeof(unsigned int) * n) == hipSuccess;
@@ -808,6 +812,9 @@ int aligner_reserve(mi_aligner* al, int n) {
     al->pc_out = (double*)dalloc(sizeof(double) * 3 * n);
     ok = ok && al->pc_out;
     if (ok) ok = hipHostMalloc((void**)&al->hstate, sizeof(EccState) * n, hipHostMallocDefault) == hipSuccess;
+    al->dstate_h = (EccStateH*)dalloc(sizeof(EccStateH) * n);
+    ok = ok && al->dstate_h;
+    if (ok) ok = hipHostMalloc((void**)&al->hstate_h, sizeof(EccStateH) * n, hipHostMallocDefault) == hipSuccess;
     if (!ok) {
         aligner_free_frames(al);
         return fail(MI_ERR_NOMEM, "out of device memory");
@@ -872,8 +879,11 @@ int aligner_build(mi_aligner* al, hipStream_t st, const void* dev_img, bool is_t
 // rarely converges in fewer), the following ones sooner
 constexpr int ECC_CHUNK_FIRST = 8, ECC_CHUNK_NEXT = 4;
 
+// `M9_out` (optional): ALIGN_HOMOGRAPHY -- the similarity is refined to 8 degrees of freedom on the finest level
+// (ecc_accumulate_h) and row f of M9_out receives the 3 x 3 matrix (moving -> reference, full-resolution pixels, M[8] = 1);
+// a frame whose refinement fails or does not raise the correlation keeps its similarity, as a 3 x 3.
 int aligner_solve(mi_aligner* al, hipStream_t st, int n, int max_iters, double eps, double* M_out, double* cc_out,
-                  int* iters_out) {
+                  int* iters_out, double* M9_out = nullptr) {
     if (max_iters < 1) max_iters = 50;
     if (!(eps > 0)) eps = 1e-8;
     auto& lv = al->lv;
@@ -955,12 +965,42 @@ int aligner_solve(mi_aligner* al, hipStream_t st, int n, int max_iters, double e
         // back to origin coordinates, then up to the next finer level (u_f = 2 u_c, x_f = 2 x_c)
         hipLaunchKernelGGL(ecc_level_end, dim3(cdiv(n, 64)), dim3(64), 0, st, al->dstate, n, cx, cy, l > 0 ? 1 : 0);
     }
+    EccStateH* const hh = al->hstate_h;
+    double Rn = 1.0, cx0 = 0.0, cy0 = 0.0;
+    if (M9_out) {
+        // 8-DoF refinement on the finest level, from the converged similarity
+        const EccLevel& L = lv[0];
+        cx0 = 0.5 * (L.w - 1);
+        cy0 = 0.5 * (L.h - 1);
+        Rn = (double)hypotf((float)cx0, (float)cy0);   // the kernel's own (float) radius
+        const size_t np = (size_t)L.h * L.w;
+        int step = 1;
+        while ((size_t)(step + 1) * (step + 1) * 500000 <= np) ++step;
+        const size_t work = (np / ((size_t)step * step) + 12287) / 12288;
+        const unsigned nblk = (unsigned)(work < 1 ? 1 : (work > (size_t)ECC_MAX_BLOCKS ? ECC_MAX_BLOCKS : work));
+        hipLaunchKernelGGL(ecc_h_from_similarity, dim3(cdiv(n, 64)), dim3(64), 0, st, (const EccState*)al->dstate, al->dstate_h, n, Rn);
+        for (int it = 0; it < max_iters;) {
+            const int chunk = std::min(it == 0 ? ECC_CHUNK_FIRST : ECC_CHUNK_NEXT, max_iters - it);
+            for (int j = 0; j < chunk; ++j)
+                hipLaunchKernelGGL(ecc_accumulate_h, dim3(nblk, n), dim3(256), 0, st, L.tmpl, L.img, np, L.h, L.w, al->dstate_h, step,
+                                   al->partial, al->ticket, eps);
+            it += chunk;
+            MI_HIP(hipMemcpyAsync(hh, al->dstate_h, sizeof(EccStateH) * n, hipMemcpyDeviceToHost, st));
+            MI_HIP(hipStreamSynchronize(st));
+            int nact = 0;
+            for (int k = 0; k < n; ++k) nact += hh[k].active;
+            if (!nact) break;
+        }
+        MI_HIP(hipGetLastError());
+    }
     MI_HIP(hipMemcpyAsync(hs, al->dstate, sizeof(EccState) * n, hipMemcpyDeviceToHost, st));
+    if (M9_out) MI_HIP(hipMemcpyAsync(hh, al->dstate_h, sizeof(EccStateH) * n, hipMemcpyDeviceToHost, st));
     MI_HIP(hipStreamSynchronize(st));
     const double s = (double)al->subsample;
     for (int k = 0; k < n; ++k) {
         const EccState& f = hs[k];
-        double* M = M_out + 6 * k;
+        double Msim[6];
+        double* M = M_out ? M_out + 6 * k : Msim;
         // M (moving -> reference) = W^-1, translation back to full-resolution pixels
         const double det = f.a * f.a + f.b * f.b;
         const bool bad = f.failed || !(det > 1e-12);
@@ -969,6 +1009,42 @@ int aligner_solve(mi_aligner* al, hipStream_t st, int n, int max_iters, double e
         M[3] = ib;  M[4] = ia;  M[5] = bad ? 0.0 : -(ib * f.T0 + ia * f.T1) * s;
         if (cc_out) cc_out[k] = bad ? -2.0 : f.rho;
         if (iters_out) iters_out[k] = f.iters;
+        if (M9_out) {
+            double* M9 = M9_out + 9 * k;
+            const EccStateH& g = hh[k];
+            bool use_h = !bad && !g.failed && g.iters > 0 && g.rho >= f.rho - 1e-9;
+            if (use_h) {
+                // W (reference -> moving) = T(c) S(R) Hn S(1/R) T(-c) at the sub-sampled scale, S(s) W S(1/s) in full-resolution
+                // pixels; M = W^-1, normalised
+                const double Hn[9] = {g.h[0], g.h[1], g.h[2], g.h[3], g.h[4], g.h[5], g.h[6], g.h[7], 1.0};
+                auto mul = [](const double* A, const double* B, double* C) {
+                    for (int i = 0; i < 3; ++i)
+                        for (int j = 0; j < 3; ++j) C[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+                };
+                const double L1[9] = {s * Rn, 0, s * cx0, 0, s * Rn, s * cy0, 0, 0, 1};                 // S(s) T(c) S(R)
+                const double R1[9] = {1 / (s * Rn), 0, -cx0 / Rn, 0, 1 / (s * Rn), -cy0 / Rn, 0, 0, 1};   // S(1/R) T(-c) S(1/s)
+                double t1[9], Wm[9];
+                mul(L1, Hn, t1);
+                mul(t1, R1, Wm);
+                const double det = Wm[0] * (Wm[4] * Wm[8] - Wm[5] * Wm[7]) - Wm[1] * (Wm[3] * Wm[8] - Wm[5] * Wm[6]) +
+                                   Wm[2] * (Wm[3] * Wm[7] - Wm[4] * Wm[6]);
+                if (fabs(det) > 1e-12) {
+                    const double id = 1.0 / det;
+                    double I[9] = {(Wm[4] * Wm[8] - Wm[5] * Wm[7]) * id, (Wm[2] * Wm[7] - Wm[1] * Wm[8]) * id, (Wm[1] * Wm[5] - Wm[2] * Wm[4]) * id,
+                                   (Wm[5] * Wm[6] - Wm[3] * Wm[8]) * id, (Wm[0] * Wm[8] - Wm[2] * Wm[6]) * id, (Wm[2] * Wm[3] - Wm[0] * Wm[5]) * id,
+                                   (Wm[3] * Wm[7] - Wm[4] * Wm[6]) * id, (Wm[1] * Wm[6] - Wm[0] * Wm[7]) * id, (Wm[0] * Wm[4] - Wm[1] * Wm[3]) * id};
+                    if (fabs(I[8]) > 1e-12) {
+                        for (int q = 0; q < 9; ++q) M9[q] = I[q] / I[8];
+                        if (cc_out) cc_out[k] = g.rho;
+                        if (iters_out) iters_out[k] = f.iters + g.iters;
+                    } else use_h = false;
+                } else use_h = false;
+            }
+            if (!use_h) {
+                for (int q = 0; q < 6; ++q) M9[q] = M[q];
+                M9[6] = 0.0; M9[7] = 0.0; M9[8] = 1.0;
+            }
+        }
     }
     return MI_OK;
 }
@@ -1941,6 +2017,30 @@ int mi_aligner_estimate_batch(mi_aligner_t al, void* stream, const void* const* 
     return aligner_solve(al, st, n, max_iters, eps, M_out, cc_out, iters_out);
 }
 
+int mi_aligner_estimate_homography_batch(mi_aligner_t al, void* stream, const void* const* dev_movs, int n, int max_iters,
+                                         double eps, double* M9_out, double* cc_out, int* iters_out) {
+    if (!al || !dev_movs || !M9_out) return fail(MI_ERR_INVALID, "null argument");
+    if (n < 1 || n > ECC_MAXF) return fail(MI_ERR_INVALID, "batch of %d frames (1..%d)", n, ECC_MAXF);
+    if (!al->have_ref) return fail(MI_ERR_STATE, "mi_aligner_set_reference has not been called");
+    for (int k = 0; k < n; ++k)
+        if (!dev_movs[k]) return fail(MI_ERR_INVALID, "null frame %d", k);
+    MI_HIP(hipSetDevice(al->device));
+    hipStream_t st = stream ? (hipStream_t)stream : al->own;
+    int rc = aligner_reserve(al, n);
+    if (rc) return rc;
+    const int split = n > 1 ? 2 : 1 << 30;
+    for (int k = 0; k < n; ++k)
+        if ((rc = aligner_build(al, st, dev_movs[k], false, k, split))) return rc;
+    for (size_t l = (size_t)split; l < al->lv.size(); ++l) {
+        const auto& a = al->lv[l - 1];
+        const auto& b = al->lv[l];
+        hipLaunchKernelGGL((ecc_blur_tile<1>), dim3(cdiv(b.w, 64), cdiv(b.h, 16), n), dim3(256), 0, st, (const float*)a.img, a.h, a.w,
+                           b.img, b.h, b.w);
+    }
+    MI_HIP(hipGetLastError());
+    return aligner_solve(al, st, n, max_iters, eps, nullptr, cc_out, iters_out, M9_out);
+}
+
 int mi_aligner_estimate(mi_aligner_t al, void* stream, const void* dev_mov, int max_iters, double eps,
                         double* M_out, double* cc_out, int* iters_out) {
     if (!dev_mov) return fail(MI_ERR_INVALID, "null argument");
@@ -1970,7 +2070,7 @@ int mi_align_stack_device(mi_stack_t* st, mi_aligner_t al, const void* dev_frame
     MI_HIP(hipSetDevice(st->p.device));
     if ((rc = mi_aligner_set_reference(al, nullptr, frames + (size_t)ref_idx * frame_stride))) return rc;
     const bool persp = o->transform == 1;
-    std::vector<double> est((size_t)n_frames * 6, 0.0);
+    std::vector<double> est((size_t)n_frames * 9, 0.0);
     std::vector<char> have((size_t)n_frames, 0);
     for (int i = 0; i < n_frames; ++i) {
         for (int k = 0; k < 9; ++k) M_out[(size_t)i * 9 + k] = 0.0;
@@ -1996,11 +2096,14 @@ int mi_align_stack_device(mi_stack_t* st, mi_aligner_t al, const void* dev_frame
                 int idx[ECC_MAXF], nb = 0;
                 for (int k = i; k < n_frames && nb < o->ecc_batch; ++k)
                     if (k != ref_idx) { idx[nb] = k; ptrs[nb++] = frames + (size_t)k * frame_stride; }
-                double Ms[ECC_MAXF * 6], ccs[ECC_MAXF];
+                double Ms[ECC_MAXF * 9], ccs[ECC_MAXF];
                 int its[ECC_MAXF];
-                if ((rc = mi_aligner_estimate_batch(al, nullptr, ptrs, nb, o->max_iters, o->eps, Ms, ccs, its))) return rc;
+                if (persp) {   // ALIGN_HOMOGRAPHY: the similarity refined to 8 degrees of freedom
+                    if ((rc = mi_aligner_estimate_homography_batch(al, nullptr, ptrs, nb, o->max_iters, o->eps, Ms, ccs, its))) return rc;
+                } else if ((rc = mi_aligner_estimate_batch(al, nullptr, ptrs, nb, o->max_iters, o->eps, Ms, ccs, its))) return rc;
+                const int per = persp ? 9 : 6;
                 for (int k = 0; k < nb; ++k) {
-                    for (int q = 0; q < 6; ++q) est[(size_t)idx[k] * 6 + q] = Ms[k * 6 + q];
+                    for (int q = 0; q < per; ++q) est[(size_t)idx[k] * 9 + q] = Ms[k * per + q];
                     cc_out[idx[k]] = ccs[k];
                     have[idx[k]] = 1;
                 }
@@ -2010,8 +2113,7 @@ int mi_align_stack_device(mi_stack_t* st, mi_aligner_t al, const void* dev_frame
                 return fail(MI_ERR_ALIGNMENT, "frame %d: correlation %.3f < %.3f", i, cc_out[i], o->min_correlation);
             }
             double* m = M_out + (size_t)i * 9;
-            for (int q = 0; q < 6; ++q) m[q] = est[(size_t)i * 6 + q];
-            if (persp) { m[6] = 0.0; m[7] = 0.0; m[8] = 1.0; }
+            for (int q = 0; q < (persp ? 9 : 6); ++q) m[q] = est[(size_t)i * 9 + q];
             if ((rc = warp_device_impl(st->p.device, st->stream, frames + (size_t)i * frame_stride, dst, dev_tmp, dev_mask, H, W,
                                        st->p.in_dtype, m, persp, o->border_mode, o->border_value, o->blur_ksize, o->blur_sigma)))
                 return rc;

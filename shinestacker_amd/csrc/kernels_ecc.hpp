@@ -497,4 +497,205 @@ __global__ __launch_bounds__(256) void ecc_accumulate(const float* __restrict__ 
     }
 }
 
+// ================================================================================================
+// ALIGN_HOMOGRAPHY (align.py:138-140 cv2.findHomography): 8-DoF refinement of the similarity the loop above finds.
+// The projective terms of a focus stack are tiny and ill-conditioned on the coarse levels, so the homography is
+// estimated at the finest level only, by the same forward-additive ECC iteration (cv2.findTransformECC's
+// MOTION_HOMOGRAPHY form), starting from the converged similarity.  Parameters in NORMALISED centred coordinates
+// (xn = (x - cx) / R, R = half the diagonal: every parameter is O(1)):
+//     xn' = (h0 xn + h1 yn + h2) / (h6 xn + h7 yn + 1),   yn' = (h3 xn + h4 yn + h5) / (h6 xn + h7 yn + 1)
+// and the sample position in the moving frame is (cx + R xn', cy + R yn').
+constexpr int ECC_NSUM_H = 66;   // 6 scalars, SJ[8], SJiw[8], SJir[8], H[36]
+
+struct EccStateH {
+    double h[8];
+    double rho, last_rho;
+    int iters, failed, active, pad_;
+};
+
+// symmetric N x N solve as ecc_solve4 (column-scaled Gaussian elimination with partial pivoting, double)
+template <int N>
+__device__ inline bool ecc_solve_n(const double* Hs, const double* r, double* d) {
+    double A[N][N + 1], sc[N];
+    {
+        double Hm[N][N];
+        int k = 0;
+        for (int i = 0; i < N; ++i)
+            for (int j = i; j < N; ++j) Hm[i][j] = Hm[j][i] = Hs[k++];
+        for (int i = 0; i < N; ++i) {
+            if (!(Hm[i][i] > 0)) return false;
+            sc[i] = 1.0 / sqrt(Hm[i][i]);
+        }
+        for (int i = 0; i < N; ++i) {
+            for (int j = 0; j < N; ++j) A[i][j] = Hm[i][j] * sc[i] * sc[j];
+            A[i][N] = r[i] * sc[i];
+        }
+    }
+    for (int c = 0; c < N; ++c) {
+        int piv = c;
+        for (int i = c + 1; i < N; ++i)
+            if (fabs(A[i][c]) > fabs(A[piv][c])) piv = i;
+        if (fabs(A[piv][c]) < 1e-12) return false;
+        if (piv != c)
+            for (int j = 0; j <= N; ++j) { const double t = A[c][j]; A[c][j] = A[piv][j]; A[piv][j] = t; }
+        for (int i = c + 1; i < N; ++i) {
+            const double f = A[i][c] / A[c][c];
+            for (int j = c; j <= N; ++j) A[i][j] -= f * A[c][j];
+        }
+    }
+    for (int i = N - 1; i >= 0; --i) {
+        double v = A[i][N];
+        for (int j = i + 1; j < N; ++j) v -= A[i][j] * d[j];
+        d[i] = v / A[i][i];
+    }
+    for (int i = 0; i < N; ++i) d[i] *= sc[i];
+    return true;
+}
+
+// the forward-additive ECC step of ecc_update for 8 parameters; `R`: the normalisation radius in pixels
+__device__ inline void ecc_update_h(EccStateH& f, const double* S, double R, double eps) {
+    ++f.iters;
+    const double cnt = S[0];
+    if (cnt < 64) { f.failed = 1; f.active = 0; return; }
+    const double mw = S[1] / cnt, mr = S[2] / cnt;
+    const double wn2 = S[3] - cnt * mw * mw, rn2 = S[4] - cnt * mr * mr, corr = S[5] - cnt * mw * mr;
+    if (!(wn2 > 0) || !(rn2 > 0)) { f.failed = 1; f.active = 0; return; }
+    f.rho = corr / sqrt(wn2 * rn2);
+    double ip[8], tp[8], Hi_ip[8];
+    for (int q = 0; q < 8; ++q) {
+        ip[q] = S[14 + q] - mw * S[6 + q];
+        tp[q] = S[22 + q] - mr * S[6 + q];
+    }
+    if (!ecc_solve_n<8>(&S[30], ip, Hi_ip)) { f.active = 0; return; }
+    double ipH = 0, tpH = 0;
+    for (int q = 0; q < 8; ++q) { ipH += ip[q] * Hi_ip[q]; tpH += tp[q] * Hi_ip[q]; }
+    const double lam_n = wn2 - ipH, lam_d = corr - tpH;
+    if (!(lam_d > 0)) { f.active = 0; return; }
+    const double lam = lam_n / lam_d;
+    double ep[8], dp[8];
+    for (int q = 0; q < 8; ++q) ep[q] = lam * tp[q] - ip[q];
+    if (!ecc_solve_n<8>(&S[30], ep, dp)) { f.active = 0; return; }
+    double move = 0.0;
+    for (int q = 0; q < 8; ++q) { f.h[q] += dp[q]; move += fabs(dp[q]); }
+    // every parameter moves a pixel of the unit disc by at most its own change: `move * R` bounds the displacement
+    if (move * R < 2e-3 || fabs(f.rho - f.last_rho) < eps) f.active = 0;
+    f.last_rho = f.rho;
+}
+
+__global__ __launch_bounds__(256) void ecc_accumulate_h(const float* __restrict__ tmpl, const float* __restrict__ img,
+                                                        size_t fstride, int h, int w, EccStateH* __restrict__ state, int step,
+                                                        double* __restrict__ partial, unsigned int* __restrict__ ticket, double eps) {
+    const int f = blockIdx.y;
+    if (!state[f].active) return;
+    float p[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) p[q] = (float)state[f].h[q];
+    img += (size_t)f * fstride;
+    partial += (size_t)f * ECC_MAX_BLOCKS * ECC_NSUM_H;
+    ticket += f;
+    double acc[ECC_NSUM_H];
+#pragma unroll
+    for (int i = 0; i < ECC_NSUM_H; ++i) acc[i] = 0.0;
+    const float cx = 0.5f * (w - 1), cy = 0.5f * (h - 1);
+    const float R = hypotf(cx, cy), iR = 1.0f / R;
+    const int nx = (w + step - 1) / step, ny = (h + step - 1) / step;
+    const unsigned total = (unsigned)nx * ny;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int y = (int)(i / nx) * step, x = (int)(i % nx) * step;
+        const float xn = (x - cx) * iR, yn = (y - cy) * iR;
+        const float den = p[6] * xn + p[7] * yn + 1.0f;
+        if (!(den > 1e-3f)) continue;
+        const float id = 1.0f / den;
+        const float xp = (p[0] * xn + p[1] * yn + p[2]) * id, yp = (p[3] * xn + p[4] * yn + p[5]) * id;
+        const float u = cx + R * xp, v = cy + R * yp;
+        const int x0 = (int)floorf(u), y0 = (int)floorf(v);
+        if (x0 < 1 || y0 < 1 || x0 >= w - 2 || y0 >= h - 2) continue;
+        const float fx = u - x0, fy = v - y0;
+        const float* r1 = img + (size_t)y0 * w + x0;
+        const float* r0 = r1 - w;
+        const float* r2 = r1 + w;
+        const float* r3 = r2 + w;
+        const float a_m = r1[-1], a_0 = r1[0], a_1 = r1[1], a_2 = r1[2];
+        const float b_m = r2[-1], b_0 = r2[0], b_1 = r2[1], b_2 = r2[2];
+        const float t_0 = r0[0], t_1 = r0[1], u_0 = r3[0], u_1 = r3[1];
+        const float iw = (a_0 + fx * (a_1 - a_0)) + fy * ((b_0 + fx * (b_1 - b_0)) - (a_0 + fx * (a_1 - a_0)));
+        const float gxa0 = 0.5f * (a_1 - a_m), gxa1 = 0.5f * (a_2 - a_0), gxb0 = 0.5f * (b_1 - b_m), gxb1 = 0.5f * (b_2 - b_0);
+        const float gya0 = 0.5f * (b_0 - t_0), gya1 = 0.5f * (b_1 - t_1), gyb0 = 0.5f * (u_0 - a_0), gyb1 = 0.5f * (u_1 - a_1);
+        const float gxt = gxa0 + fx * (gxa1 - gxa0), gxb = gxb0 + fx * (gxb1 - gxb0);
+        const float gyt = gya0 + fx * (gya1 - gya0), gyb = gyb0 + fx * (gyb1 - gyb0);
+        // gradients with respect to the NORMALISED warped coordinates (a step of 1 in xn' is R pixels)
+        const float dgx = (gxt + fy * (gxb - gxt)) * R, dgy = (gyt + fy * (gyb - gyt)) * R;
+        const float ir = tmpl[(size_t)y * w + x];
+        const float gxd = dgx * id, gyd = dgy * id, pr = -(dgx * xp + dgy * yp) * id;
+        const float J[8] = {gxd * xn, gxd * yn, gxd, gyd * xn, gyd * yn, gyd, pr * xn, pr * yn};
+        acc[0] += 1.0;
+        acc[1] += iw;
+        acc[2] += ir;
+        acc[3] += (double)iw * iw;
+        acc[4] += (double)ir * ir;
+        acc[5] += (double)iw * ir;
+        int hk = 30;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            acc[6 + k] += J[k];
+            acc[14 + k] += (double)J[k] * iw;
+            acc[22 + k] += (double)J[k] * ir;
+#pragma unroll
+            for (int m = k; m < 8; ++m) acc[hk++] += (double)J[k] * J[m];
+        }
+    }
+    __shared__ double red[4][ECC_NSUM_H];
+    __shared__ bool last;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int s = 0; s < ECC_NSUM_H; ++s) {
+        const double v = wave_sum(acc[s]);
+        if (lane == 0) red[wave][s] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < ECC_NSUM_H)
+        partial[(size_t)blockIdx.x * ECC_NSUM_H + threadIdx.x] =
+            ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    // fixed summation order (3 interleaved slices of the block list, then the slices in order)
+    constexpr int SLICES = 3;
+    __shared__ double slice[SLICES][ECC_NSUM_H];
+    if (threadIdx.x < ECC_NSUM_H * SLICES) {
+        const int sidx = threadIdx.x % ECC_NSUM_H, part = threadIdx.x / ECC_NSUM_H;
+        double t = 0.0;
+        for (unsigned bk = part; bk < gridDim.x; bk += SLICES)
+            t += __builtin_nontemporal_load(&partial[(size_t)bk * ECC_NSUM_H + sidx]);
+        slice[part][sidx] = t;
+    }
+    __syncthreads();
+    __shared__ double tot[ECC_NSUM_H];
+    if (threadIdx.x < ECC_NSUM_H) tot[threadIdx.x] = (slice[0][threadIdx.x] + slice[1][threadIdx.x]) + slice[2][threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        EccStateH fs = state[f];
+        ecc_update_h(fs, tot, (double)R, eps);
+        state[f] = fs;
+        *ticket = 0;
+    }
+}
+
+// the converged similarity of the finest level (centred a, b, tx, ty in pixels) as the homography's starting point
+__global__ void ecc_h_from_similarity(const EccState* __restrict__ sim, EccStateH* __restrict__ hs, int n, double R) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const EccState& s = sim[k];
+    EccStateH o{};
+    o.h[0] = s.a; o.h[1] = -s.b; o.h[2] = s.tx / R;
+    o.h[3] = s.b; o.h[4] = s.a;  o.h[5] = s.ty / R;
+    o.h[6] = 0.0; o.h[7] = 0.0;
+    o.rho = s.rho; o.last_rho = -2.0;
+    o.iters = 0; o.failed = s.failed; o.active = !s.failed;
+    hs[k] = o;
+}
+
 }  // namespace mi

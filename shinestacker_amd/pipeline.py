@@ -388,7 +388,8 @@ def align_and_stack_device(dev_frames, n_frames, height, width, dtype, ref_idx=-
     def estimate_from(i):
         """transforms of the next `ecc_batch` moving frames starting at frame i"""
         idx = [k for k in range(i, n_frames) if k != ref_idx][:ecc_batch]
-        ms, cs, _ = aligner.estimate_batch([dev_frames + k * fb for k in idx], max_iters=max_iters)
+        fit = aligner.estimate_homography_batch if homography else aligner.estimate_batch
+        ms, cs, _ = fit([dev_frames + k * fb for k in idx], max_iters=max_iters)
         for k, m, c in zip(idx, ms, cs):
             estimates[k] = (m, float(c))
 
@@ -424,8 +425,6 @@ def align_and_stack_device(dev_frames, n_frames, height, width, dtype, ref_idx=-
                 m, cc = estimates.pop(i)
                 if not cc >= min_correlation:
                     raise AlignmentError(i, f"correlation {cc:.3f} < {min_correlation}")
-                if homography:
-                    m = np.vstack([m, [0.0, 0.0, 1.0]])
                 mm = (C.c_double * m.size)(*m.reshape(-1))
                 warp = lib.mi_warp_perspective_device if homography else lib.mi_warp_affine_device
                 _lib.check(warp(device, st, src, dst, tmp.ptr, mask.ptr, height, width, _lib.DTYPE_CODE[dt], mm, mode, bv, 21,

@@ -510,3 +510,78 @@ def test_phase_correlation_extends_the_capture_range_of_the_ecc_estimator(L, ora
     good = out[True]
     assert good is not None and good[0] < 0.005 and good[1] < 1e-4 and good[2] < 0.2 and good[3] > 0.9, out
     assert out[False] is None or out[False][2] > 5.0 or out[False][3] < 0.5, out    # the plain estimator does not get there
+
+
+def _corner_error(M_est, M_true, h, w):
+    pts = np.array([[0, 0, 1], [w - 1, 0, 1], [0, h - 1, 1], [w - 1, h - 1, 1], [(w - 1) / 2, (h - 1) / 2, 1]], float).T
+    a, b = M_est @ pts, M_true @ pts
+    return np.abs(a[:2] / a[2] - b[:2] / b[2]).max()
+
+
+@pytest.mark.parametrize("dtype,subsample", [(np.uint8, 1), (np.uint16, 1), (np.uint8, 2)])
+def test_homography_refinement_recovers_a_projective_transform(L, oracle, dtype, subsample):
+    """ALIGN_HOMOGRAPHY without OpenCV (cv2.findHomography's role, align.py:138-140): the ECC similarity refined to 8
+    degrees of freedom on the finest level (mi_aligner_estimate_homography_batch).  A frame seen through a mild
+    perspective -- 2.5 % change of scale across the frame on top of a rotation, scale and shift -- is registered with all
+    four corners within 0.2 px (the shift tolerance of tests/test_0031_align_precision.py:62-65); the plain similarity
+    leaves more than a pixel; a frame that IS a similarity gives the same transform either way."""
+    h, w = 768, 1024
+    cx, cy = (w - 1) / 2, (h - 1) / 2
+    S = np.vstack([similarity(0.4, 1.003, 6.0, -4.0, cx, cy), [0, 0, 1]])
+    P = np.array([[1, 0, 0], [0, 1, 0], [2.4e-5, -1.2e-5, 1]], float)
+    C, Ci = np.array([[1, 0, cx], [0, 1, cy], [0, 0, 1.0]]), np.array([[1, 0, -cx], [0, 1, -cy], [0, 0, 1.0]])
+    T = S @ C @ P @ Ci                                   # reference -> moving: perspective about the centre, then the similarity
+    T /= T[2, 2]
+    base = np.clip(np.repeat(texture(h, w, 17)[:, :, None], 3, 2), 0, 255).astype(np.uint8)
+    rng = np.random.default_rng(9)
+    mov8 = oracle.warp_perspective(base, T, border_mode=oracle.BORDER_REPLICATE)
+    scale = 1 if dtype == np.uint8 else 257
+    ref = (np.clip(base + rng.normal(0, 2, base.shape), 0, 255) * scale).astype(dtype)
+    mov = (np.clip(mov8 + rng.normal(0, 2, base.shape), 0, 255) * scale).astype(dtype)
+    want = np.linalg.inv(T)
+    want /= want[2, 2]
+    buf = L.DeviceBuffer(2 * ref.nbytes)
+    buf.upload(ref)
+    buf.upload(mov, ref.nbytes)
+    al = L.Aligner(h, w, dtype, subsample=subsample)
+    al.set_reference(buf.ptr)
+    ms, ccs, its = al.estimate_homography_batch([buf.ptr + ref.nbytes])
+    m_sim, cc_sim, _ = al.estimate(buf.ptr + ref.nbytes)
+    e_h = _corner_error(ms[0], want, h, w)
+    e_s = _corner_error(np.vstack([m_sim, [0, 0, 1]]), want, h, w)
+    assert ms[0].shape == (3, 3) and ms[0][2, 2] == 1.0 and ccs[0] >= cc_sim - 1e-9
+    assert e_h < 0.2 and e_s > 1.0, (e_h, e_s, ccs[0], cc_sim, its)
+    # the apply step takes the matrix as it is: the warped frame matches the reference better than the similarity's
+    got_h = L.warp_perspective(mov, ms[0], border_mode=L.BORDER_REPLICATE)
+    got_s = L.warp_affine(mov, m_sim, border_mode=L.BORDER_REPLICATE)
+    inner = (slice(60, h - 60), slice(60, w - 60))
+    err = lambda a: np.abs(a[inner].astype(np.float64) - ref[inner]).mean() / scale   # noqa: E731
+    assert err(got_h) < err(got_s)
+    # a frame that is a similarity: the refinement has nothing to add
+    ref2, mov2 = make_pair(oracle, similarity(0.3, 1.002, 5.0, -3.0, cx, cy), h=h, w=w, seed=23, noise=2.0, dtype=dtype)
+    buf.upload(ref2)
+    buf.upload(mov2, ref.nbytes)
+    al.set_reference(buf.ptr)
+    ms2, _, _ = al.estimate_homography_batch([buf.ptr + ref.nbytes])
+    m2, _, _ = al.estimate(buf.ptr + ref.nbytes)
+    assert _corner_error(ms2[0], np.vstack([m2, [0, 0, 1]]), h, w) < 0.1
+    al.close()
+    buf.free()
+
+
+def test_align_images_homography_with_the_gpu_estimator(L, oracle):
+    """`align_images(..., transform=ALIGN_HOMOGRAPHY)` with `ecc_estimator()`: a 3 x 3 matrix that is NOT affine comes back
+    and the warp is applied through mi_warp_perspective."""
+    from shinestacker_amd.align import align_images, ecc_estimator
+    from shinestacker_amd.defaults import constants as c
+    h, w = 512, 640
+    cx, cy = (w - 1) / 2, (h - 1) / 2
+    T = np.array([[1, 0, 3.0], [0, 1, -2.0], [0, 0, 1.0]]) @ np.array([[1, 0, cx], [0, 1, cy], [0, 0, 1.0]]) @ \
+        np.array([[1, 0, 0], [0, 1, 0], [4e-5, 3e-5, 1.0]]) @ np.array([[1, 0, -cx], [0, 1, -cy], [0, 0, 1.0]])
+    base = np.clip(np.repeat(texture(h, w, 5)[:, :, None], 3, 2), 0, 255).astype(np.uint8)
+    mov = oracle.warp_perspective(base, T / T[2, 2], border_mode=oracle.BORDER_REPLICATE)
+    n, m, warp = align_images(base, mov, alignment_config={'transform': c.ALIGN_HOMOGRAPHY, 'subsample': 1},
+                              estimator=ecc_estimator())
+    want = np.linalg.inv(T)
+    assert n == 1000 and m.shape == (3, 3) and abs(m[2, 0]) > 1e-5 and _corner_error(m, want / want[2, 2], h, w) < 0.2
+    assert np.array_equal(warp, oracle.warp_perspective(mov, m))
