@@ -136,12 +136,15 @@ def _align_chains_device(lib, dev_frames, aligned, n_frames, height, width, dt, 
             prev = ref_idx
             for i in indices:
                 aligner.set_reference(aligned + prev * fb)
-                m, cc, _ = aligner.estimate(dev_frames + i * fb, max_iters=max_iters)
+                if homography:   # the similarity refined to 8 degrees of freedom
+                    ms, cs, _ = aligner.estimate_homography_batch([dev_frames + i * fb], max_iters=max_iters)
+                    m, cc = ms[0], cs[0]
+                else:
+                    m, cc, _ = aligner.estimate(dev_frames + i * fb, max_iters=max_iters)
                 if not cc >= min_correlation:
                     raise AlignmentError(i, f"correlation {cc:.3f} < {min_correlation}")
                 transforms[i], ccs[i] = m, float(cc)
-                mm = np.vstack([m, [0.0, 0.0, 1.0]]) if homography else m
-                arr = (C.c_double * mm.size)(*mm.reshape(-1))
+                arr = (C.c_double * m.size)(*m.reshape(-1))
                 warp = lib.mi_warp_perspective_device if homography else lib.mi_warp_affine_device
                 _lib.check(warp(device, None, dev_frames + i * fb, aligned + i * fb, tmp.ptr, mask.ptr, height, width,
                                 _lib.DTYPE_CODE[dt], arr, mode, bv, 21, float(cfg['border_blur'])))
