@@ -495,12 +495,50 @@ def align_case():
     _save("align", **arrays)
 
 
+def api_case():
+    """The drop-in boundary as the reference declares it: constructor / function signatures -- parameter
+    names, order, kinds and defaults -- of the classes the mirrors stand in for, read from the reference's OWN modules with
+    `inspect` and frozen as tests/golden/api_surface.json (tests/test_host_logic.py compares the mirrors with it)."""
+    import importlib
+    import inspect
+    al = ri.load_align_module()
+    sf = importlib.import_module("shinestacker.algorithms.stack_framework")
+    st = importlib.import_module("shinestacker.algorithms.stack")
+    bal = importlib.import_module("shinestacker.algorithms.balance")
+    pyr = sys.modules["shinestacker.algorithms.pyramid"]
+    dm = importlib.import_module("shinestacker.algorithms.depth_map")
+    objs = {"StackJob": sf.StackJob, "FocusStack": st.FocusStack, "FocusStackBunch": st.FocusStackBunch,
+            "CombinedActions": sf.CombinedActions, "AlignFrames": al.AlignFrames, "BalanceFrames": bal.BalanceFrames,
+            "PyramidStack": pyr.PyramidStack, "DepthMapStack": dm.DepthMapStack, "align_images": al.align_images,
+            "get_bunches": st.get_bunches, "img_subsample": importlib.import_module("shinestacker.algorithms.utils").img_subsample}
+    out = {}
+    for name, obj in objs.items():
+        params = []
+        for k, v in inspect.signature(obj).parameters.items():
+            params.append({"name": k, "kind": v.kind.name,
+                           "default": None if v.default is inspect.Parameter.empty else repr(v.default),
+                           "has_default": v.default is not inspect.Parameter.empty})
+        entry = {"params": params}
+        if inspect.isclass(obj):
+            entry["protocol"] = sorted(n for n in ("name", "steps_per_frame", "focus_stack", "print_message", "run", "run_core",
+                                                   "run_frame", "run_step", "begin", "end", "add_action", "init", "callback",
+                                                   "sub_message", "sub_message_r", "img_ref", "process_frame", "align_images")
+                                       if callable(getattr(obj, n, None)))
+        out[name] = entry
+    with open(os.path.join(OUT, "api_surface.json"), "w") as fh:
+        json.dump(out, fh, indent=1)
+    print("  wrote api_surface.json", {k: len(v["params"]) for k, v in out.items()})
+
+
 def main():
     assert ri.available(), "needs /root/reference"
     os.makedirs(OUT, exist_ok=True)
     orc.build()
     if "--only-align" in sys.argv:
         align_case()
+        return
+    if "--only-api" in sys.argv:
+        api_case()
         return
     if "--only-depth-map" in sys.argv:
         depth_map_case()
@@ -547,6 +585,8 @@ def main():
     depth_map_case()
     print("alignment (the reference's align_images)")
     align_case()
+    print("API surface")
+    api_case()
     print("G5 primitives")
     primitive_cases()
     print("G7 base")

@@ -108,12 +108,16 @@ class StackJob(ActionBase):
         # 'tqdm' selects the reference's progress-bar callbacks (core/framework.py:158): bars are out of scope, the job runs
         self.callbacks = None if callbacks == 'tqdm' else callbacks
 
+    def init(self, a):
+        """stack_framework.py:23-24: the job hands itself to the action (paths, working directory)"""
+        a.init(self)
+
     def add_action(self, a):
         a.id = self.action_counter
         self.action_counter += 1
         a.logger = self.logger
         a.callbacks = self.callbacks
-        a.init(self)
+        self.init(a)
         self._actions.append(a)
 
     def run_core(self):

@@ -353,3 +353,41 @@ def test_png16_roundtrip_and_all_scanline_filters(tmp_path):
     a8 = (a >> 8).astype(np.uint8)
     io.write_img(str(tmp_path / "b.png"), a8)
     assert np.array_equal(io.read_img(str(tmp_path / "b.png")), a8)
+
+
+def test_mirrors_present_the_reference_api_surface():
+    """the one-import swap only works if the mirrors take what the reference's classes take.
+    tests/golden/api_surface.json was read from the reference's OWN modules with `inspect` (oracle/gen_golden.py::api_case):
+    every positional / keyword parameter of the reference exists in the mirror at the same position with the same
+    default (mirrors may ADD keyword-only extensions), the reference's `**kwargs` sinks are kept, and the protocol
+    methods the actions call on each other exist."""
+    import inspect
+    import json
+    import os
+    import shinestacker_amd as sa
+    from shinestacker_amd import actions, align
+    with open(os.path.join(os.path.dirname(__file__), "golden", "api_surface.json")) as fh:
+        gold = json.load(fh)
+    mine = {"StackJob": sa.StackJob, "FocusStack": sa.FocusStack, "FocusStackBunch": sa.FocusStackBunch,
+            "CombinedActions": sa.CombinedActions, "AlignFrames": sa.AlignFrames, "BalanceFrames": sa.BalanceFrames,
+            "PyramidStack": sa.PyramidStack, "DepthMapStack": sa.DepthMapStack, "align_images": align.align_images,
+            "get_bunches": actions.get_bunches, "img_subsample": align.img_subsample}
+    assert sorted(mine) == sorted(gold)
+    for name, ref in gold.items():
+        sig = inspect.signature(mine[name]).parameters
+        ref_pos = [p for p in ref["params"] if p["kind"] == "POSITIONAL_OR_KEYWORD"]
+        my_pos = [k for k, v in sig.items() if v.kind == v.POSITIONAL_OR_KEYWORD]
+        assert my_pos[:len(ref_pos)] == [p["name"] for p in ref_pos], (name, my_pos)
+        for p in ref_pos:
+            v = sig[p["name"]]
+            assert (v.default is not inspect.Parameter.empty) == p["has_default"], (name, p["name"])
+            if p["has_default"] and not (name == "CombinedActions" and p["name"] == "actions"):   # [] there, None here: same meaning
+                assert repr(v.default) == p["default"], (name, p["name"], v.default, p["default"])
+        if any(p["kind"] == "VAR_KEYWORD" for p in ref["params"]):
+            assert any(v.kind == v.VAR_KEYWORD for v in sig.values()), name
+        # what the mirror adds is keyword-only or defaulted: a reference call never has to change
+        for k, v in sig.items():
+            if k not in [p["name"] for p in ref["params"]] and v.kind in (v.POSITIONAL_OR_KEYWORD, v.KEYWORD_ONLY):
+                assert v.default is not inspect.Parameter.empty, (name, k)
+        for m in ref.get("protocol") or []:
+            assert callable(getattr(mine[name], m, None)), (name, m)
