@@ -426,6 +426,17 @@ MI_API int mi_dmap_create(mi_dmap_t** out, const mi_dmap_params_t* params);
 MI_API void mi_dmap_destroy(mi_dmap_t* d);
 MI_API int mi_dmap_reset(mi_dmap_t* d);                    /* forget the frames, keep the buffers */
 MI_API int mi_dmap_frames_pushed(const mi_dmap_t* d, int* n);
+/* the MAX map's temperature as a double: mi_dmap_params_t carries it as a float, which is exact for float-32 stacks (NumPy
+ * divides a float32 array by the float32 of a Python float) but not for float-64 ones (depth_map.py:60) */
+MI_API int mi_dmap_set_temperature(mi_dmap_t* d, double temperature);
+/* The stacker's steps one at a time, on n host planes of height x width -- the reference's public methods of the same
+ * names (depth_map.py:28-62; its tests call them), run by the kernels of the fused path with the handle's options:
+ *   stage 0  get_sobel_map      gray planes (float_type) -> |Sobel x| + |Sobel y|                (:28-34)
+ *   stage 1  get_laplacian_map  gray planes (float_type) -> |Laplacian(GaussianBlur)|            (:36-41)
+ *   stage 2  smooth_energy      energy planes (float_type) -> float32 planes, cv2.bilateralFilter (:43-52)
+ *   stage 3  get_focus_map      n energy planes -> n weight planes; both float32 when smooth_size > 0 or float_type is
+ *                               float-32, else float64; a zero total gives weight 0          (:54-62) */
+MI_API int mi_dmap_planes(mi_dmap_t* d, int stage, const void* host_in, int n, void* host_out);
 /* H x W x 3 BGR frame of `dtype`; row_stride_bytes 0 = packed.  The host form returns once the caller's
  * buffer may be reused; the device form copies on the handle's stream. */
 MI_API int mi_dmap_push_frame(mi_dmap_t* d, const void* host_bgr, size_t row_stride_bytes);

@@ -495,6 +495,39 @@ def align_case():
     _save("align", **arrays)
 
 
+def depth_map_steps_case():
+    """The reference's DepthMapStack step methods (depth_map.py:28-62: get_sobel_map, get_laplacian_map, smooth_energy,
+    get_focus_map -- public, and called by its own tests) run here over the cv2 shim on small gray stacks, float-32 and
+    float-64, both map types; the GPU test compares `shinestacker_amd.DepthMapStack`'s methods of the same names."""
+    import importlib
+    ri.load_pyramid_module()
+    mod = importlib.import_module("shinestacker.algorithms.depth_map")
+    mod.np = ri._NumpyWithExactExp()
+    rng = np.random.default_rng(77)
+    arrays, meta = {}, []
+    for tag, ft, shape, kw in (("f32", "float-32", (3, 45, 70), {}),
+                               ("f32_k3", "float-32", (2, 40, 52), {"kernel_size": 3, "blur_size": 3, "smooth_size": 9}),
+                               ("f64", "float-64", (3, 37, 51), {}),
+                               ("f64_max_nosmooth", "float-64", (3, 33, 40), {"map_type": "max", "smooth_size": 0, "temperature": 0.3}),
+                               ("f32_max", "float-32", (4, 30, 44), {"map_type": "max", "temperature": 0.5})):
+        algo = mod.DepthMapStack(float_type=ft, **kw)
+        n, h, w = shape
+        yy, xx = np.mgrid[0:h, 0:w]
+        gray = np.stack([np.clip(120 + 60 * np.sin(xx / (3.0 + i)) * np.cos(yy / (4.0 + i)) + rng.normal(0, 12, (h, w)), 0, 255)
+                         .astype(np.uint8) for i in range(n)]).astype(algo.float_type)
+        sob = algo.get_sobel_map(gray)
+        lap = algo.get_laplacian_map(gray)
+        en = lap / lap.max()
+        sm = algo.smooth_energy(en)
+        fm = algo.get_focus_map(sm)
+        arrays.update({f"{tag}_gray": gray, f"{tag}_sobel": sob, f"{tag}_laplacian": lap, f"{tag}_energy": en,
+                       f"{tag}_smoothed": sm, f"{tag}_focus": fm})
+        meta.append({"tag": tag, "float_type": ft, "kwargs": kw})
+        print("  ", tag, sob.dtype, lap.dtype, sm.dtype, fm.dtype)
+    arrays["meta"] = np.array(json.dumps(meta))
+    _save("depth_map_steps", **arrays)
+
+
 def api_case():
     """The drop-in boundary as the reference declares it: constructor / function signatures -- parameter
     names, order, kinds and defaults -- of the classes the mirrors stand in for, read from the reference's OWN modules with
@@ -539,6 +572,9 @@ def main():
         return
     if "--only-api" in sys.argv:
         api_case()
+        return
+    if "--only-depth-map-steps" in sys.argv:
+        depth_map_steps_case()
         return
     if "--only-depth-map" in sys.argv:
         depth_map_case()
@@ -587,6 +623,8 @@ def main():
     align_case()
     print("API surface")
     api_case()
+    print("depth map steps")
+    depth_map_steps_case()
     print("G5 primitives")
     primitive_cases()
     print("G7 base")

@@ -169,6 +169,8 @@ SIGNATURES = {
     "mi_dmap_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(DepthMapParams)]),
     "mi_dmap_destroy": (None, [C.c_void_p]),
     "mi_dmap_reset": (C.c_int, [C.c_void_p]),
+    "mi_dmap_set_temperature": (C.c_int, [C.c_void_p, C.c_double]),
+    "mi_dmap_planes": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "mi_dmap_frames_pushed": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "mi_dmap_push_frame": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "mi_dmap_push_frame_device": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -516,6 +518,8 @@ class DepthMap:
         h = C.c_void_p()
         check(lib.mi_dmap_create(C.byref(h), C.byref(p)))
         self._h = h
+        if int(map_type) == DM_MAP_MAX:
+            check(lib.mi_dmap_set_temperature(h, float(temperature)))   # the exact double (float-64 stacks divide by it)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -536,6 +540,15 @@ class DepthMap:
 
     def reset(self):
         check(load().mi_dmap_reset(self._h))
+
+    def planes(self, stage, planes, out_dtype):
+        """mi_dmap_planes: one step of the stacker on n host planes (n x H x W) -> n planes of `out_dtype`"""
+        a = np.ascontiguousarray(planes)
+        if a.ndim != 3 or a.shape[1:] != (self.height, self.width):
+            raise ValueError(f"planes of shape {a.shape}, expected (n, {self.height}, {self.width})")
+        out = np.empty(a.shape, out_dtype)
+        check(load().mi_dmap_planes(self._h, int(stage), a.ctypes.data, a.shape[0], out.ctypes.data))
+        return out
 
     @property
     def frames_pushed(self):

@@ -9,6 +9,7 @@
 
 struct mi_dmap {
     mi_dmap_params_t p{};
+    double temperature = 0.1;        // p.temperature, or the exact double handed to mi_dmap_set_temperature (float-64 stacks)
     size_t esz = 1;                  // bytes per input element
     hipStream_t stream = nullptr;
     std::vector<void*> frames;       // device copies of the pushed frames (kept across reset for reuse)
@@ -224,7 +225,7 @@ int dmap_focus_map(mi_dmap* d) {
     if (d->p.map_type == MI_DM_MAP_MAX)
         for (int i = 0; i < d->n; ++i)
             hipLaunchKernelGGL((dm_relative<W>), dm_grid1(np), dim3(256), 0, d->stream, (W*)d->en[i], (const W*)d->mx, np,
-                               (W)d->p.temperature, (W*)d->tot, i == 0);
+                               (W)d->temperature, (W*)d->tot, i == 0);
     MI_HIP(hipGetLastError());
     return MI_OK;
 }
@@ -286,9 +287,129 @@ int dmap_finish_t(mi_dmap* d) {
     return dmap_blend<T, F, F>(d);
 }
 
+// The stacker's steps one at a time on host planes (the reference's public methods, depth_map.py:28-62): same kernels as the
+// fused path, scratch planes allocated per call.
+template <typename F>
+int dmap_planes_t(mi_dmap* d, int stage, const void* host_in, int n, void* host_out) {
+    const int h = d->p.height, w = d->p.width;
+    const size_t np = (size_t)h * w;
+    hipStream_t st = d->stream;
+    const bool smoothed_w = d->p.smooth_size > 0 || sizeof(F) == 4;   // type of the planes the focus map works on (W)
+    struct Scratch {   // freed on every way out, the early returns of MI_HIP included
+        hipStream_t st;
+        std::vector<void*> v;
+        ~Scratch() {
+            (void)hipStreamSynchronize(st);
+            for (void* q : v) (void)hipFree(q);
+        }
+    } tmp{st, {}};
+    auto dalloc = [&](size_t bytes) -> void* {
+        void* q = nullptr;
+        if (hipMalloc(&q, bytes ? bytes : 1) != hipSuccess) return nullptr;
+        tmp.v.push_back(q);
+        return q;
+    };
+    auto cleanup = [&](int rc) { return rc; };
+    const DmTapsT<F>& taps = [&]() -> const DmTapsT<F>& {
+        if constexpr (sizeof(F) == 4) return d->taps; else return d->tapsd;
+    }();
+    if (stage == 0 || stage == 1) {            // get_sobel_map / get_laplacian_map: gray planes (F) -> energies (F)
+        F* in = (F*)dalloc(np * sizeof(F));
+        F *tB = (F*)dalloc(np * sizeof(F)), *tC = (F*)dalloc(np * sizeof(F)), *en = (F*)dalloc(np * sizeof(F)), *gmax = (F*)dalloc(sizeof(F));
+        if (!in || !tB || !tC || !en || !gmax) return cleanup(fail(MI_ERR_NOMEM, "out of device memory"));
+        for (int i = 0; i < n; ++i) {
+            MI_HIP(hipMemcpyAsync(in, (const F*)host_in + (size_t)i * np, np * sizeof(F), hipMemcpyHostToDevice, st));
+            MI_HIP(hipMemsetAsync(gmax, 0, sizeof(F), st));
+            if (stage == 0) {
+                hipLaunchKernelGGL((dm_sobel<F>), dm_grid2(h, w), dim3(256), 0, st, (const F*)in, h, w, en, gmax);
+            } else {
+                hipLaunchKernelGGL((dm_blur<true, F>), dm_grid2(h, w), dim3(256), 0, st, (const F*)in, h, w, tB, taps);
+                hipLaunchKernelGGL((dm_blur<false, F>), dm_grid2(h, w), dim3(256), 0, st, (const F*)tB, h, w, tC, taps);
+                if (d->k2.ksize == 5)
+                    hipLaunchKernelGGL((dm_laplacian_rows<5, F>), dim3(cdiv(w, 64), cdiv(h, 4 * DM_LAP_ROWS)), dim3(256), 0, st, (const F*)tC, h, w, en, gmax, d->k2);
+                else if (d->k2.ksize == 3)
+                    hipLaunchKernelGGL((dm_laplacian_rows<3, F>), dim3(cdiv(w, 64), cdiv(h, 4 * DM_LAP_ROWS)), dim3(256), 0, st, (const F*)tC, h, w, en, gmax, d->k2);
+                else
+                    hipLaunchKernelGGL((dm_laplacian<0, F>), dm_grid2(h, w), dim3(256), 0, st, (const F*)tC, h, w, en, gmax, d->k2);
+            }
+            MI_HIP(hipGetLastError());
+            MI_HIP(hipMemcpyAsync((F*)host_out + (size_t)i * np, en, np * sizeof(F), hipMemcpyDeviceToHost, st));
+            MI_HIP(hipStreamSynchronize(st));
+        }
+        return cleanup(MI_OK);
+    }
+    if (stage == 2) {                          // smooth_energy: planes (F) -> float32 planes (cv2.bilateralFilter on float32)
+        if (d->p.smooth_size <= 0) return cleanup(fail(MI_ERR_STATE, "smooth_size <= 0: nothing to smooth"));
+        static const uint32_t mm_init[2] = {0x7f800000u, 0u};
+        const dim3 gnorm((unsigned)std::min<size_t>((np + 255) / 256, 4096));
+        F* in = (F*)dalloc(np * sizeof(F));
+        float *f32 = (float*)dalloc(np * 4), *out = (float*)dalloc(np * 4), *acc = (float*)dalloc(np * 4), *sc = (float*)dalloc(8 * 4);
+        if (!in || !f32 || !out || !acc || !sc) return cleanup(fail(MI_ERR_NOMEM, "out of device memory"));
+        MI_HIP(hipMemsetAsync(sc, 0, 8 * 4, st));
+        for (int i = 0; i < n; ++i) {
+            MI_HIP(hipMemcpyAsync(in, (const F*)host_in + (size_t)i * np, np * sizeof(F), hipMemcpyHostToDevice, st));
+            const float* src = (const float*)in;
+            if constexpr (sizeof(F) == 8) {
+                hipLaunchKernelGGL(dm_to_f32, dm_grid1(np), dim3(256), 0, st, (const double*)in, np, f32);
+                src = f32;
+            }
+            MI_HIP(hipMemcpyAsync(sc, mm_init, 8, hipMemcpyHostToDevice, st));
+            // *gmax = sc[4] = 0: the plane is left as it is, only its min / max are taken
+            hipLaunchKernelGGL((dm_normalise<float>), gnorm, dim3(256), 0, st, (float*)src, np, (const float*)(sc + 4), sc);
+            hipLaunchKernelGGL(dm_bilateral_lut, dim3(1), dim3(1024), 0, st, (const float*)sc, d->color_coeff, d->lut, sc + 2);
+            DmBilateral a{src, out, h, w, d->radius, d->ntaps, d->disc, d->lut, sc + 2, acc, 0, 1};
+            hipLaunchKernelGGL(dm_bilateral, dim3(cdiv(w, 64), cdiv(h, 16)), dim3(256), 0, st, a);
+            MI_HIP(hipGetLastError());
+            MI_HIP(hipMemcpyAsync((float*)host_out + (size_t)i * np, out, np * 4, hipMemcpyDeviceToHost, st));
+            MI_HIP(hipStreamSynchronize(st));
+        }
+        return cleanup(MI_OK);
+    }
+    if (stage == 3) {                          // get_focus_map: n energy planes -> n weight planes, same type (W)
+        auto run = [&](auto zero) -> int {
+            using W = decltype(zero);
+            W* e = (W*)dalloc(np * sizeof(W) * (size_t)n);
+            W *tot = (W*)dalloc(np * sizeof(W)), *mx = (W*)dalloc(np * sizeof(W)), *wgt = (W*)dalloc(np * sizeof(W));
+            if (!e || !tot || !mx || !wgt) return fail(MI_ERR_NOMEM, "out of device memory");
+            MI_HIP(hipMemcpyAsync(e, host_in, np * sizeof(W) * (size_t)n, hipMemcpyHostToDevice, st));
+            const bool avg = d->p.map_type == MI_DM_MAP_AVERAGE;
+            for (int i = 0; i < n; ++i)
+                hipLaunchKernelGGL((dm_accumulate<W>), dm_grid1(np), dim3(256), 0, st, (const W*)(e + (size_t)i * np), np, avg ? tot : mx,
+                                   avg ? 0 : 1, i == 0);
+            if (!avg)
+                for (int i = 0; i < n; ++i)
+                    hipLaunchKernelGGL((dm_relative<W>), dm_grid1(np), dim3(256), 0, st, e + (size_t)i * np, (const W*)mx, np,
+                                       (W)d->temperature, tot, i == 0);
+            for (int i = 0; i < n; ++i) {
+                hipLaunchKernelGGL((dm_weight<W>), dm_grid1(np), dim3(256), 0, st, (const W*)(e + (size_t)i * np), (const W*)tot, np,
+                                   avg ? 1 : 0, wgt);
+                MI_HIP(hipGetLastError());
+                MI_HIP(hipMemcpyAsync((W*)host_out + (size_t)i * np, wgt, np * sizeof(W), hipMemcpyDeviceToHost, st));
+                MI_HIP(hipStreamSynchronize(st));
+            }
+            return MI_OK;
+        };
+        return cleanup(smoothed_w ? run(0.0f) : run(F(0)));
+    }
+    return cleanup(fail(MI_ERR_INVALID, "stage must be 0 .. 3"));
+}
+
 }  // namespace
 
 extern "C" {
+
+int mi_dmap_set_temperature(mi_dmap_t* d, double temperature) {
+    if (!d) return fail(MI_ERR_INVALID, "null handle");
+    if (d->p.map_type == MI_DM_MAP_MAX && !(temperature != 0.0)) return fail(MI_ERR_INVALID, "temperature must not be 0");
+    d->temperature = temperature;
+    return MI_OK;
+}
+
+int mi_dmap_planes(mi_dmap_t* d, int stage, const void* host_in, int n, void* host_out) {
+    if (!d || !host_in || !host_out || n < 1) return fail(MI_ERR_INVALID, "bad argument");
+    MI_HIP(hipSetDevice(d->p.device));
+    return d->f64 ? dmap_planes_t<double>(d, stage, host_in, n, host_out) : dmap_planes_t<float>(d, stage, host_in, n, host_out);
+}
 
 void mi_dmap_default_params(mi_dmap_params_t* p) {
     if (!p) return;
@@ -332,6 +453,7 @@ int mi_dmap_create(mi_dmap_t** out, const mi_dmap_params_t* params) {
     mi_dmap* d = new (std::nothrow) mi_dmap();
     if (!d) return fail(MI_ERR_NOMEM, "out of host memory");
     d->p = p;
+    d->temperature = (double)p.temperature;
     d->esz = p.dtype == MI_U8 ? 1 : 2;
     d->f64 = p.float_type == MI_F64;
     d->fsz = d->f64 ? 8 : 4;

@@ -90,6 +90,49 @@ class DepthMapStack(BaseStackAlgo):
             raise InvalidOptionError("map_type", self.map_type, details=" valid values are "
                                      f"{constants.DM_MAP_AVERAGE} and {constants.DM_MAP_MAX}.")
 
+    # ------------------------------------------------------------------ the steps, one at a time (depth_map.py:28-62)
+    # The reference's public methods of the same names; its tests call them (tests/test_0061_depth_map.py:30-41).  Same
+    # kernels as focus_stack, run on host arrays: `gray_images` / `energies` are (n, H, W) arrays as the reference passes them.
+    def _step_handle(self, planes):
+        planes = np.asarray(planes)
+        if planes.ndim != 3:
+            raise ValueError("expected an array of shape (n, H, W)")
+        return self._handle(planes.shape[1:], np.uint8), planes
+
+    def get_sobel_map(self, gray_images):
+        """depth_map.py:28-34: |Sobel_x| + |Sobel_y| (ksize 3) of every gray plane, in `float_type`."""
+        saved, self.energy = self.energy, constants.DM_ENERGY_SOBEL
+        try:
+            d, g = self._step_handle(gray_images)
+            return d.planes(0, g.astype(self.float_type), self.float_type)
+        finally:
+            self.energy = saved
+
+    def get_laplacian_map(self, gray_images):
+        """depth_map.py:36-41: |Laplacian(GaussianBlur(gray, blur_size), kernel_size)|, in `float_type`."""
+        saved, self.energy = self.energy, constants.DM_ENERGY_LAPLACIAN
+        try:
+            d, g = self._step_handle(gray_images)
+            return d.planes(1, g.astype(self.float_type), self.float_type)
+        finally:
+            self.energy = saved
+
+    def smooth_energy(self, energy_map):
+        """depth_map.py:43-52: cv2.bilateralFilter(energy, smooth_size, 25, 25) plane by plane; float32 out (the reference
+        fills a float32 array), the input unchanged when smooth_size <= 0."""
+        if self.smooth_size <= 0:
+            return energy_map
+        d, e = self._step_handle(energy_map)
+        return d.planes(2, e.astype(self.float_type), np.float32)
+
+    def get_focus_map(self, energies):
+        """depth_map.py:54-62: AVERAGE e / sum(e) (0 where the sum is 0: the reference leaves those undefined), MAX the
+        softmax of (e - max) / temperature; float32 unless a float-64 stacker runs without smoothing."""
+        self._check_map()
+        d, e = self._step_handle(energies)
+        wt = np.float32 if (self.smooth_size > 0 or self.float_type is np.float32) else np.float64
+        return d.planes(3, e.astype(wt), wt)
+
     # ------------------------------------------------------------------ the stacker
     def focus_stack(self, filenames):
         """depth_map.py:64-123.  `filenames`: sorted list of image paths."""

@@ -246,3 +246,37 @@ def test_full_size_properties(L):
     err_sharp = np.abs(out.astype(np.int16) - sharp.astype(np.int16))[inner].mean()
     err_soft = np.abs(out.astype(np.int16) - soft.astype(np.int16))[inner].mean()
     assert err_sharp < 0.35 * err_soft, (err_sharp, err_soft)
+
+
+def test_step_methods_equal_the_reference_methods_of_the_same_names(L):
+    """DepthMapStack.get_sobel_map / get_laplacian_map / smooth_energy / get_focus_map (depth_map.py:28-62: public methods
+    the reference's own tests call) against recordings of the REFERENCE's methods run over the cv2 shim
+    (oracle/gen_golden.py::depth_map_steps_case): float-32 and float-64, both map types, several kernel sizes.  Bit-equal
+    for the float-32 planes; float-64: the device library's exp / the fma contraction of a 25-tap float-64 chain may differ
+    in the last place (the tolerance the fused path's tests use)."""
+    import json
+    from shinestacker_amd import DepthMapStack
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "depth_map_steps.npz"))
+    for e in json.loads(str(z["meta"])):
+        t = e["tag"]
+        dms = DepthMapStack(float_type=e["float_type"], **e["kwargs"])
+        f64 = e["float_type"] == "float-64"
+
+        def same(got, want, what):
+            assert got.dtype == want.dtype and got.shape == want.shape, (t, what, got.dtype, want.dtype)
+            if f64 and want.dtype == np.float64:
+                assert np.allclose(got, want, rtol=1e-13, atol=1e-13 * max(1.0, float(np.abs(want).max()))), (t, what)
+            else:
+                assert np.array_equal(got, want), (t, what, float(np.abs(got.astype(np.float64) - want).max()))
+        same(dms.get_sobel_map(z[f"{t}_gray"]), z[f"{t}_sobel"], "sobel")
+        same(dms.get_laplacian_map(z[f"{t}_gray"]), z[f"{t}_laplacian"], "laplacian")
+        sm = dms.smooth_energy(z[f"{t}_energy"])
+        same(sm, z[f"{t}_smoothed"], "smoothed")
+        fm = dms.get_focus_map(z[f"{t}_smoothed"])
+        want = z[f"{t}_focus"]
+        if e["kwargs"].get("map_type", "average") == "average":
+            ok = z[f"{t}_smoothed"].sum(axis=0) != 0          # the reference leaves zero-total pixels uninitialised
+            assert fm.dtype == want.dtype and np.array_equal(fm[:, ok], want[:, ok]) and np.all(fm[:, ~ok] == 0), t
+        else:
+            same(fm, want, "focus")
+        dms.close()

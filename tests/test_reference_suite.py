@@ -144,6 +144,20 @@ def test_initialization():
     assert dms.energy == constants.DEFAULT_DM_ENERGY
 
 
+def test_sobel_map_with_examples():
+    filenames = [os.path.join("examples/input/img-jpg/", f"000{i}.jpg") for i in range(6)]
+    dms = DepthMapStack()
+    gray_images = []
+    for img_path in filenames[:3]:
+        img = read_img(img_path)          # (the reference reads with cv2.IMREAD_GRAYSCALE; any gray plane serves)
+        gray_images.append(img[..., 1].astype(np.float32))
+    gray_images = np.array(gray_images)
+    sobel_map = dms.get_sobel_map(gray_images)
+    assert sobel_map.shape == gray_images.shape
+    assert sobel_map.dtype == np.float32
+    assert np.all(sobel_map >= 0)  # Energy should always be positive
+
+
 def test_focus_stack_with_examples():
     filenames = [os.path.join("examples/input/img-jpg/", f"000{i}.jpg") for i in range(6)]
     dms = DepthMapStack()
