@@ -123,6 +123,18 @@ MI_API int mi_memcpy_d2h(int device, void* host_dst, const void* dev_src, size_t
 MI_API int mi_memcpy_d2d(int device, void* dev_dst, const void* dev_src, size_t bytes);
 MI_API int mi_memcpy_d2d_async(int device, void* stream, void* dev_dst, const void* dev_src, size_t bytes);
 MI_API int mi_device_synchronize(int device);
+/* ---- PyramidStack's step methods, one at a time, on host float32 images of c = 1 or 3 interleaved channels -- the
+ * reference's public methods of the same names (pyramid.py:24-63), always in ITS evaluation order (row-major 25-tap chain):
+ *   MI_PYR_CONVOLVE        in (h, w, c)                  -> out (h, w, c)             cv2.filter2D, REFLECT101   (:24-25)
+ *   MI_PYR_REDUCE          in (h, w, c)                  -> out (ceil(h/2), ceil(w/2), c)                      (:27-32)
+ *   MI_PYR_EXPAND          in (h, w, c)                  -> out (2h, 2w, c)                                    (:34-46)
+ *   MI_PYR_FUSE_LAPLACIAN  in (n, h, w, 3)               -> out (h, w, 3)   energy, first arg-max, where-sum  (:48-55)
+ *   MI_PYR_COLLAPSE_STEP   in = layer (h, w, c), in2 = coarser image (h2, w2, c) -> expand(in2)[:h, :w] + in   (:59-63)
+ *   MI_PYR_CLIP_ABS        in (h, w, c)                  -> clip(abs(in), 0, maxv)                             (:64)    */
+enum { MI_PYR_CONVOLVE = 0, MI_PYR_REDUCE = 1, MI_PYR_EXPAND = 2, MI_PYR_FUSE_LAPLACIAN = 3, MI_PYR_COLLAPSE_STEP = 4,
+       MI_PYR_CLIP_ABS = 5 };
+MI_API int mi_pyr_step(int device, int op, int use_fma, double gen_kernel, const void* host_in, const void* host_in2, int n,
+                int h, int w, int c, int h2, int w2, double maxv, void* host_out);
 /* free / total device memory in bytes (hipMemGetInfo): callers size resident stacks and batches with it */
 MI_API int mi_device_mem_info(int device, size_t* free_bytes, size_t* total_bytes);
 

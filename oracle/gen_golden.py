@@ -528,6 +528,48 @@ def depth_map_steps_case():
     _save("depth_map_steps", **arrays)
 
 
+def pyramid_steps_case():
+    """The reference's PyramidStack methods one at a time (pyramid.py:24-148: convolve, reduce_layer, expand_layer,
+    process_single_image, fuse_laplacian, get_fused_base, fuse_pyramids, collapse) on a small stack, over the cv2 shim; the
+    GPU test compares `shinestacker_amd.PyramidStack`'s methods of the same names with these recordings."""
+    rng = np.random.default_rng(99)
+    arrays = {}
+    for tag, dtype, (n, h, w), levels, use_fma in (("u8", np.uint8, (3, 44, 61), 2, True), ("u16", np.uint16, (3, 37, 50), 2, True),
+                                                   ("u8_nofma", np.uint8, (2, 40, 40), 1, False)):
+        mod = ri.load_pyramid_module(use_fma=use_fma, exact_log=True)
+        algo = mod.PyramidStack(min_size=8)
+        algo.process = ri.FakeProcess()
+        algo.dtype = dtype
+        hi = 256 if dtype == np.uint8 else 65536
+        algo.num_pixel_values, algo.max_pixel_value = hi, hi - 1
+        yy, xx = np.mgrid[0:h, 0:w]
+        frames = []
+        for i in range(n):
+            f = (0.5 + 0.4 * np.sin(xx / (2.5 + i)) * np.cos(yy / (3.0 + i)))[..., None] * np.array([0.9, 1.0, 0.8]) * (hi - 1)
+            frames.append(np.clip(f + rng.normal(0, hi / 30, f.shape), 0, hi - 1).astype(dtype))
+        f32 = frames[0].astype(np.float32)
+        arrays[f"{tag}_frames"] = np.stack(frames)
+        arrays[f"{tag}_convolve3"] = algo.convolve(f32)
+        arrays[f"{tag}_convolve1"] = algo.convolve(np.ascontiguousarray(f32[..., 1]))
+        arrays[f"{tag}_reduce3"] = algo.reduce_layer(f32)
+        arrays[f"{tag}_reduce1"] = algo.reduce_layer(np.ascontiguousarray(f32[..., 0]))
+        arrays[f"{tag}_expand3"] = algo.expand_layer(f32)
+        arrays[f"{tag}_expand1"] = algo.expand_layer(np.ascontiguousarray(f32[..., 2]))
+        pyrs = [algo.process_single_image(f, levels) for f in frames]
+        for i, p in enumerate(pyrs):
+            for lv, a in enumerate(p):
+                arrays[f"{tag}_pyr{i}_{lv}"] = a
+        arrays[f"{tag}_fuse_lap0"] = algo.fuse_laplacian(np.stack([p[0] for p in pyrs], axis=0))
+        arrays[f"{tag}_fused_base"] = algo.get_fused_base(np.stack([p[-1] for p in pyrs], axis=0))
+        fused = algo.fuse_pyramids(pyrs)
+        for lv, a in enumerate(fused):
+            arrays[f"{tag}_fused{lv}"] = a
+        arrays[f"{tag}_collapsed"] = algo.collapse(fused)
+        arrays[f"{tag}_meta"] = np.array(json.dumps({"levels": levels, "use_fma": use_fma, "dtype": np.dtype(dtype).name, "n": n}))
+        print("  ", tag, [a.shape for a in fused], arrays[f"{tag}_collapsed"].dtype)
+    _save("pyramid_steps", **arrays)
+
+
 def api_case():
     """The drop-in boundary as the reference declares it: constructor / function signatures -- parameter
     names, order, kinds and defaults -- of the classes the mirrors stand in for, read from the reference's OWN modules with
@@ -572,6 +614,9 @@ def main():
         return
     if "--only-api" in sys.argv:
         api_case()
+        return
+    if "--only-pyramid-steps" in sys.argv:
+        pyramid_steps_case()
         return
     if "--only-depth-map-steps" in sys.argv:
         depth_map_steps_case()
@@ -625,6 +670,8 @@ def main():
     api_case()
     print("depth map steps")
     depth_map_steps_case()
+    print("pyramid steps")
+    pyramid_steps_case()
     print("G5 primitives")
     primitive_cases()
     print("G7 base")

@@ -47,6 +47,8 @@ def make_cv2_shim(use_fma=True):
 
     def filter2D(img, ddepth, kernel, borderType=None, **_kw):
         assert ddepth == -1 and borderType == cv2.BORDER_REFLECT101
+        if img.ndim == 3:   # cv2 filters the channels of an interleaved image independently
+            return np.stack([orc.filter2D(np.ascontiguousarray(img[..., c]), kernel, use_fma) for c in range(img.shape[2])], axis=-1)
         return orc.filter2D(np.ascontiguousarray(img), kernel, use_fma)
 
     def cvtColor(img, code):

@@ -78,6 +78,8 @@ SIGNATURES = {
     "mi_memcpy_d2d": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]),
     "mi_memcpy_d2d_async": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "mi_device_synchronize": (C.c_int, [C.c_int]),
+    "mi_pyr_step": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                              C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p]),
     "mi_device_mem_info": (C.c_int, [C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "mi_stack_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(StackParams)]),
     "mi_stack_destroy": (None, [C.c_void_p]),
@@ -284,6 +286,32 @@ def is_pinned(arr):
     a0 = arr.ctypes.data
     a1 = a0 + arr.nbytes
     return any(b <= a0 and a1 <= b + n for b, n in _PINNED.items())
+
+
+PYR_CONVOLVE, PYR_REDUCE, PYR_EXPAND, PYR_FUSE_LAPLACIAN, PYR_COLLAPSE_STEP, PYR_CLIP_ABS = range(6)
+
+
+def pyr_step(op, img, img2=None, gen_kernel=0.4, use_fma=True, maxv=255.0, device=0):
+    """mi_pyr_step on float32 host arrays: (h, w), (h, w, 1 | 3), or (n, h, w, 3) for PYR_FUSE_LAPLACIAN"""
+    require_device()
+    a = np.ascontiguousarray(img, np.float32)
+    n = 1
+    if op == PYR_FUSE_LAPLACIAN:
+        n, h, w, c = a.shape
+    else:
+        h, w = a.shape[:2]
+        c = 1 if a.ndim == 2 else a.shape[2]
+    tail = () if a.ndim == 2 else (c,)
+    shape = {PYR_REDUCE: ((h + 1) // 2, (w + 1) // 2), PYR_EXPAND: (2 * h, 2 * w)}.get(op, (h, w)) + tail
+    out = np.empty(shape, np.float32)
+    b, h2, w2 = None, 0, 0
+    if img2 is not None:
+        b = np.ascontiguousarray(img2, np.float32)
+        h2, w2 = b.shape[:2]
+    check(load().mi_pyr_step(device, int(op), int(bool(use_fma)), float(gen_kernel), a.ctypes.data,
+                             b.ctypes.data if b is not None else None, int(n), int(h), int(w), int(c), int(h2), int(w2),
+                             float(maxv), out.ctypes.data))
+    return out
 
 
 def mem_info(device=0):

@@ -23,6 +23,7 @@
 #include "kernels_phase.hpp"
 #include "kernels_balance.hpp"
 #include "kernels_f64.hpp"
+#include "kernels_steps.hpp"
 
 using namespace mi;
 
@@ -1130,6 +1131,77 @@ int mi_memcpy_d2d_async(int device, void* stream, void* dev_dst, const void* dev
 int mi_device_synchronize(int device) {
     MI_HIP(hipSetDevice(device));
     MI_HIP(hipDeviceSynchronize());
+    return MI_OK;
+}
+
+int mi_pyr_step(int device, int op, int use_fma, double gen_kernel, const void* host_in, const void* host_in2, int n, int h,
+                int w, int c, int h2, int w2, double maxv, void* host_out) {
+    if (!host_in || !host_out) return fail(MI_ERR_INVALID, "null argument");
+    if (h < 1 || w < 1 || (c != 1 && c != 3) || n < 1) return fail(MI_ERR_INVALID, "bad geometry");
+    if (op < MI_PYR_CONVOLVE || op > MI_PYR_CLIP_ABS) return fail(MI_ERR_INVALID, "bad op %d", op);
+    MI_HIP(hipSetDevice(device));
+    K25 K{};
+    {
+        const double a = gen_kernel, k[5] = {0.25 - a / 2.0, 0.25, a, 0.25, 0.25 - a / 2.0};
+        for (int i = 0; i < 5; ++i)
+            for (int j = 0; j < 5; ++j) K.k[i * 5 + j] = (float)(k[i] * k[j]);
+    }
+    const size_t npx = (size_t)h * w;
+    size_t in_elems = npx * c, out_elems = npx * c, in2_elems = 0;
+    if (op == MI_PYR_REDUCE) out_elems = (size_t)((h + 1) / 2) * ((w + 1) / 2) * c;
+    else if (op == MI_PYR_EXPAND) out_elems = npx * 4 * c;
+    else if (op == MI_PYR_FUSE_LAPLACIAN) {
+        if (c != 3) return fail(MI_ERR_INVALID, "fuse_laplacian takes 3-channel images");
+        in_elems = npx * 3 * n;
+        out_elems = npx * 3;
+    } else if (op == MI_PYR_COLLAPSE_STEP) {
+        if (!host_in2 || h2 < 1 || w2 < 1 || 2 * h2 < h || 2 * w2 < w) return fail(MI_ERR_INVALID, "bad coarse level");
+        in2_elems = (size_t)h2 * w2 * c;
+    }
+    struct Scratch {
+        std::vector<void*> v;
+        ~Scratch() {
+            (void)hipDeviceSynchronize();
+            for (void* q : v) (void)hipFree(q);
+        }
+        float* get(size_t elems) {
+            void* q = nullptr;
+            if (hipMalloc(&q, (elems ? elems : 1) * sizeof(float)) != hipSuccess) return nullptr;
+            v.push_back(q);
+            return (float*)q;
+        }
+    } tmp;
+    float *din = tmp.get(in_elems), *dout = tmp.get(out_elems), *din2 = in2_elems ? tmp.get(in2_elems) : nullptr;
+    if (!din || !dout || (in2_elems && !din2)) return fail(MI_ERR_NOMEM, "out of device memory");
+    hipStream_t st = nullptr;
+    MI_HIP(hipMemcpyAsync(din, host_in, in_elems * sizeof(float), hipMemcpyHostToDevice, st));
+    const bool fma = use_fma != 0;
+    if (op <= MI_PYR_EXPAND) {
+        if (c == 3) fma ? pyr_step_launch<3, true>(op, st, din, h, w, dout, K) : pyr_step_launch<3, false>(op, st, din, h, w, dout, K);
+        else fma ? pyr_step_launch<1, true>(op, st, din, h, w, dout, K) : pyr_step_launch<1, false>(op, st, din, h, w, dout, K);
+    } else if (op == MI_PYR_FUSE_LAPLACIAN) {
+        float *q = tmp.get(npx * n), *e = tmp.get(npx * n);
+        if (!q || !e) return fail(MI_ERR_NOMEM, "out of device memory");
+        const unsigned g1 = (unsigned)((npx * n + 255) / 256);
+        if (fma) hipLaunchKernelGGL((step_gray_sq<true>), dim3(g1), dim3(256), 0, st, (const float*)din, npx * n, q);
+        else hipLaunchKernelGGL((step_gray_sq<false>), dim3(g1), dim3(256), 0, st, (const float*)din, npx * n, q);
+        for (int i = 0; i < n; ++i)
+            fma ? pyr_step_launch<1, true>(MI_PYR_CONVOLVE, st, q + (size_t)i * npx, h, w, e + (size_t)i * npx, K)
+                : pyr_step_launch<1, false>(MI_PYR_CONVOLVE, st, q + (size_t)i * npx, h, w, e + (size_t)i * npx, K);
+        hipLaunchKernelGGL(step_fuse, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, st, (const float*)e, (const float*)din, n, npx, dout);
+    } else if (op == MI_PYR_COLLAPSE_STEP) {
+        MI_HIP(hipMemcpyAsync(din2, host_in2, in2_elems * sizeof(float), hipMemcpyHostToDevice, st));
+        float* up = tmp.get((size_t)h2 * w2 * 4 * c);
+        if (!up) return fail(MI_ERR_NOMEM, "out of device memory");
+        if (c == 3) fma ? pyr_step_launch<3, true>(MI_PYR_EXPAND, st, din2, h2, w2, up, K) : pyr_step_launch<3, false>(MI_PYR_EXPAND, st, din2, h2, w2, up, K);
+        else fma ? pyr_step_launch<1, true>(MI_PYR_EXPAND, st, din2, h2, w2, up, K) : pyr_step_launch<1, false>(MI_PYR_EXPAND, st, din2, h2, w2, up, K);
+        hipLaunchKernelGGL(step_add_crop, dim3(cdiv(w, 64), cdiv(h, 4)), dim3(64, 4), 0, st, (const float*)up, 2 * w2, (const float*)din, h, w, c, dout);
+    } else {   // MI_PYR_CLIP_ABS
+        hipLaunchKernelGGL(step_clip_abs, dim3((unsigned)((out_elems + 255) / 256)), dim3(256), 0, st, (const float*)din, out_elems, (float)maxv, dout);
+    }
+    MI_HIP(hipGetLastError());
+    MI_HIP(hipMemcpyAsync(host_out, dout, out_elems * sizeof(float), hipMemcpyDeviceToHost, st));
+    MI_HIP(hipStreamSynchronize(st));
     return MI_OK;
 }
 

@@ -164,6 +164,95 @@ class PyramidStack(BaseStackAlgo):
             self._stack.close()
             self._stack = None
 
+    # ------------------------------------------------------------------ the steps, one at a time (pyramid.py:24-148)
+    # The reference's public methods of the same names, on NumPy arrays, run on the GPU.  They always use the reference's
+    # own evaluation order (the 25-tap chain) whatever `arith` the stacker fuses with, and float-32 arithmetic.
+    def _f32_steps(self):
+        if self.float_type is not np.float32:
+            raise InvalidOptionError("float_type", "float-64", details=" the step methods run in float-32; focus_stack supports both")
+
+    def _pyr(self, op, img, img2=None, maxv=255.0):
+        self._f32_steps()
+        return _lib.pyr_step(op, img, img2, gen_kernel=self.gen_kernel_a, use_fma=self.use_fma, maxv=maxv, device=self.device)
+
+    def convolve(self, image):
+        """pyramid.py:24-25: cv2.filter2D(image, -1, gen_kernel, BORDER_REFLECT101), 2-D or H x W x C."""
+        return self._pyr(_lib.PYR_CONVOLVE, image)
+
+    def reduce_layer(self, layer):
+        """pyramid.py:27-32: convolve(layer)[::2, ::2] per channel."""
+        return self._pyr(_lib.PYR_REDUCE, layer)
+
+    def expand_layer(self, layer):
+        """pyramid.py:34-46: 4 * convolve(zero-stuffed 2h x 2w image) per channel."""
+        return self._pyr(_lib.PYR_EXPAND, layer)
+
+    def fuse_laplacian(self, laplacians):
+        """pyramid.py:48-55: energy = convolve(gray(lap)^2), first arg-max over the stack, sum of np.where(best == i, lap, 0)."""
+        return self._pyr(_lib.PYR_FUSE_LAPLACIAN, np.stack([np.asarray(lap, np.float32) for lap in laplacians]))
+
+    def collapse(self, pyramid):
+        """pyramid.py:57-64: from the base up, expand_layer(img)[:h, :w] + layer, then clip(abs(.), 0, max_pixel_value)."""
+        img = np.asarray(pyramid[-1], np.float32)
+        for layer in pyramid[-2::-1]:
+            img = self._pyr(_lib.PYR_COLLAPSE_STEP, layer, img)
+        return self._pyr(_lib.PYR_CLIP_ABS, img, maxv=float(self.max_pixel_value))
+
+    def process_single_image(self, img, levels):
+        """pyramid.py:125-139: the Laplacian pyramid of one frame, [lap_0, ..., lap_{levels-1}, base] -- produced by the fused
+        level kernels themselves: in a stack of ONE frame that frame wins every pixel, so the stack's fused Laplacians are
+        the frame's own and its coarsest Gaussian is the base."""
+        self._f32_steps()
+        img = np.ascontiguousarray(img)
+        h, w = img.shape[:2]
+        if levels < 1:
+            return [img.astype(np.float32)]
+        min_size = max(1, int(min(h, w) // (1 << levels)))
+        while int(np.log2(min(h, w) / min_size)) > levels:      # int(log2(min / min_size)) must be exactly `levels`
+            min_size += 1
+        st = _lib.Stack(h, w, in_dtype=img.dtype if img.dtype in (np.uint8, np.uint16) else np.float32,
+                        out_dtype=self.dtype if self.dtype is not None else np.uint8, min_size=min_size,
+                        kernel_size=self.kernel_size, gen_kernel=self.gen_kernel_a, use_fma=self.use_fma, device=self.device,
+                        arith="exact")
+        try:
+            # (the reference stops early when a level would get a side below 4 pixels, :129-130: so does the library)
+            st.push_frame(img if img.dtype in (np.uint8, np.uint16) else img.astype(np.float32))
+            out = [st.tap(_lib.TAP_FUSED_LAP, lv) for lv in range(st.levels)]
+            out.append(st.tap(_lib.TAP_GAUSS, st.levels))
+            return out
+        finally:
+            st.close()
+
+    def get_fused_base(self, images):
+        """pyramid.py:95-111: entropy / deviation rule over the stack of base images (n, h, w, 3) -- a stack without
+        Laplacian levels run through the library, whose fused base is tapped before the final clip and cast."""
+        self._f32_steps()
+        images = np.ascontiguousarray(images, np.float32)
+        n, h, w = images.shape[:3]
+        out_dtype = self.dtype if self.dtype is not None else np.uint8
+        st = _lib.Stack(h, w, in_dtype=np.float32, out_dtype=out_dtype, min_size=max(h, w) + 1, kernel_size=self.kernel_size,
+                        gen_kernel=self.gen_kernel_a, use_fma=self.use_fma, device=self.device, arith="exact")
+        try:
+            assert st.levels == 0
+            for i in range(n):
+                st.push_frame(images[i])
+            st.finish()
+            return st.tap(_lib.TAP_FUSED_BASE)
+        finally:
+            st.close()
+
+    def fuse_pyramids(self, all_laplacians):
+        """pyramid.py:141-148: the base by get_fused_base, every other level by fuse_laplacian, coarsest first; returned in
+        the order [lap_0, ..., base] the reference returns (fused[::-1])."""
+        fused = [self.get_fused_base(np.stack([lap[-1] for lap in all_laplacians], axis=0))]
+        for layer in range(len(all_laplacians[0]) - 2, -1, -1):
+            if self.process is not None:
+                self.print_message(f': fusing pyramids, layer: {layer + 1}')
+            fused.append(self.fuse_laplacian(np.stack([lap[layer] for lap in all_laplacians], axis=0)))
+        if self.process is not None:
+            self.print_message(': pyramids fusion completed')
+        return fused[::-1]
+
     # ------------------------------------------------------------------ callbacks
     def _step(self, i):
         if self.do_step_callback:

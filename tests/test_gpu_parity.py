@@ -590,3 +590,46 @@ def test_pinned_frames_are_uploaded_without_the_bounce_copy_and_give_the_same_st
     assert np.array_equal(st.finish(), want)
     st.close()
     del pinned, ring
+
+
+@pytest.mark.parametrize("tag", ["u8", "u16", "u8_nofma"])
+def test_step_methods_equal_the_reference_methods_of_the_same_names(L, tag):
+    """SURVEY 8(a) P2-P9 one method at a time: PyramidStack.convolve / reduce_layer / expand_layer / process_single_image /
+    fuse_laplacian / get_fused_base / fuse_pyramids / collapse (pyramid.py:24-148) against recordings of the REFERENCE's own
+    methods run over the cv2 shim (oracle/gen_golden.py::pyramid_steps_case): 2-D and 3-channel images, odd sizes, 8 and 16
+    bit, with and without fused multiply-add.  Bit-equal (-0.0 == +0.0 being the only slack)."""
+    from shinestacker_amd import PyramidStack
+    z = np.load(os.path.join(GOLDEN, "pyramid_steps.npz"))
+    meta = json.loads(str(z[f"{tag}_meta"]))
+    dt = np.dtype(meta["dtype"])
+    algo = PyramidStack(min_size=8, use_fma=meta["use_fma"])
+    algo._set_dtype(dt)
+    frames = z[f"{tag}_frames"]
+    f32 = frames[0].astype(np.float32)
+
+    def same(got, want, what):
+        assert got.dtype == want.dtype and got.shape == want.shape, (what, got.dtype, got.shape, want.dtype, want.shape)
+        assert np.array_equal(got, want), (what, float(np.abs(got - want).max()))
+    same(algo.convolve(f32), z[f"{tag}_convolve3"], "convolve3")
+    same(algo.convolve(np.ascontiguousarray(f32[..., 1])), z[f"{tag}_convolve1"], "convolve1")
+    same(algo.reduce_layer(f32), z[f"{tag}_reduce3"], "reduce3")
+    same(algo.reduce_layer(np.ascontiguousarray(f32[..., 0])), z[f"{tag}_reduce1"], "reduce1")
+    same(algo.expand_layer(f32), z[f"{tag}_expand3"], "expand3")
+    same(algo.expand_layer(np.ascontiguousarray(f32[..., 2])), z[f"{tag}_expand1"], "expand1")
+    L_, n = meta["levels"], meta["n"]
+    pyrs = [algo.process_single_image(frames[i], L_) for i in range(n)]
+    for i, p in enumerate(pyrs):
+        assert len(p) == L_ + 1
+        for lv, a in enumerate(p):
+            same(a, z[f"{tag}_pyr{i}_{lv}"], f"pyr{i}_{lv}")
+    same(algo.fuse_laplacian(np.stack([p[0] for p in pyrs], axis=0)), z[f"{tag}_fuse_lap0"], "fuse_laplacian")
+    same(algo.get_fused_base(np.stack([p[-1] for p in pyrs], axis=0)), z[f"{tag}_fused_base"], "get_fused_base")
+    fused = algo.fuse_pyramids(pyrs)
+    for lv, a in enumerate(fused):
+        same(a, z[f"{tag}_fused{lv}"], f"fused{lv}")
+    same(algo.collapse(fused), z[f"{tag}_collapsed"], "collapse")
+    # and the whole thing is what focus_stack does: collapse(fuse_pyramids(...)).astype(dtype) == the exact-mode stack
+    if L_ == int(np.log2(min(frames.shape[1:3]) / 8)):    # (the recording of u8_nofma was made with fewer levels than focus_stack picks)
+        want = PyramidStack(min_size=8, use_fma=meta["use_fma"], arith="exact").focus_stack_arrays(list(frames))
+        assert np.array_equal(z[f"{tag}_collapsed"].astype(dt), want)
+    algo.close()
