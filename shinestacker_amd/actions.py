@@ -57,6 +57,14 @@ class ActionBase:
         self.base_message = ''
         self._t0 = None
 
+    def time(self):
+        """core/framework.py:160-161: seconds since run() started"""
+        return time.time() - self._t0
+
+    def set_terminator(self, tqdm=False, end='\n'):
+        """core/framework.py:112-116 switches the console handler's line terminator for its progress bars; there are no
+        bars here (out of scope), the call is accepted and does nothing"""
+
     def callback(self, key, *args):
         cbs = getattr(self, 'callbacks', None)
         if cbs is not None:
@@ -149,6 +157,10 @@ class FrameDirectory:
         self.scratch_output_dir = scratch_output_dir
         self.input_full_path = None
         self.filenames = None
+
+    def folder_list_str(self):
+        """stack_framework.py:106-111"""
+        return "folder: " + self.input_full_path.replace(self.working_path, '').lstrip('/')
 
     def folder_filelist(self):
         _dirpath, _, names = next(os.walk(self.input_full_path))
