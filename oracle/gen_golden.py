@@ -585,6 +585,8 @@ def api_case():
     objs = {"StackJob": sf.StackJob, "FocusStack": st.FocusStack, "FocusStackBunch": st.FocusStackBunch,
             "CombinedActions": sf.CombinedActions, "AlignFrames": al.AlignFrames, "BalanceFrames": bal.BalanceFrames,
             "PyramidStack": pyr.PyramidStack, "DepthMapStack": dm.DepthMapStack, "align_images": al.align_images,
+            "detect_and_compute": al.detect_and_compute, "get_good_matches": al.get_good_matches,
+            "find_transform": al.find_transform, "validate_align_config": al.validate_align_config,
             "get_bunches": st.get_bunches, "img_subsample": importlib.import_module("shinestacker.algorithms.utils").img_subsample}
     out = {}
     for name, obj in objs.items():
@@ -597,7 +599,11 @@ def api_case():
         if inspect.isclass(obj):
             entry["protocol"] = sorted(n for n in ("name", "steps_per_frame", "focus_stack", "print_message", "run", "run_core",
                                                    "run_frame", "run_step", "begin", "end", "add_action", "init", "callback",
-                                                   "sub_message", "sub_message_r", "img_ref", "process_frame", "align_images")
+                                                   "sub_message", "sub_message_r", "img_ref", "process_frame", "align_images",
+                                                   "convolve", "reduce_layer", "expand_layer", "process_single_image",
+                                                   "fuse_laplacian", "get_fused_base", "fuse_pyramids", "collapse",
+                                                   "get_sobel_map", "get_laplacian_map", "smooth_energy", "get_focus_map",
+                                                   "time", "set_terminator", "folder_list_str")
                                        if callable(getattr(obj, n, None)))
         out[name] = entry
     with open(os.path.join(OUT, "api_surface.json"), "w") as fh:

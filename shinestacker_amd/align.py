@@ -95,12 +95,7 @@ def validate_align_config(detector, descriptor, match_method):
         raise ValueError(f"Detector {detector} and descriptor {descriptor} require matching method Hamming distance")
 
 
-def opencv_estimator(img_0_sub, img_1_sub, feature_config, matching_config, alignment_config):
-    """The reference's estimator (align.py:48-151, :186-199) on OpenCV: returns (n_good_matches, M or None); M maps
-    img_0 (moving) onto img_1 (reference): 2x3 for ALIGN_RIGID, 3x3 for ALIGN_HOMOGRAPHY."""
-    detector_name, descriptor_name = feature_config['detector'], feature_config['descriptor']
-    match_method = matching_config['match_method']
-    validate_align_config(detector_name, descriptor_name, match_method)
+def _cv2():
     try:
         import cv2
     except ImportError as e:
@@ -108,6 +103,33 @@ def opencv_estimator(img_0_sub, img_1_sub, feature_config, matching_config, alig
             "opencv_estimator needs OpenCV (cv2), which is not installed; use estimator='auto' / ecc_estimator(), or "
             "pass estimator=callable(img_0_sub, img_1_sub, feature_cfg, matching_cfg, alignment_cfg) "
             "-> (n_good_matches, M)") from e
+    return cv2
+
+
+def get_good_matches(des_0, des_1, matching_config=None):
+    """align.py:48-68: FLANN k-nearest-neighbour matches through Lowe's ratio test, or Hamming brute force with cross-check,
+    sorted by distance."""
+    cv2 = _cv2()
+    matching_config = {**_DEFAULT_MATCHING_CONFIG, **(matching_config or {})}
+    match_method = matching_config['match_method']
+    c = constants
+    if match_method == c.MATCHING_KNN:
+        flann = cv2.FlannBasedMatcher({'algorithm': matching_config['flann_idx_kdtree'], 'trees': matching_config['flann_trees']},
+                                      {'checks': matching_config['flann_checks']})
+        return [m for m, n in flann.knnMatch(des_0, des_1, k=2) if m.distance < matching_config['threshold'] * n.distance]
+    if match_method == c.MATCHING_NORM_HAMMING:
+        return sorted(cv2.BFMatcher(cv2.NORM_HAMMING, crossCheck=True).match(des_0, des_1), key=lambda x: x.distance)
+    raise InvalidOptionError('match_method', match_method, f". Valid options are: {c.MATCHING_KNN}, {c.MATCHING_NORM_HAMMING}")
+
+
+def detect_and_compute(img_0, img_1, feature_config=None, matching_config=None):
+    """align.py:90-122: key points and descriptors of both images (8-bit gray, utils.py:37-43) and their good matches:
+    returns (kp_0, kp_1, good_matches)."""
+    feature_config = {**_DEFAULT_FEATURE_CONFIG, **(feature_config or {})}
+    matching_config = {**_DEFAULT_MATCHING_CONFIG, **(matching_config or {})}
+    detector_name, descriptor_name = feature_config['detector'], feature_config['descriptor']
+    validate_align_config(detector_name, descriptor_name, matching_config['match_method'])
+    cv2 = _cv2()
     c = constants
 
     def gray8(im):  # (utils.py:37-43 img_bw_8bit)
@@ -118,7 +140,7 @@ def opencv_estimator(img_0_sub, img_1_sub, feature_config, matching_config, alig
                c.DETECTOR_BRISK: cv2.BRISK_create}
     des_map = {c.DESCRIPTOR_SIFT: cv2.SIFT_create, c.DESCRIPTOR_ORB: cv2.ORB_create,
                c.DESCRIPTOR_AKAZE: cv2.AKAZE_create, c.DESCRIPTOR_BRISK: cv2.BRISK_create}
-    g0, g1 = gray8(img_0_sub), gray8(img_1_sub)
+    g0, g1 = gray8(img_0), gray8(img_1)
     det = det_map[detector_name]()
     if detector_name == descriptor_name and detector_name in (c.DETECTOR_SIFT, c.DETECTOR_AKAZE, c.DETECTOR_BRISK):
         kp0, d0 = det.detectAndCompute(g0, None)
@@ -127,29 +149,38 @@ def opencv_estimator(img_0_sub, img_1_sub, feature_config, matching_config, alig
         des = des_map[descriptor_name]()
         kp0, d0 = des.compute(g0, det.detect(g0, None))
         kp1, d1 = des.compute(g1, det.detect(g1, None))
-    if match_method == c.MATCHING_KNN:
-        flann = cv2.FlannBasedMatcher({'algorithm': matching_config['flann_idx_kdtree'], 'trees': matching_config['flann_trees']},
-                                      {'checks': matching_config['flann_checks']})
-        good = [m for m, n in flann.knnMatch(d0, d1, k=2) if m.distance < matching_config['threshold'] * n.distance]
-    elif match_method == c.MATCHING_NORM_HAMMING:
-        good = sorted(cv2.BFMatcher(cv2.NORM_HAMMING, crossCheck=True).match(d0, d1), key=lambda x: x.distance)
-    else:
-        raise InvalidOptionError('match_method', match_method, f". Valid options are: {c.MATCHING_KNN}, {c.MATCHING_NORM_HAMMING}")
+    return kp0, kp1, get_good_matches(d0, d1, matching_config)
+
+
+def find_transform(src_pts, dst_pts, transform=constants.DEFAULT_TRANSFORM, method='RANSAC', rans_threshold=3.0,
+                   max_iters=2000, align_confidence=99.9, refine_iters=100):
+    """align.py:125-151: cv2.findHomography / cv2.estimateAffinePartial2D with the reference's arguments; returns what
+    they return, (matrix, inlier mask)."""
+    cv2 = _cv2()
+    c = constants
+    cv2_method = {'RANSAC': cv2.RANSAC, 'LMEDS': cv2.LMEDS}.get(method)
+    if cv2_method is None:
+        raise InvalidOptionError('align_method', method, f". Valid options are: {c.ALIGN_RANSAC}, {c.ALIGN_LMEDS}")
+    if transform == c.ALIGN_HOMOGRAPHY:
+        return cv2.findHomography(src_pts, dst_pts, method=cv2_method, ransacReprojThreshold=rans_threshold, maxIters=max_iters)
+    if transform == c.ALIGN_RIGID:
+        return cv2.estimateAffinePartial2D(src_pts, dst_pts, method=cv2_method, ransacReprojThreshold=rans_threshold,
+                                           confidence=align_confidence / 100.0, refineIters=refine_iters)
+    raise InvalidOptionError("transform", transform)
+
+
+def opencv_estimator(img_0_sub, img_1_sub, feature_config, matching_config, alignment_config):
+    """The reference's estimator (align.py:48-151, :186-199) on OpenCV -- `detect_and_compute`, `get_good_matches`,
+    `find_transform` above, in the reference's order: returns (n_good_matches, M or None); M maps img_0 (moving) onto
+    img_1 (reference): 2x3 for ALIGN_RIGID, 3x3 for ALIGN_HOMOGRAPHY."""
+    kp0, kp1, good = detect_and_compute(img_0_sub, img_1_sub, feature_config, matching_config)
     transform = alignment_config['transform']
-    if len(good) < (4 if transform == c.ALIGN_HOMOGRAPHY else 3):
+    if len(good) < (4 if transform == constants.ALIGN_HOMOGRAPHY else 3):
         return len(good), None
-    method = {'RANSAC': cv2.RANSAC, 'LMEDS': cv2.LMEDS}.get(alignment_config['align_method'])
-    if method is None:
-        raise InvalidOptionError('align_method', alignment_config['align_method'], f". Valid options are: {c.ALIGN_RANSAC}, {c.ALIGN_LMEDS}")
     src = np.float32([kp0[m.queryIdx].pt for m in good]).reshape(-1, 1, 2)
     dst = np.float32([kp1[m.trainIdx].pt for m in good]).reshape(-1, 1, 2)
-    if transform == c.ALIGN_HOMOGRAPHY:
-        m, _ = cv2.findHomography(src, dst, method=method, ransacReprojThreshold=alignment_config['rans_threshold'],
-                                  maxIters=alignment_config['max_iters'])
-    else:
-        m, _ = cv2.estimateAffinePartial2D(src, dst, method=method, ransacReprojThreshold=alignment_config['rans_threshold'],
-                                           confidence=alignment_config['align_confidence'] / 100.0,
-                                           refineIters=alignment_config['refine_iters'])
+    m, _ = find_transform(src, dst, transform, alignment_config['align_method'],
+                          *(alignment_config[k] for k in ['rans_threshold', 'max_iters', 'align_confidence', 'refine_iters']))
     return len(good), m
 
 

@@ -371,6 +371,8 @@ def test_mirrors_present_the_reference_api_surface():
     mine = {"StackJob": sa.StackJob, "FocusStack": sa.FocusStack, "FocusStackBunch": sa.FocusStackBunch,
             "CombinedActions": sa.CombinedActions, "AlignFrames": sa.AlignFrames, "BalanceFrames": sa.BalanceFrames,
             "PyramidStack": sa.PyramidStack, "DepthMapStack": sa.DepthMapStack, "align_images": align.align_images,
+            "detect_and_compute": align.detect_and_compute, "get_good_matches": align.get_good_matches,
+            "find_transform": align.find_transform, "validate_align_config": align.validate_align_config,
             "get_bunches": actions.get_bunches, "img_subsample": align.img_subsample}
     assert sorted(mine) == sorted(gold)
     for name, ref in gold.items():
