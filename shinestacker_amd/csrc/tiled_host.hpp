@@ -17,6 +17,9 @@
 
 namespace mi {
 
+#ifndef MI_NUP
+#define MI_NUP 64
+#endif
 struct TiledState {
     int bcap = 0;                   // frames per fused launch of the host-frame ring (and of MI_ARITH_EXACT)
     int dev_cap = 0;                // MI_ARITH_SEPARABLE, frames resident in HBM: largest batch (0 = not decided yet)
@@ -54,7 +57,7 @@ struct TiledState {
     hipEvent_t evInput = nullptr;                           // device pushes: the frames are complete in s->stream order
     long pin_no = 0;
     // zero-copy uploads (mi_stack_push_frame_pinned): one event per upload in a ring, for mi_stack_wait_uploads
-    static constexpr int NUP = 64;
+    static constexpr int NUP = MI_NUP;
     hipEvent_t evUp[NUP] = {};
     long up_no = 0;
 };
@@ -895,7 +898,19 @@ int tiled_push_host(mi_stack* s, const void* host_bgr, size_t row_stride_bytes, 
         MI_HIP(hipStreamSynchronize(s->stream));
     } else {
         if (!t->stc) {
-            MI_HIP(hipStreamCreateWithFlags(&t->stc, hipStreamNonBlocking));
+            // The copy stream gets a priority class of its own -- the LOW one: the main stream is normal, the side streams
+            // high, and no kernel ever runs at low priority.  HIP maps a process's streams onto a handful of hardware queues
+            // per priority class, and a copy that shares a queue with ANOTHER handle's kernels waits behind them: two handles
+            // that alternate (pipeline.bunches_then_stack) then upload and compute one after the other instead of side by
+            // side (measured: 60 ms per 10-frame bunch = 52 upload + 8 compute).  MI_COPY_PRIO: 0 plain, 1 high, 2 low.
+#ifndef MI_COPY_PRIO
+#define MI_COPY_PRIO 2
+#endif
+            if (MI_COPY_PRIO) {
+                int prio_lo = 0, prio_hi = 0;
+                MI_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+                MI_HIP(hipStreamCreateWithPriority(&t->stc, hipStreamNonBlocking, MI_COPY_PRIO == 1 ? prio_hi : prio_lo));
+            } else MI_HIP(hipStreamCreateWithFlags(&t->stc, hipStreamNonBlocking));
             MI_HIP(hipEventCreateWithFlags(&t->evCopied, hipEventDisableTiming));
             MI_HIP(hipEventCreateWithFlags(&t->evRingFree, hipEventDisableTiming));
         }

@@ -458,7 +458,7 @@ def align_and_stack_device(dev_frames, n_frames, height, width, dtype, ref_idx=-
 
 def bunches_then_stack(get_frame, n_frames, height, width, dtype, frames=constants.DEFAULT_FRAMES,
                        overlap=constants.DEFAULT_OVERLAP, device=0, out_dev=None, on_bunch=None, on_final=None,
-                       check_running=None, stacks=None, **stack_kwargs):
+                       check_running=None, stacks=None, results_buf=None, **stack_kwargs):
     """BASELINE config 5's two-stage flow in memory (the reference's `FocusStackBunch` followed by `FocusStack`,
     stack.py:61-113, examples/stack-from-frames): the frames are fused in bunches of `frames` with `overlap` shared
     (`get_bunches`), every bunch result is the stacker's OUTPUT type -- truncated to the input dtype exactly as the file
@@ -474,7 +474,9 @@ def bunches_then_stack(get_frame, n_frames, height, width, dtype, frames=constan
     `on_bunch(k, stack)` / `on_final(stack, results_buffer)`: called after a bunch's / the final stack's frames were pushed and before it is
     finished (tests tap the selection state there).  `stacks`: optional `_lib.Stack` handles to reuse, the LAST one for stage 2
     and the others (one, or two that alternate so that uploads and kernels of neighbouring bunches overlap) for stage 1 -- a handle owns pinned upload buffers and gigabytes of device buffers whose allocation costs more than a
-    short job; they are reset, not closed.  Returns the fused image (or None when `out_dev` is given) and the list of
+    short job; they are reset, not closed.  `results_buf`: an optional `_lib.DeviceBuffer` of at least n_bunches frames for the
+    bunch results (`hipMalloc` / `hipFree` of the 38 GB a 1024-frame job needs cost ~2 s: a caller that runs job after job
+    keeps it); it is not freed here.  Returns the fused image (or None when `out_dev` is given) and the list of
     bunches (frame indices)."""
     from .actions import get_bunches
     _lib.require_device()
@@ -485,7 +487,10 @@ def bunches_then_stack(get_frame, n_frames, height, width, dtype, frames=constan
     bunches = get_bunches(list(range(n_frames)), frames, overlap)
     if not bunches:
         raise ValueError("no frames")
-    results = _lib.DeviceBuffer(fb * len(bunches), device)
+    own_results = results_buf is None
+    if not own_results and results_buf.nbytes < fb * len(bunches):
+        raise InvalidOptionError("results_buf", results_buf.nbytes, f": {len(bunches)} bunch results need {fb * len(bunches)} bytes")
+    results = _lib.DeviceBuffer(fb * len(bunches), device) if own_results else results_buf
     # Stage 1 alternates between TWO handles: resetting a handle waits for ITS previous bunch only, so the uploads of bunch
     # k + 1 (handle B's copy stream) run while bunch k is still being fused (handle A) -- with one handle the PCIe link
     # idled through every bunch's kernels and collapse (measured: 38 GB/s of a 57 GB/s link; config 5 is upload-bound).
@@ -514,7 +519,8 @@ def bunches_then_stack(get_frame, n_frames, height, width, dtype, frames=constan
                 st.sync()       # a reused handle may still be writing into `results`
             else:
                 st.close()
-        results.free()
+        if own_results:
+            results.free()
         raise
     if not stacks:
         for st in stage1:
@@ -536,5 +542,6 @@ def bunches_then_stack(get_frame, n_frames, height, width, dtype, frames=constan
             st2.close()
         else:
             st2.sync()      # `results` is freed below
-        results.free()
+        if own_results:
+            results.free()
     return out, bunches

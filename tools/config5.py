@@ -44,11 +44,19 @@ def two_stage(args):
         host.append(fr)
     # this box's pinned host-to-device rate: the ceiling of any upload path
     pin0 = host[0] if not args.pageable else L.host_alloc((H, W, 3), np.uint16)
-    L.load().mi_memcpy_h2d(0, buf.ptr, pin0.ctypes.data, per)
-    t0 = time.perf_counter()
-    for _ in range(5):
-        L.check(L.load().mi_memcpy_h2d(0, buf.ptr, pin0.ctypes.data, per))
-    pinned_rate = 5 * per / (time.perf_counter() - t0)
+    # ... measured through the library's own copy stream (asynchronous copies out of pinned memory, ten frames back to back,
+    # the best of three rounds; a synchronous hipMemcpy read 29 or 57 GB/s from run to run on the same box)
+    cal = L.Stack(H, W, in_dtype=np.uint16, out_dtype=np.uint16)
+    rates = []
+    for _ in range(3):
+        cal.reset()
+        t0 = time.perf_counter()
+        for _k in range(10):
+            cal.push_frame(pin0)
+        cal.wait_uploads(0)
+        rates.append(10 * per / (time.perf_counter() - t0))
+    cal.close()
+    pinned_rate = max(rates)
     out = L.DeviceBuffer(per)
     marks = {}
 
@@ -59,10 +67,19 @@ def two_stage(args):
     nst = 2 if args.one_handle else 3     # stage 1 alternates between two handles unless --one-handle (the round-3 flow)
     stacks = tuple(L.Stack(H, W, in_dtype=np.uint16, out_dtype=np.uint16) for _ in range(nst))
 
+    # the buffer of the bunch results is made once, like the handles (a job of many stacks keeps it): allocating and freeing
+    # it costs ~50 ms per GB, 2 s for the 38 GB of a 1024-frame job, and is reported separately
+    from shinestacker_amd.actions import get_bunches
+    nbunch = len(get_bunches(list(range(N)), 10, 2))
+    t0 = time.perf_counter()
+    results = L.DeviceBuffer(per * nbunch)
+    L.check(L.load().mi_device_synchronize(0))
+    results_alloc_s = time.perf_counter() - t0
+
     def run():
         t0 = time.perf_counter()
         _, bunches = bunches_then_stack(lambda i: host[i % ndist], N, H, W, np.uint16, out_dev=out.ptr, on_final=on_final,
-                                        stacks=stacks)
+                                        stacks=stacks, results_buf=results)
         t1 = time.perf_counter()
         return bunches, marks["stage1_done"] - t0, t1 - marks["stage1_done"]
     run()
@@ -91,6 +108,7 @@ def two_stage(args):
                       "host_to_device_GB_per_s": pushed * per / s1 / 1e9,
                       "pinned_memcpy_GB_per_s": pinned_rate / 1e9, "upload_s": upload_s, "compute_s": compute_s, "wall_s": s1,
                       "overlap_efficiency": max(upload_s, compute_s) / s1,
+                      "results_buffer_GB": per * nbunch / 1e9, "results_alloc_s": results_alloc_s,
                       "stage1_handles": nst - 1, "upload_path": "bounce copy (3 pinned buffers, copy-thread pool)" if args.pageable else
                                      "zero-copy from pinned frames (mi_stack_push_frame_pinned)"}))
     for s_ in stacks:
