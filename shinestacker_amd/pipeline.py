@@ -10,6 +10,7 @@ followed by `PyramidStack` on the aligned frames -- without the intermediate qua
 two-action reference job writes, which for lossless formats changes nothing.
 """
 import ctypes as C
+import time
 
 import numpy as np
 
@@ -458,7 +459,7 @@ def align_and_stack_device(dev_frames, n_frames, height, width, dtype, ref_idx=-
 
 def bunches_then_stack(get_frame, n_frames, height, width, dtype, frames=constants.DEFAULT_FRAMES,
                        overlap=constants.DEFAULT_OVERLAP, device=0, out_dev=None, on_bunch=None, on_final=None,
-                       check_running=None, stacks=None, results_buf=None, **stack_kwargs):
+                       check_running=None, stacks=None, results_buf=None, info=None, **stack_kwargs):
     """BASELINE config 5's two-stage flow in memory (the reference's `FocusStackBunch` followed by `FocusStack`,
     stack.py:61-113, examples/stack-from-frames): the frames are fused in bunches of `frames` with `overlap` shared
     (`get_bunches`), every bunch result is the stacker's OUTPUT type -- truncated to the input dtype exactly as the file
@@ -476,7 +477,8 @@ def bunches_then_stack(get_frame, n_frames, height, width, dtype, frames=constan
     and the others (one, or two that alternate so that uploads and kernels of neighbouring bunches overlap) for stage 1 -- a handle owns pinned upload buffers and gigabytes of device buffers whose allocation costs more than a
     short job; they are reset, not closed.  `results_buf`: an optional `_lib.DeviceBuffer` of at least n_bunches frames for the
     bunch results (`hipMalloc` / `hipFree` of the 38 GB a 1024-frame job needs cost ~2 s: a caller that runs job after job
-    keeps it); it is not freed here.  Returns the fused image (or None when `out_dev` is given) and the list of
+    keeps it); it is not freed here.  `info`: an optional dict that receives `stage1_s` (first push to the last bunch result
+    on the device) and `stage2_s` (the stack over the bunch results, to its result).  Returns the fused image (or None when `out_dev` is given) and the list of
     bunches (frame indices)."""
     from .actions import get_bunches
     _lib.require_device()
@@ -491,6 +493,7 @@ def bunches_then_stack(get_frame, n_frames, height, width, dtype, frames=constan
     if not own_results and results_buf.nbytes < fb * len(bunches):
         raise InvalidOptionError("results_buf", results_buf.nbytes, f": {len(bunches)} bunch results need {fb * len(bunches)} bytes")
     results = _lib.DeviceBuffer(fb * len(bunches), device) if own_results else results_buf
+    t_start = time.perf_counter()
     # Stage 1 alternates between TWO handles: resetting a handle waits for ITS previous bunch only, so the uploads of bunch
     # k + 1 (handle B's copy stream) run while bunch k is still being fused (handle A) -- with one handle the PCIe link
     # idled through every bunch's kernels and collapse (measured: 38 GB/s of a 57 GB/s link; config 5 is upload-bound).
@@ -526,6 +529,7 @@ def bunches_then_stack(get_frame, n_frames, height, width, dtype, frames=constan
         for st in stage1:
             st.close()
     st2 = stacks[-1] if stacks else _lib.Stack(height, width, in_dtype=dt, out_dtype=dt, device=device, **stack_kwargs)
+    t_stage1 = time.perf_counter()
     try:
         st2.reset()
         st2.push_frames_device(results.ptr, len(bunches), fb)
@@ -544,4 +548,6 @@ def bunches_then_stack(get_frame, n_frames, height, width, dtype, frames=constan
             st2.sync()      # `results` is freed below
         if own_results:
             results.free()
+    if info is not None:
+        info.update(stage1_s=t_stage1 - t_start, stage2_s=time.perf_counter() - t_stage1)
     return out, bunches

@@ -58,12 +58,6 @@ def two_stage(args):
     cal.close()
     pinned_rate = max(rates)
     out = L.DeviceBuffer(per)
-    marks = {}
-
-    def on_final(st2, _results):
-        L.check(L.load().mi_device_synchronize(0))
-        marks["stage1_done"] = time.perf_counter()
-
     nst = 2 if args.one_handle else 3     # stage 1 alternates between two handles unless --one-handle (the round-3 flow)
     stacks = tuple(L.Stack(H, W, in_dtype=np.uint16, out_dtype=np.uint16) for _ in range(nst))
 
@@ -77,11 +71,10 @@ def two_stage(args):
     results_alloc_s = time.perf_counter() - t0
 
     def run():
-        t0 = time.perf_counter()
-        _, bunches = bunches_then_stack(lambda i: host[i % ndist], N, H, W, np.uint16, out_dev=out.ptr, on_final=on_final,
-                                        stacks=stacks, results_buf=results)
-        t1 = time.perf_counter()
-        return bunches, marks["stage1_done"] - t0, t1 - marks["stage1_done"]
+        info = {}
+        _, bunches = bunches_then_stack(lambda i: host[i % ndist], N, H, W, np.uint16, out_dev=out.ptr,
+                                        stacks=stacks, results_buf=results, info=info)
+        return bunches, info["stage1_s"], info["stage2_s"]
     run()
     bunches, s1, s2 = run()
     pushed = sum(len(b) for b in bunches)
