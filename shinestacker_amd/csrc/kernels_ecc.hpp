@@ -142,23 +142,179 @@ __global__ __launch_bounds__(256) void ecc_gray_s2(const T* __restrict__ img, in
     for (int q = 0; q < min(4, w - x0); ++q) d[q] = o[q];
 }
 
+// four consecutive gray values of an INTERIOR tile (every source pixel inside the frame), 8-bit frames, area rule: the
+// channel sums of a 2 x 2 source block straight from the loaded words -- v_dot4_u32_u8 with a 0 / 1 weight per byte adds the
+// bytes of one channel that a word holds to the running sum (which starts at the rounding constant 2): at most four
+// instructions per sum instead of four byte extractions and three adds.  Same integers, same floats as ecc_gray4.
+__device__ __forceinline__ void ecc_gray4_u8_area(const uint32_t r0[6], const uint32_t r1[6], float o[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float c[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int A = 6 * q + k, B = A + 3;                     // byte offsets of the pair's two pixels, channel k
+            const int a = A >> 2, b = B >> 2;
+            const uint32_t wa = 1u << (8 * (A & 3)), wb = 1u << (8 * (B & 3));
+            uint32_t sum = 2u;
+            if (a == b) {
+                sum = __builtin_amdgcn_udot4(r0[a], wa | wb, sum, false);
+                sum = __builtin_amdgcn_udot4(r1[a], wa | wb, sum, false);
+            } else {
+                sum = __builtin_amdgcn_udot4(r0[a], wa, sum, false);
+                sum = __builtin_amdgcn_udot4(r0[b], wb, sum, false);
+                sum = __builtin_amdgcn_udot4(r1[a], wa, sum, false);
+                sum = __builtin_amdgcn_udot4(r1[b], wb, sum, false);
+            }
+            c[k] = (float)(sum >> 2);
+        }
+        o[q] = 0.114f * c[0] + 0.587f * c[1] + 0.299f * c[2];
+    }
+}
+
 // ecc_pyramid2: sub-sampled gray, level 0 (= 5 x 5 binomial blur of it) and level 1 (= blur + 2x decimation of level 0) of
 // one frame in ONE pass over it: the three kernels above / below read and wrote the gray image and level 0 twice each
 // (100 us per 24 MP frame for what is one 72 MB read and 30 MB of writes).  A workgroup owns a 64 x 32 tile of level 0 and
 // the 32 x 16 tile of level 1 under it: gray patch (halo 4) -> row pass -> level-0 patch (halo 2: what level 1's taps
 // reach) -> row pass -> level-1 tile, all through LDS.  Replicate borders = clamped reads of in-image patch entries, the
 // sums in ecc_blur_tile's order: the pyramids are bit-identical to the separate kernels' (GPU test).
+//
+// Round 4: the kernel was VALU-bound (~1350 instructions per thread: an index division, five clamps and five address
+// computations per output and pass).  A tile whose patches lie inside the image -- all but the frame's rim -- takes the
+// INTERIOR path: no clamps, four outputs per thread from two 16-byte LDS reads in the row passes, a register window sliding
+// down a column in the column passes, the 8-bit area sums by v_dot4 (above).  Every sum keeps its order (the leading
+// `0.f + k[0] * v` of the generic form is exact: the products are >= +0), so both paths give the same bits.
+constexpr int ECC_P2_GS = 76;   // gray patch row stride: a multiple of 4 (16-byte LDS accesses of the interior path)
+
+template <typename T, bool AREA>
+__device__ __forceinline__ void ecc_pyramid2_interior(const T* __restrict__ img, int src_h, int src_w, int w,
+                                                      float* __restrict__ L0, int w1, float* __restrict__ L1,
+                                                      float* sG, float* sR, float* sP, int x0, int y0, int tid) {
+    constexpr int TW = 64, TH = 32;
+    constexpr int GW = TW + 8, GH = TH + 8, GS = ECC_P2_GS;
+    constexpr int PW = TW + 4, PH = TH + 4, PS = PW + 1;
+    constexpr float k0 = 1.f / 16, k1 = 4.f / 16, k2 = 6.f / 16;
+    // ---- gray patch: 40 rows x 18 groups of four
+    if constexpr (AREA && sizeof(T) == 1) {
+        // a thread's three groups: all six 24-byte loads issued before the first sum (the third group of the last 48
+        // threads does not exist: they load their second one again and drop it)
+        constexpr int NG = GH * (GW / 4), NR = (NG + 255) / 256;
+        uint32_t r0[NR][6], r1[NR][6];
+#pragma unroll
+        for (int n = 0; n < NR; ++n) {
+            const int g = min(tid + 256 * n, NG - 1);
+            const int r = g / (GW / 4), c = 4 * (g - r * (GW / 4));
+            const uint8_t* p0 = (const uint8_t*)img + ((size_t)2 * (y0 - 4 + r) * src_w + 2 * (x0 - 4 + c)) * 3;
+            __builtin_memcpy(r0[n], p0, 24);
+            __builtin_memcpy(r1[n], p0 + (size_t)src_w * 3, 24);
+        }
+#pragma unroll
+        for (int n = 0; n < NR; ++n) {
+            const int g = tid + 256 * n;
+            if (g < NG) {
+                const int r = g / (GW / 4), c = 4 * (g - r * (GW / 4));
+                float o[4];
+                ecc_gray4_u8_area(r0[n], r1[n], o);
+                *reinterpret_cast<float4*>(sG + r * GS + c) = make_float4(o[0], o[1], o[2], o[3]);
+            }
+        }
+    } else {
+        for (int g = tid; g < GH * (GW / 4); g += 256) {
+            const int r = g / (GW / 4), c = 4 * (g - r * (GW / 4));
+            float o[4];
+            ecc_gray4<T, AREA>(img, src_h, src_w, w, x0 - 4 + c, y0 - 4 + r, o);
+            *reinterpret_cast<float4*>(sG + r * GS + c) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
+    __syncthreads();
+    // ---- level 0, row pass: 40 rows x 17 groups of four columns of the level-0 patch (patch column c reads gray c .. c+4)
+    for (int g = tid; g < GH * (PW / 4); g += 256) {
+        const int r = g / (PW / 4), c = 4 * (g - r * (PW / 4));
+        const float4 a = *reinterpret_cast<const float4*>(sG + r * GS + c);
+        const float4 b = *reinterpret_cast<const float4*>(sG + r * GS + c + 4);
+        const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float row = k0 * v[q];
+            row += k1 * v[q + 1];
+            row += k2 * v[q + 2];
+            row += k1 * v[q + 3];
+            row += k0 * v[q + 4];
+            sR[r * PS + c + q] = row;
+        }
+    }
+    __syncthreads();
+    // ---- level 0, column pass: 68 columns x 3 runs of 12 rows; a run slides a 5-row window down its column
+    if (tid < 3 * PW) {
+        const int run = tid / PW, c = tid - run * PW;
+        const int r0 = 12 * run;                      // patch rows r0 .. r0+11 read row-pass rows r0 .. r0+15
+        const float* col = sR + r0 * PS + c;
+        float v0 = col[0], v1 = col[PS], v2 = col[2 * PS], v3 = col[3 * PS];
+        const bool cin = c >= 2 && c < PW - 2;
+#pragma unroll
+        for (int j = 0; j < 12; ++j) {
+            const float v4 = col[(j + 4) * PS];
+            float acc = k0 * v0;
+            acc += k1 * v1;
+            acc += k2 * v2;
+            acc += k1 * v3;
+            acc += k0 * v4;
+            const int r = r0 + j;
+            sP[r * PS + c] = acc;
+            if (cin && r >= 2 && r < PH - 2) L0[(size_t)(y0 - 2 + r) * w + (x0 - 2 + c)] = acc;
+            v0 = v1; v1 = v2; v2 = v3; v3 = v4;
+        }
+    }
+    __syncthreads();
+    // ---- level 1, row pass (decimating): 36 rows x 32 columns; column j reads patch columns 2j .. 2j+4
+    float* sR1 = sR;
+    constexpr int R1S = TW / 2 + 1;
+    for (int i = tid; i < PH * (TW / 2); i += 256) {
+        const int r = i >> 5, j = i & 31;
+        const float* p = sP + r * PS + 2 * j;
+        float row = k0 * p[0];
+        row += k1 * p[1];
+        row += k2 * p[2];
+        row += k1 * p[3];
+        row += k0 * p[4];
+        sR1[r * R1S + j] = row;
+    }
+    __syncthreads();
+    // ---- level 1, column pass: 16 x 32 outputs, two per thread (rows yl and yl + 8)
+    {
+        const int j = tid & 31, yl = tid >> 5;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int y = yl + 8 * e;
+            const float* p = sR1 + (2 * y) * R1S + j;
+            float acc = k0 * p[0];
+            acc += k1 * p[R1S];
+            acc += k2 * p[2 * R1S];
+            acc += k1 * p[3 * R1S];
+            acc += k0 * p[4 * R1S];
+            L1[(size_t)(y0 / 2 + y) * w1 + (x0 / 2 + j)] = acc;
+        }
+    }
+}
+
 template <typename T, bool AREA>
 __global__ __launch_bounds__(256) void ecc_pyramid2(const T* __restrict__ img, int src_h, int src_w, int h, int w,
                                                     float* __restrict__ L0, int h1, int w1, float* __restrict__ L1) {
     constexpr int TW = 64, TH = 32;
-    constexpr int GW = TW + 8, GH = TH + 8, GS = GW + 1;      // gray patch: level coordinates x0-4 .., y0-4 ..
+    constexpr int GW = TW + 8, GH = TH + 8, GS = ECC_P2_GS;   // gray patch: level coordinates x0-4 .., y0-4 ..
     constexpr int PW = TW + 4, PH = TH + 4, PS = PW + 1;      // level-0 patch: x0-2 .., y0-2 ..
-    __shared__ float sG[GH * GS];      // later: level 1's row pass [PH][TW / 2 + 1]
-    __shared__ float sR[GH * PS];      // level 0's row pass
-    __shared__ float sP[PH * PS];      // level-0 patch
-    static_assert(PH * (TW / 2 + 1) <= GH * GS, "level 1's row pass aliases the gray patch");
+    // two LDS images (23 KB: six workgroups per CU): the gray patch, whose space the level-0 patch takes once the row pass
+    // has consumed it, and the row pass of level 0, whose space the row pass of level 1 takes
+    __shared__ __attribute__((aligned(16))) float sG[GH * GS];
+    __shared__ float sR[GH * PS];
+    float* sP = sG;
+    static_assert(PH * PS <= GH * GS, "the level-0 patch aliases the gray patch");
+    static_assert(PH * (TW / 2 + 1) <= GH * PS, "level 1's row pass aliases level 0's");
     const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH, tid = threadIdx.x;
+    // interior: the gray patch and the source pixels under it inside the frame (the level-1 tile then is, too)
+    if (x0 >= 4 && y0 >= 4 && x0 + TW + 4 <= w && y0 + TH + 4 <= h && 2 * (x0 + TW + 4) <= src_w && 2 * (y0 + TH + 4) <= src_h) {
+        ecc_pyramid2_interior<T, AREA>(img, src_h, src_w, w, L0, w1, L1, sG, sR, sP, x0, y0, tid);
+        return;
+    }
     const float k[5] = {1.f / 16, 4.f / 16, 6.f / 16, 4.f / 16, 1.f / 16};
     // ---- gray patch, four entries per thread and step (the patch starts on a multiple of 4)
     for (int g = tid; g < GH * (GW / 4); g += 256) {
@@ -195,7 +351,7 @@ __global__ __launch_bounds__(256) void ecc_pyramid2(const T* __restrict__ img, i
     }
     __syncthreads();
     // ---- level 1, row pass (decimating): every in-image row of the level-0 patch x the tile's 32 columns
-    float* sR1 = sG;
+    float* sR1 = sR;
     constexpr int R1S = TW / 2 + 1;
     for (int i = tid; i < PH * (TW / 2); i += 256) {
         const int r = i / (TW / 2), j = i - r * (TW / 2);
