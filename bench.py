@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--arith", default="separable", choices=["separable", "exact"])
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--batch", type=int, default=0, help="frames per fused launch (0 = library default)")
-    ap.add_argument("--source", default="device", choices=["device", "host"],
+    ap.add_argument("--source", default="device", choices=["device", "host", "host-pinned"],
                     help="host: frames are pushed from host memory one by one (PCIe-inclusive rate; "
                          "never the headline value)")
     ap.add_argument("--no-verify", action="store_true")
@@ -442,9 +442,14 @@ def main():
     out_dt = np.uint16 if args.dtype == "u16" else np.uint8
 
     host_frames = None
-    if args.source == "host":
+    if args.source != "device":
         nh = min(F, 8)  # a few distinct host frames, cycled
         host_frames = [buf.download((H, W, 3), dt, offset=i * per) for i in range(nh)]
+        if args.source == "host-pinned":   # the caller's frames lie in pinned memory: uploaded without the bounce copy
+            pinned = [L.host_alloc((H, W, 3), dt) for _ in host_frames]
+            for a, b in zip(pinned, host_frames):
+                a[...] = b
+            host_frames = pinned
 
     def barrier(st):
         if world > 1 or force_dist:
@@ -563,7 +568,7 @@ def main():
             "warmup": args.warmup, "setup_pass_outside_timing": args.warmup == 0, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{total_frames}x{W}x{H}x3 {args.dtype} frames "
-                                   f"{'resident in HBM' if args.source == 'device' else 'pushed from host memory (PCIe inside the timed region)'}, "
+                                   f"{'resident in HBM' if args.source == 'device' else 'pushed from ' + ('pinned ' if args.source == 'host-pinned' else '') + 'host memory (PCIe inside the timed region)'}, "
                                    f"{st.levels}-level Laplacian pyramid fusion "
                                    f"(BASELINE.json configs[{1 if world == 1 or args.scaling == 'weak' else 2}])",
                        "frames_per_gpu": F, "source": args.source, "arith": args.arith,
