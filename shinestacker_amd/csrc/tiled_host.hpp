@@ -250,16 +250,16 @@ inline int level_chunk_frames(int nb, int tiles, bool* parallel) {
 
 // Super-block order of an interior launch: longest-processing-time-first assignment of the super-blocks (weight = tiles
 // inside the interior rectangle) to the eight XCDs; group g = 8 * round + XCD of the launch takes order[g].
-inline int build_sb_order(mi_stack* s, int l, int nty, int ntx) {
+inline int build_sb_order(mi_stack* s, int l, int nty, int ntx, int sbw = SB, int sbh = SB) {
     TiledState* t = tstate(s);
     if ((int)t->sbOrder.size() <= l) { t->sbOrder.resize(l + 1, nullptr); t->sbGroups.resize(l + 1, 0); }
     if (t->sbOrder[l]) return MI_OK;
-    const int sbx = cdiv(ntx, SB), sby = cdiv(nty, SB), nsb = sbx * sby;
+    const int sbx = cdiv(ntx, sbw), sby = cdiv(nty, sbh), nsb = sbx * sby;
     if (nsb >= 0xFFFF) return MI_OK;   // (never: 65 535 super-blocks are 4 M tiles) keep the plain order
     std::vector<std::pair<int, int>> sb(nsb);   // (tiles, index)
     for (int S = 0; S < nsb; ++S) {
         const int y = S / sbx, x = S - y * sbx;
-        sb[S] = {std::min(SB, nty - y * SB) * std::min(SB, ntx - x * SB), S};
+        sb[S] = {std::min(sbh, nty - y * sbh) * std::min(sbw, ntx - x * sbw), S};
     }
     std::stable_sort(sb.begin(), sb.end(), [](const std::pair<int, int>& a, const std::pair<int, int>& b) { return a.first > b.first; });
     std::vector<int> lists[8];
@@ -446,6 +446,9 @@ int launch_level_sep(mi_stack* s, int l, int set, const void* src, size_t src_st
     LevelArgs a{};
     a.src = src;
     a.src_stride = src_stride;
+#ifdef MI_STUDY_SAME_FRAME   // study: every frame of a level-0 launch reads frame 0's addresses (L2 / Infinity Cache instead of HBM)
+    if (l == 0) a.src_stride = 0;
+#endif
     a.gnext = t->Gb[set][l + 1];
     a.gnext_stride = t->gstride[l + 1];
     a.nframes = nb;
@@ -540,10 +543,10 @@ int launch_level_sep(mi_stack* s, int l, int set, const void* src, size_t src_st
     // parallel chunks: one launch over all the frames; otherwise consecutive launches of `fc` frames (the interior and the
     // border launches of a level touch disjoint pixels, so each sequence only has to keep its own order)
     const int nborder = ntiles - nyi * nxi;
-    const int nsb = cdiv(nxi, SB) * cdiv(nyi, SB);
-    int ngroups = cdiv(nsb, 8) * 8;   // 64-workgroup groups of the interior launch
+    const int nsb = cdiv(nxi, SEP_SBW) * cdiv(nyi, SEP_SBH);
+    int ngroups = cdiv(nsb, 8) * 8;   // super-block-sized groups of workgroups of the interior launch
     if (nyi > 0 && !MI_ABL(4096)) {
-        int rc = build_sb_order(s, l, nyi, nxi);
+        int rc = build_sb_order(s, l, nyi, nxi, SEP_SBW, SEP_SBH);
         if (rc) return rc;
         if (t->sbOrder[l]) { a.sb_order = t->sbOrder[l]; ngroups = t->sbGroups[l]; }
     }
@@ -554,6 +557,9 @@ int launch_level_sep(mi_stack* s, int l, int set, const void* src, size_t src_st
     auto frames_of = [&](int f0) {
         const int nf = parallel ? nb : std::min(fc, f_end - f0);
         a.src = (const char*)src + (size_t)f0 * src_stride;
+#ifdef MI_STUDY_SAME_FRAME
+        if (l == 0) a.src = src;
+#endif
         a.gnext = t->Gb[set][l + 1] + (size_t)f0 * a.gnext_stride;
         a.nframes = nf;
         a.chunk_frames = parallel ? fc : nf;
@@ -575,7 +581,7 @@ int launch_level_sep(mi_stack* s, int l, int set, const void* src, size_t src_st
         ps.r.launches = nlaunch;
         for (int f0 = f_begin; f0 < f_end; f0 += step) {
             frames_of(f0);
-            hipLaunchKernelGGL(kin, dim3(ngroups * SB * SB, nchunks), dim3(NT), lds_in, st_in, a);
+            hipLaunchKernelGGL(kin, dim3(ngroups * SEP_SBW * SEP_SBH, nchunks), dim3(NT), lds_in, st_in, a);
         }
     }
     if (nchunks > 1) {
