@@ -72,6 +72,14 @@ template <typename TIn> constexpr int sep_nt() { return sizeof(TIn) == 4 ? MI_SE
 #ifndef MI_SEP_TOUCH
 #define MI_SEP_TOUCH 0
 #endif
+// V rows a lane of P1 produces for 8 / 16-bit interior tiles (one float4 column group each): R rows read 2 R + 3 patch rows
+// -- 3.5 conversions and LDS reads per output at R = 2, 2.75 at 4, 2.5 at 6 -- on correspondingly fewer lanes (the integer
+// kernels are VALU-bound: what counts is the number of wave instructions, not how many waves share them).  When R does not
+// divide the NH rows the last group starts at row NH - R: the rows it shares with the group before are written twice with
+// the same bits.
+#ifndef MI_SEP_P1_ROWS
+#define MI_SEP_P1_ROWS 4
+#endif
 #ifndef MI_SEP_LAUNDER
 #define MI_SEP_LAUNDER 1
 #endif
@@ -194,6 +202,9 @@ template <typename TIn> struct PreChunk;
 template <> struct PreChunk<float> {
     v4f v;
     __device__ __forceinline__ void store_raw(uint32_t*) const {}                       // never used: fp32 stages as fp32
+    typedef uint32_t raw_t;
+    static __device__ __forceinline__ raw_t ld_raw(const uint32_t*) { return 0u; }
+    static __device__ __forceinline__ v4f cvt_raw(raw_t) { return v4f{}; }
     static __device__ __forceinline__ v4f unpack_raw(const uint32_t*) { return v4f{}; }
     static __device__ __forceinline__ void unpack6(const uint32_t*, int, v2f*) {}
     __device__ __forceinline__ void load(const char* p) { __builtin_memcpy(&v, p, 16); }
@@ -208,10 +219,14 @@ template <> struct PreChunk<uint8_t> {
     uint32_t v;
     // raw LDS form: one dword = four elements
     __device__ __forceinline__ void store_raw(uint32_t* q) const { *q = v; }
-    static __device__ __forceinline__ v4f unpack_raw(const uint32_t* q) {
-        const uint32_t w = *(const volatile uint32_t __attribute__((address_space(3)))*)(size_t)(uint32_t)(uintptr_t)q;
+    typedef uint32_t raw_t;   // four elements as staged
+    static __device__ __forceinline__ raw_t ld_raw(const uint32_t* q) {
+        return *(const volatile uint32_t __attribute__((address_space(3)))*)(size_t)(uint32_t)(uintptr_t)q;
+    }
+    static __device__ __forceinline__ v4f cvt_raw(raw_t w) {
         return v4f{(float)(w & 0xffu), (float)((w >> 8) & 0xffu), (float)((w >> 16) & 0xffu), (float)(w >> 24)};
     }
+    static __device__ __forceinline__ v4f unpack_raw(const uint32_t* q) { return cvt_raw(ld_raw(q)); }
     // six consecutive elements (two pixels) starting at element `e0` (even) of the row at `row`, channel by channel:
     // out[c] = (pixel 0, pixel 1) of channel c.  v_alignbyte takes the byte offset from the low two bits of e0.
     static __device__ __forceinline__ void unpack6(const uint32_t* row, int e0, v2f* out) {
@@ -236,10 +251,14 @@ template <> struct PreChunk<uint16_t> {
     uint32_t v0, v1;
     // raw LDS form: two dwords = four elements
     __device__ __forceinline__ void store_raw(uint32_t* q) const { *reinterpret_cast<v2u*>(q) = v2u{v0, v1}; }
-    static __device__ __forceinline__ v4f unpack_raw(const uint32_t* q) {
-        const v2u w = *(const volatile v2u __attribute__((address_space(3)))*)(size_t)(uint32_t)(uintptr_t)q;
+    typedef v2u raw_t;
+    static __device__ __forceinline__ raw_t ld_raw(const uint32_t* q) {
+        return *(const volatile v2u __attribute__((address_space(3)))*)(size_t)(uint32_t)(uintptr_t)q;
+    }
+    static __device__ __forceinline__ v4f cvt_raw(raw_t w) {
         return v4f{(float)(w.x & 0xffffu), (float)(w.x >> 16), (float)(w.y & 0xffffu), (float)(w.y >> 16)};
     }
+    static __device__ __forceinline__ v4f unpack_raw(const uint32_t* q) { return cvt_raw(ld_raw(q)); }
     // six consecutive elements (two pixels) starting at element `e0` (even) of the row at `row`, channel by channel
     static __device__ __forceinline__ void unpack6(const uint32_t* row, int e0, v2f* out) {
         const uint32_t* q = row + (e0 >> 1);
@@ -545,7 +564,35 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
         MI_TICK(2);   // prefetch issue
         const BufRsrc gn_rs = make_rsrc(gnext0 + (size_t)b * a.gnext_stride, (uint32_t)hn * (uint32_t)wn * 12u);
 
-        // ---------------- P1: vertical reduce, 2 V rows x one float4 column group per lane
+        // ---------------- P1: vertical reduce, P1R V rows x one float4 column group per lane
+        constexpr int P1R = (RAW && MI_SEP_P1_ROWS > 2 && G::NH >= MI_SEP_P1_ROWS) ? MI_SEP_P1_ROWS : 2;
+        if constexpr (P1R > 2) {
+            constexpr int P1G = (G::NH + P1R - 1) / P1R;
+            if (lt < P1G * CPR && !MI_ABL(1)) {
+                const int rg = SmallDiv<CPR, NT>::div(lt), g = lt - mul24(rg, CPR);
+                const int v0 = min(P1R * rg, G::NH - P1R);
+                const uint32_t* p = sGr + RD * (mul24(2 * v0, CPR) + g);
+                // rows in their raw form one output ahead (2 / 4 registers per row), the floats in a five-row window that
+                // slides down two rows per output: the 64-register budget of these kernels holds
+                typedef PreChunk<TIn> PC;
+                auto ld = [&](int t) { return PC::ld_raw(p + t * (RD * CPR)); };
+                const typename PC::raw_t q0 = ld(0), q1 = ld(1), q2 = ld(2);
+                typename PC::raw_t n3 = ld(3), n4 = ld(4);
+                float* d = sV + mul24(v0, G::VS) + 4 * g;
+                v4f w0 = PC::cvt_raw(q0), w1 = PC::cvt_raw(q1), w2 = PC::cvt_raw(q2);
+#pragma unroll
+                for (int u = 0; u < P1R; ++u) {
+                    typename PC::raw_t f3 = n3, f4 = n4;
+                    if (u < P1R - 1) { f3 = ld(2 * u + 5); f4 = ld(2 * u + 6); }
+                    const v4f w3 = PC::cvt_raw(n3), w4 = PC::cvt_raw(n4);
+                    const v2f lo = s5(w0.xy, w1.xy, w2.xy, w3.xy, w4.xy, k0, k1, k2);
+                    const v2f hi = s5(w0.zw, w1.zw, w2.zw, w3.zw, w4.zw, k0, k1, k2);
+                    lds_store4(d + u * G::VS, lo.x, lo.y, hi.x, hi.y);
+                    w0 = w2; w1 = w3; w2 = w4;
+                    n3 = f3; n4 = f4;
+                }
+            }
+        } else
         if (lt < (G::NH / 2) * CPR && !MI_ABL(1)) {
             const int rp = SmallDiv<CPR, NT>::div(lt), g = lt - mul24(rp, CPR);
             v2f a0, a1, b0, b1;   // (row 2rp | 2rp+1) x (floats 4g, 4g+1 | 4g+2, 4g+3)
