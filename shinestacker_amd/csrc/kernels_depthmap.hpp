@@ -160,6 +160,130 @@ __global__ __launch_bounds__(256) void dm_laplacian_rows(const F* __restrict__ s
     block_max_to(emax, gmax);
 }
 
+// dm_gray -> dm_blur<rows> -> dm_blur<cols> -> dm_laplacian_rows<5> of one frame in ONE pass (float32 planes, 5-tap blur, 5 x 5
+// aperture: the defaults): the four kernels read and wrote three float planes between them (330 us per 24 MP frame for
+// one 72 MB read and one 96 MB write).  A workgroup owns a 64 x 32 tile: gray patch (halo 4) -> row blur (halo 2 in x) ->
+// column blur (halo 2) -> Laplacian, through two LDS images.  The gray patch is filled with gray(r101(y), r101(x)) at EVERY
+// position, also those outside the image; the blurs then run over the whole patch without any border logic and still
+// produce, at a position outside the image, the value the separate kernels have at its mirror position inside: a blur's
+// window around the mirrored position is the mirror image of the window around the position, its taps are symmetric and
+// each pair (S[-j] + S[j]) is summed first -- the same products in the same order, float addition being commutative.
+// Every in-image value therefore carries the bits of the separate kernels (GPU test), whose order it keeps:
+// k[2] S[0] + k[3] (S[-1] + S[1]) + k[4] (S[-2] + S[2]), the Laplacian as the row-major float64 chain over its non-zero taps.
+struct DmK25 {
+    double k[25];
+};
+template <typename T>
+__global__ __launch_bounds__(256) void dm_energy_lap5(const T* __restrict__ img, int h, int w, float* __restrict__ out,
+                                                      float* __restrict__ gmax, DmTapsT<float> taps, DmK25 K) {
+    constexpr int TW = 64, TH = 32;
+    constexpr int GW = TW + 8, GH = TH + 8, GS = GW + 4;      // gray patch: x0-4 .., y0-4 ..; rows 16-byte aligned
+    constexpr int RW = TW + 4, RS = RW + 1;                   // row blur: x0-2 .., same rows as the gray patch
+    constexpr int CH = TH + 4;                                // column blur: y0-2 ..
+    __shared__ __attribute__((aligned(16))) float sG[GH * GS];   // later: the column blur [CH][RS]
+    __shared__ float sR[GH * RS];
+    float* sC = sG;
+    static_assert(CH * RS <= GH * GS, "the column blur aliases the gray patch");
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH, tid = threadIdx.x;
+    const float kc = taps.k[2], k1 = taps.k[3], k2 = taps.k[4];
+    const bool interior = x0 >= 4 && y0 >= 4 && x0 + TW + 4 <= w && y0 + TH + 4 <= h;
+    // ---- gray patch, four entries per thread and step
+    for (int g = tid; g < GH * (GW / 4); g += 256) {
+        const int r = g / (GW / 4), c = 4 * (g - r * (GW / 4));
+        const int y = y0 - 4 + r, x = x0 - 4 + c;
+        float o[4];
+        if (interior) {
+            T px[12];
+            __builtin_memcpy(px, img + ((size_t)y * w + x) * 3, sizeof px);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[q] = (float)bgr2gray_int(px[3 * q], px[3 * q + 1], px[3 * q + 2]);
+        } else {
+            const T* row = img + (size_t)r101_loop(y, h) * w * 3;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const T* p = row + (size_t)r101_loop(x + q, w) * 3;
+                o[q] = (float)bgr2gray_int(p[0], p[1], p[2]);
+            }
+        }
+        *reinterpret_cast<float4*>(sG + r * GS + c) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+    __syncthreads();
+    // ---- row blur: 40 rows x 17 groups of four columns (column c reads gray c .. c+4)
+    for (int g = tid; g < GH * (RW / 4); g += 256) {
+        const int r = g / (RW / 4), c = 4 * (g - r * (RW / 4));
+        const float4 a = *reinterpret_cast<const float4*>(sG + r * GS + c);
+        const float4 b = *reinterpret_cast<const float4*>(sG + r * GS + c + 4);
+        const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float acc = kc * v[q + 2];
+            const float p1 = k1 * (v[q + 1] + v[q + 3]);
+            acc = acc + p1;
+            const float p2 = k2 * (v[q] + v[q + 4]);
+            acc = acc + p2;
+            sR[r * RS + c + q] = acc;
+        }
+    }
+    __syncthreads();
+    // ---- column blur: 68 columns x 3 runs of 12 rows, a five-row window sliding down the column
+    if (tid < 3 * RW) {
+        const int run = tid / RW, c = tid - run * RW, r0 = 12 * run;
+        const float* col = sR + r0 * RS + c;
+        float v0 = col[0], v1 = col[RS], v2 = col[2 * RS], v3 = col[3 * RS];
+#pragma unroll
+        for (int j = 0; j < 12; ++j) {
+            const float v4 = col[(j + 4) * RS];
+            float acc = kc * v2;
+            const float p1 = k1 * (v1 + v3);
+            acc = acc + p1;
+            const float p2 = k2 * (v0 + v4);
+            acc = acc + p2;
+            sC[(r0 + j) * RS + c] = acc;
+            v0 = v1; v1 = v2; v2 = v3; v3 = v4;
+        }
+    }
+    __syncthreads();
+    // ---- Laplacian: a thread walks 8 rows of one column, the 5 x 5 window sliding down (output (yl, xl) reads column-blur
+    // rows yl .. yl+4, columns xl .. xl+4)
+    float emax = 0.f;
+    {
+        const int xl = tid & 63, yb = 8 * (tid >> 6);
+        const float* base = sC + yb * RS + xl;
+        float win[5][5];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 5; ++j) win[i + 1][j] = base[i * RS + j];
+        const int x = x0 + xl;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 5; ++j) win[i][j] = win[i + 1][j];
+#pragma unroll
+            for (int j = 0; j < 5; ++j) win[4][j] = base[(q + 4) * RS + j];
+            double s = 0.0;
+#pragma unroll
+            for (int i = 0; i < 5; ++i)
+#pragma unroll
+                for (int j = 0; j < 5; ++j) {
+                    const double k = K.k[i * 5 + j];
+                    if (k == 0.0) continue;
+                    const double pr = k * (double)win[i][j];
+                    s = s + pr;
+                }
+            const int y = y0 + yb + q;
+            if (x < w && y < h) {
+                const float e = (float)fabs(s);
+                out[(size_t)y * w + x] = e;
+                emax = e > emax ? e : emax;
+            }
+        }
+    }
+    block_max_to(emax, gmax);
+}
+
 template <int KS, typename F>
 __global__ __launch_bounds__(256) void dm_laplacian(const F* __restrict__ src, int h, int w,
                                                     F* __restrict__ out, F* __restrict__ gmax, DmK2 K) {
