@@ -141,9 +141,11 @@ int dmap_energy(mi_dmap* d, int i) {
         if constexpr (sizeof(F) == 4) return d->taps; else return d->tapsd;
     }();
     if constexpr (sizeof(F) == 4) {
-        // the defaults (5-tap blur, 5 x 5 aperture) in one pass over the frame; MI_DMAP_SEPARATE_ENERGY=1 keeps the four kernels
-        static const bool separate = getenv("MI_DMAP_SEPARATE_ENERGY") != nullptr;
-        if (!separate && d->p.energy == MI_DM_ENERGY_LAPLACIAN && taps.ksize == 5 && d->k2.ksize == 5 && h >= 8 && w >= 8) {
+        // the defaults (5-tap blur, 5 x 5 aperture) in one pass over the frame; -DMI_DMAP_SEPARATE_ENERGY=1 keeps the four kernels
+#ifndef MI_DMAP_SEPARATE_ENERGY
+#define MI_DMAP_SEPARATE_ENERGY 0
+#endif
+        if (!MI_DMAP_SEPARATE_ENERGY && d->p.energy == MI_DM_ENERGY_LAPLACIAN && taps.ksize == 5 && d->k2.ksize == 5 && h >= 8 && w >= 8) {
             DmK25 K;
             for (int q = 0; q < 25; ++q) K.k[q] = d->k2.k[q];
             hipLaunchKernelGGL((dm_energy_lap5<T>), dim3(cdiv(w, 64), cdiv(h, 32)), dim3(256), 0, st, (const T*)d->frames[i], h, w, en,
