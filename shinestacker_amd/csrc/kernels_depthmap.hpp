@@ -672,6 +672,32 @@ __global__ __launch_bounds__(256) void dm_lap_blend_quad(const TFine* __restrict
     if (2 * j >= w || 2 * i >= h) return;
     F up[4][3];
     pyrup_quad3<F>(coarse, hc, wc, h, w, i, j, up);
+    if (2 * j + 1 < w) {
+        // both pixels of a quad row lie side by side: the pair's six values, its two weights and its six sums as one
+        // wide access each instead of one per element (the lanes of a wave then cover a row contiguously)
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            const int y = 2 * i + d;
+            if (y >= h) continue;
+            const size_t p = (size_t)y * w + 2 * j;
+            TFine fv[6];
+            W wv[2];
+            F bv[6];
+            __builtin_memcpy(fv, fine + p * 3, sizeof fv);
+            __builtin_memcpy(wv, wgt + p, sizeof wv);
+            if (!first) __builtin_memcpy(bv, blend + p * 3, sizeof bv);
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const F lap = (F)fv[3 * e + c] - up[2 * d + e][c];
+                    const F cur = lap * (F)wv[e];
+                    bv[3 * e + c] = first ? cur : bv[3 * e + c] + cur;
+                }
+            __builtin_memcpy(blend + p * 3, bv, sizeof bv);
+        }
+        return;
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int y = 2 * i + (q >> 1), x = 2 * j + (q & 1);
