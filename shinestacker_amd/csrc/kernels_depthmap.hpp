@@ -384,6 +384,11 @@ __global__ __launch_bounds__(256) void dm_to_f32(const double* __restrict__ src,
 }
 
 constexpr int DM_LUT_BINS = 4096;
+// dm_bilateral<NP>: NP pixels of a thread go through the taps together (rows tq, tq + 4, ...: independent chains that hide
+// the latency of the patch read and of the range-table gather); the tile is 4 NP rows of 64 pixels.  LDS of a launch:
+inline size_t dm_bilateral_lds(int np, int radius) {
+    return sizeof(float) * (2 * (DM_LUT_BINS + 1) + (size_t)(4 * np + 2 * radius) * (64 + 2 * radius));
+}
 
 // expLUT of cv2.bilateralFilter (float32 images).  bp[0] = scale_index, bp[1] = 1 if the image is constant.
 __global__ __launch_bounds__(1024) void dm_bilateral_lut(const float* __restrict__ mm, double color_coeff,
@@ -420,10 +425,13 @@ struct DmBilateral {
 // cv2.bilateralFilter(e, d, 25, 25) on a float32 plane; the smoothed plane also goes into the running
 // sum / maximum over frames (np.sum / np.max over axis 0 add the planes in frame order).
 // 16 x 64 pixels per workgroup; the patch (radius <= 15) and the range table live in LDS.
+template <int NP>
 __global__ __launch_bounds__(256) void dm_bilateral(DmBilateral a) {
-    constexpr int TH = 16, TW = 64, RMAX = 15;
-    __shared__ float sP[(TH + 2 * RMAX) * (TW + 2 * RMAX)];
-    __shared__ __attribute__((aligned(8))) float sL[2 * (DM_LUT_BINS + 1)];   // (lut[i], lut[i+1] - lut[i]) pairs
+    constexpr int TH = 4 * NP, TW = 64;   // NP pixels (rows tq + 4 k) per thread
+    // dynamic LDS (dm_bilateral_lds): the range table as (lut[i], lut[i+1] - lut[i]) pairs, then the (TH + 2 r) x (TW + 2 r) patch
+    extern __shared__ __attribute__((aligned(16))) float dm_bil_lds[];
+    float* sL = dm_bil_lds;
+    float* sP = dm_bil_lds + 2 * (DM_LUT_BINS + 1);
     const int t = threadIdx.x, r = a.radius;
     const int y0 = blockIdx.y * TH, x0 = blockIdx.x * TW;
     const bool flat = a.bp[1] != 0.f;
@@ -445,16 +453,16 @@ __global__ __launch_bounds__(256) void dm_bilateral(DmBilateral a) {
     // the thread's four pixels (rows tq, tq+4, tq+8, tq+12 of column tx) go through the taps together: four
     // independent chains hide the LDS latency of the patch read and of the range-table gather
     const float* c = sP + (tq + r) * pw + (tx + r);
-    float v0[4], sum[4] = {0.f, 0.f, 0.f, 0.f}, wsum[4] = {0.f, 0.f, 0.f, 0.f};
+    float v0[NP], sum[NP], wsum[NP];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) v0[k] = c[4 * k * pw];
+    for (int k = 0; k < NP; ++k) { v0[k] = c[4 * k * pw]; sum[k] = 0.f; wsum[k] = 0.f; }
     if (!flat) {
 #pragma unroll 2
         for (int n = 0; n < a.ntaps; ++n) {
             const int2 tap = a.taps[n];                // (dy * pw + dx, bits of the space weight): a scalar load
             const float swn = __int_as_float(tap.y);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < NP; ++k) {
                 const float val = c[4 * k * pw + tap.x];
                 const float alpha = fabsf(val - v0[k]) * scale_index;   // 0 <= alpha <= DM_LUT_BINS
                 const int idx = (int)alpha;                               // floor of a non-negative value
@@ -470,7 +478,7 @@ __global__ __launch_bounds__(256) void dm_bilateral(DmBilateral a) {
         }
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < NP; ++k) {
         const int y = y0 + tq + 4 * k, x = x0 + tx;
         if (y >= a.h || x >= a.w) continue;
         const size_t pi = (size_t)y * a.w + x;
