@@ -134,8 +134,10 @@ void dm_pyrdown_launch(hipStream_t st, const TSrc* src, int h, int w, F* dst, in
 // 64 x 24 MP, ms per frame of the whole stacker: 4 pixels 1.726, 6 -> 1.69, 8 -> 1.94 (two workgroups per CU) / 2.33 (three)
 constexpr int DM_BIL_NP = 6;
 inline void dm_bilateral_launch(hipStream_t st, const DmBilateral& a) {
-    hipLaunchKernelGGL(dm_bilateral<DM_BIL_NP>, dim3(cdiv(a.w, 64), cdiv(a.h, 4 * DM_BIL_NP)), dim3(256),
-                       dm_bilateral_lds(DM_BIL_NP, a.radius), st, a);
+    const dim3 grid(cdiv(a.w, 64), cdiv(a.h, 4 * DM_BIL_NP));
+    const size_t lds = dm_bilateral_lds(DM_BIL_NP, a.radius);
+    if (a.radius == 7) hipLaunchKernelGGL((dm_bilateral<DM_BIL_NP, 7>), grid, dim3(256), lds, st, a);   // smooth_size 15: the default
+    else hipLaunchKernelGGL((dm_bilateral<DM_BIL_NP, 0>), grid, dim3(256), lds, st, a);
 }
 
 // pass 1 for the frame just stored in d->frames[i]

@@ -425,14 +425,16 @@ struct DmBilateral {
 // cv2.bilateralFilter(e, d, 25, 25) on a float32 plane; the smoothed plane also goes into the running
 // sum / maximum over frames (np.sum / np.max over axis 0 add the planes in frame order).
 // 16 x 64 pixels per workgroup; the patch (radius <= 15) and the range table live in LDS.
-template <int NP>
+// RC: the radius as a compile-time constant (the patch row length then is one too, and the rows of a thread's pixels become
+// immediate offsets of its LDS reads instead of an address addition per pixel and tap), or 0 for any radius
+template <int NP, int RC>
 __global__ __launch_bounds__(256) void dm_bilateral(DmBilateral a) {
     constexpr int TH = 4 * NP, TW = 64;   // NP pixels (rows tq + 4 k) per thread
     // dynamic LDS (dm_bilateral_lds): the range table as (lut[i], lut[i+1] - lut[i]) pairs, then the (TH + 2 r) x (TW + 2 r) patch
     extern __shared__ __attribute__((aligned(16))) float dm_bil_lds[];
     float* sL = dm_bil_lds;
     float* sP = dm_bil_lds + 2 * (DM_LUT_BINS + 1);
-    const int t = threadIdx.x, r = a.radius;
+    const int t = threadIdx.x, r = RC > 0 ? RC : a.radius;
     const int y0 = blockIdx.y * TH, x0 = blockIdx.x * TW;
     const bool flat = a.bp[1] != 0.f;
     const int pw = TW + 2 * r, ph = TH + 2 * r;
