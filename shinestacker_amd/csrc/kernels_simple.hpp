@@ -241,6 +241,63 @@ __global__ void base_feat_batch(const int32_t* __restrict__ lev, const float* __
     o[1] = dev;
 }
 
+// np_sum for a compile-time n >= 8, every index a constant (the elements may live in registers)
+template <int N, typename F>
+__device__ __forceinline__ float np_sum_c(F elem) {
+    static_assert(N >= 8 && N <= 128, "pairwise block of NumPy's add.reduce");
+    float r[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = elem(j);
+#pragma unroll
+    for (int i = 8; i < N - (N % 8); i += 8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] += elem(i + j);
+    }
+    float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+#pragma unroll
+    for (int i = N - (N % 8); i < N; ++i) res += elem(i);
+    return res;
+}
+
+// base_feat_batch for a compile-time window (PAD = 2: the default 5 x 5): the window's levels and their log-probability
+// terms are gathered ONCE into registers -- the generic kernel recomputes two reflections, a division and a modulo per tap
+// in each of its three passes (3000 instructions per pixel: 118 us for 256 bases of 63 x 94) -- then the same three sums.
+template <int PAD>
+__global__ void base_feat_batch_c(const int32_t* __restrict__ lev, const float* __restrict__ logp, int nlevels, int hb,
+                                  int wb, float* __restrict__ feat) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y, f = blockIdx.z;
+    if (y >= hb || x >= wb) return;
+    constexpr int WIN = 2 * PAD + 1, N = WIN * WIN;
+    const int npix = hb * wb;
+    const int32_t* lv = lev + (size_t)f * npix;
+    const float* lp = logp + (size_t)f * nlevels;
+    int xs[WIN], ys[WIN];
+#pragma unroll
+    for (int o = 0; o < WIN; ++o) {
+        xs[o] = r101_loop(x + o - PAD, wb);
+        ys[o] = r101_loop(y + o - PAD, hb) * wb;
+    }
+    float lf[N], term[N];
+#pragma unroll
+    for (int t = 0; t < N; ++t) {
+        const int l = lv[ys[t / WIN] + xs[t % WIN]];
+        lf[t] = (float)l;
+        term[t] = (float)l * lp[l];
+    }
+    const float ent = -1.0f * np_sum_c<N>([&](int t) { return term[t]; });
+    double isum = 0.0;
+#pragma unroll
+    for (int t = 0; t < N; ++t) isum += (double)(int)lf[t];
+    const float mean = (float)(isum / (double)N);
+    const float dev = np_sum_c<N>([&](int t) {
+                          const float d = lf[t] - mean;
+                          return d * d;
+                      }) / (float)N;
+    float* o = feat + ((size_t)f * npix + (size_t)y * wb + x) * 2;
+    o[0] = ent;
+    o[1] = dev;
+}
+
 __global__ void base_select_batch(const float* __restrict__ feat, const float* __restrict__ bases, size_t base_stride,
                                   int nframes, int npix, int frame_idx0, int first, float* __restrict__ best_ent,
                                   float* __restrict__ best_dev, int32_t* __restrict__ idx_e,
@@ -268,6 +325,58 @@ __global__ void base_select_batch(const float* __restrict__ feat, const float* _
     }
     if (fd >= 0) {
         const float* b = bases + (size_t)fd * base_stride + (size_t)p * 3;
+        base_d[p * 3 + 0] = b[0]; base_d[p * 3 + 1] = b[1]; base_d[p * 3 + 2] = b[2];
+    }
+}
+
+// The same scan with the frames of a pixel split over SEG neighbouring lanes (one thread per pixel walking 256 frames left
+// 93 waves and 72 us of pure load latency): every lane scans its contiguous share with the strict '>', then the shares are
+// merged in frame order, again with the strict '>' -- the earliest frame holding the maximum wins, as in the serial scan.
+template <int SEG>
+__global__ __launch_bounds__(256) void base_select_batch_seg(const float* __restrict__ feat, const float* __restrict__ bases,
+                                                             size_t base_stride, int nframes, int npix, int frame_idx0, int first,
+                                                             float* __restrict__ best_ent, float* __restrict__ best_dev,
+                                                             int32_t* __restrict__ idx_e, int32_t* __restrict__ idx_d,
+                                                             float* __restrict__ base_e, float* __restrict__ base_d) {
+    const int t = blockIdx.x * 256 + threadIdx.x, p = t / SEG, seg = t % SEG;
+    const bool live = p < npix;
+    const int per = (nframes + SEG - 1) / SEG, f_lo = seg * per, f_hi = min(nframes, f_lo + per);
+    float be = -INFINITY, bd = -INFINITY;
+    int fe = -1, fd = -1;
+    if (live)
+        for (int f = f_lo; f < f_hi; ++f) {
+            const float ent = feat[((size_t)f * npix + p) * 2], dev = feat[((size_t)f * npix + p) * 2 + 1];
+            if (ent > be || (first && f == 0)) { be = ent; fe = f; }
+            if (dev > bd || (first && f == 0)) { bd = dev; fd = f; }
+        }
+    // merge the SEG shares (lanes lane0 .. lane0 + SEG - 1 of the wave) in frame order
+    const int lane0 = (threadIdx.x & 63) - seg;
+    float me = -INFINITY, md = -INFINITY;
+    int ge = -1, gd = -1;
+#pragma unroll
+    for (int q = 0; q < SEG; ++q) {
+        const float e2 = __shfl(be, lane0 + q), d2 = __shfl(bd, lane0 + q);
+        const int fe2 = __shfl(fe, lane0 + q), fd2 = __shfl(fd, lane0 + q);
+        if (fe2 >= 0 && (e2 > me || (first && fe2 == 0))) { me = e2; ge = fe2; }
+        if (fd2 >= 0 && (d2 > md || (first && fd2 == 0))) { md = d2; gd = fd2; }
+    }
+    if (!live || seg != 0) return;
+    // against the running state of earlier batches (a fresh stack has none)
+    if (!first) {
+        const float pe = best_ent[p], pd = best_dev[p];
+        if (!(ge >= 0 && me > pe)) ge = -1;
+        if (!(gd >= 0 && md > pd)) gd = -1;
+    }
+    if (ge >= 0) {
+        best_ent[p] = me;
+        idx_e[p] = frame_idx0 + ge;
+        const float* b = bases + (size_t)ge * base_stride + (size_t)p * 3;
+        base_e[p * 3 + 0] = b[0]; base_e[p * 3 + 1] = b[1]; base_e[p * 3 + 2] = b[2];
+    }
+    if (gd >= 0) {
+        best_dev[p] = md;
+        idx_d[p] = frame_idx0 + gd;
+        const float* b = bases + (size_t)gd * base_stride + (size_t)p * 3;
         base_d[p * 3 + 0] = b[0]; base_d[p * 3 + 1] = b[1]; base_d[p * 3 + 2] = b[2];
     }
 }

@@ -714,11 +714,19 @@ int run_batch(mi_stack* s, const void* frames, size_t stride, int nb) {
         const dim3 blk(16, 4);
         dim3 grd = grid2d(wb, hb, blk);
         grd.z = nb;
-        hipLaunchKernelGGL(base_feat_batch, grd, blk, 0, st2, t->lev[set], t->logp[set], s->nlevels_hist, hb, wb, s->pad,
-                           t->feat[set]);
-        hipLaunchKernelGGL(base_select_batch, dim3(cdiv(npix, 64)), dim3(64), 0, st2, t->feat[set], t->Gb[set][L],
-                           t->gstride[L], nb, npix, s->first_index + s->n_pushed, s->n_pushed == 0, s->bEnt, s->bDev,
-                           s->idxE, s->idxD, s->baseE, s->baseD);
+        if (s->pad == 2)
+            hipLaunchKernelGGL(base_feat_batch_c<2>, grd, blk, 0, st2, t->lev[set], t->logp[set], s->nlevels_hist, hb, wb, t->feat[set]);
+        else
+            hipLaunchKernelGGL(base_feat_batch, grd, blk, 0, st2, t->lev[set], t->logp[set], s->nlevels_hist, hb, wb, s->pad,
+                               t->feat[set]);
+        if (nb >= 32)   // many frames: a pixel's scan over eight lanes
+            hipLaunchKernelGGL(base_select_batch_seg<8>, dim3(cdiv(npix * 8, 256)), dim3(256), 0, st2, t->feat[set], t->Gb[set][L],
+                               t->gstride[L], nb, npix, s->first_index + s->n_pushed, s->n_pushed == 0, s->bEnt, s->bDev,
+                               s->idxE, s->idxD, s->baseE, s->baseD);
+        else
+            hipLaunchKernelGGL(base_select_batch, dim3(cdiv(npix, 64)), dim3(64), 0, st2, t->feat[set], t->Gb[set][L],
+                               t->gstride[L], nb, npix, s->first_index + s->n_pushed, s->n_pushed == 0, s->bEnt, s->bDev,
+                               s->idxE, s->idxD, s->baseE, s->baseD);
         MI_HIP(hipGetLastError());
     }
     MI_HIP(hipEventRecord(t->evRest[set], st2));
