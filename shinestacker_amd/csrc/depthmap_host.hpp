@@ -23,6 +23,9 @@ struct mi_dmap {
     void *tot = nullptr, *mx = nullptr;                       // running sum / maximum of the (smoothed) energies (W)
     void* scalF = nullptr;           // F: [0] global max, [1..2] min / max written by dm_normalise<F>
     float* scalf = nullptr;          // float: [0..1] min / max of the bilateral input, [2..3] scale / flat flag, [4] = 0
+    float* fmm = nullptr;            // [DM_FMM_FRAMES][2] per-frame raw energy min (preset +inf) / max (preset 0):
+                                     // written by dm_energy_lap5 so that finish needs no dm_normalise pass (float-32, smoothing on)
+    std::vector<char> have_fmm;      // per frame: fmm[i] is valid
     float* lut = nullptr;
     int2* disc = nullptr;            // bilateral disc: (LDS patch offset, space weight bits) per tap
     int radius = 0, ntaps = 0;
@@ -141,6 +144,8 @@ inline void dm_bilateral_launch(hipStream_t st, const DmBilateral& a) {
 }
 
 // pass 1 for the frame just stored in d->frames[i]
+constexpr int DM_FMM_FRAMES = 4096;   // frames with a per-frame min / max slot (more: the normalising pass stays)
+
 template <typename T, typename F>
 int dmap_energy(mi_dmap* d, int i) {
     const int h = d->p.height, w = d->p.width;
@@ -158,12 +163,17 @@ int dmap_energy(mi_dmap* d, int i) {
         if (!MI_DMAP_SEPARATE_ENERGY && d->p.energy == MI_DM_ENERGY_LAPLACIAN && taps.ksize == 5 && d->k2.ksize == 5 && h >= 8 && w >= 8) {
             DmK25 K;
             for (int q = 0; q < 25; ++q) K.k[q] = d->k2.k[q];
+            float* fmm = (d->fmm && i < DM_FMM_FRAMES && d->p.smooth_size > 0) ? d->fmm + 2 * i : nullptr;
             hipLaunchKernelGGL((dm_energy_lap5<T>), dim3(cdiv(w, 64), cdiv(h, 32)), dim3(256), 0, st, (const T*)d->frames[i], h, w, en,
-                               gmax, taps, K);
+                               gmax, taps, K, fmm);
+            if ((int)d->have_fmm.size() <= i) d->have_fmm.resize(i + 1, 0);
+            d->have_fmm[i] = fmm != nullptr;
             MI_HIP(hipGetLastError());
             return MI_OK;
         }
     }
+    if ((int)d->have_fmm.size() <= i) d->have_fmm.resize(i + 1, 0);
+    d->have_fmm[i] = 0;
     hipLaunchKernelGGL((dm_gray<T, F>), dm_grid1(np), dim3(256), 0, st, (const T*)d->frames[i], np, tA);
     if (d->p.energy == MI_DM_ENERGY_SOBEL) {
         hipLaunchKernelGGL((dm_sobel<F>), dm_grid2(h, w), dim3(256), 0, st, (const F*)tA, h, w, en, gmax);
@@ -266,7 +276,10 @@ int dmap_finish_t(mi_dmap* d) {
     F* sF = (F*)d->scalF;
     // energies / max, smoothing, running sum (AVERAGE) or maximum (MAX) over the frames
     for (int i = 0; i < N; ++i) {
-        if (sizeof(F) == 4 && smooth) {   // float-32: min / max of the normalised plane feed the bilateral filter
+        const bool folded = sizeof(F) == 4 && smooth && i < (int)d->have_fmm.size() && d->have_fmm[i];
+        if (folded) {
+            // the energy kernel left the frame's raw min / max in fmm: no normalising pass, dm_bilateral divides as it stages
+        } else if (sizeof(F) == 4 && smooth) {   // float-32: min / max of the normalised plane feed the bilateral filter
             MI_HIP(hipMemcpyAsync(d->scalf, mm_init, 8, hipMemcpyHostToDevice, st));
             hipLaunchKernelGGL((dm_normalise<float>), gnorm, dim3(256), 0, st, (float*)d->en[i], np, (const float*)d->scalF,
                                d->scalf);
@@ -286,10 +299,11 @@ int dmap_finish_t(mi_dmap* d) {
                 bsrc = (const float*)d->tmpA;
                 bdst = (float*)d->en[i];
             }
-            hipLaunchKernelGGL(dm_bilateral_lut, dim3(1), dim3(1024), 0, st, (const float*)d->scalf, d->color_coeff, d->lut,
-                               d->scalf + 2);
+            const float* nrm = folded ? (const float*)d->scalF : nullptr;
+            hipLaunchKernelGGL(dm_bilateral_lut, dim3(1), dim3(1024), 0, st, folded ? (const float*)(d->fmm + 2 * i) : (const float*)d->scalf,
+                               d->color_coeff, d->lut, d->scalf + 2, nrm);
             DmBilateral a{bsrc, bdst, h, w, d->radius, d->ntaps, d->disc, d->lut, d->scalf + 2,
-                          (float*)(avg ? d->tot : d->mx), avg ? 0 : 1, i == 0};
+                          (float*)(avg ? d->tot : d->mx), avg ? 0 : 1, i == 0, nrm};
             dm_bilateral_launch(st, a);
             if (sizeof(F) == 4) {
                 void* t = d->en[i];
@@ -381,7 +395,7 @@ int dmap_planes_t(mi_dmap* d, int stage, const void* host_in, int n, void* host_
             // *gmax = sc[4] = 0: the plane is left as it is, only its min / max are taken
             hipLaunchKernelGGL((dm_normalise<float>), gnorm, dim3(256), 0, st, (float*)src, np, (const float*)(sc + 4), sc);
             hipLaunchKernelGGL(dm_bilateral_lut, dim3(1), dim3(1024), 0, st, (const float*)sc, d->color_coeff, d->lut, sc + 2);
-            DmBilateral a{src, out, h, w, d->radius, d->ntaps, d->disc, d->lut, sc + 2, acc, 0, 1};
+            DmBilateral a{src, out, h, w, d->radius, d->ntaps, d->disc, d->lut, sc + 2, acc, 0, 1, nullptr};
             dm_bilateral_launch(st, a);
             MI_HIP(hipGetLastError());
             MI_HIP(hipMemcpyAsync((float*)host_out + (size_t)i * np, out, np * 4, hipMemcpyDeviceToHost, st));
@@ -497,6 +511,7 @@ int mi_dmap_create(mi_dmap_t** out, const mi_dmap_params_t* params) {
             (r = dmap_alloc(d, &d->lut, DM_LUT_BINS + 2)))
             return r;
         if (!d->f64 && (r = dmap_alloc(d, &d->spare, np))) return r;
+        if (!d->f64 && (r = dmap_alloc(d, &d->fmm, 2 * DM_FMM_FRAMES))) return r;
         if (p.map_type == MI_DM_MAP_MAX && (r = dmap_alloc_bytes(d, &d->mx, np * fsz))) return r;
         if ((r = dmap_alloc_bytes(d, &d->out_dev, np * 3 * d->esz))) return r;
         if (p.smooth_size > 0) {   // bilateral disc, cv2.bilateralFilter(e, smooth_size, 25, 25) (depth_map.py:50)
@@ -535,6 +550,7 @@ int mi_dmap_create(mi_dmap_t** out, const mi_dmap_params_t* params) {
         }
         MI_HIP(hipMemsetAsync(d->scalF, 0, 64, d->stream));
         MI_HIP(hipMemsetAsync(d->scalf, 0, 64, d->stream));
+        if (d->fmm) hipLaunchKernelGGL(dm_fmm_reset, dim3(cdiv(DM_FMM_FRAMES, 256)), dim3(256), 0, d->stream, d->fmm, DM_FMM_FRAMES);
         return MI_OK;
     };
     rc = body();
@@ -561,6 +577,7 @@ int mi_dmap_reset(mi_dmap_t* d) {
     d->n = 0;
     d->finished = false;
     MI_HIP(hipMemsetAsync(d->scalF, 0, 64, d->stream));
+    if (d->fmm) hipLaunchKernelGGL(dm_fmm_reset, dim3(cdiv(DM_FMM_FRAMES, 256)), dim3(256), 0, d->stream, d->fmm, DM_FMM_FRAMES);
     return MI_OK;
 }
 

@@ -170,12 +170,18 @@ __global__ __launch_bounds__(256) void dm_laplacian_rows(const F* __restrict__ s
 // each pair (S[-j] + S[j]) is summed first -- the same products in the same order, float addition being commutative.
 // Every in-image value therefore carries the bits of the separate kernels (GPU test), whose order it keeps:
 // k[2] S[0] + k[3] (S[-1] + S[1]) + k[4] (S[-2] + S[2]), the Laplacian as the row-major float64 chain over its non-zero taps.
+// per-frame (min, max) slots of the raw energies: (+inf, 0)
+__global__ void dm_fmm_reset(float* __restrict__ fmm, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { fmm[2 * i] = INFINITY; fmm[2 * i + 1] = 0.f; }
+}
 struct DmK25 {
     double k[25];
 };
 template <typename T>
 __global__ __launch_bounds__(256) void dm_energy_lap5(const T* __restrict__ img, int h, int w, float* __restrict__ out,
-                                                      float* __restrict__ gmax, DmTapsT<float> taps, DmK25 K) {
+                                                      float* __restrict__ gmax, DmTapsT<float> taps, DmK25 K,
+                                                      float* __restrict__ fmm) {
     constexpr int TW = 64, TH = 32;
     constexpr int GW = TW + 8, GH = TH + 8, GS = GW + 4;      // gray patch: x0-4 .., y0-4 ..; rows 16-byte aligned
     constexpr int RW = TW + 4, RS = RW + 1;                   // row blur: x0-2 .., same rows as the gray patch
@@ -245,7 +251,7 @@ __global__ __launch_bounds__(256) void dm_energy_lap5(const T* __restrict__ img,
     __syncthreads();
     // ---- Laplacian: a thread walks 8 rows of one column, the 5 x 5 window sliding down (output (yl, xl) reads column-blur
     // rows yl .. yl+4, columns xl .. xl+4)
-    float emax = 0.f;
+    float emax = 0.f, emin = INFINITY;
     {
         const int xl = tid & 63, yb = 8 * (tid >> 6);
         const float* base = sC + yb * RS + xl;
@@ -278,10 +284,19 @@ __global__ __launch_bounds__(256) void dm_energy_lap5(const T* __restrict__ img,
                 const float e = (float)fabs(s);
                 out[(size_t)y * w + x] = e;
                 emax = e > emax ? e : emax;
+                emin = e < emin ? e : emin;
             }
         }
     }
     block_max_to(emax, gmax);
+    // the frame's own minimum / maximum (fmm[0] preset to +inf, fmm[1] to 0: dm_fmm_reset): what dm_normalise used to find in a
+    // pass of its own -- min / max of e / m are min / max of e, divided (a division by m > 0 is monotone under rounding)
+    if (fmm) {
+        __syncthreads();
+        block_max_to(emax, fmm + 1);
+        __syncthreads();
+        block_min_to(emin, fmm);
+    }
 }
 
 template <int KS, typename F>
@@ -392,8 +407,12 @@ inline size_t dm_bilateral_lds(int np, int radius) {
 
 // expLUT of cv2.bilateralFilter (float32 images).  bp[0] = scale_index, bp[1] = 1 if the image is constant.
 __global__ __launch_bounds__(1024) void dm_bilateral_lut(const float* __restrict__ mm, double color_coeff,
-                                                         float* __restrict__ lut, float* __restrict__ bp) {
-    const float lo = mm[0], hi = mm[1];
+                                                         float* __restrict__ lut, float* __restrict__ bp,
+                                                         const float* __restrict__ norm = nullptr) {
+    // norm: the global maximum the plane has NOT been divided by yet (dm_bilateral<.., NORM> divides as it stages):
+    // mm then holds the raw plane's min / max, and the normalised plane's are their quotients
+    float lo = mm[0], hi = mm[1];
+    if (norm && *norm > 0) { lo = lo / *norm; hi = hi / *norm; }
     const bool flat = fabs((double)lo - (double)hi) < (double)1.1920928955078125e-07f;
     const float len = (float)((double)hi - (double)lo);
     const float scale_index = (float)DM_LUT_BINS / len;
@@ -420,6 +439,7 @@ struct DmBilateral {
     float* acc;           // AVERAGE: running sum of the smoothed energies; MAX: running maximum
     int mode;             // 0 = sum, 1 = max
     int first;
+    const float* norm;    // not null: src is divided by *norm (if > 0) as it is staged (the dm_normalise pass folded in)
 };
 
 // cv2.bilateralFilter(e, d, 25, 25) on a float32 plane; the smoothed plane also goes into the running
@@ -437,6 +457,7 @@ __global__ __launch_bounds__(256) void dm_bilateral(DmBilateral a) {
     const int t = threadIdx.x, r = RC > 0 ? RC : a.radius;
     const int y0 = blockIdx.y * TH, x0 = blockIdx.x * TW;
     const bool flat = a.bp[1] != 0.f;
+    const float nm = a.norm ? *a.norm : 0.f;
     const int pw = TW + 2 * r, ph = TH + 2 * r;
     if (!flat) {
         for (int i = t; i < DM_LUT_BINS + 1; i += 256) {
@@ -446,7 +467,9 @@ __global__ __launch_bounds__(256) void dm_bilateral(DmBilateral a) {
         }
         for (int i = t; i < ph * pw; i += 256) {
             const int py = i / pw, px = i - py * pw;
-            sP[i] = a.src[(size_t)r101_loop(y0 + py - r, a.h) * a.w + r101_loop(x0 + px - r, a.w)];
+            float v = a.src[(size_t)r101_loop(y0 + py - r, a.h) * a.w + r101_loop(x0 + px - r, a.w)];
+            if (nm > 0) v = v / nm;
+            sP[i] = v;
         }
     }
     __syncthreads();
@@ -484,7 +507,11 @@ __global__ __launch_bounds__(256) void dm_bilateral(DmBilateral a) {
         const int y = y0 + tq + 4 * k, x = x0 + tx;
         if (y >= a.h || x >= a.w) continue;
         const size_t pi = (size_t)y * a.w + x;
-        const float res = flat ? a.src[pi] : sum[k] / wsum[k];
+        float res;
+        if (flat) {
+            res = a.src[pi];
+            if (nm > 0) res = res / nm;
+        } else res = sum[k] / wsum[k];
         a.dst[pi] = res;
         if (a.mode == 0) a.acc[pi] = a.first ? 0.f + res : a.acc[pi] + res;
         else a.acc[pi] = a.first ? res : fmaxf(a.acc[pi], res);
