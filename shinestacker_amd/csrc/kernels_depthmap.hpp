@@ -613,19 +613,36 @@ template <typename TSrc, int C, typename F, int TH>
 __global__ __launch_bounds__(256) void dm_pyrdown_tile(const TSrc* __restrict__ src, int h, int w, F* __restrict__ dst,
                                                        int ho, int wo) {
     constexpr int TW = 64, IW = 2 * (TW - 1) + 5, IH = 2 * (TH - 1) + 5;
-    __shared__ TSrc s_in[IH * IW * C];
+    constexpr int ND = (IW * C * (int)sizeof(TSrc) + 3) / 4;   // dwords per staged row (padded: rows start on a dword)
+    __shared__ uint32_t s_in_dw[IH * ND];
     __shared__ F s_row[IH * TW * C];
     const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH, tid = threadIdx.x;
-    for (int i = tid; i < IH * IW; i += 256) {
-        const int r = i / IW, q = i - r * IW;
-        const TSrc* px = src + ((size_t)r101_loop(2 * y0 - 2 + r, h) * w + r101_loop(2 * x0 - 2 + q, w)) * C;
+    // Interior tiles (the patch, plus the padding bytes of its rows, inside the image): the patch rows are contiguous in
+    // memory -- copied a dword at a time (unaligned global loads) instead of element by element through two reflection
+    // loops and an index division each, which was more than half of this kernel's instructions.
+    const bool interior = 2 * x0 - 2 >= 0 && 2 * y0 - 2 >= 0 && 2 * x0 - 2 + IW + 2 <= w && 2 * y0 - 2 + IH <= h;
+    if (interior) {
+        const char* base = (const char*)(src + ((size_t)(2 * y0 - 2) * w + (2 * x0 - 2)) * C);
+        const size_t pitch = (size_t)w * C * sizeof(TSrc);
+        for (int i = tid; i < IH * ND; i += 256) {
+            const int r = i / ND, q = i - r * ND;
+            uint32_t v;
+            __builtin_memcpy(&v, base + (size_t)r * pitch + 4 * q, 4);
+            s_in_dw[i] = v;
+        }
+    } else {
+        for (int i = tid; i < IH * IW; i += 256) {
+            const int r = i / IW, q = i - r * IW;
+            const TSrc* px = src + ((size_t)r101_loop(2 * y0 - 2 + r, h) * w + r101_loop(2 * x0 - 2 + q, w)) * C;
+            TSrc* d = reinterpret_cast<TSrc*>(s_in_dw + r * ND) + q * C;
 #pragma unroll
-        for (int c = 0; c < C; ++c) s_in[i * C + c] = px[c];
+            for (int c = 0; c < C; ++c) d[c] = px[c];
+        }
     }
     __syncthreads();
     for (int i = tid; i < IH * TW; i += 256) {
         const int r = i / TW, x = i - r * TW;
-        const TSrc* p = s_in + (r * IW + 2 * x) * C;
+        const TSrc* p = reinterpret_cast<const TSrc*>(s_in_dw + r * ND) + 2 * x * C;
 #pragma unroll
         for (int c = 0; c < C; ++c) {
             const F m2 = (F)p[c], m1 = (F)p[C + c], c0 = (F)p[2 * C + c], p1 = (F)p[3 * C + c], p2 = (F)p[4 * C + c];

@@ -90,6 +90,7 @@ CASES = [
     (np.uint16, 2, 130, 259, {"levels": 6}),
     (np.uint8, 2, 141, 270, {"levels": 4}),        # 8-bit tiles of the one-pass energy kernel's interior path (and its rim)
     (np.uint8, 2, 141, 270, {"map_type": "max", "smooth_size": 0, "levels": 2}),
+    (np.uint8, 2, 134, 530, {"levels": 3, "smooth_size": 5}),   # level 1 wide enough for dm_pyrdown_tile's interior staging (3-channel float)
     (np.uint8, 4, 61, 83, {"float_type": "float-64"}),
     (np.uint16, 3, 50, 77, {"float_type": "float-64", "map_type": "max"}),
     (np.uint16, 3, 47, 66, {"float_type": "float-64", "smooth_size": 0, "levels": 4}),
