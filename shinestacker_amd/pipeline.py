@@ -218,8 +218,22 @@ def _make_correction(balance, device):
     return classes[channel](device=device, **opts)
 
 
+def auto_batch_frames(n_frames, height, width, dtype, device=0, share=0.25):
+    """Warped frames per push into the stacker for the resident align -> stack flow: as many as the job has (a multiple of 16,
+    at most 128) while two input batches plus the stacker's two sets of coarser Gaussian levels stay inside `share` of the
+    free device memory.  Bigger pushes fuse more efficiently (the coarse levels of a 16-frame push are launch-bound): config 4,
+    128 x 24 MP u8, 0.0417 s at 16 frames per push, 0.0400 at 32, 0.0387 at 64, 0.0367 at 128."""
+    dt = np.dtype(dtype)
+    px = int(height) * int(width)
+    per_frame = 2 * px * 3 * dt.itemsize + 2 * (px // 3 + 1) * 12   # two batch buffers + two sets of G_1.. (fp32 RGB, P_0 / 3 pixels)
+    free, _total = _lib.mem_info(device)
+    fit = int(share * free // max(per_frame, 1))
+    want = min(128, -(-int(n_frames) // 16) * 16)
+    return max(16, min(want, fit // 16 * 16))
+
+
 def align_and_stack_device(dev_frames, n_frames, height, width, dtype, ref_idx=-1, alignment_config=None,
-                           min_correlation=0.5, max_iters=60, device=0, batch_frames=16, out_dev=None,
+                           min_correlation=0.5, max_iters=60, device=0, batch_frames=None, out_dev=None,
                            balance=None, ecc_batch=16, step_process=False, native_loop=True, handles=None,
                            keep_handles=False, info=None, **stack_kwargs):
     """BASELINE config 4 with every frame resident in HBM: `dev_frames` is the device address of
@@ -296,6 +310,8 @@ def align_and_stack_device(dev_frames, n_frames, height, width, dtype, ref_idx=-
             aligned.free()
         return out, transforms, ccs
     ecc_batch = max(1, min(int(ecc_batch), _lib.Aligner.MAX_BATCH))
+    if batch_frames is None:   # handles of an earlier call fix it; else as many frames per push as memory allows
+        batch_frames = handles.geometry["batch_frames"] if handles is not None else auto_batch_frames(n_frames, height, width, dt, device)
     geometry = dict(height=int(height), width=int(width), dtype=dt.name, batch_frames=int(batch_frames),
                     subsample=max(1, int(cfg['subsample'])), fast=bool(cfg['fast_subsampling']), device=int(device))
     # everything that can be refused is refused BEFORE anything is allocated

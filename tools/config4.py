@@ -52,7 +52,7 @@ def main():
     ap.add_argument("--balance", action="store_true", help="also balance every frame (LUMI / LINEAR, sub-sample 8)")
     ap.add_argument("--resident", action="store_true", help="frames resident in HBM (mi_aligner_* + device warp)")
     ap.add_argument("--homography", action="store_true", help="ALIGN_HOMOGRAPHY: the estimate applied with warpPerspective (resident mode)")
-    ap.add_argument("--batch", type=int, default=16, help="warped frames per push into the stacker (resident mode)")
+    ap.add_argument("--batch", type=int, default=0, help="warped frames per push into the stacker (resident mode; 0 = the pipeline's choice: as many as memory allows, up to 128)")
     ap.add_argument("--step-process", action="store_true", help="the reference's chained order (resident mode)")
     ap.add_argument("--arith", default="exact", choices=["exact", "separable"], help="stacker arithmetic (resident mode)")
     ap.add_argument("--ecc-batch", type=int, default=0, help="frames per batched Gauss-Newton (0 = the pipeline's default)")
@@ -97,12 +97,12 @@ def main():
         out = L.DeviceBuffer(fb)
         bal = {'channel': 'LUMI', 'corr_map': 'LINEAR', 'subsample': 8} if args.balance else None
         acfg = {'transform': 'ALIGN_HOMOGRAPHY'} if args.homography else None
-        align_and_stack_device(buf.ptr, min(N, 4), H, W, np.uint8, out_dev=out.ptr, balance=bal, arith=args.arith, step_process=args.step_process, batch_frames=args.batch, alignment_config=acfg, native_loop=not args.python_loop, **({'ecc_batch': args.ecc_batch} if args.ecc_batch else {}))   # warm-up
+        align_and_stack_device(buf.ptr, min(N, 4), H, W, np.uint8, out_dev=out.ptr, balance=bal, arith=args.arith, step_process=args.step_process, batch_frames=(args.batch or None), alignment_config=acfg, native_loop=not args.python_loop, **({'ecc_batch': args.ecc_batch} if args.ecc_batch else {}))   # warm-up
         if args.reuse_handles:   # what a job of many stacks pays per stack: the handles exist already
             if args.step_process or args.python_loop:
                 # (round 3 dropped these flags silently here and wrote a non-chained run into config4_resident_step.json)
                 raise SystemExit("--reuse-handles times the native non-chained loop; it cannot be combined with --step-process / --python-loop")
-            kw = dict(balance=bal, arith=args.arith, batch_frames=args.batch, alignment_config=acfg, **({'ecc_batch': args.ecc_batch} if args.ecc_batch else {}))
+            kw = dict(balance=bal, arith=args.arith, batch_frames=(args.batch or None), alignment_config=acfg, **({'ecc_batch': args.ecc_batch} if args.ecc_batch else {}))
             from shinestacker_amd.pipeline import close_handles
             *_, hd = align_and_stack_device(buf.ptr, N, H, W, np.uint8, ref_idx=ref, out_dev=out.ptr, keep_handles=True, **kw)
             t0 = time.perf_counter()
@@ -115,7 +115,7 @@ def main():
             report(N, H, W, dt, recovered, truth, ref, cx, cy, "resident, handles reused", list(out.download((H, W, 3), np.uint8).shape))
             return
         t0 = time.perf_counter()
-        _, tr, ccs = align_and_stack_device(buf.ptr, N, H, W, np.uint8, ref_idx=ref, out_dev=out.ptr, balance=bal, arith=args.arith, step_process=args.step_process, batch_frames=args.batch, alignment_config=acfg, native_loop=not args.python_loop, **({'ecc_batch': args.ecc_batch} if args.ecc_batch else {}))
+        _, tr, ccs = align_and_stack_device(buf.ptr, N, H, W, np.uint8, ref_idx=ref, out_dev=out.ptr, balance=bal, arith=args.arith, step_process=args.step_process, batch_frames=(args.batch or None), alignment_config=acfg, native_loop=not args.python_loop, **({'ecc_batch': args.ecc_batch} if args.ecc_batch else {}))
         dt = time.perf_counter() - t0
         recovered = {k: m.copy() for k, m in enumerate(t for t in tr if t is not None)}
         for m in recovered.values():
