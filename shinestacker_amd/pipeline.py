@@ -248,6 +248,10 @@ def align_and_stack_device(dev_frames, n_frames, height, width, dtype, ref_idx=-
     fused in order.  (Estimating on helper threads, one handle each or one batch ahead, measured no
     faster: the round trips serialise in the runtime.)
 
+    `batch_frames`: warped frames per push into the stacker; None (default) = `auto_batch_frames`: the whole job in one
+    push when the device memory allows it (the coarse pyramid levels of small pushes are launch-bound: config 4 takes 0.042 s
+    at 16 frames per push, 0.037 s at 128); handles of an earlier call keep the value they were created with.
+
     `balance`: optional dict of BalanceFrames options (channel, corr_map, subsample, fast_subsampling,
     mask_size, intensity_interval): every aligned frame is then balanced against the reference frame
     (balance.py; the order of the reference's example projects: align, balance, stack) in place on the
