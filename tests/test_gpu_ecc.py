@@ -585,3 +585,18 @@ def test_align_images_homography_with_the_gpu_estimator(L, oracle):
     want = np.linalg.inv(T)
     assert n == 1000 and m.shape == (3, 3) and abs(m[2, 0]) > 1e-5 and _corner_error(m, want / want[2, 2], h, w) < 0.2
     assert np.array_equal(warp, oracle.warp_perspective(mov, m))
+
+
+def test_auto_batch_frames_is_bounded_by_the_job_and_by_memory(L):
+    """pipeline.auto_batch_frames: a multiple of 16 between 16 and 128, never more than the job needs, and small when the
+    share of device memory it may use is small."""
+    from shinestacker_amd.pipeline import auto_batch_frames
+    assert auto_batch_frames(5, 4000, 6000, np.uint8) == 16
+    assert auto_batch_frames(40, 4000, 6000, np.uint8) == 48
+    assert auto_batch_frames(1000, 400, 600, np.uint8) == 128
+    free, _ = L.mem_info()
+    per_frame = 2 * 4000 * 6000 * 3 + 2 * (4000 * 6000 // 3 + 1) * 12
+    tight = 40 * per_frame / free          # room for 40 frames -> 32
+    assert auto_batch_frames(1000, 4000, 6000, np.uint8, share=tight) == 32
+    assert auto_batch_frames(1000, 4000, 6000, np.uint8, share=1e-9) == 16
+
