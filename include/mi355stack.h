@@ -79,7 +79,12 @@ enum {
 
 /* arithmetic of the pyramid stencils (mi_stack_params.arith)
  *   MI_ARITH_EXACT      every 5x5 stencil as the reference's own 25-tap row-major chain (cv2.filter2D order as
- *                       restated in oracle/): every intermediate bit-identical to the oracle.  The drop-in default.
+ *                       restated in oracle/): every intermediate bit-identical to the oracle.  The value of a
+ *                       zero-initialised struct and of mi_stack_default_params: at the C boundary the caller NAMES the
+ *                       arithmetic, and what it gets without naming one is the bit-pinned order (the audit mode).  The
+ *                       Python host mirror's high-level entry points (PyramidStack, align_and_stack[_device],
+ *                       bunches_then_stack) all pass ONE default explicitly -- defaults.resolve_arith, "separable" -- so no
+ *                       two of them differ for the same input (round 5).
  *   MI_ARITH_SEPARABLE  the same stencils as two 5-tap passes with the float32 generating kernel (polyphase for
  *                       the expand): ~half the arithmetic, coefficients within the float32 forward-error bound
  *                       of a float64 evaluation, per-pixel arg-max may flip at near ties (tolerance in
@@ -104,7 +109,7 @@ typedef struct mi_stack_params {
                             * per-batch buffers fit a quarter of the free device memory (allocated on demand).
                             * > 0: batches of exactly this many frames, buffers allocated by mi_stack_create (for
                             * callers that push batch after batch and must not stall on an allocation)           */
-    int32_t arith;         /* MI_ARITH_*; 0 = exact (default)                                  */
+    int32_t arith;         /* MI_ARITH_*; 0 = exact (the C default, see the enum's comment)     */
     int32_t reserved[4];
 } mi_stack_params_t;
 

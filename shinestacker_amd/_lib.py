@@ -242,13 +242,14 @@ def require_device():
                           "(there is no CPU fallback)")
 
 
-# ---- pinned host memory (zero-copy uploads: Stack.push_frame sends an array that lies in it straight over PCIe)
+# ---- pinned host memory (zero-copy uploads: Stack.push_frame(frame, zero_copy=True) sends an array that lies in it
+# straight over PCIe)
 _PINNED = {}    # base address -> bytes, of every live pinned range this module knows about
 
 
 def host_alloc(shape, dtype):
-    """An ndarray in pinned host memory (mi_host_alloc): decode / generate into it, then `Stack.push_frame` uploads it
-    without the bounce copy.  Freed when the array (and every view of it) is garbage collected."""
+    """An ndarray in pinned host memory (mi_host_alloc): decode / generate into it, then `Stack.push_frame(arr,
+    zero_copy=True)` uploads it without the bounce copy.  Freed when the array (and every view of it) is garbage collected."""
     import weakref
     dt = np.dtype(dtype)
     nbytes = int(np.prod(shape)) * dt.itemsize
@@ -267,12 +268,27 @@ def host_alloc(shape, dtype):
 
 
 def host_register(arr):
-    """Pin the memory of an existing C-contiguous array in place (mi_host_register); undo with host_unregister."""
+    """Pin the memory of an existing C-contiguous array in place (mi_host_register); undo with host_unregister.  The
+    registration also ends when the array that owns the memory is garbage collected, so a later allocation at the same
+    address is never mistaken for pinned memory."""
+    import weakref
     a = np.asarray(arr)
     if not a.flags.c_contiguous:
         raise ValueError("only C-contiguous arrays can be pinned")
-    check(load().mi_host_register(a.ctypes.data, a.nbytes))
-    _PINNED[a.ctypes.data] = a.nbytes
+    addr = a.ctypes.data
+    check(load().mi_host_register(addr, a.nbytes))
+    _PINNED[addr] = a.nbytes
+    owner = a
+    while isinstance(owner.base, np.ndarray):   # the array whose death frees the memory
+        owner = owner.base
+
+    def release(ad=addr):
+        if _PINNED.pop(ad, None) is not None:
+            load().mi_host_unregister(ad)
+    try:
+        weakref.finalize(owner, release)
+    except TypeError:       # an owner that cannot be weakly referenced: the caller unregisters
+        pass
 
 
 def host_unregister(arr):
@@ -396,8 +412,9 @@ class Stack:
     # -- lifecycle
     def close(self):
         if getattr(self, "_h", None):
-            load().mi_stack_destroy(self._h)
+            load().mi_stack_destroy(self._h)   # waits for the handle's streams: no upload reads a pinned frame any more
             self._h = None
+        self._inflight = []
 
     def __del__(self):
         try:
@@ -412,7 +429,8 @@ class Stack:
         self.close()
 
     def reset(self):
-        check(load().mi_stack_reset(self._h))
+        check(load().mi_stack_reset(self._h))   # synchronises the handle: every upload has completed
+        self._inflight = []
 
     # -- geometry
     def level_shape(self, level):
@@ -430,7 +448,12 @@ class Stack:
         check(load().mi_stack_set_first_index(self._h, int(idx)))
 
     # -- data path
-    def push_frame(self, frame):
+    def push_frame(self, frame, zero_copy=False):
+        """Push one host frame.  Default: the frame is copied (bounce buffers) before the call returns, whatever memory it
+        lies in -- the caller may overwrite it at once.  `zero_copy=True` asks for the asynchronous upload straight out of
+        the caller's PINNED array (`host_alloc` / `host_register`): the array is kept alive here and must not be modified
+        until `wait_uploads()` (or any sync / reset / finish of the handle) has returned; an array that turns out not to
+        be pinned takes the copying path."""
         a = np.asarray(frame)
         if a.shape != (self.height, self.width, 3):
             raise ValueError(f"frame shape {a.shape} != {(self.height, self.width, 3)}")
@@ -441,15 +464,16 @@ class Stack:
                 check(load().mi_stack_push_frame(self._h, a.ctypes.data, a.strides[0]))
                 return
             a = np.ascontiguousarray(a)
-        if _PINNED and is_pinned(a):
-            # zero-copy: the upload reads the caller's pinned array; it is kept alive here and must not be modified
-            # until wait_uploads() (or any sync / finish of the handle) has returned
-            check(load().mi_stack_push_frame_pinned(self._h, a.ctypes.data, 0))
-            self._inflight = getattr(self, "_inflight", [])
-            self._inflight.append(a)
-            if len(self._inflight) > 64:
-                self.wait_uploads(32)
-            return
+        if zero_copy and is_pinned(a):
+            rc = load().mi_stack_push_frame_pinned(self._h, a.ctypes.data, 0)
+            if rc == MI_OK:
+                self._inflight = getattr(self, "_inflight", [])
+                self._inflight.append(a)
+                if len(self._inflight) > 64:
+                    self.wait_uploads(32)
+                return
+            if rc != MI_ERR_INVALID:     # MI_ERR_INVALID: the library does not see pinned memory there (stale record)
+                check(rc)
         check(load().mi_stack_push_frame(self._h, a.ctypes.data, 0))
 
     def wait_uploads(self, max_outstanding=0):
@@ -479,6 +503,9 @@ class Stack:
         return out
 
     def finish_device(self, dev_ptr=None):
+        # the collapse is enqueued behind every push of the handle; the uploads themselves have been waited for by then
+        # (a frame's kernels run behind its copy), but the result is asynchronous: the pinned frames stay referenced until
+        # the next sync / reset / wait_uploads
         check(load().mi_stack_finish_device(self._h, dev_ptr))
 
     # -- taps

@@ -12,7 +12,10 @@ constants = SimpleNamespace(
     # evaluation order of the pyramid stencils -- an option the reference does not have:
     # "separable" (5 + 5 tap form, within the stated float-32 tolerance of the reference's float-64 mode; the default of
     # PyramidStack()) or "exact" (the reference's own row-major 25-tap order, bit-identical to its restatement: the audit
-    # mode).  The environment variable SHINESTACKER_AMD_ARITH overrides the default without a code change.
+    # mode).  ONE default for every high-level entry point (PyramidStack, align_and_stack, align_and_stack_device,
+    # bunches_then_stack -- they all go through resolve_arith below); the C struct's zero value / `_lib.Stack` (the thin
+    # binding) stay "exact", see include/mi355stack.h.  No environment override: the arithmetic a job ran with is the
+    # stacker's `arith` attribute and is logged with the job (round 5).
     DEFAULT_PY_ARITH="separable",
     DEFAULT_FRAMES=10, DEFAULT_OVERLAP=2, DEFAULT_STACK_PREFIX="stack_",
     DEFAULT_PLOT_STACK=True, DEFAULT_PLOTS_PATH="plots", DEFAULT_FILE_REVERSE_ORDER=False,
@@ -38,3 +41,12 @@ constants = SimpleNamespace(
     DEFAULT_DM_MAP="average", DEFAULT_DM_ENERGY="laplacian", DEFAULT_DM_KERNEL_SIZE=5,
     DEFAULT_DM_BLUR_SIZE=5, DEFAULT_DM_SMOOTH_SIZE=15, DEFAULT_DM_TEMPERATURE=0.1, DEFAULT_DM_LEVELS=3,
 )
+
+
+def resolve_arith(arith=None, float_type=None):
+    """The evaluation order a stack runs with: the caller's choice, else constants.DEFAULT_PY_ARITH ("exact" for float-64
+    stacks, which the separable kernels do not serve)."""
+    f64 = float_type in (constants.FLOAT_64, "float64") or getattr(float_type, "__name__", None) == "float64"
+    if arith is None:
+        return "exact" if f64 else constants.DEFAULT_PY_ARITH
+    return arith

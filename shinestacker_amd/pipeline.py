@@ -17,7 +17,7 @@ import numpy as np
 from . import _lib
 from .align import (_BORDER_CODE, _DEFAULT_ALIGNMENT_CONFIG, _DEFAULT_FEATURE_CONFIG,
                     _DEFAULT_MATCHING_CONFIG, img_subsample, rescale_transform, resolve_estimator)
-from .defaults import constants
+from .defaults import constants, resolve_arith
 from .errors import AlignmentError, InvalidOptionError
 from .imageio import validate_image
 
@@ -49,6 +49,7 @@ def align_and_stack(frames, ref_idx=-1, estimator=None, alignment_config=None, f
     dt = ref.dtype
     fb = h * w * 3 * dt.itemsize
     lib = _lib.load()
+    stack_kwargs["arith"] = resolve_arith(stack_kwargs.get("arith"))   # one default for every entry point
     stack = _lib.Stack(h, w, in_dtype=dt, out_dtype=dt, device=device, batch_frames=batch_frames,
                        **stack_kwargs)
     src = _lib.DeviceBuffer(fb, device)            # uploaded moving frame
@@ -274,6 +275,7 @@ def align_and_stack_device(dev_frames, n_frames, height, width, dtype, ref_idx=-
 
     Returns (fused image as ndarray, or None when `out_dev` -- a device address for the result --
     is given; list of 2x3 transforms, None at ref_idx; list of correlation coefficients)."""
+    stack_kwargs["arith"] = resolve_arith(stack_kwargs.get("arith"))   # one default for every entry point
     _lib.require_device()
     if n_frames < 1:
         raise ValueError("no frames")
@@ -317,7 +319,8 @@ def align_and_stack_device(dev_frames, n_frames, height, width, dtype, ref_idx=-
     if batch_frames is None:   # handles of an earlier call fix it; else as many frames per push as memory allows
         batch_frames = handles.geometry["batch_frames"] if handles is not None else auto_batch_frames(n_frames, height, width, dt, device)
     geometry = dict(height=int(height), width=int(width), dtype=dt.name, batch_frames=int(batch_frames),
-                    subsample=max(1, int(cfg['subsample'])), fast=bool(cfg['fast_subsampling']), device=int(device))
+                    subsample=max(1, int(cfg['subsample'])), fast=bool(cfg['fast_subsampling']), device=int(device),
+                    stack_kwargs=tuple(sorted((k, repr(v)) for k, v in stack_kwargs.items())))   # the stacker's own options
     # everything that can be refused is refused BEFORE anything is allocated
     corr = bal_opts = None
     if balance is not None:
@@ -341,15 +344,15 @@ def align_and_stack_device(dev_frames, n_frames, height, width, dtype, ref_idx=-
         aligner = _lib.Aligner(height, width, dt, subsample=max(1, int(cfg['subsample'])), device=device,
                                fast=bool(cfg['fast_subsampling']))
         created = [stack, aligner]     # released here whenever an exception leaves this call
-    if corr is not None:
-        corr.begin_device(dev_frames + ref_idx * fb, height, width, dt, n_frames)
-        bal_opts = corr.native_linear_opts() if native else None
     if native:
         # the whole loop below in ONE library call (mi_align_stack_device): same kernels in the same order on the same
         # streams; the ~25 ctypes calls per frame of the Python loop made the pipeline's pace depend on how busy the host is
         # (0.08 s on an idle box, 0.3 s on a shared one, for 128 x 24 MP)
         done = False
         try:
+            if corr is not None:
+                corr.begin_device(dev_frames + ref_idx * fb, height, width, dt, n_frames)
+                bal_opts = corr.native_linear_opts()
             if handles is None:
                 batches = _lib.DeviceBuffer(2 * fb * batch_frames, device)
                 created.append(batches)
@@ -397,6 +400,13 @@ def align_and_stack_device(dev_frames, n_frames, height, width, dtype, ref_idx=-
             return out, transforms, ccs, (handles if handles is not None else
                                           StackHandles(stack, aligner, batches, tmp, mask, **geometry))
         return out, transforms, ccs
+    try:
+        if corr is not None:
+            corr.begin_device(dev_frames + ref_idx * fb, height, width, dt, n_frames)
+    except BaseException:
+        for obj in created or ():
+            obj.close()
+        raise
     tmp = _lib.DeviceBuffer(fb, device)
     mask = _lib.DeviceBuffer(height * width, device)
     # two batches of warped frames: one is being fused while the next is being filled
@@ -479,7 +489,7 @@ def align_and_stack_device(dev_frames, n_frames, height, width, dtype, ref_idx=-
 
 def bunches_then_stack(get_frame, n_frames, height, width, dtype, frames=constants.DEFAULT_FRAMES,
                        overlap=constants.DEFAULT_OVERLAP, device=0, out_dev=None, on_bunch=None, on_final=None,
-                       check_running=None, stacks=None, results_buf=None, info=None, **stack_kwargs):
+                       check_running=None, stacks=None, results_buf=None, info=None, zero_copy=False, **stack_kwargs):
     """BASELINE config 5's two-stage flow in memory (the reference's `FocusStackBunch` followed by `FocusStack`,
     stack.py:61-113, examples/stack-from-frames): the frames are fused in bunches of `frames` with `overlap` shared
     (`get_bunches`), every bunch result is the stacker's OUTPUT type -- truncated to the input dtype exactly as the file
@@ -501,6 +511,7 @@ def bunches_then_stack(get_frame, n_frames, height, width, dtype, frames=constan
     on the device) and `stage2_s` (the stack over the bunch results, to its result).  Returns the fused image (or None when `out_dev` is given) and the list of
     bunches (frame indices)."""
     from .actions import get_bunches
+    stack_kwargs["arith"] = resolve_arith(stack_kwargs.get("arith"))   # one default for every entry point
     _lib.require_device()
     if overlap >= frames:
         raise InvalidOptionError("overlap", overlap, "overlap must be smaller than batch size")
@@ -509,6 +520,8 @@ def bunches_then_stack(get_frame, n_frames, height, width, dtype, frames=constan
     bunches = get_bunches(list(range(n_frames)), frames, overlap)
     if not bunches:
         raise ValueError("no frames")
+    if stacks is not None and len(stacks) < 2:
+        raise InvalidOptionError("stacks", len(stacks), ": at least two handles are needed (the last one is stage 2, the others stage 1)")
     own_results = results_buf is None
     if not own_results and results_buf.nbytes < fb * len(bunches):
         raise InvalidOptionError("results_buf", results_buf.nbytes, f": {len(bunches)} bunch results need {fb * len(bunches)} bytes")
@@ -527,7 +540,7 @@ def bunches_then_stack(get_frame, n_frames, height, width, dtype, frames=constan
             st = stage1[k % len(stage1)]
             st.reset()      # a handle serves every other bunch, as one stacker object serves FocusStackBunch (stack.py:94-97)
             for i in bunch:
-                st.push_frame(get_frame(i))
+                st.push_frame(get_frame(i), zero_copy=zero_copy)
                 if check_running is not None and check_running() is False:
                     from .errors import RunStopException
                     raise RunStopException("bunches_then_stack")
@@ -538,10 +551,13 @@ def bunches_then_stack(get_frame, n_frames, height, width, dtype, frames=constan
             st.sync()
     except BaseException:
         for st in stage1:
-            if stacks:
-                st.sync()       # a reused handle may still be writing into `results`
-            else:
-                st.close()
+            try:                # the cleanup must not mask the exception that brought us here
+                if stacks:
+                    st.sync()   # a reused handle may still be writing into `results`
+                else:
+                    st.close()
+            except Exception:   # noqa: BLE001
+                pass
         if own_results:
             results.free()
         raise

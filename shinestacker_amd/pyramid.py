@@ -21,10 +21,12 @@ reference decodes twice, pyramid.py:158 and :172) and is pushed to the device du
 validation pass, and no per-frame pyramid is kept -- selection is a running first-max on the
 device.
 """
+import logging
+
 import numpy as np
 
 from . import _lib
-from .defaults import constants
+from .defaults import constants, resolve_arith
 from .errors import ImageLoadError, InvalidOptionError, RunStopException
 from .imageio import get_img_metadata, read_img, validate_image
 
@@ -115,12 +117,9 @@ class PyramidStack(BaseStackAlgo):
         #                 of the reference's float-64 mode, ~1.3x the throughput -- the default since round 4
         #                 (constants.DEFAULT_PY_ARITH; float-64 stacks always run "exact")
         #   "exact"     = the reference's own row-major 25-tap order: bit-identical to its restatement, the audit mode
-        # None -> $SHINESTACKER_AMD_ARITH, else the default.
-        if arith is None:
-            import os
-            arith = os.environ.get("SHINESTACKER_AMD_ARITH") or constants.DEFAULT_PY_ARITH
-            if float_type == constants.FLOAT_64:
-                arith = "exact"
+        # None -> the default (defaults.resolve_arith: the same rule in every high-level entry point).  The arithmetic a
+        # stack ran with is `self.arith`, part of `name()`'s sibling `describe()` and of the job log.
+        arith = resolve_arith(arith, float_type)
         if arith not in _lib.ARITH_CODE:
             raise InvalidOptionError("arith", arith, details=" valid values are 'exact' and 'separable'")
         if arith == "separable" and float_type == constants.FLOAT_64:
@@ -157,7 +156,14 @@ class PyramidStack(BaseStackAlgo):
                                  batch_frames=self.batch_frames, arith=self.arith,
                                  float_type=_lib.MI_F64 if self.float_type is np.float64 else _lib.MI_F32)
         self._stack_key = key
+        # which arithmetic this stack runs with goes to the log (not to print_message: the callback trace is the reference's)
+        logging.getLogger("shinestacker_amd").info("PyramidStack: %s", self.describe())
         return self._stack
+
+    def describe(self):
+        """the options that decide the bits of the result, for logs and output metadata"""
+        return (f"arith={self.arith} float_type={'float-64' if self.float_type is np.float64 else 'float-32'} "
+                f"min_size={self.min_size} kernel_size={self.kernel_size} gen_kernel={self.gen_kernel_a} use_fma={self.use_fma}")
 
     def close(self):
         if self._stack is not None:

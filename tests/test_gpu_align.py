@@ -146,7 +146,7 @@ def test_align_and_stack_pipeline_equals_two_step_path(L, oracle):
         else:
             _n, _m, wimg = align_images(frames[2], f, estimator=est, alignment_config=cfg)
             aligned.append(wimg)
-    so = oracle.StreamingOracle(160, 208, np.uint8)
+    so = oracle.StreamingOracle(160, 208, np.uint8, arith="separable")   # the default of every high-level entry point
     for f in aligned:
         so.push_frame(f)
     assert matches == [500, 500, 0, 500, 500]

@@ -146,7 +146,7 @@ def test_resident_pipeline_with_balance(L, oracle, channel, corr_map):
     c = cls(corr_map=corr_map, subsample=2, fast_subsampling=True)
     c.begin(frames[1], n, 1)
     balanced = [a if i == 1 else c.apply_correction(i, a) for i, a in enumerate(aligned)]
-    want = PyramidStack(arith="exact").focus_stack_arrays(balanced)   # align_and_stack_device: the library default
+    want = PyramidStack().focus_stack_arrays(balanced)   # the same default arithmetic behind both entry points
     assert np.array_equal(fused_bal, want)
     # LINEAR runs inside the library's frame loop (mi_align_stack_device with mi_balance_linear_opts_t); the call-by-call
     # Python loop must give the same bytes

@@ -265,7 +265,7 @@ def test_align_and_stack_device_step_process_chains(L, oracle):
             assert np.allclose(m, tr[i], rtol=0, atol=1e-9), i
             aligned[i] = L.warp_affine(frames[i], tr[i])
             prev = i
-    so = oracle.StreamingOracle(h, w, np.uint8, keep_gauss=False)
+    so = oracle.StreamingOracle(h, w, np.uint8, keep_gauss=False, arith="separable")   # the entry points' default
     for i in range(n):
         so.push_frame(aligned[i])
     assert np.array_equal(fused, so.finish())
@@ -371,7 +371,7 @@ def test_step_process_chains_balance_before_the_next_reference(L, oracle):
             assert np.allclose(m, tr[i], rtol=0, atol=1e-9), i
             out[i] = corr.apply_correction(i, L.warp_affine(frames[i], tr[i]))
             prev = i
-    so = oracle.StreamingOracle(h, w, np.uint8, keep_gauss=False)
+    so = oracle.StreamingOracle(h, w, np.uint8, keep_gauss=False, arith="separable")   # the entry points' default
     for i in range(n):
         so.push_frame(out[i])
     assert np.array_equal(fused, so.finish())
@@ -411,6 +411,7 @@ def test_handles_of_one_stack_serve_the_next_and_are_checked_against_its_geometr
     assert hd2 is hd and np.array_equal(out, fresh_a)
     for bad_kw, bad_shape in ((dict(alignment_config=cfg, batch_frames=8), (h, w)),
                               (dict(alignment_config={'subsample': 2}, batch_frames=4), (h, w)),
+                              (dict(kw, arith="exact"), (h, w)),          # the stacker's own options are part of the geometry
                               (kw, (h // 2, w))):
         with pytest.raises(InvalidOptionError, match="handles"):
             align_and_stack_device(a.ptr, n, bad_shape[0], bad_shape[1], np.uint8, handles=hd, **bad_kw)

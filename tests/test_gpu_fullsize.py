@@ -263,7 +263,7 @@ def test_config5_two_stage_16_bunches_50mp_u16(L, oracle):
     checked = []
 
     def on_bunch(k, st):
-        so = oracle.StreamingOracle(c, c, np.uint16, levels=1)
+        so = oracle.StreamingOracle(c, c, np.uint16, levels=1, arith="separable")   # bunches_then_stack's default
         for i in want[k]:
             so.push_frame(crop(i))
         assert np.array_equal(st.tap(L.TAP_FUSED_LAP, 0)[:good, :good], so.best_lap[0][:good, :good]), k
@@ -273,7 +273,7 @@ def test_config5_two_stage_16_bunches_50mp_u16(L, oracle):
     final = {}
 
     def on_final(st2, results):
-        so = oracle.StreamingOracle(c, c, np.uint16, levels=1)
+        so = oracle.StreamingOracle(c, c, np.uint16, levels=1, arith="separable")
         for k in range(len(want)):
             # rows 0..c-1 of bunch result k, then the corner of them
             rows = results.download((c, W, 3), np.uint16, offset=k * per)

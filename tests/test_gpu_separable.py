@@ -206,7 +206,7 @@ def test_separable_tiled_equals_simple_on_random_shapes(L, seed):
 def test_pyramid_stack_arith_option(L, oracle):
     """PyramidStack(arith="separable") -- the keyword the drop-in class adds -- fuses with the separable arithmetic
     (== its oracle) and is what PyramidStack() gives (constants.DEFAULT_PY_ARITH, round 4); arith="exact" is the reference's
-    evaluation order (== the exact oracle); $SHINESTACKER_AMD_ARITH overrides the default; float-64 stacks stay exact; bad
+    evaluation order (== the exact oracle); the environment cannot change it; float-64 stacks stay exact; bad
     combinations are refused."""
     from shinestacker_amd.errors import InvalidOptionError
     from shinestacker_amd.pyramid import PyramidStack
@@ -221,13 +221,15 @@ def test_pyramid_stack_arith_option(L, oracle):
     assert np.array_equal(PyramidStack(arith="exact").focus_stack_arrays(frames), want_exact)
     assert PyramidStack().arith == "separable" and PyramidStack(float_type="float-64").arith == "exact"
     assert np.array_equal(PyramidStack().focus_stack_arrays(frames), so.finish())
+    # one default behind every high-level entry point, and no environment override (round 5)
+    from shinestacker_amd.defaults import resolve_arith
     import os
     os.environ["SHINESTACKER_AMD_ARITH"] = "exact"
     try:
-        assert PyramidStack().arith == "exact"
-        assert np.array_equal(PyramidStack().focus_stack_arrays(frames), want_exact)
+        assert PyramidStack().arith == "separable" == resolve_arith() and resolve_arith(None, "float-64") == "exact"
     finally:
         del os.environ["SHINESTACKER_AMD_ARITH"]
+    assert "arith=separable" in PyramidStack().describe()
     with pytest.raises(InvalidOptionError):
         PyramidStack(arith="fast")
     with pytest.raises(InvalidOptionError):
