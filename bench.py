@@ -475,7 +475,7 @@ def main():
             t0 = time.perf_counter()
             if host_frames is not None:
                 for i in range(F):
-                    st.push_frame(host_frames[i % len(host_frames)])
+                    st.push_frame(host_frames[i % len(host_frames)], zero_copy=args.source == "host-pinned")
             else:
                 st.push_frames_device(buf.ptr, F)
             if combiner is not None:

@@ -146,6 +146,17 @@ def k3_f32(a=0.4):
     return np.ascontiguousarray(gen_kernel_1d(a)[:3].astype(np.float32))
 
 
+def red_taps_f32(a=0.4):
+    """MI_ARITH_SEPARABLE, taps of the reduce (w0, w1, w2, rs): the integers 20 k and rs = float32(1/400) when 20 k is
+    integral, else float32(k) and 1 (separable_oracle.c; the same rule as csrc/common.hpp::red_taps)."""
+    k = gen_kernel_1d(a)[:3].astype(np.float64)
+    w = 20.0 * np.array([0.25 - a / 2.0, 0.25, a])
+    r = np.round(w)
+    if np.all(np.abs(w - r) < 1e-9):
+        return np.ascontiguousarray(np.array([r[0], 5.0, r[2], 1.0 / 400.0]).astype(np.float32))
+    return np.ascontiguousarray(np.array([k[0], k[1], k[2], 1.0]).astype(np.float32))
+
+
 def num_levels(h, w, min_size=32):
     """pyramid.py:165 (requested levels) + :129-130 (early stop when a side < 4)."""
     req = int(np.log2(min(h, w) / min_size))
@@ -346,6 +357,7 @@ class StreamingOracle:
         # level rule and the final cast are the same in both modes
         self.sep = arith == "separable"
         self.k3 = k3_f32(gen_kernel)
+        self.rk = red_taps_f32(gen_kernel)
         self.keep_gauss = keep_gauss
         self.h, self.w, self.dtype = h, w, np.dtype(dtype)
         self.levels = num_levels(h, w, min_size) if levels is None else levels
@@ -383,7 +395,7 @@ class StreamingOracle:
         for lv in range(self.levels):
             h, w = self.shapes[lv]
             if self.sep:
-                lib().orc_sep_reduce_f32(g[lv], h, w, self.k3, g[lv + 1])
+                lib().orc_sep_reduce_f32(g[lv], h, w, self.rk, g[lv + 1])
             else:
                 lib().orc_reduce_f32(g[lv], h, w, 3, self.k, g[lv + 1], self.fma)
         return g

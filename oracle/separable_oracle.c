@@ -7,8 +7,13 @@
  *
  *     s5(a, b, c, d, e) = fma(k0, a + e, fma(k1, b + d, k2 * c))
  *
- *   reduce   (pyramid.py:27-32)  V = s5 down the rows at even rows (REFLECT101), G' = s5 along the rows of V
- *            at even columns
+ *   reduce   (pyramid.py:27-32)  V = s5r down the rows at even rows (REFLECT101), G' = rs * s5r along the rows of V
+ *            at even columns, with  s5r(a, b, c, d, e) = fma(w1, b + d, fma(w0, a + e, w2 * c))  and
+ *            rk = (w0, w1, w2, rs) = oracle.red_taps_f32(gen_kernel): INTEGER taps 20 k and rs = float32(1/400) when 20 k
+ *            is integral (gen_kernel 0.4, the reference's default: 1 5 8 5 1) -- for integer-valued input every
+ *            product and partial sum is then exact, the only roundings are that of the exact integer sum S (none for
+ *            8-bit input: S < 2^24) and of fl(S) * rs -- else float32(k) and rs = 1 (round 5; the kernels' MFMA form of
+ *            the 8-bit level-0 reduce computes S in 32-bit integers and must give the same bits)
  *   expand   (pyramid.py:34-46)  on the zero-stuffed grid only every second tap is non-zero: with ce = 2 k0,
  *            cc = 2 k2, co = 2 k1 (the reference's factor 4, split over the two dimensions)
  *                even position 2j   : fma(ce, N[j-1] + N[j+1], cc * N[j])
@@ -48,14 +53,18 @@ static inline float s5(float a, float b, float c, float d, float e, const float*
     const float t0 = a + e, t1 = b + d;
     return __builtin_fmaf(k[0], t0, __builtin_fmaf(k[1], t1, k[2] * c));
 }
+static inline float s5r(float a, float b, float c, float d, float e, const float* rk) {
+    const float t0 = a + e, t1 = b + d;
+    return __builtin_fmaf(rk[1], t1, __builtin_fmaf(rk[0], t0, rk[2] * c));
+}
 static inline float ex_even(float l, float c, float r, float ce, float cc) { return __builtin_fmaf(ce, l + r, cc * c); }
 static inline float ex_odd(float c, float r, float co) { return co * (c + r); }
 static inline float gray_of(float b, float g, float r) {
     return __builtin_fmaf(r, 0.299f, __builtin_fmaf(g, 0.587f, b * 0.114f));
 }
 
-/* reduce_layer: g is h x w x 3, out is ceil(h/2) x ceil(w/2) x 3; k3 = float32(k0, k1, k2) */
-ORC_API void orc_sep_reduce_f32(const float* g, int h, int w, const float* k3, float* out) {
+/* reduce_layer: g is h x w x 3, out is ceil(h/2) x ceil(w/2) x 3; rk = (w0, w1, w2, rs) */
+ORC_API void orc_sep_reduce_f32(const float* g, int h, int w, const float* rk, float* out) {
     const int ho = (h + 1) / 2, wo = (w + 1) / 2;
 #pragma omp parallel
     {
@@ -64,13 +73,13 @@ ORC_API void orc_sep_reduce_f32(const float* g, int h, int w, const float* k3, f
         for (int i = 0; i < ho; ++i) {
             const float* row[5];
             for (int t = 0; t < 5; ++t) row[t] = g + (size_t)r101(2 * i - 2 + t, h) * w * 3;
-            for (int f = 0; f < w * 3; ++f) V[f] = s5(row[0][f], row[1][f], row[2][f], row[3][f], row[4][f], k3);
+            for (int f = 0; f < w * 3; ++f) V[f] = s5r(row[0][f], row[1][f], row[2][f], row[3][f], row[4][f], rk);
             for (int j = 0; j < wo; ++j) {
                 int x[5];
                 for (int t = 0; t < 5; ++t) x[t] = r101(2 * j - 2 + t, w);
                 for (int c = 0; c < 3; ++c)
                     out[((size_t)i * wo + j) * 3 + c] =
-                        s5(V[x[0] * 3 + c], V[x[1] * 3 + c], V[x[2] * 3 + c], V[x[3] * 3 + c], V[x[4] * 3 + c], k3);
+                        s5r(V[x[0] * 3 + c], V[x[1] * 3 + c], V[x[2] * 3 + c], V[x[3] * 3 + c], V[x[4] * 3 + c], rk) * rk[3];
             }
         }
         free(V);

@@ -404,6 +404,7 @@ class Stack:
         h = C.c_void_p()
         check(lib.mi_stack_create(C.byref(h), C.byref(p)))
         self._h = h
+        self._inflight = []     # pinned frames whose zero-copy upload may still be running (push_frame(zero_copy=True))
         n = C.c_int()
         check(lib.mi_stack_levels(self._h, C.byref(n)))
         self.levels = n.value

@@ -72,6 +72,8 @@ struct mi_stack {
     std::vector<int> lh, lw;  // level shapes, 0..L
     K25 K{};
     float k1d[3] = {0.f, 0.f, 0.f};   // MI_ARITH_SEPARABLE: float32 of the 1-D generating kernel (k0, k1, k2)
+    float rk[4] = {0.f, 0.f, 0.f, 1.f};   // MI_ARITH_SEPARABLE, reduce: taps (w0, w1, w2) and final scale (red_taps)
+    bool mfma_ok = false;             // integer taps small enough for the MFMA form of the level-0 reduce
     bool sep = false;         // p.arith == MI_ARITH_SEPARABLE
     K25d Kd{};                // float-64 mode: the float64 generating kernel (np.outer, pyramid.py:21)
     bool f64 = false;         // float_type == MI_F64: float buffers below hold doubles (allocated twice as large)
@@ -202,10 +204,11 @@ int process_frame_simple(mi_stack* s, const TIn* frame) {
         ProfScope ps(s, MI_PROF_LEVEL, algorithmic_bytes_per_frame(s));
         const float k0 = s->k1d[0], k1 = s->k1d[1], k2 = s->k1d[2];
         hipLaunchKernelGGL((reduce_sep_simple<TIn>), grid2d(s->lw[1], s->lh[1], blk), blk, 0, s->stream, frame, s->lh[0],
-                           s->lw[0], s->G[1], s->lh[1], s->lw[1], k0, k1, k2);
+                           s->lw[0], s->G[1], s->lh[1], s->lw[1], s->rk[0], s->rk[1], s->rk[2], s->rk[3]);
         for (int l = 1; l < s->L; ++l)
             hipLaunchKernelGGL((reduce_sep_simple<float>), grid2d(s->lw[l + 1], s->lh[l + 1], blk), blk, 0, s->stream,
-                               (const float*)s->G[l], s->lh[l], s->lw[l], s->G[l + 1], s->lh[l + 1], s->lw[l + 1], k0, k1, k2);
+                               (const float*)s->G[l], s->lh[l], s->lw[l], s->G[l + 1], s->lh[l + 1], s->lw[l + 1], s->rk[0],
+                               s->rk[1], s->rk[2], s->rk[3]);
         for (int l = 0; l < s->L; ++l) {
             dim3 g = grid2d(s->lw[l], s->lh[l], blk);
             if (l == 0)
@@ -1275,6 +1278,7 @@ int mi_stack_create(mi_stack_t** out, const mi_stack_params_t* params) {
             }
         for (int i = 0; i < 3; ++i) s->k1d[i] = (float)k[i];
         s->sep = p.arith == MI_ARITH_SEPARABLE;
+        s->mfma_ok = red_taps(a, s->rk);
     }
     s->pad = (p.kernel_size - 1) / 2;
     s->nlevels_hist = p.out_dtype == MI_U8 ? 256 : 65536;

@@ -98,6 +98,24 @@ __device__ __forceinline__ uint32_t lowbias32(uint32_t x) {
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// MI_ARITH_SEPARABLE, taps of the reduce (kernels_sep.hpp header, oracle/oracle.py::red_taps_f32 is the same rule): when 20 k is
+// integral for the generating kernel k = [1/4 - a/2, 1/4, a, 1/4, 1/4 - a/2] (a = 0.4, the reference's default: 1 5 8 5 1) the
+// taps are those integers and the result is scaled once by float32(1/400); else float32(k) and scale 1.  Returns whether
+// the integer (MFMA) form of the level-0 reduce applies: non-negative integer taps whose products fit a signed byte.
+inline bool red_taps(double a, float rk[4]) {
+    const double k0 = 0.25 - a / 2.0, k1 = 0.25, k2 = a;
+    const double w0 = 20.0 * k0, w1 = 20.0 * k1, w2 = 20.0 * k2;
+    const double r0 = (double)(long long)(w0 + (w0 < 0 ? -0.5 : 0.5)), r2 = (double)(long long)(w2 + (w2 < 0 ? -0.5 : 0.5));
+    const bool integral = (w0 - r0 < 1e-9 && r0 - w0 < 1e-9) && (w2 - r2 < 1e-9 && r2 - w2 < 1e-9) && w1 == 5.0;
+    if (!integral) {
+        rk[0] = (float)k0; rk[1] = (float)k1; rk[2] = (float)k2; rk[3] = 1.0f;
+        return false;
+    }
+    rk[0] = (float)r0; rk[1] = 5.0f; rk[2] = (float)r2; rk[3] = (float)(1.0 / 400.0);
+    const double m = r2 > r0 ? r2 : r0;
+    return r0 >= 0.0 && r2 >= 0.0 && m * (m > 5.0 ? m : 5.0) <= 127.0;
+}
+
 // Timing-study knobs (phase ablation, tile / batch variants) exist only in -DMI_STUDY builds (tools/study_build.sh
 // -> libmi355stack_study.so); the release library reads no environment variable on its compute paths.
 #ifdef MI_STUDY

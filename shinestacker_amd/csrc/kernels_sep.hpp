@@ -6,7 +6,13 @@
 //
 //     s5(a, b, c, d, e) = fma(k0, a + e, fma(k1, b + d, k2 * c))
 //
-//   reduce   V = s5 down the rows at even rows, G_{l+1} = s5 along the rows at even columns   (pyramid.py:27-32)
+//   reduce   V = s5r down the rows at even rows, G_{l+1} = rs * s5r along the rows at even columns   (pyramid.py:27-32)
+//            s5r(a, b, c, d, e) = fma(w1, b + d, fma(w0, a + e, w2 * c)) with (w0, w1, w2, rs) = red_taps(gen_kernel):
+//            when 20 k is integral -- the reference's default 0.4 gives (1, 5, 8) -- the taps are those INTEGERS and
+//            rs = float32(1 / 400): every product and every partial sum of integer-valued input (8 / 16-bit frames, fp32
+//            frames holding such values) is exact, the one rounding of the sum is that of the exact integer sum S, and
+//            G_{l+1} = fl(fl(S) * rs) -- two roundings instead of ten, and an integer pipeline (level_sep's MFMA form for
+//            8-bit frames) reproduces it bit for bit.  Otherwise (w0, w1, w2) = float32(k) and rs = 1 (round 5).
 //   expand   X = along the rows:  even column  fma(2k0, N[j-1] + N[j+1], 2k2 * N[j]),  odd  2k1 * (N[j] + N[j+1])
 //            then the same down the rows (the zero-stuffed grid's zero taps skipped)           (pyramid.py:34-46)
 //   lap      G_l - expand(G_{l+1})                                                             (pyramid.py:133-138)
@@ -86,6 +92,13 @@ template <typename TIn> constexpr int sep_nt() { return sizeof(TIn) == 4 ? MI_SE
 #ifndef MI_SEP_DMA
 #define MI_SEP_DMA 0
 #endif
+// Level 0 of 8-bit frames with integer reduce taps (red_taps: the default generating kernel): the 5 x 5 reduce as exact
+// integer arithmetic on the matrix pipe (v_mfma_i32_16x16x64_i8 on the staged bytes) instead of ~45 % of the kernel's VALU
+// instructions -- see level_sep_body, "MF".  Tile height 24 (the G_{l+1} patch is then 16 rows = one MFMA column block).
+#ifndef MI_SEP_MFMA
+#define MI_SEP_MFMA 1
+#endif
+constexpr int SEP_MF_TH = 24, SEP_MF_NT = 512;
 
 template <int TH_, int NT_>
 struct SepGeom {
@@ -107,6 +120,11 @@ struct SepGeom {
     static constexpr int lds_floats(int esize, bool interior) {
         return (interior && esize <= 2 ? GH * (GD / 4) * esize : GH * GS) + NH * VS + NH * XS;
     }
+    // MF (integer reduce on the matrix pipe, 8-bit frames): raw patch at a 208-byte row pitch (52 chunks of 4 bytes: the
+    // MFMA operand reads want 8-byte alignment), gray of the G_{l+1} patch (NH x (NW + 2): one pad column per side, pitch
+    // 34 = conflict-free for the MFMA result layout), HB, and the three weight operands (64 lanes x 16 bytes each)
+    static constexpr int MF_CPR = 52, MF_GP = NW + 2;
+    static constexpr int lds_floats_mf() { return GH * MF_CPR + NH * MF_GP + HBH * HBS + 3 * 64 * 4; }
     static_assert(GD % 4 == 0 && NW == 32, "tile width is fixed by the 32-lane quad rows");
     static_assert(QY * QL <= NT, "one quad per lane (a ninth wave, if any, only stages, reduces and carries P2 items)");
     static_assert(HBH * HBS <= NH * VS, "HB aliases V");
@@ -125,6 +143,18 @@ __device__ __forceinline__ v2f s5(v2f a, v2f b, v2f c, v2f d, v2f e, float k0, f
 __device__ __forceinline__ float s5(float a, float b, float c, float d, float e, float k0, float k1, float k2) {
     const float t0 = a + e, t1 = b + d;
     return __builtin_fmaf(k0, t0, __builtin_fmaf(k1, t1, k2 * c));
+}
+// the reduce's tap order (see the header): the centre and outer taps first, the inner pair last -- with integer taps the last
+// fma is then the only operation that can round (16-bit input: w0 (a + e) + w2 c <= 10 * 20 * 65535 < 2^24)
+__device__ __forceinline__ v2f s5r(v2f a, v2f b, v2f c, v2f d, v2f e, float w0, float w1, float w2) {
+    const v2f t0 = a + e, t1 = b + d;
+    v2f m = c * w2;
+    m = pk_fma((v2f)w0, t0, m);
+    return pk_fma((v2f)w1, t1, m);
+}
+__device__ __forceinline__ float s5r(float a, float b, float c, float d, float e, float w0, float w1, float w2) {
+    const float t0 = a + e, t1 = b + d;
+    return __builtin_fmaf(w1, t1, __builtin_fmaf(w0, t0, w2 * c));
 }
 // expand, one dimension: even position from (left, centre, right), odd position from (centre, right)
 __device__ __forceinline__ float ex_even(float l, float c, float r, float ce, float cc) {
@@ -288,7 +318,9 @@ template <> struct PreChunk<uint16_t> {
     }
 };
 
-template <typename TIn, bool INTERIOR, int TH, int NT>
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+template <typename TIn, bool INTERIOR, int TH, int NT, bool MF_ = false>
 __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
     using G = SepGeom<TH, NT>;
     constexpr int TW = G::TW;
@@ -296,11 +328,23 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
     constexpr bool RAW = INTERIOR && sizeof(TIn) <= 2;   // staged patch kept in the input type (see SepGeom::lds_floats)
     constexpr bool DMA = MI_SEP_DMA && INTERIOR && sizeof(TIn) == 4;   // patch staged by LDS-DMA (see MI_SEP_DMA)
     constexpr int RD = (int)sizeof(TIn);                 // dwords per 4-element chunk in that form
+    // MF: the reduce of 8-bit frames on the matrix pipe.  P1 + P2 become one phase: wave v computes the G_{l+1} patch rows
+    // 2v, 2v + 1 (16 rows = 8 waves) with five v_mfma_i32_16x16x64_i8 -- one per tap row -- whose DATA operand is read
+    // straight from the staged bytes (column n of the operand = a 64-byte window of a patch row: 24 n bytes along the row,
+    // i.e. four output pixels further per window) and whose WEIGHT operand holds kv[t] * kh[tau] at byte 6 p + 3 tau + c of
+    // the window for output slot (pixel p, channel c); the result layout gives every lane the three channel sums S of ONE
+    // G_{l+1} pixel (+ an empty fourth slot), 32 consecutive pixels of a row on 32 lanes.  The staged bytes carry x ^ 0x80
+    // (= x - 128 as the signed byte the instruction takes); the accumulator starts at 128 * 400.  S is the exact integer
+    // sum, G_{l+1} = float(S) * rs: bit-identical to the float evaluation of red_taps' integer taps (header).
+    static_assert(!MF_ || (INTERIOR && sizeof(TIn) == 1 && G::NH == 16 && NT == 512), "MF geometry");
+    constexpr bool MF = MF_;
     float* sG = smem;
     uint32_t* sGr = reinterpret_cast<uint32_t*>(smem);
-    float* sV = smem + (G::lds_floats((int)sizeof(TIn), INTERIOR) - G::NH * G::VS - G::NH * G::XS);
+    float* sV = smem + (MF ? 0 : G::lds_floats((int)sizeof(TIn), INTERIOR) - G::NH * G::VS - G::NH * G::XS);
     float* sX = sV + G::NH * G::VS;
-    float* sHB = sV;   // V is dead once P2 has read it
+    float* sGg = smem + G::GH * G::MF_CPR;            // MF: gray of the G_{l+1} patch, [NH][NW + 2]
+    float* sHB = MF ? sGg + G::NH * G::MF_GP : sV;     // V is dead once P2 has read it
+    uint32_t* sW = reinterpret_cast<uint32_t*>(sGg + G::NH * G::MF_GP + G::HBH * G::HBS);   // MF: weight operands
     const int tid = threadIdx.x;
     const int h = a.h, w = a.w, hn = a.hn, wn = a.wn;
 
@@ -353,6 +397,7 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
     }
 
     const float k0 = a.k1d[0], k1 = a.k1d[1], k2 = a.k1d[2];
+    const float w0 = a.rk[0], w1 = a.rk[1], w2 = a.rk[2], rs = a.rk[3];   // reduce taps and final scale (red_taps)
     const float ce = 2.0f * k0, cc = 2.0f * k2, co = 2.0f * k1;   // expand taps (the reference's 4 * K, per dimension)
 
     // ---- which frames?  (levels with few tiles split the batch into chunks along blockIdx.y, see LevelArgs)
@@ -399,9 +444,10 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
     // inside LDS after the staging barrier (6 columns per side; edge tiles pay one more barrier per frame).  Patch rows
     // start 2 elements off the 4-element chunk grid of an image row, so the chunk that straddles an image edge holds 2
     // in-image elements: it is loaded 2 elements further inside the row and stored rotated by 2.
-    constexpr int CPR = G::GD / 4;   // chunks per patch row
-    PreChunk<TIn> pre[G::NPRE];
-    uint32_t goff[G::NPRE];          // interior / edge: byte offset of the chunk inside a frame
+    constexpr int CPR = MF ? G::MF_CPR : G::GD / 4;   // chunks per patch row (MF: one more, for a 208-byte LDS row pitch)
+    constexpr int NCH = G::GH * CPR, NPRE = (NCH + NT - 1) / NT;
+    PreChunk<TIn> pre[NPRE];
+    uint32_t goff[NPRE];          // interior / edge: byte offset of the chunk inside a frame
     bool edge = false;
     int colL = -1, colR = -1;        // edge: the straddling chunk column at the left / right image edge (-1: none)
     int peR = -1;                    // edge: patch column of the image's last column when the patch crosses it
@@ -413,7 +459,7 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
             if (rel < G::GD) { peR = w - 1 - (x0 - 6); if ((rel & 3) == 2) colR = (rel - 2) >> 2; }
         }
 #pragma unroll
-        for (int n = 0; n < G::NPRE; ++n) {
+        for (int n = 0; n < NPRE; ++n) {
             const int id = tid + n * NT, row = id / CPR, col = id - row * CPR;
             int e0 = 4 * col;                              // first element of the chunk, relative to the patch row start
             int gy = y0 - 6 + row;
@@ -428,14 +474,14 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
     }
     const uint32_t frame_bytes = (uint32_t)h * (uint32_t)w * 3u * (uint32_t)sizeof(TIn);
     // chunks [n0, n1) of frame b
-    auto prefetch = [&](int b, int n0 = 0, int n1 = G::NPRE) {
+    auto prefetch = [&](int b, int n0 = 0, int n1 = NPRE) {
         const char* frb = src0 + (size_t)b * a.src_stride;
         const BufRsrc rs = make_rsrc(frb, frame_bytes);
 #pragma unroll
-        for (int n = 0; n < G::NPRE; ++n) {
+        for (int n = 0; n < NPRE; ++n) {
             if (n < n0 || n >= n1) continue;
             const int id = tid + n * NT;
-            if ((n + 1) * NT > G::NCH && id >= G::NCH) continue;
+            if ((n + 1) * NT > NCH && id >= NCH) continue;
             if constexpr (INTERIOR) {
                 pre[n].load(rs, goff[n]);
             } else {
@@ -463,8 +509,8 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
         if constexpr (DMA) {
             const v4u rs = make_rsrc_words(src0 + (size_t)b * a.src_stride, frame_bytes);
 #pragma unroll
-            for (int n = 0; n < G::NPRE; ++n) {
-                if ((n + 1) * NT > G::NCH && tid + n * NT >= G::NCH) continue;
+            for (int n = 0; n < NPRE; ++n) {
+                if ((n + 1) * NT > NCH && tid + n * NT >= NCH) continue;
                 lds_dma16(rs, goff[n], dma_base + 16u * (uint32_t)(n * NT));
             }
         }
@@ -498,9 +544,9 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
                 // the chunk that straddles an image edge was fetched 2 elements further in: rotate it in place, then the
                 // mirrored columns as below
 #pragma unroll
-                for (int n = 0; n < G::NPRE; ++n) {
+                for (int n = 0; n < NPRE; ++n) {
                     const int id = lt + n * NT;
-                    if ((n + 1) * NT > G::NCH && id >= G::NCH) continue;
+                    if ((n + 1) * NT > NCH && id >= NCH) continue;
                     const int col = id - (id / CPR) * CPR;
                     if (col == colL || col == colR) {
                         const v4f c = lds_load4(sG + 4 * id);
@@ -517,9 +563,9 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
             }
         } else if (INTERIOR && edge) {
 #pragma unroll
-            for (int n = 0; n < G::NPRE; ++n) {
+            for (int n = 0; n < NPRE; ++n) {
                 const int id = lt + n * NT;
-                if ((n + 1) * NT > G::NCH && id >= G::NCH) continue;
+                if ((n + 1) * NT > NCH && id >= NCH) continue;
                 const int col = id - (id / CPR) * CPR;
                 PreChunk<TIn> c = pre[n];
                 if (col == colL || col == colR) c.rot2();
@@ -531,7 +577,7 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
             for (int e = lt; e < G::GH * 18; e += NT) {
                 const int r = e / 18, k = e - r * 18, pc = k / 3, c = k - pc * 3;
                 if constexpr (RAW) {
-                    TIn* rowp = reinterpret_cast<TIn*>(sGr) + mul24(r, G::GD);
+                    TIn* rowp = reinterpret_cast<TIn*>(sGr) + mul24(r, 4 * CPR);   // a raw row = CPR chunks of 4 elements
                     if (colL >= 0) rowp[3 * pc + c] = rowp[3 * (12 - pc) + c];
                     if (peR >= 0 && peR + 1 + pc < G::GW) rowp[3 * (peR + 1 + pc) + c] = rowp[3 * (peR - 1 - pc) + c];
                 } else {
@@ -542,8 +588,8 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
             }
         } else {
 #pragma unroll
-            for (int n = 0; n < G::NPRE; ++n) {
-                if ((n + 1) * NT > G::NCH && lt + n * NT >= G::NCH) continue;
+            for (int n = 0; n < NPRE; ++n) {
+                if ((n + 1) * NT > NCH && lt + n * NT >= NCH) continue;
                 if constexpr (RAW) pre[n].store_raw(sGr + RD * (lt + n * NT));
                 else *reinterpret_cast<v4f*>(sG + 4 * (lt + n * NT)) = pre[n].get();
             }
@@ -553,7 +599,7 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
         MI_TICK(1);   // barrier 1
         // the next frame's loads: all here (0), or spread over the phases (MI_SEP_PF_SPLIT) so that the eight waves do
         // not queue up at the texture-address unit together (an issue stalls while its queue is full)
-        constexpr int PF_A = MI_SEP_PF_SPLIT == 0 ? G::NPRE : MI_SEP_PF_SPLIT == 1 ? (G::NPRE + 1) / 2 : 1;
+        constexpr int PF_A = MI_SEP_PF_SPLIT == 0 ? NPRE : MI_SEP_PF_SPLIT == 1 ? (NPRE + 1) / 2 : 1;
         if (!DMA && b + 1 < nfr && !MI_ABL(16)) prefetch(b + 1, 0, PF_A);
         if constexpr (TOUCH) {
             touch_acc ^= touch_val;   // last frame's touch has long returned: keeps the load alive for the compiler
@@ -579,16 +625,16 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
                 const typename PC::raw_t q0 = ld(0), q1 = ld(1), q2 = ld(2);
                 typename PC::raw_t n3 = ld(3), n4 = ld(4);
                 float* d = sV + mul24(v0, G::VS) + 4 * g;
-                v4f w0 = PC::cvt_raw(q0), w1 = PC::cvt_raw(q1), w2 = PC::cvt_raw(q2);
+                v4f r0 = PC::cvt_raw(q0), r1 = PC::cvt_raw(q1), r2 = PC::cvt_raw(q2);
 #pragma unroll
                 for (int u = 0; u < P1R; ++u) {
                     typename PC::raw_t f3 = n3, f4 = n4;
                     if (u < P1R - 1) { f3 = ld(2 * u + 5); f4 = ld(2 * u + 6); }
-                    const v4f w3 = PC::cvt_raw(n3), w4 = PC::cvt_raw(n4);
-                    const v2f lo = s5(w0.xy, w1.xy, w2.xy, w3.xy, w4.xy, k0, k1, k2);
-                    const v2f hi = s5(w0.zw, w1.zw, w2.zw, w3.zw, w4.zw, k0, k1, k2);
+                    const v4f r3 = PC::cvt_raw(n3), r4 = PC::cvt_raw(n4);
+                    const v2f lo = s5r(r0.xy, r1.xy, r2.xy, r3.xy, r4.xy, w0, w1, w2);
+                    const v2f hi = s5r(r0.zw, r1.zw, r2.zw, r3.zw, r4.zw, w0, w1, w2);
                     lds_store4(d + u * G::VS, lo.x, lo.y, hi.x, hi.y);
-                    w0 = w2; w1 = w3; w2 = w4;
+                    r0 = r2; r1 = r3; r2 = r4;
                     n3 = f3; n4 = f4;
                 }
             }
@@ -607,10 +653,10 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
 #pragma unroll
                     for (int t = 0; t < 7; ++t) r[t] = lds_load4(p + t * G::GS);
                 }
-                a0 = s5(r[0].xy, r[1].xy, r[2].xy, r[3].xy, r[4].xy, k0, k1, k2);
-                a1 = s5(r[0].zw, r[1].zw, r[2].zw, r[3].zw, r[4].zw, k0, k1, k2);
-                b0 = s5(r[2].xy, r[3].xy, r[4].xy, r[5].xy, r[6].xy, k0, k1, k2);
-                b1 = s5(r[2].zw, r[3].zw, r[4].zw, r[5].zw, r[6].zw, k0, k1, k2);
+                a0 = s5r(r[0].xy, r[1].xy, r[2].xy, r[3].xy, r[4].xy, w0, w1, w2);
+                a1 = s5r(r[0].zw, r[1].zw, r[2].zw, r[3].zw, r[4].zw, w0, w1, w2);
+                b0 = s5r(r[2].xy, r[3].xy, r[4].xy, r[5].xy, r[6].xy, w0, w1, w2);
+                b1 = s5r(r[2].zw, r[3].zw, r[4].zw, r[5].zw, r[6].zw, w0, w1, w2);
             } else {
                 // a cell outside G_{l+1} is computed at its mirror position (REFLECT101 acts on the zero-stuffed
                 // grid: V[-1] = G[1], V[n] = G[n-1]); the staged patch already holds reflected rows
@@ -622,8 +668,8 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
                     v4f r[5];
 #pragma unroll
                     for (int t = 0; t < 5; ++t) r[t] = lds_load4(sG + mul24(clampi(r0 + t, 0, G::GH - 1), G::GS) + 4 * g);
-                    o[u][0] = s5(r[0].xy, r[1].xy, r[2].xy, r[3].xy, r[4].xy, k0, k1, k2);
-                    o[u][1] = s5(r[0].zw, r[1].zw, r[2].zw, r[3].zw, r[4].zw, k0, k1, k2);
+                    o[u][0] = s5r(r[0].xy, r[1].xy, r[2].xy, r[3].xy, r[4].xy, w0, w1, w2);
+                    o[u][1] = s5r(r[0].zw, r[1].zw, r[2].zw, r[3].zw, r[4].zw, w0, w1, w2);
                 }
                 a0 = o[0][0]; a1 = o[0][1]; b0 = o[1][0]; b1 = o[1][1];
             }
@@ -645,7 +691,7 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
                 gq_o = v2f{gray_of<true>(go[0].x, go[0].y, go[1].x), gray_of<true>(go[1].y, go[2].x, go[2].y)};
             }
         }
-        if (!DMA && MI_SEP_PF_SPLIT == 1 && b + 1 < nfr && !MI_ABL(16)) prefetch(b + 1, PF_A, G::NPRE);
+        if (!DMA && MI_SEP_PF_SPLIT == 1 && b + 1 < nfr && !MI_ABL(16)) prefetch(b + 1, PF_A, NPRE);
         if (!DMA && MI_SEP_PF_SPLIT == 2 && b + 1 < nfr && !MI_ABL(16)) prefetch(b + 1, 1, 2);
         MI_TICK(3);   // P1
         __syncthreads();
@@ -669,7 +715,7 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
                     v[2 * t] = q.x; v[2 * t + 1] = q.y;
                 }
 #pragma unroll
-                for (int c = 0; c < 3; ++c) n[c] = s5(v[c], v[3 + c], v[6 + c], v[9 + c], v[12 + c], k0, k1, k2);
+                for (int c = 0; c < 3; ++c) n[c] = s5r(v[c], v[3 + c], v[6 + c], v[9 + c], v[12 + c], w0, w1, w2) * rs;
             } else {
                 const int jm = map_expand_src(x0 / 2 - 2 + jp, wn);
                 const int c0 = 2 * jm - 2 - (x0 - 6);
@@ -681,7 +727,7 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
                     t5[t][0] = q[0]; t5[t][1] = q[1]; t5[t][2] = q[2];
                 }
 #pragma unroll
-                for (int c = 0; c < 3; ++c) n[c] = s5(t5[0][c], t5[1][c], t5[2][c], t5[3][c], t5[4][c], k0, k1, k2);
+                for (int c = 0; c < 3; ++c) n[c] = s5r(t5[0][c], t5[1][c], t5[2][c], t5[3][c], t5[4][c], w0, w1, w2) * rs;
             }
             // tile centre of G_{l+1} -> global (input of the next level)
             {
@@ -768,7 +814,7 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
                 lds_store2(sHB + mul24(2 * qy3 + rr, G::HBS) + 2 * ql3, hb0, hb1);
             }
         }
-        if (!DMA && MI_SEP_PF_SPLIT == 2 && b + 1 < nfr && !MI_ABL(16)) prefetch(b + 1, 3, G::NPRE);
+        if (!DMA && MI_SEP_PF_SPLIT == 2 && b + 1 < nfr && !MI_ABL(16)) prefetch(b + 1, 3, NPRE);
         MI_TICK(7);   // P3
         __syncthreads();
         MI_TICK(8);   // barrier 4
@@ -931,25 +977,25 @@ __global__ void sep_payload(const void* __restrict__ src, size_t src_stride, con
 
 // V(i, x) of a source row pair: s5 down the rows 2i-2 .. 2i+2 (REFLECT101), one channel
 template <typename TIn>
-__device__ __forceinline__ float sep_v(const TIn* __restrict__ g, int h, int w, int i, int x, int c, float k0, float k1,
-                                       float k2) {
+__device__ __forceinline__ float sep_v(const TIn* __restrict__ g, int h, int w, int i, int x, int c, float w0, float w1,
+                                       float w2) {
     float v[5];
 #pragma unroll
     for (int t = 0; t < 5; ++t) v[t] = to_f32(g[((size_t)r101(2 * i - 2 + t, h) * w + x) * 3 + c]);
-    return s5(v[0], v[1], v[2], v[3], v[4], k0, k1, k2);
+    return s5r(v[0], v[1], v[2], v[3], v[4], w0, w1, w2);
 }
 
 template <typename TIn>
 __global__ void reduce_sep_simple(const TIn* __restrict__ g, int h, int w, float* __restrict__ out, int ho, int wo,
-                                  float k0, float k1, float k2) {
+                                  float w0, float w1, float w2, float rs) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y * blockDim.y + threadIdx.y;
     if (i >= ho || j >= wo) return;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         float v[5];
 #pragma unroll
-        for (int t = 0; t < 5; ++t) v[t] = sep_v(g, h, w, i, r101(2 * j - 2 + t, w), c, k0, k1, k2);
-        out[((size_t)i * wo + j) * 3 + c] = s5(v[0], v[1], v[2], v[3], v[4], k0, k1, k2);
+        for (int t = 0; t < 5; ++t) v[t] = sep_v(g, h, w, i, r101(2 * j - 2 + t, w), c, w0, w1, w2);
+        out[((size_t)i * wo + j) * 3 + c] = s5r(v[0], v[1], v[2], v[3], v[4], w0, w1, w2) * rs;
     }
 }
 

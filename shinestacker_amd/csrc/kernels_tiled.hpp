@@ -69,6 +69,8 @@ struct LevelArgs {
 #endif
     K6 K;
     float k1d[3];           // MI_ARITH_SEPARABLE: float32 of the 1-D generating kernel (k0, k1, k2)
+    float rk[4];            // MI_ARITH_SEPARABLE, reduce: taps (w0, w1, w2) and the final scale (red_taps, kernels_sep.hpp)
+    int mfma_ok;            // the integer (MFMA) form of the level-0 reduce may be used: small non-negative integer taps
     // MI_ARITH_SEPARABLE, frame chunks: blockIdx.y = c works on frames [c * chunk_frames, (c + 1) * chunk_frames) of the
     // batch.  Chunk 0 continues the running state; chunk c > 0 starts from nothing and leaves its (max, arg-max) in
     // part_e / part_idx [(c - 1) * part_stride + pixel]; merge_chunks folds them into the running state in chunk order.

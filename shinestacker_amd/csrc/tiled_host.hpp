@@ -478,6 +478,8 @@ int launch_level_sep(mi_stack* s, int l, int set, const void* src, size_t src_st
     a.first = s->n_pushed == 0;
     a.frame_idx0 = s->first_index + s->n_pushed;
     for (int i = 0; i < 3; ++i) a.k1d[i] = s->k1d[i];
+    for (int i = 0; i < 4; ++i) a.rk[i] = s->rk[i];
+    a.mfma_ok = s->mfma_ok;
     a.ablate = study_env("MI_ABLATE", 0);   // -DMI_STUDY builds only (results are wrong when set)
 #ifdef MI_PHASE_CLOCK
     static unsigned long long* dbg_dev = nullptr;

@@ -562,11 +562,25 @@ def test_pinned_frames_are_uploaded_without_the_bounce_copy_and_give_the_same_st
     for p, f in zip(pinned, frames):
         p[...] = f
         assert L.is_pinned(p) and not L.is_pinned(f)
-        st.push_frame(p)
+        st.push_frame(p, zero_copy=True)
     assert len(st._inflight) == N
     st.wait_uploads(0)
     assert st._inflight == []
     assert np.array_equal(st.finish(), want)
+    # the default is the copying path whatever memory the frame lies in: the caller's buffer is free on return, and a
+    # pageable array with zero_copy=True takes the copying path too
+    st.reset()
+    scratch = pinned[0].copy()
+    for f in frames:
+        pinned[0][...] = f
+        st.push_frame(pinned[0])              # one reused pinned buffer, overwritten right after the call
+    assert st._inflight == []
+    assert np.array_equal(st.finish(), want)
+    pinned[0][...] = scratch
+    st.reset()
+    for f in frames:
+        st.push_frame(f, zero_copy=True)
+    assert st._inflight == [] and np.array_equal(st.finish(), want)
     # pageable memory through the pinned entry point: refused, nothing pushed
     st.reset()
     rc = L.load().mi_stack_push_frame_pinned(st._h, frames[0].ctypes.data, 0)
@@ -575,7 +589,7 @@ def test_pinned_frames_are_uploaded_without_the_bounce_copy_and_give_the_same_st
     reg = [f.copy() for f in frames]
     for r in reg:
         L.host_register(r)
-        st.push_frame(r)
+        st.push_frame(r, zero_copy=True)
     assert np.array_equal(st.finish(), want)
     for r in reg:
         L.host_unregister(r)
@@ -586,7 +600,7 @@ def test_pinned_frames_are_uploaded_without_the_bounce_copy_and_give_the_same_st
     for i, f in enumerate(frames):
         st.wait_uploads(1)          # the buffer about to be overwritten (pushed two frames ago) is on the device
         ring[i % 2][...] = f
-        st.push_frame(ring[i % 2])
+        st.push_frame(ring[i % 2], zero_copy=True)
     assert np.array_equal(st.finish(), want)
     st.close()
     del pinned, ring

@@ -52,7 +52,7 @@ def two_stage(args):
         cal.reset()
         t0 = time.perf_counter()
         for _k in range(10):
-            cal.push_frame(pin0)
+            cal.push_frame(pin0, zero_copy=True)
         cal.wait_uploads(0)
         rates.append(10 * per / (time.perf_counter() - t0))
     cal.close()
@@ -73,7 +73,7 @@ def two_stage(args):
     def run():
         info = {}
         _, bunches = bunches_then_stack(lambda i: host[i % ndist], N, H, W, np.uint16, out_dev=out.ptr,
-                                        stacks=stacks, results_buf=results, info=info)
+                                        stacks=stacks, results_buf=results, info=info, zero_copy=not args.pageable)
         return bunches, info["stage1_s"], info["stage2_s"]
     run()
     bunches, s1, s2 = run()
@@ -147,7 +147,7 @@ def main():
         for b in bunches:
             st.reset()
             for f in b:
-                st.push_frame(host[f % ndist])
+                st.push_frame(host[f % ndist], zero_copy=not args.pageable)
                 pushed += 1
             st.finish_device(out.ptr)
         st.sync()
