@@ -474,7 +474,7 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
     }
     const uint32_t frame_bytes = (uint32_t)h * (uint32_t)w * 3u * (uint32_t)sizeof(TIn);
     // chunks [n0, n1) of frame b
-    auto prefetch = [&](int b, int n0 = 0, int n1 = NPRE) {
+    auto prefetch = [&](int b, int n0, int n1) {
         const char* frb = src0 + (size_t)b * a.src_stride;
         const BufRsrc rs = make_rsrc(frb, frame_bytes);
 #pragma unroll
@@ -516,7 +516,7 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
         }
     };
     if constexpr (DMA) dma_issue(0);
-    else prefetch(0);
+    else prefetch(0, 0, NPRE);
     constexpr bool TOUCH = MI_SEP_TOUCH > 0 && INTERIOR && !DMA;
     constexpr int TOUCH_PER_ROW = (G::GD * (int)sizeof(TIn) + 127) / 128 + 1;   // lines a patch row can straddle
     uint32_t touch_off = 0, touch_val = 0, touch_acc = 0;
