@@ -89,14 +89,26 @@ template <typename TIn> constexpr int sep_nt() { return sizeof(TIn) == 4 ? MI_SE
 #ifndef MI_SEP_LAUNDER
 #define MI_SEP_LAUNDER 1
 #endif
+// MF: interior tiles fetch their patch rows as 16-byte pieces (one / two loads per lane instead of four).  Measured slower
+// (u8 level-0 launch 0.854 -> 0.901 ms: the pieces start 2 bytes off a dword boundary); off.
+#ifndef MI_SEP_MF_WIDE
+#define MI_SEP_MF_WIDE 0
+#endif
+#ifndef MI_SEP_MF_LAUNDER
+#define MI_SEP_MF_LAUNDER 1
+#endif
 #ifndef MI_SEP_DMA
 #define MI_SEP_DMA 0
 #endif
-// Level 0 of 8-bit frames with integer reduce taps (red_taps: the default generating kernel): the 5 x 5 reduce as exact
-// integer arithmetic on the matrix pipe (v_mfma_i32_16x16x64_i8 on the staged bytes) instead of ~45 % of the kernel's VALU
-// instructions -- see level_sep_body, "MF".  Tile height 24 (the G_{l+1} patch is then 16 rows = one MFMA column block).
+// Level 0 of 8- and 16-bit frames with integer reduce taps (red_taps: the default generating kernel): the 5 x 5 reduce as
+// exact integer arithmetic on the matrix pipe (v_mfma_i32_16x16x64_i8 on the staged bytes) instead of P1 + P2's VALU work --
+// see level_sep_body, "MF".  Tile height 24 (the G_{l+1} patch is then 16 rows = two per wave).  Bit-identical to the VALU
+// form (all of tests/test_gpu_separable.py and test_gpu_parity.py pass with it) and NOT faster (round 5, docs/studies.md):
+// 154 instead of 197 VALU instructions per wave and frame, but 17 % more workgroups (24-row tiles), more LDS conflicts, and
+// the kernel is bound by the sum of its phases' latencies rather than by VALU issue alone: 8-bit level-0 launch 0.841 ->
+// 0.854 ms, 16-bit (two byte planes, ten matrix instructions per wave) 0.962 -> 1.154 ms.  Off; -DMI_SEP_MFMA=1 builds it.
 #ifndef MI_SEP_MFMA
-#define MI_SEP_MFMA 1
+#define MI_SEP_MFMA 0
 #endif
 constexpr int SEP_MF_TH = 24, SEP_MF_NT = 512;
 
@@ -120,17 +132,19 @@ struct SepGeom {
     static constexpr int lds_floats(int esize, bool interior) {
         return (interior && esize <= 2 ? GH * (GD / 4) * esize : GH * GS) + NH * VS + NH * XS;
     }
-    // MF (integer reduce on the matrix pipe, 8-bit frames): raw patch at a 208-byte row pitch (52 chunks of 4 bytes: the
-    // MFMA operand reads want 8-byte alignment), gray of the G_{l+1} patch (NH x (NW + 2): one pad column per side, pitch
-    // 34 = conflict-free for the MFMA result layout), HB, and the three weight operands (64 lanes x 16 bytes each)
-    static constexpr int MF_CPR = 52, MF_GP = NW + 2;
-    static constexpr int lds_floats_mf() { return GH * MF_CPR + NH * MF_GP + HBH * HBS + 3 * 64 * 4; }
+    // MF (integer reduce on the matrix pipe): the staged patch as BYTE PLANES at a 208-byte row pitch (52 dwords: the MFMA
+    // operand reads want 8-byte alignment) -- one plane for 8-bit frames, low bytes | high bytes for 16-bit frames --, then X,
+    // HB (its own array: V does not exist) and the three weight operands (64 lanes x 16 bytes each)
+    static constexpr int MF_CPR = 52, MF_PLANE = GH * MF_CPR;   // dwords
+    static constexpr int lds_floats_mf(int esize) { return esize * MF_PLANE + NH * XS + HBH * HBS + 3 * 64 * 4; }
     static_assert(GD % 4 == 0 && NW == 32, "tile width is fixed by the 32-lane quad rows");
     static_assert(QY * QL <= NT, "one quad per lane (a ninth wave, if any, only stages, reduces and carries P2 items)");
     static_assert(HBH * HBS <= NH * VS, "HB aliases V");
     static_assert((NH / 2) * (GD / 4) <= NT && NH % 2 == 0 && NT % 64 == 0, "phase items");
 };
 
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+typedef uint32_t v2u __attribute__((ext_vector_type(2)));
 struct __attribute__((packed, aligned(4))) Px3 { float v[3]; };   // one pixel: a 12-byte load / store
 
 __device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
@@ -197,7 +211,6 @@ __device__ __forceinline__ v2f lds_load2s(const float* p) {
 
 // ---- LDS-DMA (gfx950: 16 bytes per lane).  Inline assembly on purpose: with the builtin the compiler drains vmcnt at every
 // workgroup barrier behind it (it cannot tell which LDS reads the transfer feeds); here the kernel places the wait itself.
-typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ v4u make_rsrc_words(const void* base, uint32_t bytes) {   // raw buffer, as make_rsrc
     const uint64_t ad = (uint64_t)(uintptr_t)base;
     return v4u{(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ad),
@@ -222,7 +235,6 @@ __device__ __forceinline__ float dpp_wave_next(float v) {
 // with scalar instructions) + ONE 32-bit lane offset per access -- no 64-bit lane addresses in the frame loop, and
 // accesses outside [0, size) return zero instead of faulting (an edge tile's don't-care chunks may point anywhere).
 typedef __amdgpu_buffer_rsrc_t BufRsrc;
-typedef uint32_t v2u __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ BufRsrc make_rsrc(const void* base, uint32_t bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);   // gfx9 raw buffer
 }
@@ -237,6 +249,10 @@ template <> struct PreChunk<float> {
     static __device__ __forceinline__ v4f cvt_raw(raw_t) { return v4f{}; }
     static __device__ __forceinline__ v4f unpack_raw(const uint32_t*) { return v4f{}; }
     static __device__ __forceinline__ void unpack6(const uint32_t*, int, v2f*) {}
+    __device__ __forceinline__ void store_mf(uint32_t*, int) const {}
+    __device__ __forceinline__ void set_raw(v4u, int) {}
+    static __device__ __forceinline__ void store_mf16(const PreChunk*, uint32_t*, int) {}
+    static __device__ __forceinline__ void unpack6_mf(const uint32_t*, int, int, v2f*) {}
     __device__ __forceinline__ void load(const char* p) { __builtin_memcpy(&v, p, 16); }
     __device__ __forceinline__ void load(BufRsrc r, uint32_t off) {
         v = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
@@ -263,6 +279,22 @@ template <> struct PreChunk<uint8_t> {
         const uint32_t* q = row + (e0 >> 2);
         const uint32_t q0 = q[0], q1 = q[1];
         const uint32_t lo = __builtin_amdgcn_alignbyte(q1, q0, (uint32_t)e0), hi = __builtin_amdgcn_alignbyte(0u, q1, (uint32_t)e0);
+        out[0] = v2f{(float)(lo & 0xffu), (float)(lo >> 24)};
+        out[1] = v2f{(float)((lo >> 8) & 0xffu), (float)(hi & 0xffu)};
+        out[2] = v2f{(float)((lo >> 16) & 0xffu), (float)((hi >> 8) & 0xffu)};
+    }
+    // MF form: the chunk's dword in the (single) byte plane, every byte as x ^ 0x80 = the signed byte x - 128 the MFMA takes
+    __device__ __forceinline__ void store_mf(uint32_t* q, int) const { *q = v ^ 0x80808080u; }
+    __device__ __forceinline__ void set_raw(v4u t, int i) { v = t[i]; }   // dword i of a 16-byte piece
+    // four chunks = one 16-byte piece, one ds_write_b128
+    static __device__ __forceinline__ void store_mf16(const PreChunk* c, uint32_t* q, int) {
+        *reinterpret_cast<v4u*>(q) = v4u{c[0].v ^ 0x80808080u, c[1].v ^ 0x80808080u, c[2].v ^ 0x80808080u, c[3].v ^ 0x80808080u};
+    }
+    static __device__ __forceinline__ void unpack6_mf(const uint32_t* row, int, int e0, v2f* out) {
+        const uint32_t* q = row + (e0 >> 2);
+        const uint32_t q0 = q[0], q1 = q[1];
+        const uint32_t lo = __builtin_amdgcn_alignbyte(q1, q0, (uint32_t)e0) ^ 0x80808080u;
+        const uint32_t hi = __builtin_amdgcn_alignbyte(0u, q1, (uint32_t)e0) ^ 0x00008080u;
         out[0] = v2f{(float)(lo & 0xffu), (float)(lo >> 24)};
         out[1] = v2f{(float)((lo >> 8) & 0xffu), (float)(hi & 0xffu)};
         out[2] = v2f{(float)((lo >> 16) & 0xffu), (float)((hi >> 8) & 0xffu)};
@@ -297,6 +329,33 @@ template <> struct PreChunk<uint16_t> {
         out[1] = v2f{(float)(q0 >> 16), (float)(q2 & 0xffffu)};
         out[2] = v2f{(float)(q1 & 0xffffu), (float)(q2 >> 16)};
     }
+    // MF form: the four low bytes -> plane 0, the four high bytes -> plane 1 (`plane` dwords further), each as x ^ 0x80
+    __device__ __forceinline__ void store_mf(uint32_t* q, int plane) const {
+        q[0] = __builtin_amdgcn_perm(v1, v0, 0x06040200u) ^ 0x80808080u;
+        q[plane] = __builtin_amdgcn_perm(v1, v0, 0x07050301u) ^ 0x80808080u;
+    }
+    __device__ __forceinline__ void set_raw(v4u t, int i) { v0 = t[2 * i]; v1 = t[2 * i + 1]; }   // chunk i of a 16-byte piece
+    // two chunks = one 16-byte piece: 8 bytes into each plane
+    static __device__ __forceinline__ void store_mf16(const PreChunk* c, uint32_t* q, int plane) {
+        *reinterpret_cast<v2u*>(q) = v2u{__builtin_amdgcn_perm(c[0].v1, c[0].v0, 0x06040200u) ^ 0x80808080u,
+                                         __builtin_amdgcn_perm(c[1].v1, c[1].v0, 0x06040200u) ^ 0x80808080u};
+        *reinterpret_cast<v2u*>(q + plane) = v2u{__builtin_amdgcn_perm(c[0].v1, c[0].v0, 0x07050301u) ^ 0x80808080u,
+                                                 __builtin_amdgcn_perm(c[1].v1, c[1].v0, 0x07050301u) ^ 0x80808080u};
+    }
+    // six consecutive elements from the two byte planes: bytes realigned per plane, re-paired into 16-bit values
+    static __device__ __forceinline__ void unpack6_mf(const uint32_t* row, int plane, int e0, v2f* out) {
+        const uint32_t* q = row + (e0 >> 2);
+        const uint32_t l0 = q[0], l1 = q[1], h0 = q[plane], h1 = q[plane + 1];
+        const uint32_t La = __builtin_amdgcn_alignbyte(l1, l0, (uint32_t)e0) ^ 0x80808080u;
+        const uint32_t Lb = __builtin_amdgcn_alignbyte(0u, l1, (uint32_t)e0) ^ 0x00008080u;
+        const uint32_t Ha = __builtin_amdgcn_alignbyte(h1, h0, (uint32_t)e0) ^ 0x80808080u;
+        const uint32_t Hb = __builtin_amdgcn_alignbyte(0u, h1, (uint32_t)e0) ^ 0x00008080u;
+        const uint32_t p01 = __builtin_amdgcn_perm(Ha, La, 0x05010400u), p23 = __builtin_amdgcn_perm(Ha, La, 0x07030602u);
+        const uint32_t p45 = __builtin_amdgcn_perm(Hb, Lb, 0x05010400u);
+        out[0] = v2f{(float)(p01 & 0xffffu), (float)(p23 >> 16)};
+        out[1] = v2f{(float)(p01 >> 16), (float)(p45 & 0xffffu)};
+        out[2] = v2f{(float)(p23 & 0xffffu), (float)(p45 >> 16)};
+    }
     __device__ __forceinline__ void load(const char* p) {
         uint64_t t;
         __builtin_memcpy(&t, p, 8);
@@ -328,23 +387,25 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
     constexpr bool RAW = INTERIOR && sizeof(TIn) <= 2;   // staged patch kept in the input type (see SepGeom::lds_floats)
     constexpr bool DMA = MI_SEP_DMA && INTERIOR && sizeof(TIn) == 4;   // patch staged by LDS-DMA (see MI_SEP_DMA)
     constexpr int RD = (int)sizeof(TIn);                 // dwords per 4-element chunk in that form
-    // MF: the reduce of 8-bit frames on the matrix pipe.  P1 + P2 become one phase: wave v computes the G_{l+1} patch rows
-    // 2v, 2v + 1 (16 rows = 8 waves) with five v_mfma_i32_16x16x64_i8 -- one per tap row -- whose DATA operand is read
-    // straight from the staged bytes (column n of the operand = a 64-byte window of a patch row: 24 n bytes along the row,
-    // i.e. four output pixels further per window) and whose WEIGHT operand holds kv[t] * kh[tau] at byte 6 p + 3 tau + c of
-    // the window for output slot (pixel p, channel c); the result layout gives every lane the three channel sums S of ONE
-    // G_{l+1} pixel (+ an empty fourth slot), 32 consecutive pixels of a row on 32 lanes.  The staged bytes carry x ^ 0x80
-    // (= x - 128 as the signed byte the instruction takes); the accumulator starts at 128 * 400.  S is the exact integer
-    // sum, G_{l+1} = float(S) * rs: bit-identical to the float evaluation of red_taps' integer taps (header).
-    static_assert(!MF_ || (INTERIOR && sizeof(TIn) == 1 && G::NH == 16 && NT == 512), "MF geometry");
+    // MF: the reduce of 8 / 16-bit frames on the matrix pipe.  P1 + P2 become one phase: wave v computes the G_{l+1} patch
+    // rows 2v, 2v + 1 (16 rows = 8 waves) with five v_mfma_i32_16x16x64_i8 per byte plane -- one per tap row -- whose DATA
+    // operand (B, 64 x 16) is read straight from the staged bytes: column n = a 64-byte window of a patch row, 24 bytes (four
+    // output pixels) further along the row per window, 8 windows per row, two rows; and whose WEIGHT operand (A, 16 x 64)
+    // holds kv[t] * kh[tau] at byte 6 p + 3 tau + c of the window in row 4 p + c (output pixel p of the window, channel c;
+    // row 4 p + 3 is empty).  The result layout then hands lane 16 p + n the three channel sums of ONE G_{l+1} pixel.  The
+    // staged bytes carry x ^ 0x80 (= x - 128 as the signed byte the instruction takes) and the accumulator starts at
+    // 128 * 400.  16-bit frames: the same on the plane of low bytes and on the plane of high bytes, S = 256 S_hi + S_lo.
+    // S is the exact integer sum and G_{l+1} = float(S) * rs: bit-identical to the float evaluation of red_taps' integer
+    // taps (header; float(S) rounds once, to nearest even, exactly where the float chain's last fma does).
+    static_assert(!MF_ || (INTERIOR && sizeof(TIn) <= 2 && G::NH == 16 && NT == 512), "MF geometry");
     constexpr bool MF = MF_;
+    constexpr int NPL = MF ? (int)sizeof(TIn) : 0;    // byte planes
     float* sG = smem;
     uint32_t* sGr = reinterpret_cast<uint32_t*>(smem);
     float* sV = smem + (MF ? 0 : G::lds_floats((int)sizeof(TIn), INTERIOR) - G::NH * G::VS - G::NH * G::XS);
-    float* sX = sV + G::NH * G::VS;
-    float* sGg = smem + G::GH * G::MF_CPR;            // MF: gray of the G_{l+1} patch, [NH][NW + 2]
-    float* sHB = MF ? sGg + G::NH * G::MF_GP : sV;     // V is dead once P2 has read it
-    uint32_t* sW = reinterpret_cast<uint32_t*>(sGg + G::NH * G::MF_GP + G::HBH * G::HBS);   // MF: weight operands
+    float* sX = MF ? smem + NPL * G::MF_PLANE : sV + G::NH * G::VS;
+    float* sHB = MF ? sX + G::NH * G::XS : sV;         // (not MF: V is dead once P2 has read it)
+    uint32_t* sW = reinterpret_cast<uint32_t*>(sHB + G::HBH * G::HBS);   // MF: weight operands, [3][64] x 16 bytes
     const int tid = threadIdx.x;
     const int h = a.h, w = a.w, hn = a.hn, wn = a.wn;
 
@@ -399,6 +460,27 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
     const float k0 = a.k1d[0], k1 = a.k1d[1], k2 = a.k1d[2];
     const float w0 = a.rk[0], w1 = a.rk[1], w2 = a.rk[2], rs = a.rk[3];   // reduce taps and final scale (red_taps)
     const float ce = 2.0f * k0, cc = 2.0f * k2, co = 2.0f * k1;   // expand taps (the reference's 4 * K, per dimension)
+    if constexpr (MF) {
+        // weight operands: class 0 = tap rows 0 and 4 (kv = w0), 1 = rows 1 and 3 (w1), 2 = row 2 (w2); lane (row s = lane & 15,
+        // k-group g = lane >> 4) holds the bytes k = 16 g .. 16 g + 15 of row s.  Visible after the first frame's barrier.
+        if (tid < 192) {
+            const int cls = tid >> 6, ln = tid & 63, sl = ln & 15, kg = ln >> 4, p = sl >> 2, c = sl & 3;
+            const int wi[3] = {(int)w0, (int)w1, (int)w2};
+            const int kv = wi[cls];
+            uint32_t wd[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int d = 16 * kg + i - 6 * p - c;
+                int wt = 0;
+#pragma unroll
+                for (int tau = 0; tau < 5; ++tau)
+                    if (c < 3 && d == 3 * tau) wt = kv * wi[tau < 3 ? tau : 4 - tau];
+                wd[i >> 2] |= (uint32_t)(wt & 0xff) << (8 * (i & 3));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sW[4 * tid + i] = wd[i];
+        }
+    }
 
     // ---- which frames?  (levels with few tiles split the batch into chunks along blockIdx.y, see LevelArgs)
     const int ck = blockIdx.y, f_lo = ck * a.chunk_frames;
@@ -446,6 +528,8 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
     // in-image elements: it is loaded 2 elements further inside the row and stored rotated by 2.
     constexpr int CPR = MF ? G::MF_CPR : G::GD / 4;   // chunks per patch row (MF: one more, for a 208-byte LDS row pitch)
     constexpr int NCH = G::GH * CPR, NPRE = (NCH + NT - 1) / NT;
+    constexpr int W16 = 13 * (int)sizeof(TIn), NW16 = G::GH * W16, NPW = (NW16 + NT - 1) / NT;   // MF: 16-byte pieces (row, patch, per lane)
+    constexpr int CP16 = 4 / (int)sizeof(TIn);                                                     // chunks per piece
     PreChunk<TIn> pre[NPRE];
     uint32_t goff[NPRE];          // interior / edge: byte offset of the chunk inside a frame
     bool edge = false;
@@ -458,6 +542,15 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
             if (x0 < 6) colL = 4;                          // elements 16 .. 19: columns -1 | 0
             if (rel < G::GD) { peR = w - 1 - (x0 - 6); if ((rel & 3) == 2) colR = (rel - 2) >> 2; }
         }
+        if (MF && MI_SEP_MF_WIDE && !edge) {
+            // MF, tiles that mirror nothing: the patch row as 16-byte pieces (four / two chunks), one / two loads per lane
+            // instead of four (the 208-byte row pitch makes the pieces 16-byte aligned in LDS)
+#pragma unroll
+            for (int m = 0; m < NPW; ++m) {
+                const int id = tid + m * NT, row = id / W16, c16 = id - row * W16;
+                goff[m] = (uint32_t)(((y0 - 6 + row) * w + (x0 - 6)) * 3 * (int)sizeof(TIn) + 16 * c16);
+            }
+        } else
 #pragma unroll
         for (int n = 0; n < NPRE; ++n) {
             const int id = tid + n * NT, row = id / CPR, col = id - row * CPR;
@@ -477,6 +570,19 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
     auto prefetch = [&](int b, int n0, int n1) {
         const char* frb = src0 + (size_t)b * a.src_stride;
         const BufRsrc rs = make_rsrc(frb, frame_bytes);
+        if constexpr (MF) {
+            if (MI_SEP_MF_WIDE && !edge) {
+#pragma unroll
+                for (int m = 0; m < NPW; ++m) {
+                    if ((m + 1) * NT > NW16 && tid + m * NT >= NW16) continue;
+                    const v4u t = __builtin_bit_cast(v4u, __builtin_amdgcn_raw_buffer_load_b128(rs, goff[m], 0, 0));
+                    pre[CP16 * m].set_raw(t, 0);
+                    if constexpr (CP16 >= 2) pre[CP16 * m + 1].set_raw(t, 1);
+                    if constexpr (CP16 == 4) { pre[4 * m + 2].set_raw(t, 2); pre[4 * m + 3].set_raw(t, 3); }
+                }
+                return;
+            }
+        }
 #pragma unroll
         for (int n = 0; n < NPRE; ++n) {
             if (n < n0 || n >= n1) continue;
@@ -535,7 +641,7 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
     for (int b = 0; b < nfr; ++b) {
         int lt = tid;
 #if MI_SEP_LAUNDER
-        asm volatile("" : "+v"(lt));   // per-frame addresses are rebuilt from this, not hoisted out of the loop
+        if (!MF || MI_SEP_MF_LAUNDER) asm volatile("" : "+v"(lt));   // per-frame addresses are rebuilt from this, not hoisted out of the loop
 #endif
         // ---------------- P0: stage
         if constexpr (DMA) {
@@ -569,14 +675,22 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
                 const int col = id - (id / CPR) * CPR;
                 PreChunk<TIn> c = pre[n];
                 if (col == colL || col == colR) c.rot2();
-                if constexpr (RAW) c.store_raw(sGr + RD * id);
+                if constexpr (MF) c.store_mf(sGr + id, G::MF_PLANE);
+                else if constexpr (RAW) c.store_raw(sGr + RD * id);
                 else *reinterpret_cast<v4f*>(sG + 4 * id) = c.get();
             }
             __syncthreads();
             // mirrored columns: patch column pc <- 12 - pc on the left, pc <- 2 peR - pc on the right (6 columns each)
             for (int e = lt; e < G::GH * 18; e += NT) {
                 const int r = e / 18, k = e - r * 18, pc = k / 3, c = k - pc * 3;
-                if constexpr (RAW) {
+                if constexpr (MF) {
+#pragma unroll
+                    for (int pl = 0; pl < NPL; ++pl) {   // byte planes: an element is one byte of each
+                        uint8_t* rowp = reinterpret_cast<uint8_t*>(sGr + pl * G::MF_PLANE) + mul24(r, 4 * CPR);
+                        if (colL >= 0) rowp[3 * pc + c] = rowp[3 * (12 - pc) + c];
+                        if (peR >= 0 && peR + 1 + pc < G::GW) rowp[3 * (peR + 1 + pc) + c] = rowp[3 * (peR - 1 - pc) + c];
+                    }
+                } else if constexpr (RAW) {
                     TIn* rowp = reinterpret_cast<TIn*>(sGr) + mul24(r, 4 * CPR);   // a raw row = CPR chunks of 4 elements
                     if (colL >= 0) rowp[3 * pc + c] = rowp[3 * (12 - pc) + c];
                     if (peR >= 0 && peR + 1 + pc < G::GW) rowp[3 * (peR + 1 + pc) + c] = rowp[3 * (peR - 1 - pc) + c];
@@ -586,11 +700,19 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
                     if (peR >= 0 && peR + 1 + pc < G::GW) rowp[3 * (peR + 1 + pc) + c] = rowp[3 * (peR - 1 - pc) + c];
                 }
             }
+        } else if (MF && MI_SEP_MF_WIDE && !edge) {
+#pragma unroll
+            for (int m = 0; m < NPW; ++m) {
+                const int id = lt + m * NT;
+                if ((m + 1) * NT > NW16 && id >= NW16) continue;
+                PreChunk<TIn>::store_mf16(pre + CP16 * m, sGr + CP16 * id, G::MF_PLANE);   // piece id = chunks CP16 id ..
+            }
         } else {
 #pragma unroll
             for (int n = 0; n < NPRE; ++n) {
                 if ((n + 1) * NT > NCH && lt + n * NT >= NCH) continue;
-                if constexpr (RAW) pre[n].store_raw(sGr + RD * (lt + n * NT));
+                if constexpr (MF) pre[n].store_mf(sGr + (lt + n * NT), G::MF_PLANE);
+                else if constexpr (RAW) pre[n].store_raw(sGr + RD * (lt + n * NT));
                 else *reinterpret_cast<v4f*>(sG + 4 * (lt + n * NT)) = pre[n].get();
             }
         }
@@ -610,6 +732,7 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
         MI_TICK(2);   // prefetch issue
         const BufRsrc gn_rs = make_rsrc(gnext0 + (size_t)b * a.gnext_stride, (uint32_t)hn * (uint32_t)wn * 12u);
 
+        if constexpr (!MF) {
         // ---------------- P1: vertical reduce, P1R V rows x one float4 column group per lane
         constexpr int P1R = (RAW && MI_SEP_P1_ROWS > 2 && G::NH >= MI_SEP_P1_ROWS) ? MI_SEP_P1_ROWS : 2;
         if constexpr (P1R > 2) {
@@ -696,10 +819,62 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
         MI_TICK(3);   // P1
         __syncthreads();
         MI_TICK(4);   // barrier 2
+        }   // !MF
         if (DMA && b + 1 < nfr && !MI_ABL(16)) dma_issue(b + 1);   // the patch is dead: the next frame streams in beside P2-P4
 
         // ---------------- P2: horizontal reduce (one G_{l+1} pixel per lane, 32 lanes per patch row), G_{l+1} store, gray,
         // horizontal expand of the gray -> X.  18 rows x 32 = 576 items: the last two rows are a second round on wave 0.
+        if constexpr (MF) { if (!MI_ABL(2)) {
+            // ---------------- MF: the whole reduce of this wave's two G_{l+1} rows on the matrix pipe (see the top of the function)
+            const int ln = lt & 63, n = ln & 15, kg = ln >> 4;
+            const int r = 2 * (lt >> 6) + (n >> 3), jp = 4 * (n & 7) + kg;    // the pixel this lane ends up with
+            typedef const volatile v4i __attribute__((address_space(3))) * lds_v4i;
+            typedef const volatile v2u __attribute__((address_space(3))) * lds_v2u;
+            const uint32_t wbase = (uint32_t)(uintptr_t)sW + 16u * (uint32_t)ln;
+            const v4i A0 = *(lds_v4i)(size_t)wbase, A1 = *(lds_v4i)(size_t)(wbase + 1024u), A2 = *(lds_v4i)(size_t)(wbase + 2048u);
+            // data: window n of patch row 2 r + t, bytes 16 kg .. 16 kg + 15 (two 8-byte reads: windows are 8-byte aligned)
+            const uint32_t dbase = (uint32_t)(uintptr_t)sGr + (uint32_t)(mul24(2 * r, 4 * CPR) + 24 * (n & 7) + 16 * kg);
+            v4i S4 = {0, 0, 0, 0};
+#pragma unroll
+            for (int pl = NPL - 1; pl >= 0; --pl) {
+                v4i acc = {128 * 400, 128 * 400, 128 * 400, 128 * 400};
+#pragma unroll
+                for (int t = 0; t < 5; ++t) {
+                    const uint32_t ad = dbase + (uint32_t)(4 * (pl * G::MF_PLANE + t * CPR));
+                    const v2u d0 = *(lds_v2u)(size_t)ad, d1 = *(lds_v2u)(size_t)(ad + 8u);
+                    const v4i B = {(int)d0.x, (int)d0.y, (int)d1.x, (int)d1.y};
+                    if (MI_ABL(64)) acc += B;   // study: the data reads without the matrix instruction
+                    else acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(t == 2 ? A2 : (t == 1 || t == 3) ? A1 : A0, B, acc, 0, 0, 0);
+                }
+                S4 = pl == NPL - 1 ? acc : (S4 << 8) + acc;   // 16-bit frames: 256 * (high-byte sum) + low-byte sum
+            }
+            float nn[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) nn[c] = (float)S4[c] * rs;
+            {
+                const int i = y0 / 2 - 2 + r, j = x0 / 2 - 2 + jp;
+                bool st = r >= 2 && r < G::NH - 2 && jp >= 2 && jp < G::NW - 2 && !MI_ABL(32);
+                st = st && i < hn && j < wn;   // edge tiles overhang the image
+                if (st) {
+                    typedef uint32_t v3u __attribute__((ext_vector_type(3)));
+                    const v3u pv = {__builtin_bit_cast(uint32_t, nn[0]), __builtin_bit_cast(uint32_t, nn[1]),
+                                    __builtin_bit_cast(uint32_t, nn[2])};
+                    __builtin_amdgcn_raw_buffer_store_b96(pv, gn_rs, times12((uint32_t)(mul24(i, wn) + j)), 0, MI_SEP_NT_STORE ? 2 : 0);
+                }
+            }
+            // gray of the pixel; its neighbours along the row sit 16 lanes away (next pixel of the window) or in the
+            // neighbouring window's lane group: two bpermutes (LDS crossbar, no memory).  Pixels 0 / 31 of a row get a wrong
+            // neighbour: X columns 0, 1, 62, 63 feed only the quads nobody owns or blurs from.
+            const float g = gray_of<true>(nn[0], nn[1], nn[2]);
+            const int lprev = kg > 0 ? ln - 16 : ln + 47, lnext = kg < 3 ? ln + 16 : ln - 47;
+            float gl, gr;
+            if (MI_ABL(128)) { gl = dpp_wave_prev(g); gr = dpp_wave_next(g); }   // study: (wrong) neighbours without the bpermutes
+            else {
+                gl = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(4 * lprev, __builtin_bit_cast(int, g)));
+                gr = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(4 * lnext, __builtin_bit_cast(int, g)));
+            }
+            lds_store2(sX + mul24(r, G::XS) + 2 * jp, ex_even(gl, g, gr, ce, cc), ex_odd(g, gr, co));
+        } } else {
 #pragma unroll
         for (int rnd = 0; rnd < (G::NH * 32 + NT - 1) / NT; ++rnd) {
             const int it = lt + rnd * NT;
@@ -748,6 +923,7 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
             const float gl = dpp_wave_prev(g), gr = dpp_wave_next(g);
             lds_store2(sX + mul24(r, G::XS) + 2 * jp, ex_even(gl, g, gr, ce, cc), ex_odd(g, gr, co));
         }
+        }   // !MF
         if (!DMA && MI_SEP_PF_SPLIT == 2 && b + 1 < nfr && !MI_ABL(16)) prefetch(b + 1, 2, 3);
         MI_TICK(5);   // P2
         __syncthreads();
@@ -765,6 +941,13 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
                 if constexpr (DMA) {
                     gge = gq_e;
                     ggo = gq_o;
+                } else if constexpr (MF) {
+                    v2f ge[3], go[3];
+                    const uint32_t* rowp = sGr + mul24(2 * qy3 + 4, CPR);
+                    PreChunk<TIn>::unpack6_mf(rowp, G::MF_PLANE, 6 * ql3 + 6, ge);
+                    PreChunk<TIn>::unpack6_mf(rowp + CPR, G::MF_PLANE, 6 * ql3 + 6, go);
+                    gge = gray_of2(ge[0], ge[1], ge[2]);
+                    ggo = gray_of2(go[0], go[1], go[2]);
                 } else if constexpr (RAW) {
                     // unpacked channel by channel ((pixel, pixel) pairs: the conversions write where they like), so the
                     // two grays of a row are one packed chain
@@ -875,6 +1058,11 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
 template <typename TIn, bool INTERIOR, int TH, int NT>
 __global__ __launch_bounds__(NT, INTERIOR ? (sizeof(TIn) <= 2 ? MI_SEP_INT_WAVES : (NT > 512 ? 7 : 1)) : MI_SEP_BD_WAVES) void level_sep(LevelArgs a) {
     level_sep_body<TIn, INTERIOR, TH, NT>(a);
+}
+// level 0 of 8 / 16-bit frames, reduce on the matrix pipe (MI_SEP_MFMA; tile height SEP_MF_TH)
+template <typename TIn, int TH, int NT>
+__global__ __launch_bounds__(NT, MI_SEP_INT_WAVES) void level_sep_mf(LevelArgs a) {
+    level_sep_body<TIn, true, TH, NT, true>(a);
 }
 template <typename TIn, bool INTERIOR, int TH, int NT>
 __global__ __launch_bounds__(NT, INTERIOR && NT > 512 ? 7 : 1) void level_sep_coarse(LevelArgs a) {

@@ -436,10 +436,12 @@ int launch_level(mi_stack* s, int l, int set, const void* src, size_t src_stride
 // `ev_bd`: recorded on st_bd behind the border kernel when the level ran in chunks (the merge on st_in waits for it).
 // `f_begin`, `f_end`: launch the frames [f_begin, f_end) of the batch only (levels that run as consecutive launches; the
 // interleaved level-0 / level-1 schedule of run_batch) -- the whole batch by default.
-template <typename TIn, bool L0_NAME>
+// `MF`: level 0 of 8 / 16-bit frames with the reduce on the matrix pipe (kernels_sep.hpp, MI_SEP_MFMA): its own tile height,
+// for the interior and the border launch alike.
+template <typename TIn, bool L0_NAME, bool MF = false>
 int launch_level_sep(mi_stack* s, int l, int set, const void* src, size_t src_stride, int nb, hipStream_t st_in,
                      hipStream_t st_bd, hipEvent_t ev_bd, int f_begin = 0, int f_end = -1) {
-    constexpr int TH = MI_SEP_TH, NT = sep_nt<TIn>();
+    constexpr int TH = MF ? SEP_MF_TH : MI_SEP_TH, NT = MF ? SEP_MF_NT : sep_nt<TIn>();
     using SG = SepGeom<TH, NT>;
     constexpr int TW = SG::TW;
     TiledState* t = tstate(s);
@@ -508,8 +510,10 @@ int launch_level_sep(mi_stack* s, int l, int set, const void* src, size_t src_st
     } else a.dbg = nullptr;
 #endif
     const size_t lds = (size_t)SG::LDS_FLOATS * sizeof(float);                                     // border tiles
-    const size_t lds_in = (size_t)SG::lds_floats((int)sizeof(TIn), true) * sizeof(float);          // interior tiles
-    auto kin = L0_NAME ? level_sep<TIn, true, TH, NT> : level_sep_coarse<TIn, true, TH, NT>;
+    const size_t lds_in = (size_t)(MF ? SG::lds_floats_mf((int)sizeof(TIn)) : SG::lds_floats((int)sizeof(TIn), true)) * sizeof(float);   // interior tiles
+    void (*kin)(LevelArgs);
+    if constexpr (MF) kin = level_sep_mf<TIn, TH, NT>;
+    else kin = L0_NAME ? level_sep<TIn, true, TH, NT> : level_sep_coarse<TIn, true, TH, NT>;
     auto kbd = level_sep<TIn, false, TH, NT>;
     static thread_local bool attr_set = false;
     if (!attr_set) {
@@ -626,6 +630,17 @@ int launch_payload_exact(mi_stack* s, int l, int set, const void* src, size_t sr
     return MI_OK;
 }
 
+// level 0 of the separable arithmetic: the matrix-pipe form of the reduce for 8 / 16-bit frames when the taps allow it
+template <typename TIn>
+int launch_level0_sep(mi_stack* s, int set, const void* src, size_t src_stride, int nb, hipStream_t st_in, hipStream_t st_bd,
+                      hipEvent_t ev_bd, int f_begin = 0, int f_end = -1) {
+    if constexpr (MI_SEP_MFMA && sizeof(TIn) <= 2) {
+        static const int mf_off = study_env("MI_NO_MFMA", 0);   // -DMI_STUDY: the VALU form, for A/B runs
+        if (s->mfma_ok && !mf_off) return launch_level_sep<TIn, true, true>(s, 0, set, src, src_stride, nb, st_in, st_bd, ev_bd, f_begin, f_end);
+    }
+    return launch_level_sep<TIn, true, false>(s, 0, set, src, src_stride, nb, st_in, st_bd, ev_bd, f_begin, f_end);
+}
+
 template <typename TIn, bool FMA>
 int run_batch(mi_stack* s, const void* frames, size_t stride, int nb) {
     TiledState* t = tstate(s);
@@ -656,11 +671,11 @@ int run_batch(mi_stack* s, const void* frames, size_t stride, int nb) {
     if (il) {
         for (int f0 = 0; f0 < nb && !rc; f0 += SEP_LAUNCH_FRAMES) {
             const int f1 = std::min(nb, f0 + SEP_LAUNCH_FRAMES);
-            rc = launch_level_sep<TIn, true>(s, 0, set, frames, stride, nb, st0, st1, t->evL0b[set], f0, f1);
+            rc = launch_level0_sep<TIn>(s, set, frames, stride, nb, st0, st1, t->evL0b[set], f0, f1);
             if (!rc) rc = launch_level_sep<float, false>(s, 1, set, t->Gb[set][1], t->gstride[1] * sizeof(float), nb, st0, st1,
                                                          t->evLvl[(set * (L + 1) + 1) * 2 + 1], f0, f1);
         }
-    } else if (s->sep) rc = launch_level_sep<TIn, true>(s, 0, set, frames, stride, nb, st0, st1, t->evL0b[set]);
+    } else if (s->sep) rc = launch_level0_sep<TIn>(s, set, frames, stride, nb, st0, st1, t->evL0b[set]);
     else
         rc = launch_level<TIn, FMA, MI_TILE0_H, MI_TILE0_W, MI_TILE0_NT, MI_TILE_PAD != 0, MI_TILE_H, MI_TILE_W, MI_TILE_NT>(
             s, 0, set, frames, stride, nb, st0, st1, t->evL0b[set]);
