@@ -1092,11 +1092,14 @@ __global__ void merge_chunks(float* __restrict__ best_e, int32_t* __restrict__ b
 // Winner's Laplacian of the frames of one batch (the level kernel keeps only the running maximum and its frame):
 // one lane per 2x2 quad of level l; a pixel whose arg-max is a frame of this batch gets
 // lap = G_l - expand(G_{l+1}) of that frame, with -0 -> +0 as the reference's np.where sum gives (pyramid.py:52-54).
+// A level that ran in frame chunks (LevelArgs::part_e) is folded here first, pixel by pixel, exactly as merge_chunks does
+// (chunk order, strict '>'): `nparts` > 0 -- one launch and one dependent-launch gap less per level and batch.
 template <typename TIn>
 __global__ void sep_payload(const void* __restrict__ src, size_t src_stride, const float* __restrict__ gnext,
                             size_t gnext_stride, int nframes, int h, int w, int hn, int wn,
-                            const int32_t* __restrict__ best_idx, int frame_idx0, float* __restrict__ best_lap, float k0,
-                            float k1, float k2) {
+                            int32_t* __restrict__ best_idx, int frame_idx0, float* __restrict__ best_lap, float k0,
+                            float k1, float k2, float* __restrict__ best_e, const float* __restrict__ part_e,
+                            const int32_t* __restrict__ part_idx, size_t part_stride, int nparts) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y * blockDim.y + threadIdx.y;
     if (2 * i >= h || 2 * j >= w) return;
     const float ce = 2.0f * k0, cc = 2.0f * k2, co = 2.0f * k1;
@@ -1107,7 +1110,18 @@ __global__ void sep_payload(const void* __restrict__ src, size_t src_stride, con
         const int y = 2 * i + (p >> 1), x = 2 * j + (p & 1);
         fr[p] = -1;
         if (y < h && x < w) {
-            const int f = best_idx[(size_t)y * w + x] - frame_idx0;
+            const size_t px = (size_t)y * w + x;
+            int32_t bi = best_idx[px];
+            if (nparts > 0) {
+                float e = best_e[px];
+                bool changed = false;
+                for (int c = 0; c < nparts; ++c) {
+                    const float pe = part_e[(size_t)c * part_stride + px];
+                    if (pe > e) { e = pe; bi = part_idx[(size_t)c * part_stride + px]; changed = true; }
+                }
+                if (changed) { best_e[px] = e; best_idx[px] = bi; }
+            }
+            const int f = bi - frame_idx0;
             if (f >= 0 && f < nframes) { fr[p] = f; any = true; }
         }
     }

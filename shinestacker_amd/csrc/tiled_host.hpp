@@ -438,9 +438,14 @@ int launch_level(mi_stack* s, int l, int set, const void* src, size_t src_stride
 // interleaved level-0 / level-1 schedule of run_batch) -- the whole batch by default.
 // `MF`: level 0 of 8 / 16-bit frames with the reduce on the matrix pipe (kernels_sep.hpp, MI_SEP_MFMA): its own tile height,
 // for the interior and the border launch alike.
+// `info` (optional): what run_batch needs to finish the level -- how many chunk partials sep_payload has to fold (it then takes
+// merge_chunks' place) and whether border tiles were launched on st_bd (only then the streams have to join).  `ev_sync`
+// (optional): recorded on st_in and waited for on st_bd in front of a border launch (everything st_in has done so far).
+struct SepLevelInfo { int nparts = 0; bool border = false; };
 template <typename TIn, bool L0_NAME, bool MF = false>
 int launch_level_sep(mi_stack* s, int l, int set, const void* src, size_t src_stride, int nb, hipStream_t st_in,
-                     hipStream_t st_bd, hipEvent_t ev_bd, int f_begin = 0, int f_end = -1) {
+                     hipStream_t st_bd, hipEvent_t ev_bd, int f_begin = 0, int f_end = -1, SepLevelInfo* info = nullptr,
+                     hipEvent_t ev_sync = nullptr) {
     constexpr int TH = MF ? SEP_MF_TH : MI_SEP_TH, NT = MF ? SEP_MF_NT : sep_nt<TIn>();
     using SG = SepGeom<TH, NT>;
     constexpr int TW = SG::TW;
@@ -574,7 +579,12 @@ int launch_level_sep(mi_stack* s, int l, int set, const void* src, size_t src_st
     };
     // one timing-event pair around each stream's sequence of launches (an event record between two kernels of a stream
     // costs a few microseconds of idle GPU: 30 launches per level pass)
+    if (info) { info->nparts = nchunks - 1; info->border = nborder > 0; }
     if (nborder > 0 && !MI_ABL(256)) {
+        if (ev_sync) {
+            MI_HIP(hipEventRecord(ev_sync, st_in));
+            MI_HIP(hipStreamWaitEvent(st_bd, ev_sync, 0));
+        }
         ProfScope ps(s, MI_PROF_LEVEL, bytes * (1.0 - frac_in) * part, st_bd);
         ps.r.launches = nlaunch;
         for (int f0 = f_begin; f0 < f_end; f0 += step) {
@@ -590,7 +600,7 @@ int launch_level_sep(mi_stack* s, int l, int set, const void* src, size_t src_st
             hipLaunchKernelGGL(kin, dim3(ngroups * SEP_SBW * SEP_SBH, nchunks), dim3(NT), lds_in, st_in, a);
         }
     }
-    if (nchunks > 1) {
+    if (nchunks > 1 && !info) {   // (callers that pass `info` fold the partials in their payload pass)
         MI_HIP(hipEventRecord(ev_bd, st_bd));
         MI_HIP(hipStreamWaitEvent(st_in, ev_bd, 0));
         ProfScope ps(s, MI_PROF_LEVEL, 0.0, st_in);
@@ -603,14 +613,16 @@ int launch_level_sep(mi_stack* s, int l, int set, const void* src, size_t src_st
 // MI_ARITH_SEPARABLE: the winners' Laplacians of level l for the frames of this batch (the level kernel keeps only
 // the running maximum and its frame index); reads the batch's G_l (level 0: the frames) and G_{l+1}.
 template <typename TIn>
-int launch_payload_sep(mi_stack* s, int l, int set, const void* src, size_t src_stride, int nb, hipStream_t st) {
+int launch_payload_sep(mi_stack* s, int l, int set, const void* src, size_t src_stride, int nb, hipStream_t st, int nparts = 0) {
     TiledState* t = tstate(s);
     const dim3 blk(32, 8);
     const dim3 grd(cdiv(cdiv(s->lw[l], 2), blk.x), cdiv(cdiv(s->lh[l], 2), blk.y));
     ProfScope ps(s, MI_PROF_LEVEL, 0.0, st);
     hipLaunchKernelGGL((sep_payload<TIn>), grd, blk, 0, st, src, src_stride, (const float*)t->Gb[set][l + 1], t->gstride[l + 1],
-                       nb, s->lh[l], s->lw[l], s->lh[l + 1], s->lw[l + 1], (const int32_t*)s->bestIdx[l],
-                       s->first_index + s->n_pushed, s->bestLap[l], s->k1d[0], s->k1d[1], s->k1d[2]);
+                       nb, s->lh[l], s->lw[l], s->lh[l + 1], s->lw[l + 1], s->bestIdx[l],
+                       s->first_index + s->n_pushed, s->bestLap[l], s->k1d[0], s->k1d[1], s->k1d[2], s->bestE[l],
+                       (const float*)(nparts > 0 ? t->partE[l] : nullptr), (const int32_t*)(nparts > 0 ? t->partI[l] : nullptr),
+                       (size_t)s->lh[l] * s->lw[l], nparts);
     return MI_OK;
 }
 
@@ -633,12 +645,13 @@ int launch_payload_exact(mi_stack* s, int l, int set, const void* src, size_t sr
 // level 0 of the separable arithmetic: the matrix-pipe form of the reduce for 8 / 16-bit frames when the taps allow it
 template <typename TIn>
 int launch_level0_sep(mi_stack* s, int set, const void* src, size_t src_stride, int nb, hipStream_t st_in, hipStream_t st_bd,
-                      hipEvent_t ev_bd, int f_begin = 0, int f_end = -1) {
+                      hipEvent_t ev_bd, int f_begin = 0, int f_end = -1, SepLevelInfo* info = nullptr) {
     if constexpr (MI_SEP_MFMA && sizeof(TIn) <= 2) {
         static const int mf_off = study_env("MI_NO_MFMA", 0);   // -DMI_STUDY: the VALU form, for A/B runs
-        if (s->mfma_ok && !mf_off) return launch_level_sep<TIn, true, true>(s, 0, set, src, src_stride, nb, st_in, st_bd, ev_bd, f_begin, f_end);
+        if (s->mfma_ok && !mf_off)
+            return launch_level_sep<TIn, true, true>(s, 0, set, src, src_stride, nb, st_in, st_bd, ev_bd, f_begin, f_end, info);
     }
-    return launch_level_sep<TIn, true, false>(s, 0, set, src, src_stride, nb, st_in, st_bd, ev_bd, f_begin, f_end);
+    return launch_level_sep<TIn, true, false>(s, 0, set, src, src_stride, nb, st_in, st_bd, ev_bd, f_begin, f_end, info);
 }
 
 template <typename TIn, bool FMA>
@@ -652,6 +665,12 @@ int run_batch(mi_stack* s, const void* frames, size_t stride, int nb) {
     // Gb[set] is free once st2 finished batch k-2 (no-op for the first two batches)
     MI_HIP(hipStreamWaitEvent(st0, t->evRest[set], 0));
     MI_HIP(hipStreamWaitEvent(st1, t->evRest[set], 0));
+    if (s->sep && !t->partE.empty() && t->part_cap[0] > 0) {
+        // level 0 in frame chunks (small frames): the previous batch's payload pass (st2) folds partE[0] / partI[0], which
+        // this batch's level-0 kernels overwrite
+        MI_HIP(hipStreamWaitEvent(st0, t->evL0done[set ^ 1], 0));
+        MI_HIP(hipStreamWaitEvent(st1, t->evL0done[set ^ 1], 0));
+    }
     // whatever produced the frames on s->stream (a warp, a table apply, a copy enqueued by the caller) is ordered
     // before the level-0 interior kernel by the stream itself; the border kernel runs on st1 and needs the event
     MI_HIP(hipEventRecord(t->evInput, st0));
@@ -661,6 +680,7 @@ int run_batch(mi_stack* s, const void* frames, size_t stride, int nb) {
     // all of level 0, then all of level 1.  Only when both levels run as consecutive launches without border tiles.
     static const int interleave01 = study_env("MI_INTERLEAVE01", 0);
     bool il = false;
+    SepLevelInfo li0;
     if (s->sep && interleave01 && L >= 2 && nb > SEP_LAUNCH_FRAMES) {
         bool p0 = false, p1 = false;
         const int nt0 = cdiv(s->lw[0], 56) * cdiv(s->lh[0], MI_SEP_TH), nt1 = cdiv(s->lw[1], 56) * cdiv(s->lh[1], MI_SEP_TH);
@@ -675,7 +695,7 @@ int run_batch(mi_stack* s, const void* frames, size_t stride, int nb) {
             if (!rc) rc = launch_level_sep<float, false>(s, 1, set, t->Gb[set][1], t->gstride[1] * sizeof(float), nb, st0, st1,
                                                          t->evLvl[(set * (L + 1) + 1) * 2 + 1], f0, f1);
         }
-    } else if (s->sep) rc = launch_level0_sep<TIn>(s, set, frames, stride, nb, st0, st1, t->evL0b[set]);
+    } else if (s->sep) rc = launch_level0_sep<TIn>(s, set, frames, stride, nb, st0, st1, t->evL0b[set], 0, -1, &li0);
     else
         rc = launch_level<TIn, FMA, MI_TILE0_H, MI_TILE0_W, MI_TILE0_NT, MI_TILE_PAD != 0, MI_TILE_H, MI_TILE_W, MI_TILE_NT>(
             s, 0, set, frames, stride, nb, st0, st1, t->evL0b[set]);
@@ -685,7 +705,7 @@ int run_batch(mi_stack* s, const void* frames, size_t stride, int nb) {
     MI_HIP(hipStreamWaitEvent(st2, t->evL0i[set], 0));
     MI_HIP(hipStreamWaitEvent(st2, t->evL0b[set], 0));
     MI_HIP(hipStreamWaitEvent(st1, t->evL0i[set], 0));
-    if ((rc = s->sep ? launch_payload_sep<TIn>(s, 0, set, frames, stride, nb, st2)
+    if ((rc = s->sep ? launch_payload_sep<TIn>(s, 0, set, frames, stride, nb, st2, li0.nparts)
                      : launch_payload_exact<TIn, FMA>(s, 0, set, frames, stride, nb, st2)))
         return rc;
     MI_HIP(hipEventRecord(t->evL0done[set], st2));   // st2 waited for both level-0 kernels above
@@ -697,11 +717,23 @@ int run_batch(mi_stack* s, const void* frames, size_t stride, int nb) {
         // level 0's tile configuration -- less halo per tile: +2 % on the 256 x 24 MP job; MI_WIDE_LEVELS overrides
         static const int wide_levels = study_env("MI_WIDE_LEVELS", -1);
         const bool wide = wide_levels >= 0 ? l <= wide_levels : (size_t)s->lh[l] * s->lw[l] >= ((size_t)4 << 20);
+        hipEvent_t ei = t->evLvl[(set * (L + 1) + l) * 2], eb = t->evLvl[(set * (L + 1) + l) * 2 + 1];
+        if (s->sep && !(il && l == 1)) {
+            // interior tiles on st2; border tiles, if the level has any, on st1 behind everything st2 has done so far (`ei`);
+            // the streams join again (`eb`) in front of the payload pass, which also folds the frame chunks' partial maxima
+            SepLevelInfo li;
+            if ((rc = launch_level_sep<float, false>(s, l, set, t->Gb[set][l], t->gstride[l] * sizeof(float), nb, st2, st1, eb, 0, -1,
+                                                     &li, ei)))
+                return rc;
+            if (li.border) {
+                MI_HIP(hipEventRecord(eb, st1));
+                MI_HIP(hipStreamWaitEvent(st2, eb, 0));
+            }
+            if ((rc = launch_payload_sep<float>(s, l, set, t->Gb[set][l], t->gstride[l] * sizeof(float), nb, st2, li.nparts))) return rc;
+            continue;
+        }
         if (s->sep && il && l == 1)
             rc = MI_OK;   // level 1 ran interleaved with level 0 on st0 (st2 waited for evL0i, recorded behind both)
-        else if (s->sep)
-            rc = launch_level_sep<float, false>(s, l, set, t->Gb[set][l], t->gstride[l] * sizeof(float), nb, st2, st1,
-                                                t->evLvl[(set * (L + 1) + l) * 2 + 1]);
         else if (wide)
             rc = launch_level<float, FMA, MI_TILE0_H, MI_TILE0_W, MI_TILE0_NT, MI_TILE_PAD != 0, MI_TILE_H, MI_TILE_W, MI_TILE_NT, true>(
                 s, l, set, t->Gb[set][l], t->gstride[l] * sizeof(float), nb, st2, st1, t->evLvl[(set * (L + 1) + l) * 2 + 1]);
@@ -710,7 +742,6 @@ int run_batch(mi_stack* s, const void* frames, size_t stride, int nb) {
                 s, l, set, t->Gb[set][l], t->gstride[l] * sizeof(float), nb, st2, st1, t->evLvl[(set * (L + 1) + l) * 2 + 1]);
         if (rc)
             return rc;
-        hipEvent_t ei = t->evLvl[(set * (L + 1) + l) * 2], eb = t->evLvl[(set * (L + 1) + l) * 2 + 1];
         MI_HIP(hipEventRecord(ei, st2));
         MI_HIP(hipEventRecord(eb, st1));
         MI_HIP(hipStreamWaitEvent(st2, eb, 0));
