@@ -313,6 +313,14 @@ MI_API int mi_aligner_estimate(mi_aligner_t al, void* stream, const void* dev_mo
 MI_API int mi_aligner_estimate_batch(mi_aligner_t al, void* stream, const void* const* dev_movs, int n, int max_iters,
                               double eps, double* M_out, double* cc_out, int* iters_out);
 
+/* The same iteration started from given transforms instead of from the identity: `M_init` (n x 6, moving -> reference,
+ * full-resolution pixels: what an earlier estimate returned) is refined on the `levels` finest pyramid levels (1 = the
+ * finest alone).  The chained order of the reference's jobs (step_process, stack_framework.py:214-232) uses it to pull
+ * every frame's chain estimate back onto the GLOBAL reference frame, so that the steps' errors do not add up
+ * (shinestacker_amd/pipeline.py::_align_chains_device).  Outputs as mi_aligner_estimate_batch. */
+MI_API int mi_aligner_refine_batch(mi_aligner_t al, void* stream, const void* const* dev_movs, int n, const double* M_init,
+                            int levels, int max_iters, double eps, double* M_out, double* cc_out, int* iters_out);
+
 /* ALIGN_HOMOGRAPHY (align.py:138-140, cv2.findHomography): the same estimate refined to 8 degrees of freedom -- the
  * forward-additive ECC iteration in cv2.findTransformECC's MOTION_HOMOGRAPHY form, on the finest level, from the
  * converged similarity.  M9_out: n x 9 doubles, row-major 3 x 3 (moving -> reference, full-resolution pixels, M[8] = 1),

@@ -164,6 +164,9 @@ SIGNATURES = {
     "mi_aligner_estimate_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int,
                                             C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                             C.POINTER(C.c_int)]),
+    "mi_aligner_refine_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_double),
+                                          C.c_int, C.c_int, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                          C.POINTER(C.c_int)]),
     "mi_align_stack_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_int,
                                         C.POINTER(AlignStackOpts), C.POINTER(BalanceLinearOpts), C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
@@ -747,6 +750,19 @@ class Aligner:
         cc = (C.c_double * n)()
         it = (C.c_int * n)()
         check(load().mi_aligner_estimate_batch(self._h, stream, ptrs, n, int(max_iters), float(eps), m, cc, it))
+        return (np.array(list(m), dtype=np.float64).reshape(n, 2, 3), np.array(list(cc), dtype=np.float64),
+                np.array(list(it), dtype=np.int32))
+
+    def refine_batch(self, dev_ptrs, m_init, levels=2, max_iters=20, eps=1e-9, stream=None):
+        """The iteration started from the transforms `m_init` (n x 2 x 3, moving -> reference, full-resolution pixels) on the
+        `levels` finest pyramid levels (mi_aligner_refine_batch).  -> as estimate_batch"""
+        n = len(dev_ptrs)
+        ptrs = (C.c_void_p * n)(*dev_ptrs)
+        m0 = (C.c_double * (6 * n))(*np.asarray(m_init, dtype=np.float64).reshape(-1))
+        m = (C.c_double * (6 * n))()
+        cc = (C.c_double * n)()
+        it = (C.c_int * n)()
+        check(load().mi_aligner_refine_batch(self._h, stream, ptrs, n, m0, int(levels), int(max_iters), float(eps), m, cc, it))
         return (np.array(list(m), dtype=np.float64).reshape(n, 2, 3), np.array(list(cc), dtype=np.float64),
                 np.array(list(it), dtype=np.int32))
 

@@ -886,19 +886,35 @@ constexpr int ECC_CHUNK_FIRST = 8, ECC_CHUNK_NEXT = 4;
 // `M9_out` (optional): ALIGN_HOMOGRAPHY -- the similarity is refined to 8 degrees of freedom on the finest level
 // (ecc_accumulate_h) and row f of M9_out receives the 3 x 3 matrix (moving -> reference, full-resolution pixels, M[8] = 1);
 // a frame whose refinement fails or does not raise the correlation keeps its similarity, as a 3 x 3.
+// `M_init` (n x 6, moving -> reference in full-resolution pixels, what a previous estimate returned) + `start_level`: the
+// iteration starts from that transform on pyramid level `start_level` instead of from the identity on the coarsest level
+// (mi_aligner_refine_batch).
 int aligner_solve(mi_aligner* al, hipStream_t st, int n, int max_iters, double eps, double* M_out, double* cc_out,
-                  int* iters_out, double* M9_out = nullptr) {
+                  int* iters_out, double* M9_out = nullptr, const double* M_init = nullptr, int start_level = -1) {
     if (max_iters < 1) max_iters = 50;
     if (!(eps > 0)) eps = 1e-8;
     auto& lv = al->lv;
     EccState* const hs = al->hstate;
+    const int l_first = M_init ? std::min(std::max(start_level, 0), (int)lv.size() - 1) : (int)lv.size() - 1;
     for (int k = 0; k < n; ++k) {
         hs[k] = EccState{};
         hs[k].a = 1.0;
         hs[k].rho = -1.0;
         hs[k].last_rho = -2.0;
+        if (M_init) {
+            // W = M^-1 (reference -> moving, what the iteration works on): A = [a -b; b a], T in origin coordinates of level
+            // l_first (sub-sampled pixels / 2^l_first) -- the inverse of the read-out at the end of this function
+            const double* M = M_init + 6 * k;
+            const double ia = M[0], ib = M[3], det = ia * ia + ib * ib;
+            if (!(det > 1e-12)) return fail(MI_ERR_INVALID, "degenerate starting transform for frame %d", k);
+            const double a = ia / det, b = -ib / det, sc = (double)al->subsample * std::ldexp(1.0, l_first);
+            hs[k].a = a;
+            hs[k].b = b;
+            hs[k].T0 = -(a * M[2] - b * M[5]) / sc;
+            hs[k].T1 = -(b * M[2] + a * M[5]) / sc;
+        }
     }
-    if (al->phase_init) {
+    if (al->phase_init && !M_init) {
         // coarse initialiser: the translation phase correlation finds on level pc_level (<= 512 pixels per side) becomes
         // the starting translation of the Gauss-Newton iteration at the coarsest level
         const EccLevel& PL = lv[al->pc_level];
@@ -935,7 +951,7 @@ int aligner_solve(mi_aligner* al, hipStream_t st, int n, int max_iters, double e
         }
     }
     MI_HIP(hipMemcpyAsync(al->dstate, hs, sizeof(EccState) * n, hipMemcpyHostToDevice, st));
-    for (int l = (int)lv.size() - 1; l >= 0; --l) {
+    for (int l = l_first; l >= 0; --l) {
         const EccLevel& L = lv[l];
         const double cx = 0.5 * (L.w - 1), cy = 0.5 * (L.h - 1);
         const size_t np = (size_t)L.h * L.w;
@@ -2091,6 +2107,31 @@ int mi_aligner_estimate_batch(mi_aligner_t al, void* stream, const void* const* 
     }
     MI_HIP(hipGetLastError());
     return aligner_solve(al, st, n, max_iters, eps, M_out, cc_out, iters_out);
+}
+
+int mi_aligner_refine_batch(mi_aligner_t al, void* stream, const void* const* dev_movs, int n, const double* M_init, int levels,
+                            int max_iters, double eps, double* M_out, double* cc_out, int* iters_out) {
+    if (!al || !dev_movs || !M_out || !M_init) return fail(MI_ERR_INVALID, "null argument");
+    if (n < 1 || n > ECC_MAXF) return fail(MI_ERR_INVALID, "batch of %d frames (1..%d)", n, ECC_MAXF);
+    if (levels < 1) return fail(MI_ERR_INVALID, "levels must be >= 1");
+    if (!al->have_ref) return fail(MI_ERR_STATE, "mi_aligner_set_reference has not been called");
+    for (int k = 0; k < n; ++k)
+        if (!dev_movs[k]) return fail(MI_ERR_INVALID, "null frame %d", k);
+    MI_HIP(hipSetDevice(al->device));
+    hipStream_t st = stream ? (hipStream_t)stream : al->own;
+    int rc = aligner_reserve(al, n);
+    if (rc) return rc;
+    const int split = n > 1 ? 2 : 1 << 30;
+    for (int k = 0; k < n; ++k)
+        if ((rc = aligner_build(al, st, dev_movs[k], false, k, split))) return rc;
+    for (size_t l = (size_t)split; l < al->lv.size(); ++l) {
+        const auto& a = al->lv[l - 1];
+        const auto& b = al->lv[l];
+        hipLaunchKernelGGL((ecc_blur_tile<1>), dim3(cdiv(b.w, 64), cdiv(b.h, 16), n), dim3(256), 0, st, (const float*)a.img, a.h, a.w,
+                           b.img, b.h, b.w);
+    }
+    MI_HIP(hipGetLastError());
+    return aligner_solve(al, st, n, max_iters, eps, M_out, cc_out, iters_out, nullptr, M_init, levels - 1);
 }
 
 int mi_aligner_estimate_homography_batch(mi_aligner_t al, void* stream, const void* const* dev_movs, int n, int max_iters,

@@ -109,8 +109,19 @@ def align_and_stack(frames, ref_idx=-1, estimator=None, alignment_config=None, f
     return out, matches
 
 
+# chain_refine: how far (pixels, at the frame corners) the refinement against the global reference frame may move a chain
+# estimate before it is distrusted and the chain estimate kept
+CHAIN_REFINE_MAX_SHIFT = 2.0
+
+
+def _corner_shift(m0, m1, height, width):
+    """largest displacement between two 2x3 transforms at the frame corners"""
+    pts = np.array([[0.0, 0.0, 1.0], [width - 1.0, 0.0, 1.0], [0.0, height - 1.0, 1.0], [width - 1.0, height - 1.0, 1.0]]).T
+    return float(np.abs(np.asarray(m0) @ pts - np.asarray(m1) @ pts).max())
+
+
 def _align_chains_device(lib, dev_frames, aligned, n_frames, height, width, dt, ref_idx, cfg, min_correlation, max_iters,
-                         device, corr=None):
+                         device, corr=None, chain_refine=True):
     """`step_process=True` (stack_framework.py:214-232, the documented default of the reference's jobs): frame ref+1 is
     aligned to the reference frame, ref+2 to the ALIGNED ref+1, ... and ref-1, ref-2, ... the same way downwards -- two
     serial chains.  Every step needs the previous step's warped frame, so the batched estimator does not apply; the two
@@ -118,7 +129,15 @@ def _align_chains_device(lib, dev_frames, aligned, n_frames, height, width, dt, 
     written to `aligned` at their own index.  `corr` (a BalanceFrames correction, already begun on the reference frame):
     every aligned frame is balanced BEFORE it becomes the next step's reference, as the reference's CombinedActions does
     (the step reference is read back from the output directory, i.e. after align AND balance,
-    stack_framework.py:259-262, :282-289).  Returns (transforms, correlation coefficients)."""
+    stack_framework.py:259-262, :282-289).  Returns (transforms, correlation coefficients).
+
+    `chain_refine` (ALIGN_RIGID): the errors of the chain's steps add up like a random walk (0.5 px at the ends of a
+    128-frame stack, against the 0.2 px a single pair is held to, tests/test_0031_align_precision.py:62-65), because each
+    step only sees the previous step's output.  Every step's estimate is therefore refined against the GLOBAL reference
+    frame -- the same iteration on the two finest pyramid levels, started from the chain estimate -- before the frame is
+    warped: the chain supplies the capture range (neighbouring frames look alike), the global frame the datum.  A
+    refinement that fails, correlates worse than `min_correlation` or moves a corner by more than CHAIN_REFINE_MAX_SHIFT
+    pixels is distrusted and the chain estimate is kept."""
     import threading
     corr_lock = threading.Lock()   # one correction object (its histogram / table scratch) serves both chains
     fb = height * width * 3 * dt.itemsize
@@ -129,10 +148,14 @@ def _align_chains_device(lib, dev_frames, aligned, n_frames, height, width, dt, 
     _lib.check(lib.mi_memcpy_d2d(device, aligned + ref_idx * fb, dev_frames + ref_idx * fb, fb))   # align.py:279-280
 
     def chain(indices):
-        aligner = tmp = mask = None
+        aligner = gref = tmp = mask = None
         try:
             aligner = _lib.Aligner(height, width, dt, subsample=max(1, int(cfg['subsample'])), device=device,
                                    fast=bool(cfg['fast_subsampling']))
+            if chain_refine and not homography and indices:
+                gref = _lib.Aligner(height, width, dt, subsample=max(1, int(cfg['subsample'])), device=device,
+                                    fast=bool(cfg['fast_subsampling']))
+                gref.set_reference(dev_frames + ref_idx * fb)
             tmp = _lib.DeviceBuffer(fb, device)
             mask = _lib.DeviceBuffer(height * width, device)
             prev = ref_idx
@@ -145,6 +168,13 @@ def _align_chains_device(lib, dev_frames, aligned, n_frames, height, width, dt, 
                     m, cc, _ = aligner.estimate(dev_frames + i * fb, max_iters=max_iters)
                 if not cc >= min_correlation:
                     raise AlignmentError(i, f"correlation {cc:.3f} < {min_correlation}")
+                if gref is not None and prev != ref_idx:   # (the first step IS an estimate against the global reference)
+                    try:
+                        m2, c2, _ = gref.refine_batch([dev_frames + i * fb], m[None], levels=2, max_iters=max_iters)
+                        if c2[0] >= min_correlation and _corner_shift(m, m2[0], height, width) <= CHAIN_REFINE_MAX_SHIFT:
+                            m = m2[0]
+                    except (_lib.DeviceError, ValueError):
+                        pass
                 transforms[i], ccs[i] = m, float(cc)
                 arr = (C.c_double * m.size)(*m.reshape(-1))
                 warp = lib.mi_warp_perspective_device if homography else lib.mi_warp_affine_device
@@ -158,8 +188,9 @@ def _align_chains_device(lib, dev_frames, aligned, n_frames, height, width, dt, 
         except Exception as e:  # noqa: BLE001  re-raised on the calling thread
             errors.append(e)
         finally:   # a chain that raises must not leak its estimator handle and buffers
-            if aligner is not None:
-                aligner.close()
+            for al in (aligner, gref):
+                if al is not None:
+                    al.close()
             for b in (tmp, mask):
                 if b is not None:
                     b.free()
@@ -236,7 +267,7 @@ def auto_batch_frames(n_frames, height, width, dtype, device=0, share=0.25):
 def align_and_stack_device(dev_frames, n_frames, height, width, dtype, ref_idx=-1, alignment_config=None,
                            min_correlation=0.5, max_iters=60, device=0, batch_frames=None, out_dev=None,
                            balance=None, ecc_batch=16, step_process=False, native_loop=True, handles=None,
-                           keep_handles=False, info=None, **stack_kwargs):
+                           keep_handles=False, info=None, chain_refine=True, **stack_kwargs):
     """BASELINE config 4 with every frame resident in HBM: `dev_frames` is the device address of
     `n_frames` contiguous H x W x 3 frames.  Each frame is registered against frames[ref_idx] by
     the device ECC estimator (mi_aligner_*), warped with the blurred replicate border of
@@ -272,6 +303,8 @@ def align_and_stack_device(dev_frames, n_frames, height, width, dtype, ref_idx=-
     `step_process=True`: the reference's chained order (see `_align_chains_device`): every frame is registered against
     its already-aligned neighbour; the aligned frames are kept in one extra device buffer (n_frames frames) and fused in
     file order afterwards, so that the stack sees them exactly as the reference's FocusStack reads the aligned files.
+    `chain_refine` (default True; ALIGN_RIGID): every chain estimate is refined against the global reference frame before the
+    frame is warped, so that the steps' errors do not add up (`_align_chains_device`); False = the plain chain.
 
     Returns (fused image as ndarray, or None when `out_dev` -- a device address for the result --
     is given; list of 2x3 transforms, None at ref_idx; list of correlation coefficients)."""
@@ -301,7 +334,7 @@ def align_and_stack_device(dev_frames, n_frames, height, width, dtype, ref_idx=-
             corr = _make_correction(balance, device)
             corr.begin_device(dev_frames + ref_idx * fb, height, width, dt, n_frames)
         transforms, ccs = _align_chains_device(lib, dev_frames, aligned.ptr, n_frames, height, width, dt, ref_idx, cfg,
-                                               min_correlation, max_iters, device, corr)
+                                               min_correlation, max_iters, device, corr, chain_refine=chain_refine)
         stack = _lib.Stack(height, width, in_dtype=dt, out_dtype=dt, device=device, **stack_kwargs)
         try:
             stack.push_frames_device(aligned.ptr, n_frames, fb)
