@@ -739,6 +739,13 @@ struct mi_aligner {
     hipStream_t own = nullptr;       // used when the caller passes no stream: handles on different host
                                      // threads then run side by side instead of serialising on stream 0
     bool have_ref = false;
+    // mi_align_stack_device: side lanes of the warp stage.  The frames of a batch are warped round-robin on the stacker's
+    // stream and on WARP_LANES - 1 streams of the handle, each with its own border-blur scratch, so that one frame's short,
+    // latency-bound kernels (tables, tile list, border blur of a few hundred tiles, scatter) run beside the next frame's warp
+    // instead of in front of it.
+    hipStream_t wst[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t wev[3] = {nullptr, nullptr, nullptr}, wstart = nullptr;
+    void *wtmp[3] = {nullptr, nullptr, nullptr}, *wmask[3] = {nullptr, nullptr, nullptr};
     // optional coarse initialiser (mi_aligner_set_phase_init): phase correlation on pyramid level `pc_level`
     bool phase_init = false;
     int pc_level = 0, pc_P = 0, pc_Q = 0;
@@ -788,6 +795,33 @@ void aligner_free(mi_aligner* al) {
     al->bufs.clear();
     if (al->own) (void)hipStreamDestroy(al->own);
     al->own = nullptr;
+    for (int j = 0; j < 3; ++j) {
+        if (al->wst[j]) (void)hipStreamDestroy(al->wst[j]);
+        if (al->wev[j]) (void)hipEventDestroy(al->wev[j]);
+        (void)hipFree(al->wtmp[j]);
+        (void)hipFree(al->wmask[j]);
+        al->wst[j] = nullptr; al->wev[j] = nullptr; al->wtmp[j] = al->wmask[j] = nullptr;
+    }
+    if (al->wstart) (void)hipEventDestroy(al->wstart);
+    al->wstart = nullptr;
+}
+
+// the side lanes of mi_align_stack_device's warp stage (created on first use; one frame + one mask of scratch each)
+#ifndef MI_WARP_LANES
+#define MI_WARP_LANES 4
+#endif
+constexpr int WARP_LANES = MI_WARP_LANES;   // 1 = every warp on the stacker's stream (round 4)
+int aligner_warp_lanes(mi_aligner* al, size_t frame_bytes, size_t mask_bytes) {
+    if (al->wstart) return MI_OK;
+    static_assert(WARP_LANES >= 1 && WARP_LANES <= 4, "lanes");
+    for (int j = 0; j < WARP_LANES - 1; ++j) {
+        MI_HIP(hipStreamCreateWithFlags(&al->wst[j], hipStreamNonBlocking));
+        MI_HIP(hipEventCreateWithFlags(&al->wev[j], hipEventDisableTiming));
+        if (hipMalloc(&al->wtmp[j], frame_bytes) != hipSuccess || hipMalloc(&al->wmask[j], mask_bytes) != hipSuccess)
+            return fail(MI_ERR_NOMEM, "out of device memory");
+    }
+    MI_HIP(hipEventCreateWithFlags(&al->wstart, hipEventDisableTiming));
+    return MI_OK;
 }
 
 // per-frame buffers for `n` moving frames
@@ -2193,9 +2227,19 @@ int mi_align_stack_device(mi_stack_t* st, mi_aligner_t al, const void* dev_frame
         for (int k = 0; k < 9; ++k) M_out[(size_t)i * 9 + k] = 0.0;
         cc_out[i] = 1.0;
     }
+    // warp lanes (see mi_aligner): not with the in-place balance, whose histogram / table scratch is one per call
+    const int lanes = bal ? 1 : WARP_LANES;
+    if (lanes > 1 && (rc = aligner_warp_lanes(al, fb, (size_t)H * W))) return rc;
+    unsigned lanes_used = 0;
     int cur = 0, filled = 0;
     auto flush = [&]() -> int {
         if (!filled) return MI_OK;
+        for (int j = 1; j < lanes; ++j)   // the batch is complete when every lane's warps are
+            if (lanes_used & (1u << j)) {
+                MI_HIP(hipEventRecord(al->wev[j - 1], al->wst[j - 1]));
+                MI_HIP(hipStreamWaitEvent(st->stream, al->wev[j - 1], 0));
+            }
+        lanes_used = 0;
         // no host synchronisation: the warps ran on the stacker's stream, where the level-0 kernels that read this batch
         // are enqueued next, and the stacker joins its side streams into that stream after every push
         int r = mi_stack_push_frames_device(st, (char*)dev_batches + (size_t)cur * B * fb, filled, fb);
@@ -2205,6 +2249,7 @@ int mi_align_stack_device(mi_stack_t* st, mi_aligner_t al, const void* dev_frame
     };
     for (int i = 0; i < n_frames; ++i) {
         char* dst = (char*)dev_batches + ((size_t)cur * B + filled) * fb;
+        if (filled == 0 && lanes > 1) MI_HIP(hipEventRecord(al->wstart, st->stream));   // this batch buffer is free from here on
         if (i == ref_idx) {
             MI_HIP(hipMemcpyAsync(dst, frames + (size_t)i * frame_stride, fb, hipMemcpyDeviceToDevice, st->stream));
         } else {
@@ -2231,8 +2276,18 @@ int mi_align_stack_device(mi_stack_t* st, mi_aligner_t al, const void* dev_frame
             }
             double* m = M_out + (size_t)i * 9;
             for (int q = 0; q < (persp ? 9 : 6); ++q) m[q] = est[(size_t)i * 9 + q];
-            if ((rc = warp_device_impl(st->p.device, st->stream, frames + (size_t)i * frame_stride, dst, dev_tmp, dev_mask, H, W,
-                                       st->p.in_dtype, m, persp, o->border_mode, o->border_value, o->blur_ksize, o->blur_sigma)))
+            // lane of this frame: the stacker's stream itself (0) or a side stream, which first waits for everything the
+            // stacker's stream has done when this batch buffer started to fill (the push that last read it, joined)
+            const int lane = lanes > 1 ? filled % lanes : 0;
+            hipStream_t ws = st->stream;
+            if (lane) {
+                ws = al->wst[lane - 1];
+                if (!(lanes_used & (1u << lane))) MI_HIP(hipStreamWaitEvent(ws, al->wstart, 0));
+                lanes_used |= 1u << lane;
+            }
+            if ((rc = warp_device_impl(st->p.device, ws, frames + (size_t)i * frame_stride, dst, lane ? al->wtmp[lane - 1] : dev_tmp,
+                                       lane ? al->wmask[lane - 1] : dev_mask, H, W, st->p.in_dtype, m, persp, o->border_mode,
+                                       o->border_value, o->blur_ksize, o->blur_sigma)))
                 return rc;
             if (bal) {   // LINEAR balance of the aligned frame, in place, no host round trip
                 const size_t npx = (size_t)H * W;
