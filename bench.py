@@ -138,6 +138,14 @@ def cpu_baseline(args, total_frames):
         out["reference_shaped"] = {"value": m * H * W / dr / 1e6, "unit": "Mpixels/s", "frames": m,
                                    "seconds": dr, "note": "oracle.RefShaped (NumPy control flow of pyramid.py, "
                                    "filter primitives in C/OpenMP); linear in the frame count"}
+    # The cv2 primitives the oracle restates are third-party code this repository cannot pin (no OpenCV in the build image,
+    # unpinned in the reference's pyproject.toml:26).  Whenever a box that runs this bench HAS OpenCV, the real primitives are
+    # compared with the restatements here (oracle/probe_cv2.py; outside every timed region) and the verdict travels in the line.
+    try:
+        from oracle import probe_cv2
+        out["cv2"] = probe_cv2.probe(write=False)
+    except Exception as e:  # noqa: BLE001  (a probe failure must not cost the bench line)
+        out["cv2"] = {"available": None, "error": f"probe failed: {type(e).__name__}: {e}"}
     return out
 
 
@@ -672,6 +680,7 @@ def main():
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, total_frames)
+            line["cv2"] = line["cpu_baseline"].pop("cv2")   # is OpenCV importable on this box, and if so: do the restatements hold?
         if world > 1 or force_dist:
             # RCCL prints its version banner through C stdio when NCCL_DEBUG is set (it is, on the GPU boxes): push
             # that out first, so that the JSON line is the last line of rank 0's stdout

@@ -18,17 +18,23 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
-def main():
+def probe(write=True):
+    """-> {"available": False, "error": ...} without OpenCV; else the comparison report ({"available": True, "cv2_version",
+    one entry per primitive}).  `write`: also save the real outputs under tests/golden/ (the script form; bench.py's
+    cpu_baseline leg passes False: a GPU box's copy of the repository is scratch)."""
     try:
         import cv2
     except Exception as e:  # noqa: BLE001
-        print(f"probe_cv2: OpenCV is not importable here ({type(e).__name__}: {e}); the cv2 primitives stay "
-              "'parity unpinned' (oracle/pyramid_oracle.c header).  Nothing written.")
-        return 0
+        return {"available": False, "error": f"{type(e).__name__}: {e}"}
+    _savez = np.savez_compressed
+
+    def savez(*a, **k):
+        if write:
+            _savez(*a, **k)
     sys.path.insert(0, ROOT)
     from oracle import oracle as orc
     orc.build()
-    report = {"cv2_version": cv2.__version__, "build": cv2.getBuildInformation().split("\n")[0:1]}
+    report = {"available": True, "cv2_version": cv2.__version__, "build": cv2.getBuildInformation().split("\n")[0:1]}
     with np.load(os.path.join(GOLDEN, "g1_u8.npz")) as z:
         frames = z["frames"]
     img = frames[0].astype(np.float32)
@@ -42,7 +48,7 @@ def main():
                     for c in range(3))]
     report["filter2D"] = {"matches_use_fma": match, "max_abs_diff_fma": float(max(
         np.abs(orc.filter2D(np.ascontiguousarray(img[:, :, c]), k2d, True) - real[:, :, c]).max() for c in range(3)))}
-    np.savez_compressed(os.path.join(GOLDEN, "cv2_filter2D.npz"), src=img, kernel=k2d, dst=real)
+    savez(os.path.join(GOLDEN, "cv2_filter2D.npz"), src=img, kernel=k2d, dst=real)
 
     # ---- cvtColor BGR2GRAY, float32 (pyramid.py:49) and uint8 (utils.py:37-43)
     lap = (img - real)
@@ -50,7 +56,7 @@ def main():
     report["cvtColor_f32"] = {"matches_use_fma": [f for f in (1, 0) if np.array_equal(orc.bgr2gray_f32(lap, bool(f)), real_g)]}
     real_g8 = cv2.cvtColor(frames[0], cv2.COLOR_BGR2GRAY)
     report["cvtColor_u8"] = {"matches": bool(np.array_equal(orc.bgr2gray_int(frames[0]), real_g8))}
-    np.savez_compressed(os.path.join(GOLDEN, "cv2_cvtColor.npz"), src_f32=lap, dst_f32=real_g, src_u8=frames[0], dst_u8=real_g8)
+    savez(os.path.join(GOLDEN, "cv2_cvtColor.npz"), src_f32=lap, dst_f32=real_g, src_u8=frames[0], dst_u8=real_g8)
 
     # ---- warpAffine + mask + GaussianBlur composite (align.py:238-251)
     h, w = frames[0].shape[:2]
@@ -65,10 +71,10 @@ def main():
     blurred16 = cv2.GaussianBlur(src16, (21, 21), sigmaX=50)
     report["GaussianBlur_21_fixed"] = {"u8": bool(np.array_equal(orc.gaussian_blur_fixed(real_w, 21, 50.0), blurred)),
                                        "u16": bool(np.array_equal(orc.gaussian_blur_fixed(src16, 21, 50.0), blurred16))}
-    np.savez_compressed(os.path.join(GOLDEN, "cv2_gaussian_blur.npz"), src_u8=real_w, dst_u8=blurred, src_u16=src16, dst_u16=blurred16)
+    savez(os.path.join(GOLDEN, "cv2_gaussian_blur.npz"), src_u8=real_w, dst_u8=blurred, src_u16=src16, dst_u16=blurred16)
     report["warpAffine"] = {"matches": bool(np.array_equal(orc.warp_affine(frames[0], M, border_mode=1), real_w))}
     report["warp+blur_composite"] = {"matches": bool(np.array_equal(orc.warp_affine(frames[0], M), comp))}
-    np.savez_compressed(os.path.join(GOLDEN, "cv2_warp.npz"), src=frames[0], M=M, warp=real_w, mask=mask, composite=comp)
+    savez(os.path.join(GOLDEN, "cv2_warp.npz"), src=frames[0], M=M, warp=real_w, mask=mask, composite=comp)
 
     # ---- resize INTER_AREA (utils.py:79-86): sizes that divide and sizes that do not (output size, partial blocks), 8 / 16 bit
     res = {}
@@ -78,14 +84,14 @@ def main():
             real_r = cv2.resize(src, (0, 0), fx=1 / s, fy=1 / s, interpolation=cv2.INTER_AREA)
             mine = orc.resize_area_int(src, s)
             res[f"{name}_{s}"] = bool(mine.shape == real_r.shape and np.array_equal(mine, real_r))
-            np.savez_compressed(os.path.join(GOLDEN, f"cv2_resize_area_{name}_{s}.npz"), src=src, dst=real_r)
+            savez(os.path.join(GOLDEN, f"cv2_resize_area_{name}_{s}.npz"), src=src, dst=real_r)
     report["resize_INTER_AREA"] = res
 
     # ---- warpPerspective + mask (align.py:240-241, ALIGN_HOMOGRAPHY)
     Hm = np.array([[0.9997, -0.0121, 2.9], [0.0119, 1.0004, -1.7], [1.5e-6, -2.0e-6, 1.0]], np.float64)
     real_p = cv2.warpPerspective(frames[0], Hm, (w, h), borderMode=cv2.BORDER_REPLICATE)
     report["warpPerspective"] = {"matches": bool(np.array_equal(orc.warp_perspective(frames[0], Hm, border_mode=1), real_p))}
-    np.savez_compressed(os.path.join(GOLDEN, "cv2_warp_perspective.npz"), src=frames[0], M=Hm, warp=real_p)
+    savez(os.path.join(GOLDEN, "cv2_warp_perspective.npz"), src=frames[0], M=Hm, warp=real_p)
 
     # ---- 8-bit BGR <-> HSV / HLS (balance.py:340-363)
     cvt = {}
@@ -97,7 +103,7 @@ def main():
         back_code, back_cv = ((orc.CVT_HSV2BGR, cv2.COLOR_HSV2BGR) if name == "BGR2HSV" else (orc.CVT_HLS2BGR, cv2.COLOR_HLS2BGR))
         real_b = cv2.cvtColor(real_c, back_cv)
         cvt[name[4:] + "2BGR"] = bool(np.array_equal(orc.cvt_color_u8(real_c, back_code), real_b))
-        np.savez_compressed(os.path.join(GOLDEN, f"cv2_cvt_{name}.npz"), src=cube, dst=real_c, back=real_b)
+        savez(os.path.join(GOLDEN, f"cv2_cvt_{name}.npz"), src=cube, dst=real_c, back=real_b)
     report["cvtColor_HSV_HLS_u8"] = cvt
 
     # ---- DepthMapStack's primitives (depth_map.py:28-62, :94-112) on the gray plane of the first frame
@@ -116,6 +122,15 @@ def main():
     dm["bilateralFilter_15"] = {"equal": bool(np.array_equal(mine_bi, real_bi)), "max_abs_diff": float(np.abs(mine_bi - real_bi).max())}
     report["depth_map_primitives"] = dm
 
+    return report
+
+
+def main():
+    report = probe(write=True)
+    if not report["available"]:
+        print(f"probe_cv2: OpenCV is not importable here ({report['error']}); the cv2 primitives stay "
+              "'parity unpinned' (oracle/pyramid_oracle.c header).  Nothing written.")
+        return 0
     print(json.dumps(report, indent=1))
     with open(os.path.join(GOLDEN, "cv2_probe_report.json"), "w") as fh:
         json.dump(report, fh, indent=1)

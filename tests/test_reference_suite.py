@@ -1,11 +1,12 @@
-"""GPU: the reference's OWN test modules (tests/test_0030_align.py, test_0040_balance.py, test_0050_align_balance.py,
-test_0060_stack.py, test_0061_depth_map.py) with nothing changed but the import lines -- `shinestacker_amd` instead of
-`shinestacker.algorithms.*` -- and the location of the example frames: the reference runs inside its repository on
-`examples/input/img-jpg` / `img-tif`; here `examples/` is a temporary directory holding the committed crops of those
-frames (tests/golden/img_jpg_crop) as 8-bit JPEG and as 16-bit TIFF.  The assertions are the reference's: the jobs run
-through, outputs have the expected type.  (Plots and progress bars -- `plot_summary`, `plot_histograms`,
-`callbacks='tqdm'` -- are accepted and ignored: out of scope)  The same classes are compared value by
-value with recordings of the reference in test_gpu_parity.py / test_align_golden.py / test_gpu_balance.py."""
+"""GPU: the job set-ups of the reference's own smoke tests (tests/test_0030_align.py, test_0040_balance.py,
+test_0050_align_balance.py, test_0060_stack.py, test_0061_depth_map.py) RE-TYPED against `shinestacker_amd`: the same
+public-API calls with the same arguments ("exactly as tests/test_0060_stack.py:7-14"), condensed --
+parametrised instead of one function per case, no try / except around the runs -- and pointed at a temporary `examples/`
+directory holding the committed crops of the reference's example frames (tests/golden/img_jpg_crop) as 8-bit JPEG and as
+16-bit TIFF.  What is asserted is what the reference asserts: the jobs run through, outputs have the expected type.  (Plots
+and progress bars -- `plot_summary`, `plot_histograms`, `callbacks='tqdm'` -- are accepted and ignored: out of scope,
+SURVEY.md 2.)  The same classes are compared value by value with recordings of the reference in test_gpu_parity.py /
+test_align_golden.py / test_gpu_balance.py."""
 import os
 from unittest.mock import MagicMock
 
