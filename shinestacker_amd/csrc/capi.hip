@@ -915,7 +915,20 @@ int aligner_build(mi_aligner* al, hipStream_t st, const void* dev_img, bool is_t
 // the method fails on (no overlap, constant image, degenerate transform) gets cc = -2.
 // iterations enqueued between two looks at the frames' `active` flags: the first look of a level comes late (a level
 // rarely converges in fewer), the following ones sooner
-constexpr int ECC_CHUNK_FIRST = 8, ECC_CHUNK_NEXT = 4;
+// (the two coarsest levels start far from their optimum; the finer ones inherit it and stop after one to three steps)
+#ifndef MI_ECC_CHUNK_FINE
+#define MI_ECC_CHUNK_FINE 4
+#endif
+constexpr int ECC_CHUNK_FIRST = 8, ECC_CHUNK_FIRST_FINE = MI_ECC_CHUNK_FINE, ECC_CHUNK_NEXT = 4;
+// samples per Gauss-Newton sum at least: levels with more pixels are sampled on every `step`-th row and column
+#ifndef MI_ECC_MIN_SAMPLES
+#define MI_ECC_MIN_SAMPLES 300000
+#endif
+inline int ecc_sample_step(size_t np) {
+    int step = 1;
+    while ((size_t)(step + 1) * (step + 1) * (size_t)MI_ECC_MIN_SAMPLES <= np) ++step;
+    return step;
+}
 
 // `M9_out` (optional): ALIGN_HOMOGRAPHY -- the similarity is refined to 8 degrees of freedom on the finest level
 // (ecc_accumulate_h) and row f of M9_out receives the 3 x 3 matrix (moving -> reference, full-resolution pixels, M[8] = 1);
@@ -989,11 +1002,11 @@ int aligner_solve(mi_aligner* al, hipStream_t st, int n, int max_iters, double e
         const EccLevel& L = lv[l];
         const double cx = 0.5 * (L.w - 1), cy = 0.5 * (L.h - 1);
         const size_t np = (size_t)L.h * L.w;
-        // sample every `step`-th pixel in both directions: half a million samples and more are plenty for 4 parameters
-        // (6 MP level: step 3 = 667 K samples; the recovered transforms of config 4 stay 100x inside the tolerances)
+        // sample every `step`-th pixel in both directions: a third of a million samples and more are plenty for 4 parameters
+        // (6 MP level: step 4 = 375 K samples, 1.5 MP level: step 2; rounds 3-4 kept half a million -- 667 K and all 1.5 M --:
+        // the recovered transforms of config 4 stay ten times inside the tolerances either way, profiles/r05)
         static const int ecc_step = study_env("MI_ECC_STEP", 0);   // -DMI_STUDY: force a step
-        int step = 1;
-        while ((size_t)(step + 1) * (step + 1) * 500000 <= np) ++step;
+        int step = ecc_sample_step(np);
         if (ecc_step > 0) step = ecc_step;
         // ~48 samples per thread (the 28 double sums cost a thread ~500 instructions to reduce, as much as 5 samples),
         // at most ECC_MAX_BLOCKS blocks (4 per CU).  Measured (round 3, config 4 / the estimate of a 16-frame batch alone):
@@ -1005,7 +1018,8 @@ int aligner_solve(mi_aligner* al, hipStream_t st, int n, int max_iters, double e
         hipLaunchKernelGGL(ecc_level_begin, dim3(cdiv(n, 64)), dim3(64), 0, st, al->dstate, n, cx, cy);
         const double reach = std::hypot(cx, cy);
         for (int it = 0; it < max_iters;) {
-            const int chunk = std::min(it == 0 ? ECC_CHUNK_FIRST : ECC_CHUNK_NEXT, max_iters - it);
+            const int chunk = std::min(it == 0 ? (l + 2 >= (int)lv.size() ? ECC_CHUNK_FIRST : ECC_CHUNK_FIRST_FINE) : ECC_CHUNK_NEXT,
+                                       max_iters - it);
             for (int j = 0; j < chunk; ++j)   // frames that have stopped leave at once
                 hipLaunchKernelGGL(ecc_accumulate, dim3(nblk, n), dim3(256), 0, st, L.tmpl, L.img, np, L.h, L.w, al->dstate, step,
                                    al->partial, al->ticket, reach, eps);
@@ -1028,8 +1042,7 @@ int aligner_solve(mi_aligner* al, hipStream_t st, int n, int max_iters, double e
         cy0 = 0.5 * (L.h - 1);
         Rn = (double)hypotf((float)cx0, (float)cy0);   // the kernel's own (float) radius
         const size_t np = (size_t)L.h * L.w;
-        int step = 1;
-        while ((size_t)(step + 1) * (step + 1) * 500000 <= np) ++step;
+        const int step = ecc_sample_step(np);
         const size_t work = (np / ((size_t)step * step) + 12287) / 12288;
         const unsigned nblk = (unsigned)(work < 1 ? 1 : (work > (size_t)ECC_MAX_BLOCKS ? ECC_MAX_BLOCKS : work));
         hipLaunchKernelGGL(ecc_h_from_similarity, dim3(cdiv(n, 64)), dim3(64), 0, st, (const EccState*)al->dstate, al->dstate_h, n, Rn);
