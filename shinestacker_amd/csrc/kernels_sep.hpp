@@ -100,17 +100,22 @@ template <typename TIn> constexpr int sep_nt() { return sizeof(TIn) == 4 ? MI_SE
 #ifndef MI_SEP_DMA
 #define MI_SEP_DMA 0
 #endif
-// Level 0 of 8- and 16-bit frames with integer reduce taps (red_taps: the default generating kernel): the 5 x 5 reduce as
-// exact integer arithmetic on the matrix pipe (v_mfma_i32_16x16x64_i8 on the staged bytes) instead of P1 + P2's VALU work --
-// see level_sep_body, "MF".  Tile height 24 (the G_{l+1} patch is then 16 rows = two per wave).  Bit-identical to the VALU
-// form (all of tests/test_gpu_separable.py and test_gpu_parity.py pass with it) and NOT faster (round 5, docs/studies.md):
-// 154 instead of 197 VALU instructions per wave and frame, but 17 % more workgroups (24-row tiles), more LDS conflicts, and
-// the kernel is bound by the sum of its phases' latencies rather than by VALU issue alone: 8-bit level-0 launch 0.841 ->
-// 0.854 ms, 16-bit (two byte planes, ten matrix instructions per wave) 0.962 -> 1.154 ms.  Off; -DMI_SEP_MFMA=1 builds it.
+// Level 0 of 8-bit frames with integer reduce taps (red_taps: the default generating kernel): the 5 x 5 reduce as exact
+// integer arithmetic on the matrix pipe (v_mfma_i32_16x16x64_i8 on the staged bytes) instead of P1 + P2's VALU work -- see
+// level_sep_body, "MF".  Bit-identical to the VALU form (all of tests/test_gpu_separable.py and test_gpu_parity.py pass with
+// it) and NOT faster (round 5, docs/studies.md): 154 instead of 197 VALU instructions per wave and frame and one barrier
+// less, but more LDS bank conflicts, and the kernel is bound by the sum of its phases (ablating the matrix instructions
+// themselves changes nothing; the phase around them costs what P1 + P2 cost).  8-bit level-0 launch, interleaved A/B:
+// 0.833 ms (VALU form) vs 0.853 ms (tile height 28, wave 0 takes a ninth row pair) and 0.854 ms (tile height 24, 17 % more
+// workgroups; the VALU form at that height: 0.936 ms).  16-bit frames (two byte planes, ten matrix instructions per row
+// pair): 0.962 -> 1.154 ms, never dispatched.  Off; -DMI_SEP_MFMA=1 builds it.
 #ifndef MI_SEP_MFMA
 #define MI_SEP_MFMA 0
 #endif
-constexpr int SEP_MF_TH = 24, SEP_MF_NT = 512;
+#ifndef MI_SEP_MF_TH
+#define MI_SEP_MF_TH 28
+#endif
+constexpr int SEP_MF_TH = MI_SEP_MF_TH, SEP_MF_NT = (MI_SEP_MF_TH / 2 + 2) * 32;
 
 template <int TH_, int NT_>
 struct SepGeom {
@@ -397,7 +402,7 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
     // 128 * 400.  16-bit frames: the same on the plane of low bytes and on the plane of high bytes, S = 256 S_hi + S_lo.
     // S is the exact integer sum and G_{l+1} = float(S) * rs: bit-identical to the float evaluation of red_taps' integer
     // taps (header; float(S) rounds once, to nearest even, exactly where the float chain's last fma does).
-    static_assert(!MF_ || (INTERIOR && sizeof(TIn) <= 2 && G::NH == 16 && NT == 512), "MF geometry");
+    static_assert(!MF_ || (INTERIOR && sizeof(TIn) <= 2 && G::NH % 2 == 0 && NT % 64 == 0), "MF geometry");
     constexpr bool MF = MF_;
     constexpr int NPL = MF ? (int)sizeof(TIn) : 0;    // byte planes
     float* sG = smem;
@@ -826,8 +831,10 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
         // horizontal expand of the gray -> X.  18 rows x 32 = 576 items: the last two rows are a second round on wave 0.
         if constexpr (MF) { if (!MI_ABL(2)) {
             // ---------------- MF: the whole reduce of this wave's two G_{l+1} rows on the matrix pipe (see the top of the function)
+            // (a task = two rows; tile height 28 has nine of them for eight waves: wave 0 takes the last one too)
             const int ln = lt & 63, n = ln & 15, kg = ln >> 4;
-            const int r = 2 * (lt >> 6) + (n >> 3), jp = 4 * (n & 7) + kg;    // the pixel this lane ends up with
+            for (int task = lt >> 6; task < G::NH / 2; task += NT / 64) {
+            const int r = 2 * task + (n >> 3), jp = 4 * (n & 7) + kg;    // the pixel this lane ends up with
             typedef const volatile v4i __attribute__((address_space(3))) * lds_v4i;
             typedef const volatile v2u __attribute__((address_space(3))) * lds_v2u;
             const uint32_t wbase = (uint32_t)(uintptr_t)sW + 16u * (uint32_t)ln;
@@ -874,6 +881,7 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
                 gr = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(4 * lnext, __builtin_bit_cast(int, g)));
             }
             lds_store2(sX + mul24(r, G::XS) + 2 * jp, ex_even(gl, g, gr, ce, cc), ex_odd(g, gr, co));
+            }   // task
         } } else {
 #pragma unroll
         for (int rnd = 0; rnd < (G::NH * 32 + NT - 1) / NT; ++rnd) {

@@ -646,7 +646,7 @@ int launch_payload_exact(mi_stack* s, int l, int set, const void* src, size_t sr
 template <typename TIn>
 int launch_level0_sep(mi_stack* s, int set, const void* src, size_t src_stride, int nb, hipStream_t st_in, hipStream_t st_bd,
                       hipEvent_t ev_bd, int f_begin = 0, int f_end = -1, SepLevelInfo* info = nullptr) {
-    if constexpr (MI_SEP_MFMA && sizeof(TIn) <= 2) {
+    if constexpr (MI_SEP_MFMA && sizeof(TIn) == 1) {   // (16-bit frames: two byte planes, ten matrix instructions per task -- measured slower)
         static const int mf_off = study_env("MI_NO_MFMA", 0);   // -DMI_STUDY: the VALU form, for A/B runs
         if (s->mfma_ok && !mf_off)
             return launch_level_sep<TIn, true, true>(s, 0, set, src, src_stride, nb, st_in, st_bd, ev_bd, f_begin, f_end, info);
