@@ -34,8 +34,11 @@ __device__ __forceinline__ int cv_round_d(double v) {
 // OpenCV's warpAffine rounds its coordinate terms in double ONCE per column (adelta / bdelta) and once per row; so does
 // this kernel, into a table the warp kernel reads: [ad: w][bd: w][X0: h][Y0: h] -- no double arithmetic per tile and row
 // in the warp itself (it was a third of the tiled kernel's instruction time).
-__global__ __launch_bounds__(256) void warp_coord_tables(AffineArgs a, int* __restrict__ tab) {
+// `clr` (optional): `nclr` dwords of the border blur's tile scratch (counter + bitmap) to zero for the warp kernel behind this
+// one -- a separate memset was a launch of its own per frame.
+__global__ __launch_bounds__(256) void warp_coord_tables(AffineArgs a, int* __restrict__ tab, uint32_t* __restrict__ clr, int nclr) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    for (int k = i; k < nclr; k += gridDim.x * blockDim.x) clr[k] = 0u;
     if (i < a.w) {
         tab[i] = cv_round_d(a.iM[0] * i * 1024.0);
         tab[a.w + i] = cv_round_d(a.iM[3] * i * 1024.0);
@@ -211,9 +214,15 @@ __global__ __launch_bounds__(256) void warp_perspective_kernel(const T* __restri
 // Tiles whose bounding box leaves the image, or does not fit the LDS budget (large rotations), take the per-pixel
 // path.
 constexpr int WT_W = 256;
-template <typename T> struct WarpTile { static constexpr int TH = sizeof(T) == 1 ? 32 : 16; };
+#ifndef MI_WARP_TH_U8
+#define MI_WARP_TH_U8 32
+#endif
+#ifndef MI_WARP_LDS_DWORDS
+#define MI_WARP_LDS_DWORDS 10240
+#endif
+template <typename T> struct WarpTile { static constexpr int TH = sizeof(T) == 1 ? MI_WARP_TH_U8 : 16; };
 constexpr int WT_SPLIT = 4;   // workgroups per outer-ring tile (divides the rows per thread: 8 / 4)
-constexpr int WT_LDS_DWORDS = 10240;   // 40 KB: four workgroups per CU
+constexpr int WT_LDS_DWORDS = MI_WARP_LDS_DWORDS;   // 40 KB: four workgroups per CU
 
 template <typename T, bool VEC>
 __global__ __launch_bounds__(256) void warp_affine_tiled(const T* __restrict__ src, T* __restrict__ dst,
