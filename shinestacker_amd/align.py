@@ -21,7 +21,7 @@ import numpy as np
 from . import _lib
 from .actions import SubAction
 from .defaults import constants
-from .errors import AlignmentError, InvalidOptionError
+from .errors import AlignmentError, DeviceError, InvalidOptionError
 from .imageio import get_img_metadata, validate_image
 
 _DEFAULT_FEATURE_CONFIG = {'detector': 'SIFT', 'descriptor': 'SIFT'}
@@ -220,23 +220,31 @@ def ecc_estimator(min_correlation=0.5, max_iters=60, device=0, phase_init=False)
         homography = (alignment_config or {}).get('transform') == constants.ALIGN_HOMOGRAPHY
         if phase_init or homography:
             ref, mov = np.ascontiguousarray(img_1_sub), np.ascontiguousarray(img_0_sub)
-            al = _lib.Aligner(ref.shape[0], ref.shape[1], ref.dtype, subsample=1, device=device, phase_init=phase_init)
-            buf = _lib.DeviceBuffer(2 * ref.nbytes, device)
+            # the same contract as _lib.ecc_similarity: the estimator reads H * W * 3 elements of the handle's dtype from
+            # each half of the buffer
+            if ref.shape != mov.shape or ref.dtype != mov.dtype or ref.ndim != 3 or ref.shape[2] != 3 \
+                    or ref.dtype not in _lib.DTYPE_CODE:
+                raise ValueError("ecc_estimator expects two H x W x 3 images of the same shape and dtype (uint8 / uint16)")
+            al = buf = None
             try:
+                al = _lib.Aligner(ref.shape[0], ref.shape[1], ref.dtype, subsample=1, device=device, phase_init=phase_init)
+                buf = _lib.DeviceBuffer(2 * ref.nbytes, device)
                 buf.upload(ref)
                 buf.upload(mov, ref.nbytes)
                 al.set_reference(buf.ptr)
-                if homography:   # the similarity refined to 8 degrees of freedom (cv2.findHomography's role, align.py:138-140)
-                    ms, ccs, _ = al.estimate_homography_batch([buf.ptr + ref.nbytes], max_iters=max_iters)
-                    m, cc = ms[0], float(ccs[0])
-                else:
-                    try:
+                try:
+                    if homography:   # the similarity refined to 8 degrees of freedom (cv2.findHomography's role, align.py:138-140)
+                        ms, ccs, _ = al.estimate_homography_batch([buf.ptr + ref.nbytes], max_iters=max_iters)
+                        m, cc = ms[0], float(ccs[0])
+                    else:
                         m, cc, _iters = al.estimate(buf.ptr + ref.nbytes, max_iters=max_iters)
-                    except Exception:   # noqa: BLE001  (no overlap / constant image: "no matches")
-                        return 0, None
+                except (DeviceError, ValueError):   # no overlap / constant image, in either motion model: "no matches"
+                    return 0, None
             finally:
-                al.close()
-                buf.free()
+                if al is not None:
+                    al.close()
+                if buf is not None:
+                    buf.free()
         else:
             m, cc, _iters = _lib.ecc_similarity(img_1_sub, img_0_sub, max_iters=max_iters, device=device)
         if not cc >= min_correlation:
