@@ -95,8 +95,14 @@ def _parity_tools():
     return parity_report
 
 
-def _assert_parity(rep, npx3):
-    assert rep["ok"], rep
+def _assert_parity(rep, npx3, base_lsb_max=None):
+    """`base_lsb_max`: None = the report's own verdict (`ok`: fused bases within 0.9 LSB of each other); a number = every
+    other statement of the report individually and that bound on the fused-base difference instead"""
+    if base_lsb_max is None:
+        assert rep["ok"], rep
+    else:
+        assert rep["base"]["fused_base_abs_diff_max_lsb"] < base_lsb_max, rep["base"]
+        assert rep["base"]["gauss_abs_diff_max_lsb"] <= rep["base"]["gauss_bound_lsb"], rep["base"]
     for row in rep["levels"]:
         assert row["energy_diff_over_bound_max"] <= 1.0, row
         if row["level"] >= 1:
@@ -131,6 +137,32 @@ def test_parity_report_on_frames_with_an_exposure_ramp(L, oracle):
           [(r["level"], r["selection_mismatches"]) for r in rep["levels"]])
     hist = _assert_parity(rep, H * W * 3)
     assert hist[1] < 5e-3 and hist[2:].sum() < 1e-4, hist
+
+
+@pytest.mark.parametrize("dtype,n", [(np.uint8, 16), (np.uint16, 12)])
+def test_parity_report_on_a_simulated_focus_stack(L, dtype, n):
+    """... and on a simulated focus stack of a natural-looking scene (tools/parity_report.py::defocus_frames: 1 / f texture,
+    hard edges, a clipped highlight, a nearly black corner, depth-dependent defocus, exposure drift, sensor noise): the
+    frames' energies fall off smoothly around the focal plane, so neighbouring frames ARE close calls at many pixels -- the
+    case where the two arithmetics could pick different frames.  Same gates as above: every flipped arg-max a proven near
+    tie, every final value off by two or more (8-bit-equivalent) counts inside the footprint of a flip.  What this content
+    adds (round 5): its frames' LOW-PASS images are nearly alike, so the base-level rule (pyramid.py:95-111: entropy of
+    the gray image TRUNCATED to integers) flips on 1-2 % of the base pixels between the two arithmetics -- a discontinuity of
+    the reference's own rule, which its float-32 and float-64 modes show against each other as well -- and the fused base
+    images differ by up to 1.4 counts (16-bit frames, in 8-bit-equivalent counts; 8-bit frames: below 0.9): a smooth
+    offset of a few 1e-5 of full scale over the collapse footprint of those pixels, recorded here rather than hidden
+    behind the synthetic generator, whose frames' base images never disagree."""
+    pr = _parity_tools()
+    H, W = 2000, 3000
+    rep = pr.report_host_frames(L, pr.defocus_frames(H, W, n, dtype))
+    print("\n[parity, simulated focus stack]", np.dtype(dtype).name,
+          {k: rep.get(k) for k in ("base", "final_abs_diff_counts_0_1_2_3plus", "final_abs_diff_counts_0_1_2_3plus_lsb8",
+                                   "final_max_abs_diff", "near_tie")},
+          [(r["level"], r["selection_mismatches"]) for r in rep["levels"]])
+    _assert_parity(rep, H * W * 3, base_lsb_max=2.0)
+    hist = np.array(rep.get("final_abs_diff_counts_0_1_2_3plus_lsb8", rep["final_abs_diff_counts_0_1_2_3plus"]), float) / (H * W * 3)
+    assert hist[1] < 5e-3 and hist[2:].sum() < 1e-4, hist   # (16-bit frames: in 8-bit-equivalent counts)
+    assert rep["final_max_abs_diff"] <= 5 * (257 if dtype == np.uint16 else 1), rep["final_max_abs_diff"]
 
 
 def test_config5_two_bunches_50mp_u16_from_host(L, oracle):
