@@ -54,7 +54,10 @@ namespace mi {
 #ifndef MI_SEP_NT_F32
 #define MI_SEP_NT_F32 ((MI_SEP_TH / 2 + 2) * 32)
 #endif
-template <typename TIn> constexpr int sep_nt() { return sizeof(TIn) == 4 ? MI_SEP_NT_F32 : (MI_SEP_TH / 2 + 2) * 32; }
+#ifndef MI_SEP_NT_INT
+#define MI_SEP_NT_INT ((MI_SEP_TH / 2 + 2) * 32)
+#endif
+template <typename TIn> constexpr int sep_nt() { return sizeof(TIn) == 4 ? MI_SEP_NT_F32 : MI_SEP_NT_INT; }
 // non-temporal G_{l+1} stores (written once, read by the next level's launch much later)
 #ifndef MI_SEP_NT_STORE
 #define MI_SEP_NT_STORE 1
