@@ -613,3 +613,49 @@ def test_auto_batch_frames_is_bounded_by_the_job_and_by_memory(L):
     assert auto_batch_frames(1000, 4000, 6000, np.uint8, share=tight) == 32
     assert auto_batch_frames(1000, 4000, 6000, np.uint8, share=1e-9) == 16
 
+
+
+def test_chain_refinement_on_a_simulated_focus_stack(L):
+    """The refinement's datum is the GLOBAL reference frame, which in a focus stack looks different from a far frame
+    (tools/parity_report.py::defocus_frames: every frame blurred by its distance from the focal plane).  With a known
+    similarity per frame (rotation, focus-breathing scale, shift) the refined chain must stay inside the 0.2 px of
+    tests/test_0031_align_precision.py:62-65 at every corner, and must not be worse than the plain chain."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import parity_report as pr
+    from shinestacker_amd.pipeline import align_and_stack_device
+    n, h, w = 12, 1000, 1500
+    frames = pr.defocus_frames(h, w, n, np.uint8)
+    ref = n // 2
+    cx, cy = (w - 1) / 2, (h - 1) / 2
+    truth, moved = [], []
+    for f in range(n):
+        d = f - ref
+        T = similarity(0.03 * d, 1 + 4e-4 * d, 0.8 * d, -0.5 * d, cx, cy)
+        truth.append(np.array(T))
+        moved.append(frames[f] if d == 0 else L.warp_affine(frames[f], np.array(T), border_mode=L.BORDER_REPLICATE))
+    fb = moved[0].nbytes
+    buf = L.DeviceBuffer(n * fb)
+    for f, fr in enumerate(moved):
+        buf.upload(fr, f * fb)
+    corners = np.array([[0, 0, 1.0], [w - 1, 0, 1], [0, h - 1, 1], [w - 1, h - 1, 1]]).T
+
+    def worst(tr):
+        out = 0.0
+        for f in range(n):
+            if f == ref:
+                continue
+            Ai = np.linalg.inv(truth[f][:, :2])
+            want = np.hstack([Ai, -Ai @ truth[f][:, 2:3]])
+            out = max(out, float(np.abs(np.asarray(tr[f])[:2] @ corners - want @ corners).max()))
+        return out
+    err = {}
+    for refine in (False, True):
+        _, tr, ccs = align_and_stack_device(buf.ptr, n, h, w, np.uint8, ref_idx=ref, alignment_config={'subsample': 1},
+                                            step_process=True, chain_refine=refine)
+        assert min(ccs) > 0.9
+        err[refine] = worst(tr)
+    print("\n[chain on a simulated focus stack] worst corner error, plain / refined:", err[False], err[True])
+    buf.free()
+    assert err[True] < 0.2 and err[True] <= err[False] + 0.02, err
