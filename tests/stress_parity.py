@@ -27,7 +27,9 @@ def main():
         dt = [np.uint8, np.uint16][int(rng.integers(0, 2))]
         n = int(rng.integers(1, 9))
         kw = {"min_size": int(rng.choice([8, 16, 32])), "use_fma": bool(rng.integers(0, 2)),
-              "kernel_size": int(rng.choice([3, 5, 7]))}
+              "kernel_size": int(rng.choice([3, 5, 7])),
+              # generating kernels with integer reduce taps (0.4, 0.3, 0.5: 20 k integral) and without (separable spec v2)
+              "gen_kernel": float(rng.choice([0.4, 0.4, 0.3, 0.5, 0.35, 0.375]))}
         batch = int(rng.integers(0, 5))
         frames = make_frames(rng, (h, w), dt, n)
         arith = ["exact", "separable"][case % 2]
