@@ -615,7 +615,8 @@ int blur_launch(int device, hipStream_t st, void* side, void* out, uint8_t* vali
         hipLaunchKernelGGL(mask_scan_tiles, dim3((unsigned)std::min<size_t>(2048, (npx / 16 + 256) / 256)), dim3(256), 0, st,
                            (const uint8_t*)valid, h, w, tiles_x, bitmap);
     }
-    hipLaunchKernelGGL(tile_bitmap_to_list, dim3(1), dim3(1024), 0, st, (const uint32_t*)bitmap, (tiles_x * tiles_y + 31) / 32, cnt, list);
+    if (!tiles_marked)   // (the affine warp kernel lists the tiles it marks)
+        hipLaunchKernelGGL(tile_bitmap_to_list, dim3(1), dim3(1024), 0, st, (const uint32_t*)bitmap, (tiles_x * tiles_y + 31) / 32, cnt, list);
     hipLaunchKernelGGL(kb, dim3(1024), dim3(256), lds_blur, st, (const T*)out, (const uint8_t*)valid, (T*)side, h, w, tiles_x, g,
                        (const uint32_t*)cnt, (const uint32_t*)list);
     hipLaunchKernelGGL((border_blur_scatter<T>), dim3(1024), dim3(256), 0, st, (T*)out, (const uint8_t*)valid, (const T*)side,
@@ -632,11 +633,10 @@ int warp_launch(int device, hipStream_t st, const void* src, void* side, void* o
         const dim3 blk(64, 4), grid(cdiv(w, 64), cdiv(h, 4));
         hipLaunchKernelGGL((warp_perspective_kernel<T>), grid, blk, 0, st, (const T*)src, (T*)out, valid, a, *persp);
     } else {
-        uint32_t *bitmap = nullptr, *cnt = nullptr;
+        uint32_t *bitmap = nullptr, *cnt = nullptr, *list = nullptr;
         size_t clear = 0;
         const int blur_tiles_x = cdiv(w, BT_W);
-        if (blur) {   // the kernel marks the blur tiles that hold masked pixels (the scratch is zeroed by warp_coord_tables)
-            uint32_t* list = nullptr;
+        if (blur) {   // the kernel marks and lists the blur tiles that hold masked pixels (the scratch is zeroed by warp_coord_tables)
             int rc = warp_scratch(device, st, (size_t)blur_tiles_x * cdiv(h, BT_H), &cnt, &bitmap, &list, &clear);
             if (rc) return rc;
             tiles_marked = true;
@@ -661,8 +661,8 @@ int warp_launch(int device, hipStream_t st, const void* src, void* side, void* o
             MI_HIP(hipFuncSetAttribute((const void*)ks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             attr_set = true;
         }
-        if (vec) hipLaunchKernelGGL(kv, grid, dim3(256), lds, st, (const T*)src, (T*)out, valid, a, bitmap, blur_tiles_x, (const int*)tab, gx, gy);
-        else hipLaunchKernelGGL(ks, grid, dim3(256), lds, st, (const T*)src, (T*)out, valid, a, bitmap, blur_tiles_x, (const int*)tab, gx, gy);
+        if (vec) hipLaunchKernelGGL(kv, grid, dim3(256), lds, st, (const T*)src, (T*)out, valid, a, bitmap, list, blur_tiles_x, (const int*)tab, gx, gy);
+        else hipLaunchKernelGGL(ks, grid, dim3(256), lds, st, (const T*)src, (T*)out, valid, a, bitmap, list, blur_tiles_x, (const int*)tab, gx, gy);
     }
     MI_HIP(hipGetLastError());
     // the warped image went straight to `out`; the few pixels outside the source frame are blurred from it into `side`

@@ -227,7 +227,8 @@ constexpr int WT_LDS_DWORDS = MI_WARP_LDS_DWORDS;   // 40 KB: four workgroups pe
 template <typename T, bool VEC>
 __global__ __launch_bounds__(256) void warp_affine_tiled(const T* __restrict__ src, T* __restrict__ dst,
                                                          uint8_t* __restrict__ valid, AffineArgs a,
-                                                         uint32_t* __restrict__ tile_bitmap, int blur_tiles_x,
+                                                         uint32_t* __restrict__ tile_bitmap, uint32_t* __restrict__ tile_list,
+                                                         int blur_tiles_x,
                                                          const int* __restrict__ tab, int gx, int gy) {
     extern __shared__ uint32_t s_src[];
     constexpr int BPP = 3 * (int)sizeof(T), TH = WarpTile<T>::TH, RPT = TH / 4;   // rows per thread
@@ -487,7 +488,10 @@ __global__ __launch_bounds__(256) void warp_affine_tiled(const T* __restrict__ s
         const unsigned long long b = __ballot(bad);
         if ((lane & 15) == 0 && ((b >> (lane & 48)) & 0xffffull) != 0) {
             const int bit = (y_t / 32) * blur_tiles_x + (xq >> 6);
-            atomicOr(&tile_bitmap[bit >> 5], 1u << (bit & 31));
+            // the first marker of a tile also appends it to the blur pass's list (count = the dword 16 in front of the bitmap:
+            // warp_scratch's layout; the list's order does not matter) -- round 5: tile_bitmap_to_list was a launch of its own
+            const uint32_t old = atomicOr(&tile_bitmap[bit >> 5], 1u << (bit & 31));
+            if (!((old >> (bit & 31)) & 1u)) tile_list[atomicAdd(tile_bitmap - 16, 1u)] = (uint32_t)bit;
         }
     }
 }
