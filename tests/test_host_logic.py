@@ -393,3 +393,19 @@ def test_mirrors_present_the_reference_api_surface():
                 assert v.default is not inspect.Parameter.empty, (name, k)
         for m in ref.get("protocol") or []:
             assert callable(getattr(mine[name], m, None)), (name, m)
+
+
+def test_chain_refinement_guard_measures_the_displacement_at_the_corners():
+    """pipeline._corner_shift: the largest displacement between two 2 x 3 transforms at the four frame corners -- what decides
+    whether a refinement against the global reference frame is trusted (CHAIN_REFINE_MAX_SHIFT); the chained entry point
+    refines by default."""
+    import inspect
+    from shinestacker_amd import pipeline
+    h, w = 400, 600
+    eye = np.array([[1.0, 0, 0], [0, 1.0, 0]])
+    assert pipeline._corner_shift(eye, eye, h, w) == 0.0
+    assert pipeline._corner_shift(eye, eye + np.array([[0, 0, 1.5], [0, 0, -0.25]]), h, w) == 1.5
+    rot = np.array([[1.0, -1e-3, 0], [1e-3, 1.0, 0]])          # a rotation about the origin moves the far corner most
+    assert abs(pipeline._corner_shift(eye, rot, h, w) - 1e-3 * (w - 1)) < 1e-9
+    assert pipeline.CHAIN_REFINE_MAX_SHIFT == 2.0
+    assert inspect.signature(pipeline.align_and_stack_device).parameters["chain_refine"].default is True
