@@ -36,7 +36,7 @@ class StackParams(C.Structure):
                 ("out_dtype", C.c_int32), ("min_size", C.c_int32), ("kernel_size", C.c_int32),
                 ("gen_kernel", C.c_double), ("float_type", C.c_int32), ("use_fma", C.c_int32),
                 ("device", C.c_int32), ("impl", C.c_int32), ("batch_frames", C.c_int32),
-                ("arith", C.c_int32), ("reserved", C.c_int32 * 4)]
+                ("arith", C.c_int32), ("pair_levels", C.c_int32), ("reserved", C.c_int32 * 3)]
 
 
 class AlignStackOpts(C.Structure):
@@ -383,7 +383,7 @@ class Stack:
 
     def __init__(self, height, width, in_dtype=np.uint8, out_dtype=None, min_size=32,
                  kernel_size=5, gen_kernel=0.4, use_fma=True, device=0, impl=IMPL_AUTO,
-                 batch_frames=0, float_type=MI_F32, arith=ARITH_EXACT):
+                 batch_frames=0, float_type=MI_F32, arith=ARITH_EXACT, pair_levels=None):
         lib = load()
         require_device()
         p = StackParams()
@@ -399,6 +399,11 @@ class Stack:
         if arith not in ARITH_CODE:
             raise InvalidOptionError("arith", arith, "valid values are 'exact' and 'separable'")
         p.arith = ARITH_CODE[arith]
+        if pair_levels is None:   # (test runs: SHINESTACKER_AMD_PAIR_LEVELS=1 sends every separable stack down the pair kernels)
+            pair_levels = int(os.environ.get("SHINESTACKER_AMD_PAIR_LEVELS", "0"))
+        if pair_levels not in (0, 1, 2):
+            raise InvalidOptionError("pair_levels", pair_levels, "0 = automatic, 1 = always, 2 = never")
+        p.pair_levels = int(pair_levels)
         self.arith = p.arith
         self.params = p
         self.in_dtype, self.out_dtype = in_dtype, out_dtype

@@ -387,38 +387,11 @@ template <> struct PreChunk<uint16_t> {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 
-template <typename TIn, bool INTERIOR, int TH, int NT, bool MF_ = false>
-__device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
-    using G = SepGeom<TH, NT>;
-    constexpr int TW = G::TW;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr bool RAW = INTERIOR && sizeof(TIn) <= 2;   // staged patch kept in the input type (see SepGeom::lds_floats)
-    constexpr bool DMA = MI_SEP_DMA && INTERIOR && sizeof(TIn) == 4;   // patch staged by LDS-DMA (see MI_SEP_DMA)
-    constexpr int RD = (int)sizeof(TIn);                 // dwords per 4-element chunk in that form
-    // MF: the reduce of 8 / 16-bit frames on the matrix pipe.  P1 + P2 become one phase: wave v computes the G_{l+1} patch
-    // rows 2v, 2v + 1 (16 rows = 8 waves) with five v_mfma_i32_16x16x64_i8 per byte plane -- one per tap row -- whose DATA
-    // operand (B, 64 x 16) is read straight from the staged bytes: column n = a 64-byte window of a patch row, 24 bytes (four
-    // output pixels) further along the row per window, 8 windows per row, two rows; and whose WEIGHT operand (A, 16 x 64)
-    // holds kv[t] * kh[tau] at byte 6 p + 3 tau + c of the window in row 4 p + c (output pixel p of the window, channel c;
-    // row 4 p + 3 is empty).  The result layout then hands lane 16 p + n the three channel sums of ONE G_{l+1} pixel.  The
-    // staged bytes carry x ^ 0x80 (= x - 128 as the signed byte the instruction takes) and the accumulator starts at
-    // 128 * 400.  16-bit frames: the same on the plane of low bytes and on the plane of high bytes, S = 256 S_hi + S_lo.
-    // S is the exact integer sum and G_{l+1} = float(S) * rs: bit-identical to the float evaluation of red_taps' integer
-    // taps (header; float(S) rounds once, to nearest even, exactly where the float chain's last fma does).
-    static_assert(!MF_ || (INTERIOR && sizeof(TIn) <= 2 && G::NH % 2 == 0 && NT % 64 == 0), "MF geometry");
-    constexpr bool MF = MF_;
-    constexpr int NPL = MF ? (int)sizeof(TIn) : 0;    // byte planes
-    float* sG = smem;
-    uint32_t* sGr = reinterpret_cast<uint32_t*>(smem);
-    float* sV = smem + (MF ? 0 : G::lds_floats((int)sizeof(TIn), INTERIOR) - G::NH * G::VS - G::NH * G::XS);
-    float* sX = MF ? smem + NPL * G::MF_PLANE : sV + G::NH * G::VS;
-    float* sHB = MF ? sX + G::NH * G::XS : sV;         // (not MF: V is dead once P2 has read it)
-    uint32_t* sW = reinterpret_cast<uint32_t*>(sHB + G::HBH * G::HBS);   // MF: weight operands, [3][64] x 16 bytes
-    const int tid = threadIdx.x;
-    const int h = a.h, w = a.w, hn = a.hn, wn = a.wn;
-
-    // ---- which tile?  (interior: 8x8-tile super-blocks, one per XCD at a time -- see kernels_tiled.hpp)
-    int y0, x0;
+// Which tile does this workgroup own?  (interior: 8x8-tile super-blocks, one per XCD at a time -- see kernels_tiled.hpp;
+// border: every tile of the TH x TW grid outside the interior rectangle.)  false: none.
+template <bool INTERIOR, int TH, int TW>
+__device__ __forceinline__ bool sep_tile_origin(const LevelArgs& a, int& y0, int& x0) {
+    const int h = a.h, w = a.w;
     if constexpr (INTERIOR) {
         const int nty = (a.iy1 - a.iy0) / TH, ntx = (a.ix1 - a.ix0) / TW;
         const int sb_x = (ntx + SEP_SBW - 1) / SEP_SBW;
@@ -430,14 +403,14 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
         const int within = slot % SBN;
         if (a.sb_order) {
             S = a.sb_order[S];
-            if (S == 0xFFFF) return;
+            if (S == 0xFFFF) return false;
         }
         const int sby = S / sb_x, sbx = S - sby * sb_x;
         const int tyi = sby * SEP_SBH + within / SEP_SBW, txi = sbx * SEP_SBW + within % SEP_SBW;
-        if (tyi >= nty || txi >= ntx) return;
+        if (tyi >= nty || txi >= ntx) return false;
         y0 = a.iy0 + tyi * TH;
         x0 = a.ix0 + txi * TW;
-        if (y0 >= h || x0 >= w) return;
+        if (y0 >= h || x0 >= w) return false;
     } else {
         // every tile of the TH x TW grid that is not inside the interior rectangle: rows above and below it,
         // then the side columns of the rows it spans
@@ -460,10 +433,62 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
             const int k = t - (t / side) * side;
             txi = k < tx_lo ? k : tx_hi + (k - tx_lo);
         }
-        if (tyi >= tiles_y || txi >= tiles_x) return;
+        if (tyi >= tiles_y || txi >= tiles_x) return false;
         y0 = tyi * TH;
         x0 = txi * TW;
     }
+
+    return true;
+}
+
+
+template <typename TIn, bool INTERIOR, int TH, int NT, bool MF_ = false, bool PAIR_ = false>
+__device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
+    using G = SepGeom<TH, NT>;
+    constexpr int TW = G::TW;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr bool RAW = INTERIOR && sizeof(TIn) <= 2;   // staged patch kept in the input type (see SepGeom::lds_floats)
+    constexpr bool DMA = MI_SEP_DMA && INTERIOR && sizeof(TIn) == 4;   // patch staged by LDS-DMA (see MI_SEP_DMA)
+    // PAIR (round 6): levels l and l + 1 as a pair.  The 18 x 32 patch of G_{l+1} this tile computes anyway is exactly the
+    // support of the tile's 7 x 14 pixels of G_{l+2} (rows 2m - 2 .. 2m + 2 of the patch's 17 leading rows), and the energy
+    // path of level l + 1 needs gray(G_{l+1}) only: the kernel keeps the three-channel patch in LDS (planar, sN -- where the
+    // staged G_l patch was: the lane's quad takes its gray of G_l in P1, so that patch is dead after P1), reduces it to
+    // G_{l+2} (V2 beside P3, H2 + the store beside P4; REFLECT101 on G_{l+1} through explicit index maps: a patch's
+    // natural twins beyond an even far edge are those of the zero-stuffed expand grid, not of the reduce) and writes
+    // gray(G_{l+1}) -- 4 bytes per pixel instead of 12 -- for level_sep_e.  G_{l+1} itself never reaches HBM (one frame per
+    // launch excepted: LevelArgs::g1_keep, the debug tap); the payload passes recompute the winners' (sep_payload_pair).
+    constexpr bool PAIR = PAIR_;
+    static_assert(!PAIR || (!MF_ && !DMA && TH % 4 == 0 && G::NH * G::NW * 3 <= G::GH * (G::GD / 4)), "PAIR geometry");
+    constexpr int N2H = TH / 4, N2W = TW / 4, NPL1 = G::NH * G::NW;   // G_{l+2} pixels of the tile; floats per plane of sN
+    constexpr bool GQ1 = DMA || (PAIR && INTERIOR);   // gray of the lane's quad of G_l taken in P1 (registers)
+    constexpr int RD = (int)sizeof(TIn);                 // dwords per 4-element chunk in that form
+    // MF: the reduce of 8 / 16-bit frames on the matrix pipe.  P1 + P2 become one phase: wave v computes the G_{l+1} patch
+    // rows 2v, 2v + 1 (16 rows = 8 waves) with five v_mfma_i32_16x16x64_i8 per byte plane -- one per tap row -- whose DATA
+    // operand (B, 64 x 16) is read straight from the staged bytes: column n = a 64-byte window of a patch row, 24 bytes (four
+    // output pixels) further along the row per window, 8 windows per row, two rows; and whose WEIGHT operand (A, 16 x 64)
+    // holds kv[t] * kh[tau] at byte 6 p + 3 tau + c of the window in row 4 p + c (output pixel p of the window, channel c;
+    // row 4 p + 3 is empty).  The result layout then hands lane 16 p + n the three channel sums of ONE G_{l+1} pixel.  The
+    // staged bytes carry x ^ 0x80 (= x - 128 as the signed byte the instruction takes) and the accumulator starts at
+    // 128 * 400.  16-bit frames: the same on the plane of low bytes and on the plane of high bytes, S = 256 S_hi + S_lo.
+    // S is the exact integer sum and G_{l+1} = float(S) * rs: bit-identical to the float evaluation of red_taps' integer
+    // taps (header; float(S) rounds once, to nearest even, exactly where the float chain's last fma does).
+    static_assert(!MF_ || (INTERIOR && sizeof(TIn) <= 2 && G::NH % 2 == 0 && NT % 64 == 0), "MF geometry");
+    constexpr bool MF = MF_;
+    constexpr int NPL = MF ? (int)sizeof(TIn) : 0;    // byte planes
+    float* sG = smem;
+    uint32_t* sGr = reinterpret_cast<uint32_t*>(smem);
+    float* sV = smem + (MF ? 0 : G::lds_floats((int)sizeof(TIn), INTERIOR) - G::NH * G::VS - G::NH * G::XS);
+    float* sX = MF ? smem + NPL * G::MF_PLANE : sV + G::NH * G::VS;
+    float* sHB = MF ? sX + G::NH * G::XS : sV;         // (not MF: V is dead once P2 has read it)
+    uint32_t* sW = reinterpret_cast<uint32_t*>(sHB + G::HBH * G::HBS);   // MF: weight operands, [3][64] x 16 bytes
+    float* sN = INTERIOR ? smem : smem + G::LDS_FLOATS;   // PAIR: G_{l+1} patch, [3][NH][NW] (border tiles: their own array)
+    float* sV2 = sV + G::HBH * G::HBS;                   // PAIR: column sums of the G_{l+2} reduce, [3][N2H][NW] (V's tail)
+    static_assert(!PAIR || G::HBH * G::HBS + 3 * N2H * G::NW <= G::NH * G::VS, "V2 fits behind HB");
+    const int tid = threadIdx.x;
+    const int h = a.h, w = a.w, hn = a.hn, wn = a.wn;
+
+    int y0, x0;
+    if (!sep_tile_origin<INTERIOR, TH, TW>(a, y0, x0)) return;
 
     const float k0 = a.k1d[0], k1 = a.k1d[1], k2 = a.k1d[2];
     const float w0 = a.rk[0], w1 = a.rk[1], w2 = a.rk[2], rs = a.rk[3];   // reduce taps and final scale (red_taps)
@@ -497,7 +522,9 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
     float* const st_e = ck ? a.part_e + (size_t)(ck - 1) * a.part_stride : a.best_e;
     int32_t* const st_i = ck ? a.part_idx + (size_t)(ck - 1) * a.part_stride : a.best_idx;
     const char* const src0 = (const char*)a.src + (size_t)f_lo * a.src_stride;
-    float* const gnext0 = a.gnext + (size_t)f_lo * a.gnext_stride;
+    float* const gnext0 = PAIR ? a.gnext : a.gnext + (size_t)f_lo * a.gnext_stride;   // (PAIR: one image, see g1_keep)
+    float* const gray1_0 = PAIR ? a.gray1 + (size_t)f_lo * a.gray1_stride : nullptr;
+    float* const g2_0 = PAIR ? a.g2 + (size_t)f_lo * a.g2_stride : nullptr;
 
     // ---- the lane's quad: rows y0-2+2qy+{0,1}, columns x0-4+2ql+{0,1}; owned = inside the tile.  Running state of
     // the quad = (max energy, its frame); the winner's Laplacian is filled in after the batch (sep_payload).
@@ -738,7 +765,10 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
                                                                  touch_off, 0, 0);
         }
         MI_TICK(2);   // prefetch issue
-        const BufRsrc gn_rs = make_rsrc(gnext0 + (size_t)b * a.gnext_stride, (uint32_t)hn * (uint32_t)wn * 12u);
+        const BufRsrc gn_rs = make_rsrc(PAIR ? gnext0 : gnext0 + (size_t)b * a.gnext_stride, (uint32_t)hn * (uint32_t)wn * 12u);
+        const BufRsrc gy_rs = make_rsrc(PAIR ? gray1_0 + (size_t)b * a.gray1_stride : nullptr, (uint32_t)hn * (uint32_t)wn * 4u);
+        const BufRsrc g2_rs = make_rsrc(PAIR ? g2_0 + (size_t)b * a.g2_stride : nullptr, (uint32_t)a.hn2 * (uint32_t)a.wn2 * 12u);
+        const bool keep3 = PAIR && f_lo + b == a.g1_keep;   // this frame's three-channel G_{l+1} goes to `gnext` (the tap)
 
         if constexpr (!MF) {
         // ---------------- P1: vertical reduce, P1R V rows x one float4 column group per lane
@@ -808,18 +838,26 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
             lds_store4(d, a0.x, a0.y, a1.x, a1.y);
             lds_store4(d + G::VS, b0.x, b0.y, b1.x, b1.y);
         }
-        if constexpr (DMA) {
+        if constexpr (GQ1) {
             // gray of the lane's quad of G_l (what P3 subtracts the expanded gray from): the last read of the staged patch
             if (lt < G::QY * G::QL) {
-                const float* gp = sG + mul24(2 * (lt >> 5) + 4, G::GS) + 6 * (lt & 31) + 6;
                 v2f ge[3], go[3];
+                if constexpr (RAW) {
+                    const uint32_t* rowp = sGr + mul24(2 * (lt >> 5) + 4, RD * CPR);
+                    PreChunk<TIn>::unpack6(rowp, 6 * (lt & 31) + 6, ge);
+                    PreChunk<TIn>::unpack6(rowp + RD * CPR, 6 * (lt & 31) + 6, go);
+                    gq_e = gray_of2(ge[0], ge[1], ge[2]);
+                    gq_o = gray_of2(go[0], go[1], go[2]);
+                } else {
+                    const float* gp = sG + mul24(2 * (lt >> 5) + 4, G::GS) + 6 * (lt & 31) + 6;
 #pragma unroll
-                for (int t = 0; t < 3; ++t) {
-                    ge[t] = lds_load2s(gp + 2 * t);
-                    go[t] = lds_load2s(gp + G::GS + 2 * t);
+                    for (int t = 0; t < 3; ++t) {
+                        ge[t] = lds_load2s(gp + 2 * t);
+                        go[t] = lds_load2s(gp + G::GS + 2 * t);
+                    }
+                    gq_e = v2f{gray_of<true>(ge[0].x, ge[0].y, ge[1].x), gray_of<true>(ge[1].y, ge[2].x, ge[2].y)};
+                    gq_o = v2f{gray_of<true>(go[0].x, go[0].y, go[1].x), gray_of<true>(go[1].y, go[2].x, go[2].y)};
                 }
-                gq_e = v2f{gray_of<true>(ge[0].x, ge[0].y, ge[1].x), gray_of<true>(ge[1].y, ge[2].x, ge[2].y)};
-                gq_o = v2f{gray_of<true>(go[0].x, go[0].y, go[1].x), gray_of<true>(go[1].y, go[2].x, go[2].y)};
             }
         }
         if (!DMA && MI_SEP_PF_SPLIT == 1 && b + 1 < nfr && !MI_ABL(16)) prefetch(b + 1, PF_A, NPRE);
@@ -915,11 +953,21 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
 #pragma unroll
                 for (int c = 0; c < 3; ++c) n[c] = s5r(t5[0][c], t5[1][c], t5[2][c], t5[3][c], t5[4][c], w0, w1, w2) * rs;
             }
-            // tile centre of G_{l+1} -> global (input of the next level)
+            // gray of the pixel, its neighbours along the row by DPP, expanded columns 2j' (even) and 2j'+1 (odd)
+            const float g = gray_of<true>(n[0], n[1], n[2]);
+            // tile centre of G_{l+1} -> global (input of the next level; PAIR: its gray, and the pixel into the LDS patch)
             {
                 const int i = y0 / 2 - 2 + r, j = x0 / 2 - 2 + jp;
                 bool st = r >= 2 && r < G::NH - 2 && jp >= 2 && jp < G::NW - 2 && !MI_ABL(32);
                 st = st && i < hn && j < wn;   // edge / border tiles overhang the image
+                if constexpr (PAIR) {
+                    float* np = sN + it;       // planar [3][NH][NW]: item `it` = pixel (r, jp)
+                    np[0] = n[0]; np[NPL1] = n[1]; np[2 * NPL1] = n[2];
+                    if (st)
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, g), gy_rs,
+                                                              (uint32_t)(mul24(i, wn) + j) << 2, 0, MI_SEP_NT_STORE ? 2 : 0);
+                    st = st && keep3;
+                }
                 if (st) {
                     typedef uint32_t v3u __attribute__((ext_vector_type(3)));
                     const v3u pv = {__builtin_bit_cast(uint32_t, n[0]), __builtin_bit_cast(uint32_t, n[1]),
@@ -929,8 +977,6 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
                     __builtin_amdgcn_raw_buffer_store_b96(pv, gn_rs, times12((uint32_t)(mul24(i, wn) + j)), 0, MI_SEP_NT_STORE ? 2 : 0);
                 }
             }
-            // gray of the pixel, its neighbours along the row by DPP, expanded columns 2j' (even) and 2j'+1 (odd)
-            const float g = gray_of<true>(n[0], n[1], n[2]);
             const float gl = dpp_wave_prev(g), gr = dpp_wave_next(g);
             lds_store2(sX + mul24(r, G::XS) + 2 * jp, ex_even(gl, g, gr, ce, cc), ex_odd(g, gr, co));
         }
@@ -949,7 +995,7 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
                 const v2f xa = lds_load2s(xr), xb = lds_load2s(xr + G::XS), xc = lds_load2s(xr + 2 * G::XS);
                 const v2f ev = ex_even(xa, xb, xc, ce, cc), od = ex_odd(xb, xc, co);
                 v2f gge, ggo;   // gray of patch rows 2qy+4, +5; columns 2ql+2, +3
-                if constexpr (DMA) {
+                if constexpr (GQ1) {
                     gge = gq_e;
                     ggo = gq_o;
                 } else if constexpr (MF) {
@@ -1008,6 +1054,26 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
                 lds_store2(sHB + mul24(2 * qy3 + rr, G::HBS) + 2 * ql3, hb0, hb1);
             }
         }
+        if constexpr (PAIR) {
+            // V2: column sums of the G_{l+2} reduce, one float4 of a patch row per lane (3 channels x N2H rows x NW / 4 groups),
+            // on the last waves (wave 0 carries P2's second round); G_{l+1} rows through REFLECT101
+            constexpr int V2N = 3 * N2H * (G::NW / 4), V2L0 = (NT - V2N) & ~63;
+            static_assert(V2N <= NT, "V2 items");
+            if (lt >= V2L0 && lt < V2L0 + V2N) {
+                const int item = lt - V2L0, c = item / (N2H * (G::NW / 4)), rem = item - c * (N2H * (G::NW / 4));
+                const int m = rem / (G::NW / 4), ch = rem - m * (G::NW / 4);
+                const int mg = y0 / 4 + m, pr0 = y0 / 2 - 2;
+                v4f rr[5];
+#pragma unroll
+                for (int t = 0; t < 5; ++t) {
+                    const int pr = clampi(r101(2 * mg - 2 + t, hn) - pr0, 0, G::NH - 1);   // (rows of G_{l+2} outside the image: anything)
+                    rr[t] = lds_load4(sN + c * NPL1 + mul24(pr, G::NW) + 4 * ch);
+                }
+                const v2f lo = s5r(rr[0].xy, rr[1].xy, rr[2].xy, rr[3].xy, rr[4].xy, w0, w1, w2);
+                const v2f hi = s5r(rr[0].zw, rr[1].zw, rr[2].zw, rr[3].zw, rr[4].zw, w0, w1, w2);
+                lds_store4(sV2 + (c * N2H + m) * G::NW + 4 * ch, lo.x, lo.y, hi.x, hi.y);
+            }
+        }
         if (!DMA && MI_SEP_PF_SPLIT == 2 && b + 1 < nfr && !MI_ABL(16)) prefetch(b + 1, 3, NPRE);
         MI_TICK(7);   // P3
         __syncthreads();
@@ -1029,6 +1095,32 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
                 const bool win = e[p] > bE[p];
                 bE[p] = win ? e[p] : bE[p];
                 bI[p] = win ? fidx : bI[p];
+            }
+        }
+        if constexpr (PAIR) {
+            // H2: the tile's N2H x N2W pixels of G_{l+2}, one per lane on the first and the last wave (their quad rows are
+            // halo: half idle in P4); G_{l+1} columns through REFLECT101
+            constexpr int H2N = N2H * N2W, H2W = (H2N + 1) / 2;
+            static_assert(H2W <= 64, "H2 items");
+            const int wv = lt >> 6, wl = lt & 63;
+            if ((wv == 0 || wv == NT / 64 - 1) && wl < H2W && (wv == 0 ? wl : H2W + wl) < H2N) {
+                const int item = wv == 0 ? wl : H2W + wl, m = item / N2W, k = item - m * N2W;
+                const int mg = y0 / 4 + m, ng = x0 / 4 + k, pc0 = x0 / 2 - 2;
+                if (mg < a.hn2 && ng < a.wn2) {
+                    int pc[5];
+#pragma unroll
+                    for (int t = 0; t < 5; ++t) pc[t] = clampi(r101(2 * ng - 2 + t, wn) - pc0, 0, G::NW - 1);
+                    float o[3];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const float* vr = sV2 + (c * N2H + m) * G::NW;
+                        o[c] = s5r(vr[pc[0]], vr[pc[1]], vr[pc[2]], vr[pc[3]], vr[pc[4]], w0, w1, w2) * rs;
+                    }
+                    typedef uint32_t v3u __attribute__((ext_vector_type(3)));
+                    const v3u pv = {__builtin_bit_cast(uint32_t, o[0]), __builtin_bit_cast(uint32_t, o[1]),
+                                    __builtin_bit_cast(uint32_t, o[2])};
+                    __builtin_amdgcn_raw_buffer_store_b96(pv, g2_rs, times12((uint32_t)(mul24(mg, a.wn2) + ng)), 0, MI_SEP_NT_STORE ? 2 : 0);
+                }
             }
         }
         MI_TICK(9);   // P4
@@ -1079,6 +1171,198 @@ template <typename TIn, bool INTERIOR, int TH, int NT>
 __global__ __launch_bounds__(NT, INTERIOR && NT > 512 ? 7 : 1) void level_sep_coarse(LevelArgs a) {
     level_sep_body<TIn, INTERIOR, TH, NT>(a);
 }
+
+// level pairs (level_sep_body, "PAIR"): the first level of a pair
+template <typename TIn, bool INTERIOR, int TH, int NT>
+__global__ __launch_bounds__(NT, INTERIOR ? (sizeof(TIn) <= 2 ? MI_SEP_INT_WAVES : 1) : MI_SEP_BD_WAVES) void level_sep_pair(LevelArgs a) {
+    level_sep_body<TIn, INTERIOR, TH, NT, false, true>(a);
+}
+
+// ================================================================================================
+// level_sep_e -- the second level of a pair: ENERGY + running first-max only.  Its Gaussian image never exists in HBM: the
+// first level's kernel left gray(G_l) (LevelArgs::src here: h x w floats per frame) and G_{l+1} (LevelArgs::gnext, READ here),
+// and that is all the energy path needs (gray is linear: Q = (gray(G_l) - expand(gray(G_{l+1})))^2, kernels_sep.hpp header).
+// Same tile, lane roles and arithmetic as level_sep's P2 (from the gray on) .. P4, so the running state is bit-identical to
+// what level_sep computes from the three-channel images; per frame 4 bytes per pixel are read instead of 12, nothing is
+// written, two barriers instead of four:
+//   P0  stage the gray patch (tile + 2 rows / + 4 columns of halo: 32 x 64 floats, one 16-byte chunk per lane, prefetched one
+//       frame ahead) and, one G_{l+1} pixel per lane (18 x 32, a 12-byte load, expand-source index map), the horizontally
+//       expanded gray X
+//   P3, P4  as level_sep
+// Edge tiles: the INTERIOR instantiation stages the patch through REFLECT101 (element by element) and runs the interior code
+// -- twins as in level_sep, same condition (even far edge; the host draws the same line); the general instantiation maps
+// every pixel.
+template <bool INTERIOR, int TH, int NT>
+__device__ __forceinline__ void level_sep_e_body(const LevelArgs& a) {
+    using G = SepGeom<TH, NT>;
+    constexpr int TW = G::TW;
+    constexpr int YH = TH + 4, YW = G::XW;   // gray patch: rows y0-2 .. y0+TH+1, columns x0-4 .. x0+TW+7 (X's and HB's columns)
+    static_assert(YH * (YW / 4) <= NT && G::NH * 32 <= 2 * NT, "one chunk of the gray patch and at most two G_{l+1} pixels per lane");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sY = smem;
+    float* sX = sY + YH * YW;
+    float* sHB = sX + G::NH * G::XS;
+    const int tid = threadIdx.x;
+    const int h = a.h, w = a.w, hn = a.hn, wn = a.wn;
+    int y0, x0;
+    if (!sep_tile_origin<INTERIOR, TH, TW>(a, y0, x0)) return;
+    const float k0 = a.k1d[0], k1 = a.k1d[1], k2 = a.k1d[2];
+    const float ce = 2.0f * k0, cc = 2.0f * k2, co = 2.0f * k1;
+
+    const int ck = blockIdx.y, f_lo = ck * a.chunk_frames;
+    const int nfr = min(a.nframes - f_lo, a.chunk_frames);
+    const bool fresh = ck > 0 || a.first;
+    float* const st_e = ck ? a.part_e + (size_t)(ck - 1) * a.part_stride : a.best_e;
+    int32_t* const st_i = ck ? a.part_idx + (size_t)(ck - 1) * a.part_stride : a.best_idx;
+    const char* const src0 = (const char*)a.src + (size_t)f_lo * a.src_stride;
+    const float* const gn0 = a.gnext + (size_t)f_lo * a.gnext_stride;
+
+    const int qy = tid >> 5, ql = tid & 31;
+    const bool own_tile = qy >= 1 && qy < G::QY - 1 && ql >= 2 && ql < G::QL - 2;
+    const int oy = y0 - 2 + 2 * qy, ox = x0 - 4 + 2 * ql;
+    float bE[4];
+    int bI[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int y = oy + (p >> 1), x = ox + (p & 1);
+        const bool valid = own_tile && y < h && x < w;
+        bE[p] = (!fresh && valid) ? st_e[(size_t)y * w + x] : -1.0f;
+        bI[p] = -1;
+    }
+
+    // ---- staging offsets
+    const bool edge = !INTERIOR || y0 < 2 || x0 < 4 || y0 + TH + 2 > h || x0 + TW + 8 > w;
+    uint32_t yoff[4];
+    {
+        const int row = tid >> 4, c4 = 4 * (tid & 15);
+        if (!edge) yoff[0] = yoff[1] = yoff[2] = yoff[3] = (uint32_t)((y0 - 2 + row) * w + (x0 - 4) + c4) * 4u;
+        else {
+            const int gy = map_clamp(y0 - 2 + row, h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) yoff[e] = (uint32_t)(gy * w + map_clamp(x0 - 4 + c4 + e, w)) * 4u;
+        }
+    }
+    uint32_t noff[2];
+#pragma unroll
+    for (int rnd = 0; rnd < 2; ++rnd) {
+        const int it = tid + rnd * NT, r = it >> 5, jp = it & 31;
+        noff[rnd] = (uint32_t)(map_expand_src(y0 / 2 - 2 + r, hn) * wn + map_expand_src(x0 / 2 - 2 + jp, wn)) * 12u;
+    }
+    const uint32_t gray_bytes = (uint32_t)h * (uint32_t)w * 4u;
+    v4f preY;
+    // G_{l+1} pixels: 12-byte loads through a uniform base + a 32-bit lane offset (always inside the image: the index map
+    // clamps).  NOT __builtin_amdgcn_raw_buffer_load_b96: this compiler (clang 19, ROCm 7.2) returns element 0 in all three
+    // lanes of its result.
+    Px3 preN[2];
+    auto prefetch = [&](int b) {
+        const BufRsrc ry = make_rsrc(src0 + (size_t)b * a.src_stride, gray_bytes);
+        const char* gnb = (const char*)(gn0 + (size_t)b * a.gnext_stride);
+        if (!edge) preY = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(ry, yoff[0], 0, 0));
+        else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) preY[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry, yoff[e], 0, 0));
+        }
+#pragma unroll
+        for (int rnd = 0; rnd < 2; ++rnd)
+            if (tid + rnd * NT < G::NH * 32) preN[rnd] = *(const Px3*)(gnb + noff[rnd]);
+    };
+    prefetch(0);
+
+    for (int b = 0; b < nfr; ++b) {
+        int lt = tid;
+#if MI_SEP_LAUNDER
+        asm volatile("" : "+v"(lt));
+#endif
+        // ---------------- P0: the gray patch, and X from the G_{l+1} pixels (one per lane; rows 16, 17: a second round on wave 0)
+        *reinterpret_cast<v4f*>(sY + 4 * lt) = preY;
+#pragma unroll
+        for (int rnd = 0; rnd < 2; ++rnd) {
+            const int it = lt + rnd * NT;
+            if (it >= G::NH * 32) break;   // uniform per wave
+            const int r = it >> 5, jp = it & 31;
+            const float g = gray_of<true>(preN[rnd].v[0], preN[rnd].v[1], preN[rnd].v[2]);
+            const float gl = dpp_wave_prev(g), gr = dpp_wave_next(g);
+            lds_store2(sX + mul24(r, G::XS) + 2 * jp, ex_even(gl, g, gr, ce, cc), ex_odd(g, gr, co));
+        }
+        __syncthreads();
+        if (b + 1 < nfr) prefetch(b + 1);
+
+        // ---------------- P3: vertical expand of the gray, gray Laplacian, Q, row blur of Q -> HB
+        if (lt < G::QY * G::QL) {
+            const int qy3 = lt >> 5, ql3 = lt & 31;
+            float q[4];
+            if constexpr (INTERIOR) {
+                const float* xr = sX + mul24(qy3, G::XS) + 2 * ql3;
+                const v2f xa = lds_load2s(xr), xb = lds_load2s(xr + G::XS), xc = lds_load2s(xr + 2 * G::XS);
+                const v2f ev = ex_even(xa, xb, xc, ce, cc), od = ex_odd(xb, xc, co);
+                const float* yp = sY + mul24(2 * qy3, YW) + 2 * ql3;
+                const v2f gge = lds_load2s(yp), ggo = lds_load2s(yp + YW);
+                const v2f le = gge - ev, lo = ggo - od;
+                const v2f qe = le * le, qo = lo * lo;
+                q[0] = qe.x; q[1] = qe.y; q[2] = qo.x; q[3] = qo.y;
+            } else {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    // the pixel at its mirror position (REFLECT101 of Q); parity is preserved by the mirror
+                    const int ym = map_clamp(y0 - 2 + 2 * qy3 + (p >> 1), h), xm = map_clamp(x0 - 4 + 2 * ql3 + (p & 1), w);
+                    const int ri = clampi((ym >> 1) - (y0 / 2 - 2), 1, G::NH - 2);
+                    const int ec = clampi(xm - (x0 - 4), 0, G::XW - 1);
+                    const float* xq = sX + mul24(ri, G::XS) + ec;
+                    const float gv = sY[mul24(clampi(ym - (y0 - 2), 0, YH - 1), YW) + clampi(xm - (x0 - 4), 0, YW - 1)];
+                    const float e = (p >> 1) == 0 ? ex_even(xq[-G::XS], xq[0], xq[G::XS], ce, cc) : ex_odd(xq[0], xq[G::XS], co);
+                    const float l = gv - e;
+                    q[p] = l * l;
+                }
+            }
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                const float q0 = q[2 * rr], q1 = q[2 * rr + 1];
+                const float l0 = dpp_wave_prev(q0), l1 = dpp_wave_prev(q1);
+                const float r0 = dpp_wave_next(q0), r1 = dpp_wave_next(q1);
+                const float hb0 = s5(l0, l1, q0, q1, r0, k0, k1, k2);
+                const float hb1 = s5(l1, q0, q1, r0, r1, k0, k1, k2);
+                lds_store2(sHB + mul24(2 * qy3 + rr, G::HBS) + 2 * ql3, hb0, hb1);
+            }
+        }
+        __syncthreads();
+
+        // ---------------- P4: column blur of HB for the own quad + running first-max
+        if (own_tile) {
+            const int qy4 = lt >> 5, ql4 = lt & 31;
+            const float* hp = sHB + mul24(2 * qy4 - 2, G::HBS) + 2 * ql4;
+            v2f hb[6];
+#pragma unroll
+            for (int t = 0; t < 6; ++t) hb[t] = lds_load2s(hp + t * G::HBS);
+            const v2f e0 = s5(hb[0], hb[1], hb[2], hb[3], hb[4], k0, k1, k2);
+            const v2f e1 = s5(hb[1], hb[2], hb[3], hb[4], hb[5], k0, k1, k2);
+            const float e[4] = {e0.x, e0.y, e1.x, e1.y};
+            const int fidx = a.frame_idx0 + f_lo + b;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const bool win = e[p] > bE[p];
+                bE[p] = win ? e[p] : bE[p];
+                bI[p] = win ? fidx : bI[p];
+            }
+        }
+        // (sY and sX are rewritten after P3's reads -- the barrier above; HB after the next frame's first barrier)
+    }
+
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int y = oy + (p >> 1), x = ox + (p & 1);
+        if (own_tile && y < h && x < w && bI[p] >= 0) {
+            const size_t px = (size_t)y * w + x;
+            st_e[px] = bE[p];
+            st_i[px] = bI[p];
+        }
+    }
+}
+template <bool INTERIOR, int TH, int NT>
+__global__ __launch_bounds__(NT, INTERIOR ? 8 : 1) void level_sep_e(LevelArgs a) {
+    level_sep_e_body<INTERIOR, TH, NT>(a);
+}
+template <int TH, int NT>
+constexpr int sep_e_lds_floats() { return (TH + 4) * SepGeom<TH, NT>::XW + SepGeom<TH, NT>::NH * SepGeom<TH, NT>::XS + SepGeom<TH, NT>::HBH * SepGeom<TH, NT>::HBS; }
 
 // Fold the chunks' partial (max, arg-max) into the running state, in chunk order with a strict '>': the earliest frame
 // holding the maximum stays the winner, as if the frames had been visited one after the other.
@@ -1180,6 +1464,217 @@ __global__ void sep_payload(const void* __restrict__ src, size_t src_stride, con
                 for (int c = 0; c < 3; ++c) o.v[c] = (to_f32(g[px * 3 + c]) - e[p][c]) + 0.0f;
             }
             *(Px3*)(best_lap + px * 3) = o;
+        }
+    }
+}
+
+// ================================================================================================
+// Payload passes of a level pair (level_sep_body "PAIR" + level_sep_e): the three-channel G_{l+1} of the batch was never
+// stored, so the winners' pixels of it are recomputed from G_l -- the same reduce (s5r down the rows, then along the rows, * rs,
+// REFLECT101), hence the same bits.  Once per level and batch; the loads mostly hit L1 / L2 (neighbouring quads share windows
+// when they share the winner).
+
+template <typename TIn>
+__device__ __forceinline__ void load_px3(const TIn* p, float o[3]) {
+    if constexpr (sizeof(TIn) == 4) {
+        const Px3 v = *(const Px3*)p;
+        o[0] = v.v[0]; o[1] = v.v[1]; o[2] = v.v[2];
+    } else {
+        o[0] = to_f32(p[0]); o[1] = to_f32(p[1]); o[2] = to_f32(p[2]);
+    }
+}
+// G_{l+1}[i, j] (inside its image) of the frame at `g` (level l, h x w): one pixel, 25 loads
+template <typename TIn>
+__device__ __forceinline__ void reduce_px(const TIn* __restrict__ g, int h, int w, int i, int j, float w0, float w1, float w2,
+                                          float rs, float o[3]) {
+    float V[5][3];
+    int rows[5];
+#pragma unroll
+    for (int u = 0; u < 5; ++u) rows[u] = r101(2 * i - 2 + u, h);
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+        const int x = r101(2 * j - 2 + t, w);
+        float p[5][3];
+#pragma unroll
+        for (int u = 0; u < 5; ++u) load_px3(g + ((size_t)rows[u] * w + x) * 3, p[u]);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) V[t][c] = s5r(p[0][c], p[1][c], p[2][c], p[3][c], p[4][c], w0, w1, w2);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) o[c] = s5r(V[0][c], V[1][c], V[2][c], V[3][c], V[4][c], w0, w1, w2) * rs;
+}
+
+// First level of a pair: lap_l = G_l - expand(G_{l+1}), the 3 x 3 patch of G_{l+1} that expands to the quad recomputed from
+// the winner's G_l (away from the image edges: its 9 x 9 window column by column, 81 pixel loads; else pixel by pixel).
+// Chunk partials are folded first, as sep_payload does.
+template <typename TIn>
+__global__ __launch_bounds__(256) void sep_payload_pair0(const void* __restrict__ src, size_t src_stride, int nframes, int h, int w,
+                                                         int hn, int wn, int32_t* __restrict__ best_idx, int frame_idx0,
+                                                         float* __restrict__ best_lap, float k0, float k1, float k2, float w0,
+                                                         float w1, float w2, float rs, float* __restrict__ best_e,
+                                                         const float* __restrict__ part_e, const int32_t* __restrict__ part_idx,
+                                                         size_t part_stride, int nparts) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y * blockDim.y + threadIdx.y;
+    if (2 * i >= h || 2 * j >= w) return;
+    const float ce = 2.0f * k0, cc = 2.0f * k2, co = 2.0f * k1;
+    int fr[4];
+    bool any = false;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int y = 2 * i + (p >> 1), x = 2 * j + (p & 1);
+        fr[p] = -1;
+        if (y < h && x < w) {
+            const size_t px = (size_t)y * w + x;
+            int32_t bi = best_idx[px];
+            if (nparts > 0) {
+                float e = best_e[px];
+                bool changed = false;
+                for (int c = 0; c < nparts; ++c) {
+                    const float pe = part_e[(size_t)c * part_stride + px];
+                    if (pe > e) { e = pe; bi = part_idx[(size_t)c * part_stride + px]; changed = true; }
+                }
+                if (changed) { best_e[px] = e; best_idx[px] = bi; }
+            }
+            const int f = bi - frame_idx0;
+            if (f >= 0 && f < nframes) { fr[p] = f; any = true; }
+        }
+    }
+    if (!any) return;
+    const int ri[3] = {map_expand_src(i - 1, hn), i, map_expand_src(i + 1, hn)};
+    const int cj[3] = {map_expand_src(j - 1, wn), j, map_expand_src(j + 1, wn)};
+    const bool inner = i >= 2 && j >= 2 && 2 * i + 4 < h && 2 * j + 4 < w;   // (then i + 1 < hn, j + 1 < wn: nothing is mapped)
+    unsigned pending = (fr[0] >= 0 ? 1u : 0u) | (fr[1] >= 0 ? 2u : 0u) | (fr[2] >= 0 ? 4u : 0u) | (fr[3] >= 0 ? 8u : 0u);
+    while (pending) {
+        const int f = (pending & 1u) ? fr[0] : (pending & 2u) ? fr[1] : (pending & 4u) ? fr[2] : fr[3];
+        const TIn* g = (const TIn*)((const char*)src + (size_t)f * src_stride);
+        float N[3][3][3];
+        if (inner) {
+            float V[3][9][3];
+            const TIn* c0 = g + ((size_t)(2 * i - 4) * w + (2 * j - 4)) * 3;
+#pragma unroll
+            for (int x = 0; x < 9; ++x) {
+                float p[9][3];
+#pragma unroll
+                for (int u = 0; u < 9; ++u) load_px3(c0 + ((size_t)u * w + x) * 3, p[u]);
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+                        V[r][x][c] = s5r(p[2 * r][c], p[2 * r + 1][c], p[2 * r + 2][c], p[2 * r + 3][c], p[2 * r + 4][c], w0, w1, w2);
+            }
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+                        N[r][q][c] = s5r(V[r][2 * q][c], V[r][2 * q + 1][c], V[r][2 * q + 2][c], V[r][2 * q + 3][c], V[r][2 * q + 4][c], w0, w1, w2) * rs;
+        } else {
+            for (int r = 0; r < 3; ++r)
+                for (int q = 0; q < 3; ++q) reduce_px(g, h, w, ri[r], cj[q], w0, w1, w2, rs, N[r][q]);
+        }
+        float e[4][3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float xe[3], xo[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                xe[r] = ex_even(N[r][0][c], N[r][1][c], N[r][2][c], ce, cc);
+                xo[r] = ex_odd(N[r][1][c], N[r][2][c], co);
+            }
+            e[0][c] = ex_even(xe[0], xe[1], xe[2], ce, cc);
+            e[1][c] = ex_even(xo[0], xo[1], xo[2], ce, cc);
+            e[2][c] = ex_odd(xe[1], xe[2], co);
+            e[3][c] = ex_odd(xo[1], xo[2], co);
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            if (!((pending >> p) & 1u) || fr[p] != f) continue;
+            pending &= ~(1u << p);
+            const size_t px = (size_t)(2 * i + (p >> 1)) * w + 2 * j + (p & 1);
+            float gv[3];
+            load_px3(g + px * 3, gv);
+            Px3 o;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) o.v[c] = (gv[c] - e[p][c]) + 0.0f;
+            *(Px3*)(best_lap + px * 3) = o;
+        }
+    }
+}
+
+// Second level of a pair (level l + 1 of h1 x w1 pixels; (h, w) = level l, the stored one): lap = G_{l+1} - expand(G_{l+2}) with
+// the winner's pixel of G_{l+1} recomputed from its G_l (`src`), G_{l+2} (`g2`, h2 x w2) as stored by the pair's first kernel.
+template <typename TIn>
+__global__ __launch_bounds__(256) void sep_payload_pair1(const void* __restrict__ src, size_t src_stride, const float* __restrict__ g2,
+                                                         size_t g2_stride, int nframes, int h, int w, int h1, int w1, int h2, int w2,
+                                                         int32_t* __restrict__ best_idx, int frame_idx0,
+                                                         float* __restrict__ best_lap, float k0, float k1, float k2, float w0,
+                                                         float w1r, float w2r, float rs, float* __restrict__ best_e,
+                                                         const float* __restrict__ part_e, const int32_t* __restrict__ part_idx,
+                                                         size_t part_stride, int nparts) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y * blockDim.y + threadIdx.y;
+    if (2 * i >= h1 || 2 * j >= w1) return;
+    const float ce = 2.0f * k0, cc = 2.0f * k2, co = 2.0f * k1;
+    int fr[4];
+    bool any = false;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int y = 2 * i + (p >> 1), x = 2 * j + (p & 1);
+        fr[p] = -1;
+        if (y < h1 && x < w1) {
+            const size_t px = (size_t)y * w1 + x;
+            int32_t bi = best_idx[px];
+            if (nparts > 0) {
+                float e = best_e[px];
+                bool changed = false;
+                for (int c = 0; c < nparts; ++c) {
+                    const float pe = part_e[(size_t)c * part_stride + px];
+                    if (pe > e) { e = pe; bi = part_idx[(size_t)c * part_stride + px]; changed = true; }
+                }
+                if (changed) { best_e[px] = e; best_idx[px] = bi; }
+            }
+            const int f = bi - frame_idx0;
+            if (f >= 0 && f < nframes) { fr[p] = f; any = true; }
+        }
+    }
+    if (!any) return;
+    const int ri[3] = {map_expand_src(i - 1, h2), i, map_expand_src(i + 1, h2)};
+    const int cj[3] = {map_expand_src(j - 1, w2), j, map_expand_src(j + 1, w2)};
+    unsigned pending = (fr[0] >= 0 ? 1u : 0u) | (fr[1] >= 0 ? 2u : 0u) | (fr[2] >= 0 ? 4u : 0u) | (fr[3] >= 0 ? 8u : 0u);
+    while (pending) {
+        const int f = (pending & 1u) ? fr[0] : (pending & 2u) ? fr[1] : (pending & 4u) ? fr[2] : fr[3];
+        const float* gn = g2 + (size_t)f * g2_stride;
+        const TIn* g = (const TIn*)((const char*)src + (size_t)f * src_stride);
+        Px3 N[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) N[r][q] = *(const Px3*)(gn + ((size_t)ri[r] * w2 + cj[q]) * 3);
+        float e[4][3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float xe[3], xo[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                xe[r] = ex_even(N[r][0].v[c], N[r][1].v[c], N[r][2].v[c], ce, cc);
+                xo[r] = ex_odd(N[r][1].v[c], N[r][2].v[c], co);
+            }
+            e[0][c] = ex_even(xe[0], xe[1], xe[2], ce, cc);
+            e[1][c] = ex_even(xo[0], xo[1], xo[2], ce, cc);
+            e[2][c] = ex_odd(xe[1], xe[2], co);
+            e[3][c] = ex_odd(xo[1], xo[2], co);
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            if (!((pending >> p) & 1u) || fr[p] != f) continue;
+            pending &= ~(1u << p);
+            const int y = 2 * i + (p >> 1), x = 2 * j + (p & 1);
+            float gv[3];
+            reduce_px(g, h, w, y, x, w0, w1r, w2r, rs, gv);
+            Px3 o;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) o.v[c] = (gv[c] - e[p][c]) + 0.0f;
+            *(Px3*)(best_lap + ((size_t)y * w1 + x) * 3) = o;
         }
     }
 }

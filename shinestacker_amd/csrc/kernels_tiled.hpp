@@ -83,6 +83,16 @@ struct LevelArgs {
     // the right / bottom edge make `round * 8 + XCD` uneven: 5 % between the XCDs at 24 MP).  nullptr: g itself.
     // (The separable kernel only: the exact kernel's 32 x 64 tiling of 24 MP is even as it is, measured no gain.)
     const uint16_t* sb_order;
+    // MI_ARITH_SEPARABLE, level pairs (kernels_sep.hpp, "PAIR"): the level-l kernel also reduces its G_{l+1} patch to the
+    // tile's G_{l+2} pixels and hands level l+1 -- whose energy path needs ONE channel -- the gray of G_{l+1}; the three-
+    // channel G_{l+1} is stored for one frame of the launch only (`g1_keep`, frame number inside the launch; < 0: none),
+    // into `gnext` (then a single image: the debug tap).
+    float* gray1;           // gray(G_{l+1}) of the batch, hn x wn floats per frame
+    size_t gray1_stride;    // floats between frames
+    float* g2;              // G_{l+2} of the batch (written)
+    size_t g2_stride;
+    int hn2, wn2;
+    int g1_keep;
 };
 
 // reduce item of lane `tid` for the 32x64 / 512-thread tile with GS = 236 (generated by the search in

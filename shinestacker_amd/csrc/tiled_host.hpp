@@ -31,6 +31,10 @@ struct TiledState {
     std::vector<uint16_t*> sbOrder; // [l] super-block order of the level's interior launch (LevelArgs::sb_order), device
     std::vector<int> sbGroups;      // [l] entries of sbOrder[l] (a multiple of 8)
     std::vector<size_t> gstride;    // floats between frames in Gb[.][l]
+    // MI_ARITH_SEPARABLE, level pairs (kernels_sep.hpp "PAIR", run_batch): a batch that runs levels 0 and 1 as a pair keeps
+    // gray(G_1) -- one float per pixel -- in Gb[set][1] and the three-channel G_1 of its LAST frame in G1keep[set] (the tap)
+    float* G1keep[2] = {nullptr, nullptr};
+    bool last_pair = false;         // the most recent batch ran as a pair
     void* ring = nullptr;           // staging ring for host-pushed frames (bcap frames, in_dtype)
     size_t frame_bytes = 0;
     int pending = 0;                // frames staged in the ring, not yet processed
@@ -103,6 +107,7 @@ int tiled_reserve(mi_stack* s, int set, int nb) {
     }
     for (int l = 1; l <= s->L; ++l)
         if ((rc = dev_alloc_t(s, &t->Gb[set][l], t->gstride[l] * nb))) return rc;
+    if (s->sep && s->L >= 2 && !t->G1keep[set] && (rc = dev_alloc_t(s, &t->G1keep[set], t->gstride[1]))) return rc;
     const size_t npb = (size_t)s->lh[s->L] * s->lw[s->L];
     if ((rc = dev_alloc_t(s, &t->lev[set], npb * nb))) return rc;
     if ((rc = dev_alloc_t(s, &t->cnt[set], (size_t)s->nlevels_hist * nb))) return rc;
@@ -213,6 +218,7 @@ const float* tiled_last_gauss(mi_stack* s, int level) {
     TiledState* t = tstate(s);
     if (s->p.impl != MI_IMPL_TILED) return s->G[level];
     int last = t->last_nb > 0 ? t->last_nb - 1 : 0;
+    if (level == 1 && t->last_pair) return t->G1keep[t->last_set];   // (Gb[.][1] holds gray(G_1) then)
     return t->Gb[t->last_set][level] + (size_t)last * t->gstride[level];
 }
 
@@ -441,8 +447,11 @@ int launch_level(mi_stack* s, int l, int set, const void* src, size_t src_stride
 // `info` (optional): what run_batch needs to finish the level -- how many chunk partials sep_payload has to fold (it then takes
 // merge_chunks' place) and whether border tiles were launched on st_bd (only then the streams have to join).  `ev_sync`
 // (optional): recorded on st_in and waited for on st_bd in front of a border launch (everything st_in has done so far).
+// `PM` (level pairs, kernels_sep.hpp "PAIR"): 0 = a level on its own; 1 = the first level of a pair (level_sep_pair: writes
+// gray(G_{l+1}) into Gb[set][l+1] -- one float per pixel --, G_{l+2} into Gb[set][l+2] and the three-channel G_{l+1} of the
+// batch's last frame into G1keep[set]); 2 = the second level of a pair (level_sep_e: `src` = that gray, reads G_{l+1}).
 struct SepLevelInfo { int nparts = 0; bool border = false; };
-template <typename TIn, bool L0_NAME, bool MF = false>
+template <typename TIn, bool L0_NAME, bool MF = false, int PM = 0>
 int launch_level_sep(mi_stack* s, int l, int set, const void* src, size_t src_stride, int nb, hipStream_t st_in,
                      hipStream_t st_bd, hipEvent_t ev_bd, int f_begin = 0, int f_end = -1, SepLevelInfo* info = nullptr,
                      hipEvent_t ev_sync = nullptr) {
@@ -463,6 +472,18 @@ int launch_level_sep(mi_stack* s, int l, int set, const void* src, size_t src_st
     a.w = s->lw[l];
     a.hn = s->lh[l + 1];
     a.wn = s->lw[l + 1];
+    a.g1_keep = -1;
+    const size_t gray_stride = (size_t)a.hn * a.wn;
+    if constexpr (PM == 1) {
+        static_assert(!MF, "the matrix-pipe reduce has no pair form");
+        if (l != 0 || l + 2 > s->L) return fail(MI_ERR_INVALID, "level pair at level %d of %d", l, s->L);
+        a.gnext = t->G1keep[set];
+        a.gnext_stride = 0;
+        a.gray1_stride = gray_stride;
+        a.g2_stride = t->gstride[l + 2];
+        a.hn2 = s->lh[l + 2];
+        a.wn2 = s->lw[l + 2];
+    }
     // The "interior" launch covers every tile whose staged patch may be mirrored into place (kernels_sep.hpp, edge tiles):
     // all of the grid, except the tile rows / columns that reach an ODD far edge (those stay with the border kernel), and
     // nothing at all on levels too small for a single reflection per side.
@@ -514,12 +535,17 @@ int launch_level_sep(mi_stack* s, int l, int set, const void* src, size_t src_st
         a.dbg = dbg_dev;
     } else a.dbg = nullptr;
 #endif
-    const size_t lds = (size_t)SG::LDS_FLOATS * sizeof(float);                                     // border tiles
-    const size_t lds_in = (size_t)(MF ? SG::lds_floats_mf((int)sizeof(TIn)) : SG::lds_floats((int)sizeof(TIn), true)) * sizeof(float);   // interior tiles
+    const size_t lds = (size_t)(PM == 2 ? sep_e_lds_floats<TH, NT>() : SG::LDS_FLOATS + (PM == 1 ? 3 * SG::NH * SG::NW : 0)) * sizeof(float);   // border tiles
+    const size_t lds_in = (size_t)(PM == 2 ? sep_e_lds_floats<TH, NT>() : MF ? SG::lds_floats_mf((int)sizeof(TIn)) : SG::lds_floats((int)sizeof(TIn), true)) * sizeof(float);   // interior tiles
     void (*kin)(LevelArgs);
-    if constexpr (MF) kin = level_sep_mf<TIn, TH, NT>;
-    else kin = L0_NAME ? level_sep<TIn, true, TH, NT> : level_sep_coarse<TIn, true, TH, NT>;
-    auto kbd = level_sep<TIn, false, TH, NT>;
+    void (*kbd)(LevelArgs);
+    if constexpr (PM == 1) { kin = level_sep_pair<TIn, true, TH, NT>; kbd = level_sep_pair<TIn, false, TH, NT>; }
+    else if constexpr (PM == 2) { kin = level_sep_e<true, TH, NT>; kbd = level_sep_e<false, TH, NT>; }
+    else {
+        if constexpr (MF) kin = level_sep_mf<TIn, TH, NT>;
+        else kin = L0_NAME ? level_sep<TIn, true, TH, NT> : level_sep_coarse<TIn, true, TH, NT>;
+        kbd = level_sep<TIn, false, TH, NT>;
+    }
     static thread_local bool attr_set = false;
     if (!attr_set) {
         int rc;
@@ -571,7 +597,11 @@ int launch_level_sep(mi_stack* s, int l, int set, const void* src, size_t src_st
 #ifdef MI_STUDY_SAME_FRAME
         if (l == 0) a.src = src;
 #endif
-        a.gnext = t->Gb[set][l + 1] + (size_t)f0 * a.gnext_stride;
+        if constexpr (PM == 1) {
+            a.gray1 = t->Gb[set][l + 1] + (size_t)f0 * gray_stride;
+            a.g2 = t->Gb[set][l + 2] + (size_t)f0 * a.g2_stride;
+            a.g1_keep = nb - 1 >= f0 && nb - 1 < f0 + nf ? nb - 1 - f0 : -1;   // the batch's last frame, if this launch holds it
+        } else a.gnext = t->Gb[set][l + 1] + (size_t)f0 * a.gnext_stride;
         a.nframes = nf;
         a.chunk_frames = parallel ? fc : nf;
         a.first = first && f0 == 0;
@@ -624,6 +654,42 @@ int launch_payload_sep(mi_stack* s, int l, int set, const void* src, size_t src_
                        (const float*)(nparts > 0 ? t->partE[l] : nullptr), (const int32_t*)(nparts > 0 ? t->partI[l] : nullptr),
                        (size_t)s->lh[l] * s->lw[l], nparts);
     return MI_OK;
+}
+
+// Level pair (0, 1): the payload passes that recompute the winners' G_1 from the frames (sep_payload_pair0 / 1)
+template <typename TIn>
+int launch_payload_pair0(mi_stack* s, int set, const void* src, size_t src_stride, int nb, hipStream_t st, int nparts) {
+    TiledState* t = tstate(s);
+    const dim3 blk(32, 8);
+    const dim3 grd(cdiv(cdiv(s->lw[0], 2), blk.x), cdiv(cdiv(s->lh[0], 2), blk.y));
+    ProfScope ps(s, MI_PROF_LEVEL, 0.0, st);
+    hipLaunchKernelGGL((sep_payload_pair0<TIn>), grd, blk, 0, st, src, src_stride, nb, s->lh[0], s->lw[0], s->lh[1], s->lw[1],
+                       s->bestIdx[0], s->first_index + s->n_pushed, s->bestLap[0], s->k1d[0], s->k1d[1], s->k1d[2], s->rk[0],
+                       s->rk[1], s->rk[2], s->rk[3], s->bestE[0], (const float*)(nparts > 0 ? t->partE[0] : nullptr),
+                       (const int32_t*)(nparts > 0 ? t->partI[0] : nullptr), (size_t)s->lh[0] * s->lw[0], nparts);
+    return MI_OK;
+}
+template <typename TIn>
+int launch_payload_pair1(mi_stack* s, int set, const void* src, size_t src_stride, int nb, hipStream_t st, int nparts) {
+    TiledState* t = tstate(s);
+    const dim3 blk(32, 8);
+    const dim3 grd(cdiv(cdiv(s->lw[1], 2), blk.x), cdiv(cdiv(s->lh[1], 2), blk.y));
+    ProfScope ps(s, MI_PROF_LEVEL, 0.0, st);
+    hipLaunchKernelGGL((sep_payload_pair1<TIn>), grd, blk, 0, st, src, src_stride, (const float*)t->Gb[set][2], t->gstride[2], nb,
+                       s->lh[0], s->lw[0], s->lh[1], s->lw[1], s->lh[2], s->lw[2], s->bestIdx[1], s->first_index + s->n_pushed,
+                       s->bestLap[1], s->k1d[0], s->k1d[1], s->k1d[2], s->rk[0], s->rk[1], s->rk[2], s->rk[3], s->bestE[1],
+                       (const float*)(nparts > 0 ? t->partE[1] : nullptr), (const int32_t*)(nparts > 0 ? t->partI[1] : nullptr),
+                       (size_t)s->lh[1] * s->lw[1], nparts);
+    return MI_OK;
+}
+// Does a batch of `nb` frames run its levels 0 and 1 as a pair?  mi_stack_params.pair_levels: 1 = always, 2 = never, 0 = when
+// the batch is long enough for the saved traffic (G_1: 3 + 3.6 of the 24 bytes per pixel and frame) to outweigh the
+// once-per-batch recomputation in the payload passes, whose gathers are three times wider where neighbouring pixels
+// have different winners.
+constexpr int SEP_PAIR_MIN_FRAMES = 32;
+inline bool sep_use_pair(const mi_stack* s, int nb) {
+    if (!s->sep || s->L < 2 || s->p.pair_levels == 2) return false;
+    return s->p.pair_levels == 1 || nb >= SEP_PAIR_MIN_FRAMES;
 }
 
 // MI_ARITH_EXACT: the same for the reference-order arithmetic (exact_payload, kernels_tiled.hpp)
@@ -681,7 +747,8 @@ int run_batch(mi_stack* s, const void* frames, size_t stride, int nb) {
     static const int interleave01 = study_env("MI_INTERLEAVE01", 0);
     bool il = false;
     SepLevelInfo li0;
-    if (s->sep && interleave01 && L >= 2 && nb > SEP_LAUNCH_FRAMES) {
+    const bool pair = sep_use_pair(s, nb);
+    if (s->sep && !pair && interleave01 && L >= 2 && nb > SEP_LAUNCH_FRAMES) {
         bool p0 = false, p1 = false;
         const int nt0 = cdiv(s->lw[0], 56) * cdiv(s->lh[0], MI_SEP_TH), nt1 = cdiv(s->lw[1], 56) * cdiv(s->lh[1], MI_SEP_TH);
         level_chunk_frames(nb, nt0, &p0);
@@ -695,7 +762,8 @@ int run_batch(mi_stack* s, const void* frames, size_t stride, int nb) {
             if (!rc) rc = launch_level_sep<float, false>(s, 1, set, t->Gb[set][1], t->gstride[1] * sizeof(float), nb, st0, st1,
                                                          t->evLvl[(set * (L + 1) + 1) * 2 + 1], f0, f1);
         }
-    } else if (s->sep) rc = launch_level0_sep<TIn>(s, set, frames, stride, nb, st0, st1, t->evL0b[set], 0, -1, &li0);
+    } else if (pair) rc = launch_level_sep<TIn, true, false, 1>(s, 0, set, frames, stride, nb, st0, st1, t->evL0b[set], 0, -1, &li0);
+    else if (s->sep) rc = launch_level0_sep<TIn>(s, set, frames, stride, nb, st0, st1, t->evL0b[set], 0, -1, &li0);
     else
         rc = launch_level<TIn, FMA, MI_TILE0_H, MI_TILE0_W, MI_TILE0_NT, MI_TILE_PAD != 0, MI_TILE_H, MI_TILE_W, MI_TILE_NT>(
             s, 0, set, frames, stride, nb, st0, st1, t->evL0b[set]);
@@ -705,8 +773,9 @@ int run_batch(mi_stack* s, const void* frames, size_t stride, int nb) {
     MI_HIP(hipStreamWaitEvent(st2, t->evL0i[set], 0));
     MI_HIP(hipStreamWaitEvent(st2, t->evL0b[set], 0));
     MI_HIP(hipStreamWaitEvent(st1, t->evL0i[set], 0));
-    if ((rc = s->sep ? launch_payload_sep<TIn>(s, 0, set, frames, stride, nb, st2, li0.nparts)
-                     : launch_payload_exact<TIn, FMA>(s, 0, set, frames, stride, nb, st2)))
+    if ((rc = pair ? launch_payload_pair0<TIn>(s, set, frames, stride, nb, st2, li0.nparts)
+             : s->sep ? launch_payload_sep<TIn>(s, 0, set, frames, stride, nb, st2, li0.nparts)
+                      : launch_payload_exact<TIn, FMA>(s, 0, set, frames, stride, nb, st2)))
         return rc;
     MI_HIP(hipEventRecord(t->evL0done[set], st2));   // st2 waited for both level-0 kernels above
     // coarser levels: interior tiles on st2, border tiles on st1 (disjoint tiles of one level run
@@ -718,6 +787,20 @@ int run_batch(mi_stack* s, const void* frames, size_t stride, int nb) {
         static const int wide_levels = study_env("MI_WIDE_LEVELS", -1);
         const bool wide = wide_levels >= 0 ? l <= wide_levels : (size_t)s->lh[l] * s->lw[l] >= ((size_t)4 << 20);
         hipEvent_t ei = t->evLvl[(set * (L + 1) + l) * 2], eb = t->evLvl[(set * (L + 1) + l) * 2 + 1];
+        if (pair && l == 1) {
+            // the second level of the pair: energy only, from gray(G_1) and G_2 (both written by level 0's kernel); its
+            // payload pass recomputes the winners' G_1 from the frames
+            SepLevelInfo li;
+            if ((rc = launch_level_sep<float, false, false, 2>(s, 1, set, t->Gb[set][1], (size_t)s->lh[1] * s->lw[1] * sizeof(float), nb,
+                                                               st2, st1, eb, 0, -1, &li, ei)))
+                return rc;
+            if (li.border) {
+                MI_HIP(hipEventRecord(eb, st1));
+                MI_HIP(hipStreamWaitEvent(st2, eb, 0));
+            }
+            if ((rc = launch_payload_pair1<TIn>(s, set, frames, stride, nb, st2, li.nparts))) return rc;
+            continue;
+        }
         if (s->sep && !(il && l == 1)) {
             // interior tiles on st2; border tiles, if the level has any, on st1 behind everything st2 has done so far (`ei`);
             // the streams join again (`eb`) in front of the payload pass, which also folds the frame chunks' partial maxima
@@ -782,6 +865,7 @@ int run_batch(mi_stack* s, const void* frames, size_t stride, int nb) {
     s->n_pushed += nb;
     t->last_nb = nb;
     t->last_set = set;
+    t->last_pair = pair;
     t->batch_no++;
     return MI_OK;
 }

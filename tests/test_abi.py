@@ -57,7 +57,7 @@ def _header_params_fields():
 
 def test_params_struct_layout(hiplib):
     """mi_stack_params_t as the header declares it == the ctypes mirror (names, order, OFFSETS, size) == the stub shown
-    in INTEGRATION.md: int32 x6, double, int32 x5 (float_type .. batch_frames), arith, reserved[4] -> 72 bytes."""
+    in INTEGRATION.md: int32 x6, double, int32 x5 (float_type .. batch_frames), arith, pair_levels, reserved[3] -> 72 bytes."""
     ct = {"int32_t": ctypes.c_int32, "double": ctypes.c_double}
     fields = _header_params_fields()
 
@@ -69,7 +69,7 @@ def test_params_struct_layout(hiplib):
         assert getattr(mine, n).offset == getattr(FromHeader, n).offset, n
         assert getattr(mine, n).size == getattr(FromHeader, n).size, n
     assert ctypes.sizeof(mine) == ctypes.sizeof(FromHeader) == 72
-    assert mine.arith.offset == 52 and mine.reserved.offset == 56 and mine.gen_kernel.offset == 24
+    assert mine.arith.offset == 52 and mine.pair_levels.offset == 56 and mine.reserved.offset == 60 and mine.gen_kernel.offset == 24
     # the reference-side stub of INTEGRATION.md lists the same members in the same order
     import re
     doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
