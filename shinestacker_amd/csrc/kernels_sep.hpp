@@ -120,6 +120,8 @@ template <typename TIn> constexpr int sep_nt() { return sizeof(TIn) == 4 ? MI_SE
 #endif
 constexpr int SEP_MF_TH = MI_SEP_MF_TH, SEP_MF_NT = (MI_SEP_MF_TH / 2 + 2) * 32;
 
+// the pair's tile-by-tile payload pass walks at most this many distinct winners per tile (level_sep_body, "PL")
+constexpr int SEP_PL_MAXF = 32;
 template <int TH_, int NT_>
 struct SepGeom {
     static constexpr int TH = TH_, TW = 56, NT = NT_;
@@ -185,6 +187,26 @@ __device__ __forceinline__ float ex_even(float l, float c, float r, float ce, fl
 __device__ __forceinline__ float ex_odd(float c, float r, float co) { return co * (c + r); }
 __device__ __forceinline__ v2f ex_even(v2f l, v2f c, v2f r, float ce, float cc) { return pk_fma((v2f)ce, l + r, c * cc); }
 __device__ __forceinline__ v2f ex_odd(v2f c, v2f r, float co) { return (c + r) * co; }
+// expand_layer(N)[y, x] for an hs x ws source given as N(row, col) (indices already inside the source), (y, x)
+// inside the 2hs x 2ws grid: along the rows first, then down the rows
+template <typename F>
+__device__ __forceinline__ float expand_sep_of(F N, int hs, int ws, int y, int x, float ce, float cc, float co) {
+    const int i = y >> 1, j = x >> 1;
+    auto M = [&](int r, int q) { return N(map_expand_src(r, hs), map_expand_src(q, ws)); };
+    auto X = [&](int r) { return (x & 1) ? ex_odd(M(r, j), M(r, j + 1), co) : ex_even(M(r, j - 1), M(r, j), M(r, j + 1), ce, cc); };
+    return (y & 1) ? ex_odd(X(i), X(i + 1), co) : ex_even(X(i - 1), X(i), X(i + 1), ce, cc);
+}
+
+// one pixel of a level-l image as floats
+template <typename TIn>
+__device__ __forceinline__ void load_px3(const TIn* p, float o[3]) {
+    if constexpr (sizeof(TIn) == 4) {
+        const Px3 v = *(const Px3*)p;
+        o[0] = v.v[0]; o[1] = v.v[1]; o[2] = v.v[2];
+    } else {
+        o[0] = to_f32(p[0]); o[1] = to_f32(p[1]); o[2] = to_f32(p[2]);
+    }
+}
 // two grays at once, each component in gray_of<true>'s order
 __device__ __forceinline__ v2f gray_of2(v2f b, v2f g, v2f r) {
     return pk_fma(r, (v2f)0.299f, pk_fma(g, (v2f)0.587f, b * 0.114f));
@@ -442,7 +464,7 @@ __device__ __forceinline__ bool sep_tile_origin(const LevelArgs& a, int& y0, int
 }
 
 
-template <typename TIn, bool INTERIOR, int TH, int NT, bool MF_ = false, bool PAIR_ = false>
+template <typename TIn, bool INTERIOR, int TH, int NT, bool MF_ = false, bool PAIR_ = false, bool PL_ = false>
 __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
     using G = SepGeom<TH, NT>;
     constexpr int TW = G::TW;
@@ -459,6 +481,13 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
     // launch excepted: LevelArgs::g1_keep, the debug tap); the payload passes recompute the winners' (sep_payload_pair).
     constexpr bool PAIR = PAIR_;
     static_assert(!PAIR || (!MF_ && !DMA && TH % 4 == 0 && G::NH * G::NW * 3 <= G::GH * (G::GD / 4)), "PAIR geometry");
+    // PL (round 6): the PAYLOAD pass of a pair, tile by tile.  The workgroup collects the distinct winners of its tile (level
+    // l: the tile's pixels; level l + 1: the tile's 14 x 28 pixels of it) -- at most SEP_PL_MAXF, else the tile is flagged and
+    // left to the per-quad kernels (sep_payload_pair0 / 1) -- and walks THOSE frames: P0 - P2 as ever give the frame's
+    // G_{l+1} patch (sN), from which the lanes fill in lap_l = G_l - expand(G_{l+1}) of the pixels that frame won and
+    // lap_{l+1} = G_{l+1} - expand(G_{l+2}) likewise.  A tile whose pixels have one winner costs one tile-frame of P0 - P2.
+    constexpr bool PL = PL_;
+    static_assert(!PL || (!PAIR && !MF_ && !DMA), "PL geometry");
     constexpr int N2H = TH / 4, N2W = TW / 4, NPL1 = G::NH * G::NW;   // G_{l+2} pixels of the tile; floats per plane of sN
     constexpr bool GQ1 = DMA || (PAIR && INTERIOR);   // gray of the lane's quad of G_l taken in P1 (registers)
     constexpr int RD = (int)sizeof(TIn);                 // dwords per 4-element chunk in that form
@@ -481,7 +510,9 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
     float* sX = MF ? smem + NPL * G::MF_PLANE : sV + G::NH * G::VS;
     float* sHB = MF ? sX + G::NH * G::XS : sV;         // (not MF: V is dead once P2 has read it)
     uint32_t* sW = reinterpret_cast<uint32_t*>(sHB + G::HBH * G::HBS);   // MF: weight operands, [3][64] x 16 bytes
-    float* sN = INTERIOR ? smem : smem + G::LDS_FLOATS;   // PAIR: G_{l+1} patch, [3][NH][NW] (border tiles: their own array)
+    // PAIR: G_{l+1} patch, [3][NH][NW] (interior tiles: over the dead G_l patch; border tiles and PL: their own array)
+    float* sN = (INTERIOR && !PL) ? smem : smem + (INTERIOR ? G::lds_floats((int)sizeof(TIn), true) : G::LDS_FLOATS);
+    uint32_t* sFL = reinterpret_cast<uint32_t*>(sN + 3 * G::NH * G::NW);   // PL: [0..7] winner bit map, [8] count, [16..] frame list
     float* sV2 = sV + G::HBH * G::HBS;                   // PAIR: column sums of the G_{l+2} reduce, [3][N2H][NW] (V's tail)
     static_assert(!PAIR || G::HBH * G::HBS + 3 * N2H * G::NW <= G::NH * G::VS, "V2 fits behind HB");
     const int tid = threadIdx.x;
@@ -517,11 +548,13 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
 
     // ---- which frames?  (levels with few tiles split the batch into chunks along blockIdx.y, see LevelArgs)
     const int ck = blockIdx.y, f_lo = ck * a.chunk_frames;
-    const int nfr = min(a.nframes - f_lo, a.chunk_frames);
+    int nfr = min(a.nframes - f_lo, a.chunk_frames);
     const bool fresh = ck > 0 || a.first;
     float* const st_e = ck ? a.part_e + (size_t)(ck - 1) * a.part_stride : a.best_e;
     int32_t* const st_i = ck ? a.part_idx + (size_t)(ck - 1) * a.part_stride : a.best_idx;
     const char* const src0 = (const char*)a.src + (size_t)f_lo * a.src_stride;
+    // the frame the loop's step b works on: b itself, or (PL) the b-th distinct winner of the tile
+    auto fid = [&](int b) { return PL ? __builtin_amdgcn_readfirstlane((int)sFL[16 + b]) : b; };
     float* const gnext0 = PAIR ? a.gnext : a.gnext + (size_t)f_lo * a.gnext_stride;   // (PAIR: one image, see g1_keep)
     float* const gray1_0 = PAIR ? a.gray1 + (size_t)f_lo * a.gray1_stride : nullptr;
     float* const g2_0 = PAIR ? a.g2 + (size_t)f_lo * a.g2_stride : nullptr;
@@ -533,6 +566,54 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
     const int oy = y0 - 2 + 2 * qy, ox = x0 - 4 + 2 * ql;
     float bE[4];
     int bI[4];
+    int f1 = -1;   // PL: the winner (frame of this batch, or -1) of the lane's pixel of level l + 1
+    if constexpr (PL) {
+        // bI[p] = the winner of the quad's pixel p as a frame of this batch (-1: none of them / outside the image)
+        if (tid < 16) sFL[tid] = 0u;
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int y = oy + (p >> 1), x = ox + (p & 1);
+            int fr = -1;
+            if (own_tile && y < h && x < w) {
+                fr = a.best_idx[(size_t)y * w + x] - a.frame_idx0;
+                if (fr < 0 || fr >= a.nframes) fr = -1;
+                else atomicOr(&sFL[fr >> 5], 1u << (fr & 31));
+            }
+            bI[p] = fr;
+            bE[p] = 0.f;
+        }
+        if (tid < (TH / 2) * (TW / 2)) {
+            const int r1 = SmallDiv<TW / 2, NT>::div(tid), c1 = tid - r1 * (TW / 2);
+            const int i1 = y0 / 2 + r1, j1 = x0 / 2 + c1;
+            if (i1 < hn && j1 < wn) {
+                f1 = a.idx1[(size_t)i1 * wn + j1] - a.frame_idx0;
+                if (f1 < 0 || f1 >= a.nframes) f1 = -1;
+                else atomicOr(&sFL[f1 >> 5], 1u << (f1 & 31));
+            }
+        }
+        __syncthreads();
+        if (tid < 256) {
+            const uint32_t wd = sFL[tid >> 5], bit = 1u << (tid & 31);
+            if (wd & bit) {
+                int pos = __builtin_popcount(wd & (bit - 1u));
+                for (int k = 0; k < (tid >> 5); ++k) pos += __builtin_popcount(sFL[k]);
+                if (pos < SEP_PL_MAXF) sFL[16 + pos] = (uint32_t)tid;
+            }
+        }
+        if (tid == 0) {
+            int n = 0;
+            for (int k = 0; k < 8; ++k) n += __builtin_popcount(sFL[k]);
+            sFL[8] = (uint32_t)n;
+        }
+        __syncthreads();
+        nfr = __builtin_amdgcn_readfirstlane((int)sFL[8]);
+        if (nfr > SEP_PL_MAXF) {   // too many winners: the per-quad kernels take this tile
+            if (tid == 0) a.tile_flag[(y0 / TH) * ((w + TW - 1) / TW) + x0 / TW] = 1;
+            return;
+        }
+        if (nfr == 0) return;
+    } else {
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const int y = oy + (p >> 1), x = ox + (p & 1);
@@ -545,6 +626,7 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
             bE[p] = -1.0f;   // every energy is >= 0: the first frame always wins
             bI[p] = -1;
         }
+    }
     }
 
     // ---- staging: chunk id = tid + n * NT covers patch row id / 51, floats 4 * (id % 51) .. +3
@@ -600,10 +682,13 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
             goff[n] = (uint32_t)((gy * w + (x0 - 6)) * 3 + e0) * (uint32_t)sizeof(TIn);
         }
     }
+    // PAIR: does the G_{l+2} reduce of this tile touch an edge of G_{l+1} (rows / columns through REFLECT101, pixels of G_{l+2}
+    // outside its image)?  Uniform per workgroup; the tiles that do not take the unmapped fast paths of V2 / H2.
+    const bool e2 = !INTERIOR || y0 < 4 || x0 < 4 || y0 / 2 + TH / 2 >= hn || x0 / 2 + TW / 2 >= wn;
     const uint32_t frame_bytes = (uint32_t)h * (uint32_t)w * 3u * (uint32_t)sizeof(TIn);
     // chunks [n0, n1) of frame b
     auto prefetch = [&](int b, int n0, int n1) {
-        const char* frb = src0 + (size_t)b * a.src_stride;
+        const char* frb = src0 + (size_t)fid(b) * a.src_stride;
         const BufRsrc rs = make_rsrc(frb, frame_bytes);
         if constexpr (MF) {
             if (MI_SEP_MF_WIDE && !edge) {
@@ -953,6 +1038,11 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
 #pragma unroll
                 for (int c = 0; c < 3; ++c) n[c] = s5r(t5[0][c], t5[1][c], t5[2][c], t5[3][c], t5[4][c], w0, w1, w2) * rs;
             }
+            if constexpr (PL) {   // the patch is all the payload phase wants
+                float* np = sN + it;
+                np[0] = n[0]; np[NPL1] = n[1]; np[2 * NPL1] = n[2];
+                continue;
+            }
             // gray of the pixel, its neighbours along the row by DPP, expanded columns 2j' (even) and 2j'+1 (odd)
             const float g = gray_of<true>(n[0], n[1], n[2]);
             // tile centre of G_{l+1} -> global (input of the next level; PAIR: its gray, and the pixel into the LDS patch)
@@ -968,7 +1058,7 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
                                                               (uint32_t)(mul24(i, wn) + j) << 2, 0, MI_SEP_NT_STORE ? 2 : 0);
                     st = st && keep3;
                 }
-                if (st) {
+                if ((!PAIR || keep3) && st) {   // (PAIR: keep3 is wave-uniform -- the whole block is skipped)
                     typedef uint32_t v3u __attribute__((ext_vector_type(3)));
                     const v3u pv = {__builtin_bit_cast(uint32_t, n[0]), __builtin_bit_cast(uint32_t, n[1]),
                                     __builtin_bit_cast(uint32_t, n[2])};
@@ -985,6 +1075,58 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
         MI_TICK(5);   // P2
         __syncthreads();
         MI_TICK(6);   // barrier 3
+
+        if constexpr (PL) {
+            // ---------------- PL: the Laplacians of the pixels this frame won, from the G_{l+1} patch.  (The next step's P2
+            // rewrites the patch two barriers from here.)
+            const int f = fid(b);
+            const TIn* gfr = (const TIn*)(src0 + (size_t)f * a.src_stride);
+            if (own_tile && (bI[0] == f || bI[1] == f || bI[2] == f || bI[3] == f)) {
+                const int qy3 = lt >> 5, ql3 = lt & 31;
+                float e[4][3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float* np = sN + c * NPL1 + mul24(qy3, G::NW) + ql3 - 1;   // G_{l+1} rows i-1 .. i+1, columns j-1 .. j+1
+                    float xe[3], xo[3];
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) {
+                        const float n0 = np[r * G::NW], n1 = np[r * G::NW + 1], n2 = np[r * G::NW + 2];
+                        xe[r] = ex_even(n0, n1, n2, ce, cc);
+                        xo[r] = ex_odd(n1, n2, co);
+                    }
+                    e[0][c] = ex_even(xe[0], xe[1], xe[2], ce, cc);
+                    e[1][c] = ex_even(xo[0], xo[1], xo[2], ce, cc);
+                    e[2][c] = ex_odd(xe[1], xe[2], co);
+                    e[3][c] = ex_odd(xo[1], xo[2], co);
+                }
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    if (bI[p] != f) continue;
+                    const size_t px = (size_t)(oy + (p >> 1)) * w + ox + (p & 1);
+                    float gv[3];
+                    load_px3(gfr + px * 3, gv);
+                    Px3 o;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) o.v[c] = (gv[c] - e[p][c]) + 0.0f;   // -0 -> +0 (pyramid.py:52-54)
+                    *(Px3*)(a.best_lap + px * 3) = o;
+                }
+            }
+            if (f1 == f) {   // (lanes below (TH / 2) * (TW / 2) only)
+                const int r1 = SmallDiv<TW / 2, NT>::div(lt), c1 = lt - r1 * (TW / 2);
+                const int i1 = y0 / 2 + r1, j1 = x0 / 2 + c1;
+                const float* g2f = a.g2 + (size_t)f * a.g2_stride;
+                const int hn2 = a.hn2, wn2 = a.wn2;
+                Px3 o;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float g1v = sN[c * NPL1 + mul24(r1 + 2, G::NW) + c1 + 2];
+                    const float ev = expand_sep_of([&](int r, int k) { return g2f[((size_t)r * wn2 + k) * 3 + c]; }, hn2, wn2, i1, j1, ce, cc, co);
+                    o.v[c] = (g1v - ev) + 0.0f;
+                }
+                *(Px3*)(a.lap1 + ((size_t)i1 * wn + j1) * 3) = o;
+            }
+            continue;
+        }
 
         // ---------------- P3: vertical expand of the gray, gray Laplacian, Q, row blur of Q -> HB
         if (lt < G::QY * G::QL && !MI_ABL(4)) {   // (uniform per wave)
@@ -1062,12 +1204,18 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
             if (lt >= V2L0 && lt < V2L0 + V2N) {
                 const int item = lt - V2L0, c = item / (N2H * (G::NW / 4)), rem = item - c * (N2H * (G::NW / 4));
                 const int m = rem / (G::NW / 4), ch = rem - m * (G::NW / 4);
-                const int mg = y0 / 4 + m, pr0 = y0 / 2 - 2;
                 v4f rr[5];
+                if (!e2) {   // (uniform) no row of the patch is mapped: rows 2m .. 2m + 4
+                    const float* p = sN + c * NPL1 + mul24(2 * m, G::NW) + 4 * ch;
 #pragma unroll
-                for (int t = 0; t < 5; ++t) {
-                    const int pr = clampi(r101(2 * mg - 2 + t, hn) - pr0, 0, G::NH - 1);   // (rows of G_{l+2} outside the image: anything)
-                    rr[t] = lds_load4(sN + c * NPL1 + mul24(pr, G::NW) + 4 * ch);
+                    for (int t = 0; t < 5; ++t) rr[t] = lds_load4(p + t * G::NW);
+                } else {
+                    const int mg = y0 / 4 + m, pr0 = y0 / 2 - 2;
+#pragma unroll
+                    for (int t = 0; t < 5; ++t) {
+                        const int pr = clampi(r101(2 * mg - 2 + t, hn) - pr0, 0, G::NH - 1);   // (rows of G_{l+2} outside the image: anything)
+                        rr[t] = lds_load4(sN + c * NPL1 + mul24(pr, G::NW) + 4 * ch);
+                    }
                 }
                 const v2f lo = s5r(rr[0].xy, rr[1].xy, rr[2].xy, rr[3].xy, rr[4].xy, w0, w1, w2);
                 const v2f hi = s5r(rr[0].zw, rr[1].zw, rr[2].zw, rr[3].zw, rr[4].zw, w0, w1, w2);
@@ -1105,17 +1253,29 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
             const int wv = lt >> 6, wl = lt & 63;
             if ((wv == 0 || wv == NT / 64 - 1) && wl < H2W && (wv == 0 ? wl : H2W + wl) < H2N) {
                 const int item = wv == 0 ? wl : H2W + wl, m = item / N2W, k = item - m * N2W;
-                const int mg = y0 / 4 + m, ng = x0 / 4 + k, pc0 = x0 / 2 - 2;
-                if (mg < a.hn2 && ng < a.wn2) {
+                const int mg = y0 / 4 + m, ng = x0 / 4 + k;
+                float o[3];
+                bool ok = true;
+                if (!e2) {   // (uniform) no column is mapped: columns 2k .. 2k + 4 of the V2 row, three 8-byte reads
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const float* vr = sV2 + (c * N2H + m) * G::NW + 2 * k;
+                        const v2f q0 = lds_load2s(vr), q1 = lds_load2s(vr + 2), q2 = lds_load2s(vr + 4);
+                        o[c] = s5r(q0.x, q0.y, q1.x, q1.y, q2.x, w0, w1, w2) * rs;
+                    }
+                } else {
+                    ok = mg < a.hn2 && ng < a.wn2;
+                    const int pc0 = x0 / 2 - 2;
                     int pc[5];
 #pragma unroll
                     for (int t = 0; t < 5; ++t) pc[t] = clampi(r101(2 * ng - 2 + t, wn) - pc0, 0, G::NW - 1);
-                    float o[3];
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
                         const float* vr = sV2 + (c * N2H + m) * G::NW;
                         o[c] = s5r(vr[pc[0]], vr[pc[1]], vr[pc[2]], vr[pc[3]], vr[pc[4]], w0, w1, w2) * rs;
                     }
+                }
+                if (ok) {
                     typedef uint32_t v3u __attribute__((ext_vector_type(3)));
                     const v3u pv = {__builtin_bit_cast(uint32_t, o[0]), __builtin_bit_cast(uint32_t, o[1]),
                                     __builtin_bit_cast(uint32_t, o[2])};
@@ -1136,6 +1296,7 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
 #endif
 
     // ---- write the running maxima back
+    if constexpr (PL) return;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const int y = oy + (p >> 1), x = ox + (p & 1);
@@ -1176,6 +1337,17 @@ __global__ __launch_bounds__(NT, INTERIOR && NT > 512 ? 7 : 1) void level_sep_co
 template <typename TIn, bool INTERIOR, int TH, int NT>
 __global__ __launch_bounds__(NT, INTERIOR ? (sizeof(TIn) <= 2 ? MI_SEP_INT_WAVES : 1) : MI_SEP_BD_WAVES) void level_sep_pair(LevelArgs a) {
     level_sep_body<TIn, INTERIOR, TH, NT, false, true>(a);
+}
+
+// the pair's payload pass, tile by tile (level_sep_body, "PL")
+template <typename TIn, bool INTERIOR, int TH, int NT>
+__global__ __launch_bounds__(NT, 1) void level_sep_pl(LevelArgs a) {
+    level_sep_body<TIn, INTERIOR, TH, NT, false, false, true>(a);
+}
+template <typename TIn, int TH, int NT>
+constexpr int sep_pl_lds_floats(bool interior) {
+    using G = SepGeom<TH, NT>;
+    return (interior ? G::lds_floats((int)sizeof(TIn), true) : G::LDS_FLOATS) + 3 * G::NH * G::NW + 16 + SEP_PL_MAXF;
 }
 
 // ================================================================================================
@@ -1474,15 +1646,6 @@ __global__ void sep_payload(const void* __restrict__ src, size_t src_stride, con
 // REFLECT101), hence the same bits.  Once per level and batch; the loads mostly hit L1 / L2 (neighbouring quads share windows
 // when they share the winner).
 
-template <typename TIn>
-__device__ __forceinline__ void load_px3(const TIn* p, float o[3]) {
-    if constexpr (sizeof(TIn) == 4) {
-        const Px3 v = *(const Px3*)p;
-        o[0] = v.v[0]; o[1] = v.v[1]; o[2] = v.v[2];
-    } else {
-        o[0] = to_f32(p[0]); o[1] = to_f32(p[1]); o[2] = to_f32(p[2]);
-    }
-}
 // G_{l+1}[i, j] (inside its image) of the frame at `g` (level l, h x w): one pixel, 25 loads
 template <typename TIn>
 __device__ __forceinline__ void reduce_px(const TIn* __restrict__ g, int h, int w, int i, int j, float w0, float w1, float w2,
@@ -1508,14 +1671,17 @@ __device__ __forceinline__ void reduce_px(const TIn* __restrict__ g, int h, int 
 // the winner's G_l (away from the image edges: its 9 x 9 window column by column, 81 pixel loads; else pixel by pixel).
 // Chunk partials are folded first, as sep_payload does.
 template <typename TIn>
-__global__ __launch_bounds__(256) void sep_payload_pair0(const void* __restrict__ src, size_t src_stride, int nframes, int h, int w,
+__global__ __launch_bounds__(256, 3) void sep_payload_pair0(const void* __restrict__ src, size_t src_stride, int nframes, int h, int w,
                                                          int hn, int wn, int32_t* __restrict__ best_idx, int frame_idx0,
                                                          float* __restrict__ best_lap, float k0, float k1, float k2, float w0,
                                                          float w1, float w2, float rs, float* __restrict__ best_e,
                                                          const float* __restrict__ part_e, const int32_t* __restrict__ part_idx,
-                                                         size_t part_stride, int nparts) {
+                                                         size_t part_stride, int nparts, const uint8_t* __restrict__ tile_flag,
+                                                         int tile_h, int tile_w) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y * blockDim.y + threadIdx.y;
     if (2 * i >= h || 2 * j >= w) return;
+    // behind the tile-by-tile pass (level_sep_pl): only the tiles it flagged
+    if (tile_flag && !tile_flag[((2 * i) / tile_h) * ((w + tile_w - 1) / tile_w) + (2 * j) / tile_w]) return;
     const float ce = 2.0f * k0, cc = 2.0f * k2, co = 2.0f * k1;
     int fr[4];
     bool any = false;
@@ -1570,8 +1736,17 @@ __global__ __launch_bounds__(256) void sep_payload_pair0(const void* __restrict_
                     for (int c = 0; c < 3; ++c)
                         N[r][q][c] = s5r(V[r][2 * q][c], V[r][2 * q + 1][c], V[r][2 * q + 2][c], V[r][2 * q + 3][c], V[r][2 * q + 4][c], w0, w1, w2) * rs;
         } else {
-            for (int r = 0; r < 3; ++r)
-                for (int q = 0; q < 3; ++q) reduce_px(g, h, w, ri[r], cj[q], w0, w1, w2, rs, N[r][q]);
+#pragma unroll 1
+            for (int rq = 0; rq < 9; ++rq) {   // (image edges only: kept rolled)
+                const int r = rq / 3, q = rq - 3 * r;
+                float o[3];
+                reduce_px(g, h, w, r == 0 ? ri[0] : r == 1 ? ri[1] : ri[2], q == 0 ? cj[0] : q == 1 ? cj[1] : cj[2], w0, w1, w2, rs, o);
+#pragma unroll
+                for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+                    for (int qq = 0; qq < 3; ++qq)
+                        if (rr == r && qq == q) { N[rr][qq][0] = o[0]; N[rr][qq][1] = o[1]; N[rr][qq][2] = o[2]; }
+            }
         }
         float e[4][3];
 #pragma unroll
@@ -1605,15 +1780,17 @@ __global__ __launch_bounds__(256) void sep_payload_pair0(const void* __restrict_
 // Second level of a pair (level l + 1 of h1 x w1 pixels; (h, w) = level l, the stored one): lap = G_{l+1} - expand(G_{l+2}) with
 // the winner's pixel of G_{l+1} recomputed from its G_l (`src`), G_{l+2} (`g2`, h2 x w2) as stored by the pair's first kernel.
 template <typename TIn>
-__global__ __launch_bounds__(256) void sep_payload_pair1(const void* __restrict__ src, size_t src_stride, const float* __restrict__ g2,
+__global__ __launch_bounds__(256, 4) void sep_payload_pair1(const void* __restrict__ src, size_t src_stride, const float* __restrict__ g2,
                                                          size_t g2_stride, int nframes, int h, int w, int h1, int w1, int h2, int w2,
                                                          int32_t* __restrict__ best_idx, int frame_idx0,
                                                          float* __restrict__ best_lap, float k0, float k1, float k2, float w0,
                                                          float w1r, float w2r, float rs, float* __restrict__ best_e,
                                                          const float* __restrict__ part_e, const int32_t* __restrict__ part_idx,
-                                                         size_t part_stride, int nparts) {
+                                                         size_t part_stride, int nparts, const uint8_t* __restrict__ tile_flag,
+                                                         int tile_h, int tile_w) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y * blockDim.y + threadIdx.y;
     if (2 * i >= h1 || 2 * j >= w1) return;
+    if (tile_flag && !tile_flag[((4 * i) / tile_h) * ((w + tile_w - 1) / tile_w) + (4 * j) / tile_w]) return;
     const float ce = 2.0f * k0, cc = 2.0f * k2, co = 2.0f * k1;
     int fr[4];
     bool any = false;
@@ -1640,6 +1817,7 @@ __global__ __launch_bounds__(256) void sep_payload_pair1(const void* __restrict_
     if (!any) return;
     const int ri[3] = {map_expand_src(i - 1, h2), i, map_expand_src(i + 1, h2)};
     const int cj[3] = {map_expand_src(j - 1, w2), j, map_expand_src(j + 1, w2)};
+    const bool inner = i >= 1 && j >= 1 && 4 * i + 4 < h && 4 * j + 4 < w && 2 * i + 1 < h1 && 2 * j + 1 < w1;
     unsigned pending = (fr[0] >= 0 ? 1u : 0u) | (fr[1] >= 0 ? 2u : 0u) | (fr[2] >= 0 ? 4u : 0u) | (fr[3] >= 0 ? 8u : 0u);
     while (pending) {
         const int f = (pending & 1u) ? fr[0] : (pending & 2u) ? fr[1] : (pending & 4u) ? fr[2] : fr[3];
@@ -1664,16 +1842,46 @@ __global__ __launch_bounds__(256) void sep_payload_pair1(const void* __restrict_
             e[2][c] = ex_odd(xe[1], xe[2], co);
             e[3][c] = ex_odd(xo[1], xo[2], co);
         }
+        if (inner && pending == 15u && fr[1] == f && fr[2] == f && fr[3] == f) {
+            // the whole quad has one winner: its 7 x 7 window of G_l column by column (49 pixel loads instead of 100)
+            pending = 0u;
+            float V[2][7][3];
+            const TIn* c0 = g + ((size_t)(4 * i - 2) * w + (4 * j - 2)) * 3;
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            if (!((pending >> p) & 1u) || fr[p] != f) continue;
+            for (int x = 0; x < 7; ++x) {
+                float p[7][3];
+#pragma unroll
+                for (int u = 0; u < 7; ++u) load_px3(c0 + ((size_t)u * w + x) * 3, p[u]);
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+                        V[r][x][c] = s5r(p[2 * r][c], p[2 * r + 1][c], p[2 * r + 2][c], p[2 * r + 3][c], p[2 * r + 4][c], w0, w1r, w2r);
+            }
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int r = p >> 1, q = p & 1;
+                Px3 o;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float gv = s5r(V[r][2 * q][c], V[r][2 * q + 1][c], V[r][2 * q + 2][c], V[r][2 * q + 3][c], V[r][2 * q + 4][c], w0, w1r, w2r) * rs;
+                    o.v[c] = (gv - e[p][c]) + 0.0f;
+                }
+                *(Px3*)(best_lap + ((size_t)(2 * i + r) * w1 + 2 * j + q) * 3) = o;
+            }
+            break;
+        }
+#pragma unroll 1
+        for (int p = 0; p < 4; ++p) {   // (mixed winners, image edges: kept rolled)
+            const int fp = p == 0 ? fr[0] : p == 1 ? fr[1] : p == 2 ? fr[2] : fr[3];
+            if (!((pending >> p) & 1u) || fp != f) continue;
             pending &= ~(1u << p);
             const int y = 2 * i + (p >> 1), x = 2 * j + (p & 1);
             float gv[3];
             reduce_px(g, h, w, y, x, w0, w1r, w2r, rs, gv);
             Px3 o;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) o.v[c] = (gv[c] - e[p][c]) + 0.0f;
+            for (int c = 0; c < 3; ++c) o.v[c] = (gv[c] - (p == 0 ? e[0][c] : p == 1 ? e[1][c] : p == 2 ? e[2][c] : e[3][c])) + 0.0f;
             *(Px3*)(best_lap + ((size_t)y * w1 + x) * 3) = o;
         }
     }
@@ -1705,16 +1913,6 @@ __global__ void reduce_sep_simple(const TIn* __restrict__ g, int h, int w, float
         for (int t = 0; t < 5; ++t) v[t] = sep_v(g, h, w, i, r101(2 * j - 2 + t, w), c, w0, w1, w2);
         out[((size_t)i * wo + j) * 3 + c] = s5r(v[0], v[1], v[2], v[3], v[4], w0, w1, w2) * rs;
     }
-}
-
-// expand_layer(N)[y, x] for an hs x ws source given as N(row, col) (indices already inside the source), (y, x)
-// inside the 2hs x 2ws grid: along the rows first, then down the rows
-template <typename F>
-__device__ __forceinline__ float expand_sep_of(F N, int hs, int ws, int y, int x, float ce, float cc, float co) {
-    const int i = y >> 1, j = x >> 1;
-    auto M = [&](int r, int q) { return N(map_expand_src(r, hs), map_expand_src(q, ws)); };
-    auto X = [&](int r) { return (x & 1) ? ex_odd(M(r, j), M(r, j + 1), co) : ex_even(M(r, j - 1), M(r, j), M(r, j + 1), ce, cc); };
-    return (y & 1) ? ex_odd(X(i), X(i + 1), co) : ex_even(X(i - 1), X(i), X(i + 1), ce, cc);
 }
 
 // Laplacian (the payload) and Q = (gray(G_l) - expand(gray(G_{l+1})))^2 (the energy path)

@@ -93,6 +93,11 @@ struct LevelArgs {
     size_t g2_stride;
     int hn2, wn2;
     int g1_keep;
+    // the pair's tile-by-tile payload pass (kernels_sep.hpp "PL"): best_idx / best_lap = the first level's, idx1 / lap1 = the
+    // second level's; tile_flag[tile] = 1: more distinct winners than the pass walks -- left to the per-quad kernels
+    const int32_t* idx1;
+    float* lap1;
+    uint8_t* tile_flag;
 };
 
 // reduce item of lane `tid` for the 32x64 / 512-thread tile with GS = 236 (generated by the search in

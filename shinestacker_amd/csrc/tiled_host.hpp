@@ -35,6 +35,7 @@ struct TiledState {
     // gray(G_1) -- one float per pixel -- in Gb[set][1] and the three-channel G_1 of its LAST frame in G1keep[set] (the tap)
     float* G1keep[2] = {nullptr, nullptr};
     bool last_pair = false;         // the most recent batch ran as a pair
+    uint8_t* tileFlag = nullptr;    // [level-0 tile] the pair's tile-by-tile payload pass left this tile to the per-quad kernels
     void* ring = nullptr;           // staging ring for host-pushed frames (bcap frames, in_dtype)
     size_t frame_bytes = 0;
     int pending = 0;                // frames staged in the ring, not yet processed
@@ -449,7 +450,9 @@ int launch_level(mi_stack* s, int l, int set, const void* src, size_t src_stride
 // (optional): recorded on st_in and waited for on st_bd in front of a border launch (everything st_in has done so far).
 // `PM` (level pairs, kernels_sep.hpp "PAIR"): 0 = a level on its own; 1 = the first level of a pair (level_sep_pair: writes
 // gray(G_{l+1}) into Gb[set][l+1] -- one float per pixel --, G_{l+2} into Gb[set][l+2] and the three-channel G_{l+1} of the
-// batch's last frame into G1keep[set]); 2 = the second level of a pair (level_sep_e: `src` = that gray, reads G_{l+1}).
+// batch's last frame into G1keep[set]); 2 = the second level of a pair (level_sep_e: `src` = that gray, reads G_{l+1});
+// 3 = the pair's payload pass tile by tile (level_sep_pl, one launch over the whole batch: fills bestLap[l] and bestLap[l+1]
+// of the tiles with few distinct winners, flags the others in tileFlag).
 struct SepLevelInfo { int nparts = 0; bool border = false; };
 template <typename TIn, bool L0_NAME, bool MF = false, int PM = 0>
 int launch_level_sep(mi_stack* s, int l, int set, const void* src, size_t src_stride, int nb, hipStream_t st_in,
@@ -474,7 +477,7 @@ int launch_level_sep(mi_stack* s, int l, int set, const void* src, size_t src_st
     a.wn = s->lw[l + 1];
     a.g1_keep = -1;
     const size_t gray_stride = (size_t)a.hn * a.wn;
-    if constexpr (PM == 1) {
+    if constexpr (PM == 1 || PM == 3) {
         static_assert(!MF, "the matrix-pipe reduce has no pair form");
         if (l != 0 || l + 2 > s->L) return fail(MI_ERR_INVALID, "level pair at level %d of %d", l, s->L);
         a.gnext = t->G1keep[set];
@@ -483,6 +486,12 @@ int launch_level_sep(mi_stack* s, int l, int set, const void* src, size_t src_st
         a.g2_stride = t->gstride[l + 2];
         a.hn2 = s->lh[l + 2];
         a.wn2 = s->lw[l + 2];
+    }
+    if constexpr (PM == 3) {
+        a.g2 = t->Gb[set][l + 2];
+        a.idx1 = s->bestIdx[l + 1];
+        a.lap1 = s->bestLap[l + 1];
+        a.tile_flag = t->tileFlag;
     }
     // The "interior" launch covers every tile whose staged patch may be mirrored into place (kernels_sep.hpp, edge tiles):
     // all of the grid, except the tile rows / columns that reach an ODD far edge (those stay with the border kernel), and
@@ -535,12 +544,15 @@ int launch_level_sep(mi_stack* s, int l, int set, const void* src, size_t src_st
         a.dbg = dbg_dev;
     } else a.dbg = nullptr;
 #endif
-    const size_t lds = (size_t)(PM == 2 ? sep_e_lds_floats<TH, NT>() : SG::LDS_FLOATS + (PM == 1 ? 3 * SG::NH * SG::NW : 0)) * sizeof(float);   // border tiles
-    const size_t lds_in = (size_t)(PM == 2 ? sep_e_lds_floats<TH, NT>() : MF ? SG::lds_floats_mf((int)sizeof(TIn)) : SG::lds_floats((int)sizeof(TIn), true)) * sizeof(float);   // interior tiles
+    const size_t lds = (size_t)(PM == 3 ? sep_pl_lds_floats<TIn, TH, NT>(false) : PM == 2 ? sep_e_lds_floats<TH, NT>()
+                                        : SG::LDS_FLOATS + (PM == 1 ? 3 * SG::NH * SG::NW : 0)) * sizeof(float);   // border tiles
+    const size_t lds_in = (size_t)(PM == 3 ? sep_pl_lds_floats<TIn, TH, NT>(true) : PM == 2 ? sep_e_lds_floats<TH, NT>()
+                                           : MF ? SG::lds_floats_mf((int)sizeof(TIn)) : SG::lds_floats((int)sizeof(TIn), true)) * sizeof(float);   // interior tiles
     void (*kin)(LevelArgs);
     void (*kbd)(LevelArgs);
     if constexpr (PM == 1) { kin = level_sep_pair<TIn, true, TH, NT>; kbd = level_sep_pair<TIn, false, TH, NT>; }
     else if constexpr (PM == 2) { kin = level_sep_e<true, TH, NT>; kbd = level_sep_e<false, TH, NT>; }
+    else if constexpr (PM == 3) { kin = level_sep_pl<TIn, true, TH, NT>; kbd = level_sep_pl<TIn, false, TH, NT>; }
     else {
         if constexpr (MF) kin = level_sep_mf<TIn, TH, NT>;
         else kin = L0_NAME ? level_sep<TIn, true, TH, NT> : level_sep_coarse<TIn, true, TH, NT>;
@@ -552,12 +564,13 @@ int launch_level_sep(mi_stack* s, int l, int set, const void* src, size_t src_st
         if ((rc = set_lds_once(kin, lds_in)) || (rc = set_lds_once(kbd, lds))) return rc;
         attr_set = true;
     }
-    const double bytes = ((double)(l == 0 ? dtype_size(s->p.in_dtype) : 4) * 3.0 * a.h * a.w + 24.0 * a.hn * a.wn) * nb;
+    const double bytes = PM == 3 ? 0.0 : ((double)(l == 0 ? dtype_size(s->p.in_dtype) : 4) * 3.0 * a.h * a.w + 24.0 * a.hn * a.wn) * nb;
     const double frac_in = (double)(std::min(a.iy1, a.h) - a.iy0) * (std::min(a.ix1, a.w) - a.ix0) / ((double)a.h * a.w);
     const int ntiles = cdiv(a.w, TW) * cdiv(a.h, TH);
     const size_t npx = (size_t)a.h * a.w;
     bool parallel = false;
-    const int fc = level_chunk_frames(nb, ntiles, &parallel);
+    int fc = level_chunk_frames(nb, ntiles, &parallel);
+    if (PM == 3) { parallel = false; fc = nb; }   // the payload pass: one launch, the workgroup picks its frames itself
     const int nchunks = parallel ? cdiv(nb, fc) : 1;
     if (nchunks > 1) {
         const size_t need = npx * (size_t)(nchunks - 1);
@@ -597,7 +610,8 @@ int launch_level_sep(mi_stack* s, int l, int set, const void* src, size_t src_st
 #ifdef MI_STUDY_SAME_FRAME
         if (l == 0) a.src = src;
 #endif
-        if constexpr (PM == 1) {
+        if constexpr (PM == 3) {
+        } else if constexpr (PM == 1) {
             a.gray1 = t->Gb[set][l + 1] + (size_t)f0 * gray_stride;
             a.g2 = t->Gb[set][l + 2] + (size_t)f0 * a.g2_stride;
             a.g1_keep = nb - 1 >= f0 && nb - 1 < f0 + nf ? nb - 1 - f0 : -1;   // the batch's last frame, if this launch holds it
@@ -623,7 +637,7 @@ int launch_level_sep(mi_stack* s, int l, int set, const void* src, size_t src_st
         }
     }
     if (nyi > 0) {
-        ProfScope ps(s, l == 0 ? MI_PROF_LEVEL0 : MI_PROF_LEVEL, bytes * frac_in * part, st_in);
+        ProfScope ps(s, l == 0 && PM != 3 ? MI_PROF_LEVEL0 : MI_PROF_LEVEL, bytes * frac_in * part, st_in);
         ps.r.launches = nlaunch;
         for (int f0 = f_begin; f0 < f_end; f0 += step) {
             frames_of(f0);
@@ -658,7 +672,8 @@ int launch_payload_sep(mi_stack* s, int l, int set, const void* src, size_t src_
 
 // Level pair (0, 1): the payload passes that recompute the winners' G_1 from the frames (sep_payload_pair0 / 1)
 template <typename TIn>
-int launch_payload_pair0(mi_stack* s, int set, const void* src, size_t src_stride, int nb, hipStream_t st, int nparts) {
+int launch_payload_pair0(mi_stack* s, int set, const void* src, size_t src_stride, int nb, hipStream_t st, int nparts,
+                         const uint8_t* tile_flag = nullptr) {
     TiledState* t = tstate(s);
     const dim3 blk(32, 8);
     const dim3 grd(cdiv(cdiv(s->lw[0], 2), blk.x), cdiv(cdiv(s->lh[0], 2), blk.y));
@@ -666,11 +681,13 @@ int launch_payload_pair0(mi_stack* s, int set, const void* src, size_t src_strid
     hipLaunchKernelGGL((sep_payload_pair0<TIn>), grd, blk, 0, st, src, src_stride, nb, s->lh[0], s->lw[0], s->lh[1], s->lw[1],
                        s->bestIdx[0], s->first_index + s->n_pushed, s->bestLap[0], s->k1d[0], s->k1d[1], s->k1d[2], s->rk[0],
                        s->rk[1], s->rk[2], s->rk[3], s->bestE[0], (const float*)(nparts > 0 ? t->partE[0] : nullptr),
-                       (const int32_t*)(nparts > 0 ? t->partI[0] : nullptr), (size_t)s->lh[0] * s->lw[0], nparts);
+                       (const int32_t*)(nparts > 0 ? t->partI[0] : nullptr), (size_t)s->lh[0] * s->lw[0], nparts, tile_flag,
+                       MI_SEP_TH, 56);
     return MI_OK;
 }
 template <typename TIn>
-int launch_payload_pair1(mi_stack* s, int set, const void* src, size_t src_stride, int nb, hipStream_t st, int nparts) {
+int launch_payload_pair1(mi_stack* s, int set, const void* src, size_t src_stride, int nb, hipStream_t st, int nparts,
+                         const uint8_t* tile_flag = nullptr) {
     TiledState* t = tstate(s);
     const dim3 blk(32, 8);
     const dim3 grd(cdiv(cdiv(s->lw[1], 2), blk.x), cdiv(cdiv(s->lh[1], 2), blk.y));
@@ -679,8 +696,23 @@ int launch_payload_pair1(mi_stack* s, int set, const void* src, size_t src_strid
                        s->lh[0], s->lw[0], s->lh[1], s->lw[1], s->lh[2], s->lw[2], s->bestIdx[1], s->first_index + s->n_pushed,
                        s->bestLap[1], s->k1d[0], s->k1d[1], s->k1d[2], s->rk[0], s->rk[1], s->rk[2], s->rk[3], s->bestE[1],
                        (const float*)(nparts > 0 ? t->partE[1] : nullptr), (const int32_t*)(nparts > 0 ? t->partI[1] : nullptr),
-                       (size_t)s->lh[1] * s->lw[1], nparts);
+                       (size_t)s->lh[1] * s->lw[1], nparts, tile_flag, MI_SEP_TH, 56);
     return MI_OK;
+}
+// The pair's payload, tile by tile (level_sep_pl) + the per-quad kernels on the tiles it flags: levels 0 and 1 at once, behind
+// both levels' energy passes.  Needs unchunked levels (the per-quad kernels alone fold chunk partials) and frame numbers
+// that fit the 256-bit winner map.
+inline bool sep_pair_tile_payload(int nb, int nparts0, int nparts1) { return nparts0 == 0 && nparts1 == 0 && nb <= 256; }
+template <typename TIn>
+int launch_payload_pair_tiles(mi_stack* s, int set, const void* src, size_t src_stride, int nb, hipStream_t st) {
+    TiledState* t = tstate(s);
+    const size_t ntiles = (size_t)cdiv(s->lw[0], 56) * cdiv(s->lh[0], MI_SEP_TH);
+    int rc;
+    if (!t->tileFlag && (rc = dev_alloc_t(s, &t->tileFlag, ntiles))) return rc;
+    MI_HIP(hipMemsetAsync(t->tileFlag, 0, ntiles, st));
+    if ((rc = launch_level_sep<TIn, false, false, 3>(s, 0, set, src, src_stride, nb, st, st, nullptr))) return rc;
+    if ((rc = launch_payload_pair0<TIn>(s, set, src, src_stride, nb, st, 0, t->tileFlag))) return rc;
+    return launch_payload_pair1<TIn>(s, set, src, src_stride, nb, st, 0, t->tileFlag);
 }
 // Does a batch of `nb` frames run its levels 0 and 1 as a pair?  mi_stack_params.pair_levels: 1 = always, 2 = never, 0 = when
 // the batch is long enough for the saved traffic (G_1: 3 + 3.6 of the 24 bytes per pixel and frame) to outweigh the
@@ -773,11 +805,16 @@ int run_batch(mi_stack* s, const void* frames, size_t stride, int nb) {
     MI_HIP(hipStreamWaitEvent(st2, t->evL0i[set], 0));
     MI_HIP(hipStreamWaitEvent(st2, t->evL0b[set], 0));
     MI_HIP(hipStreamWaitEvent(st1, t->evL0i[set], 0));
-    if ((rc = pair ? launch_payload_pair0<TIn>(s, set, frames, stride, nb, st2, li0.nparts)
-             : s->sep ? launch_payload_sep<TIn>(s, 0, set, frames, stride, nb, st2, li0.nparts)
-                      : launch_payload_exact<TIn, FMA>(s, 0, set, frames, stride, nb, st2)))
-        return rc;
-    MI_HIP(hipEventRecord(t->evL0done[set], st2));   // st2 waited for both level-0 kernels above
+    // a pair whose levels both run unchunked fills in the Laplacians of levels 0 and 1 in one tile-by-tile pass behind level
+    // 1's energy pass (below); level 0's state is final only then
+    bool tile_payload = pair && li0.nparts == 0 && nb <= 256;
+    if (!tile_payload) {
+        if ((rc = pair ? launch_payload_pair0<TIn>(s, set, frames, stride, nb, st2, li0.nparts)
+                 : s->sep ? launch_payload_sep<TIn>(s, 0, set, frames, stride, nb, st2, li0.nparts)
+                          : launch_payload_exact<TIn, FMA>(s, 0, set, frames, stride, nb, st2)))
+            return rc;
+        MI_HIP(hipEventRecord(t->evL0done[set], st2));   // st2 waited for both level-0 kernels above
+    }
     // coarser levels: interior tiles on st2, border tiles on st1 (disjoint tiles of one level run
     // side by side); both streams join after every level because level l+1 reads all of G_{l+1}
     static const int only_l0 = study_env("MI_ONLY_L0", 0);   // -DMI_STUDY: level 0 alone on the GPU (results are wrong)
@@ -798,7 +835,16 @@ int run_batch(mi_stack* s, const void* frames, size_t stride, int nb) {
                 MI_HIP(hipEventRecord(eb, st1));
                 MI_HIP(hipStreamWaitEvent(st2, eb, 0));
             }
-            if ((rc = launch_payload_pair1<TIn>(s, set, frames, stride, nb, st2, li.nparts))) return rc;
+            if (tile_payload && li.nparts == 0) {
+                if ((rc = launch_payload_pair_tiles<TIn>(s, set, frames, stride, nb, st2))) return rc;
+                MI_HIP(hipEventRecord(t->evL0done[set], st2));
+            } else {
+                if (tile_payload) {   // (level 1 ran in chunks after all: level 0's payload on its own, late)
+                    if ((rc = launch_payload_pair0<TIn>(s, set, frames, stride, nb, st2, 0))) return rc;
+                    MI_HIP(hipEventRecord(t->evL0done[set], st2));
+                }
+                if ((rc = launch_payload_pair1<TIn>(s, set, frames, stride, nb, st2, li.nparts))) return rc;
+            }
             continue;
         }
         if (s->sep && !(il && l == 1)) {

@@ -129,3 +129,29 @@ def test_pair_needs_two_levels(L, oracle):
     st.close()
     with pytest.raises(Exception):
         L.Stack(h, w, in_dtype=np.uint8, arith="separable", pair_levels=3)
+
+
+@pytest.mark.parametrize("kind", ["coherent", "noise", "mixed"])
+def test_pair_tile_payload(L, oracle, kind):
+    """frames large enough for levels 0 AND 1 to run unchunked (> 1536 tiles each): the pair's payload is the tile-by-tile pass
+    (level_sep_pl) -- `coherent`: few winners per tile, no tile is flagged; `noise`: 36 frames of noise, every tile has more
+    than 32 winners and goes to the per-quad kernels; `mixed`: both kinds of tile in one image"""
+    h, w, n = 2912, 3472, 36
+    rng = np.random.default_rng(11)
+    if kind == "noise":
+        frames = [rng.integers(0, 256, (h, w, 3)).astype(np.uint8) for _ in range(n)]
+    else:
+        frames = [oracle.synth_frame_numpy(h, w, f, n) for f in range(n)]
+        if kind == "mixed":
+            for f in frames:
+                f[:, : w // 2] = rng.integers(0, 256, (h, w // 2, 3)).astype(np.uint8)
+    so, gs = run_oracle(oracle, frames)
+    fb = h * w * 3
+    buf = L.DeviceBuffer(fb * n)
+    for i, f in enumerate(frames):
+        buf.upload(f, i * fb)
+    st = L.Stack(h, w, in_dtype=np.uint8, arith="separable", pair_levels=1)
+    st.push_frames_device(buf.ptr, n)
+    compare(L, st, so, gs[-1])
+    st.close()
+    buf.free()
