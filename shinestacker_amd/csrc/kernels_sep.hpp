@@ -489,7 +489,11 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
     constexpr bool PL = PL_;
     static_assert(!PL || (!PAIR && !MF_ && !DMA), "PL geometry");
     constexpr int N2H = TH / 4, N2W = TW / 4, NPL1 = G::NH * G::NW;   // G_{l+2} pixels of the tile; floats per plane of sN
-    constexpr bool GQ1 = DMA || (PAIR && INTERIOR);   // gray of the lane's quad of G_l taken in P1 (registers)
+    // fp32 interior tiles: the G_{l+1} patch goes where the staged G_l patch was, whose last reader -- the gray of the lane's quad
+    // of G_l -- moves from P3 to P1 (registers).  8 / 16-bit tiles keep that gray in P3 (their P1 runs on half the waves: it is
+    // the critical path of its phase) and give the patch its own LDS (8-bit: 34.4 KB, still four workgroups per CU).
+    constexpr bool SN_ALIAS = PAIR && INTERIOR && sizeof(TIn) == 4;
+    constexpr bool GQ1 = DMA || SN_ALIAS;   // gray of the lane's quad of G_l taken in P1 (registers)
     constexpr int RD = (int)sizeof(TIn);                 // dwords per 4-element chunk in that form
     // MF: the reduce of 8 / 16-bit frames on the matrix pipe.  P1 + P2 become one phase: wave v computes the G_{l+1} patch
     // rows 2v, 2v + 1 (16 rows = 8 waves) with five v_mfma_i32_16x16x64_i8 per byte plane -- one per tap row -- whose DATA
@@ -511,8 +515,9 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
     float* sHB = MF ? sX + G::NH * G::XS : sV;         // (not MF: V is dead once P2 has read it)
     uint32_t* sW = reinterpret_cast<uint32_t*>(sHB + G::HBH * G::HBS);   // MF: weight operands, [3][64] x 16 bytes
     // PAIR: G_{l+1} patch, [3][NH][NW] (interior tiles: over the dead G_l patch; border tiles and PL: their own array)
-    float* sN = (INTERIOR && !PL) ? smem : smem + (INTERIOR ? G::lds_floats((int)sizeof(TIn), true) : G::LDS_FLOATS);
-    uint32_t* sFL = reinterpret_cast<uint32_t*>(sN + 3 * G::NH * G::NW);   // PL: [0..7] winner bit map, [8] count, [16..] frame list
+    float* sN = (SN_ALIAS || (PL && INTERIOR)) ? smem : smem + (INTERIOR ? G::lds_floats((int)sizeof(TIn), true) : G::LDS_FLOATS);
+    // PL: [0..7] winner bit map, [8] count, [16..] frame list -- behind everything else (interior tiles: the patch is over G_l's)
+    uint32_t* sFL = reinterpret_cast<uint32_t*>(smem + (INTERIOR ? G::lds_floats((int)sizeof(TIn), true) : G::LDS_FLOATS + 3 * G::NH * G::NW));
     float* sV2 = sV + G::HBH * G::HBS;                   // PAIR: column sums of the G_{l+2} reduce, [3][N2H][NW] (V's tail)
     static_assert(!PAIR || G::HBH * G::HBS + 3 * N2H * G::NW <= G::NH * G::VS, "V2 fits behind HB");
     const int tid = threadIdx.x;
@@ -1077,8 +1082,7 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
         MI_TICK(6);   // barrier 3
 
         if constexpr (PL) {
-            // ---------------- PL: the Laplacians of the pixels this frame won, from the G_{l+1} patch.  (The next step's P2
-            // rewrites the patch two barriers from here.)
+            // ---------------- PL: the Laplacians of the pixels this frame won, from the G_{l+1} patch
             const int f = fid(b);
             const TIn* gfr = (const TIn*)(src0 + (size_t)f * a.src_stride);
             if (own_tile && (bI[0] == f || bI[1] == f || bI[2] == f || bI[3] == f)) {
@@ -1125,6 +1129,7 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
                 }
                 *(Px3*)(a.lap1 + ((size_t)i1 * wn + j1) * 3) = o;
             }
+            if constexpr (INTERIOR) __syncthreads();   // the patch lies over G_l's: the next step's staging must not overtake these reads
             continue;
         }
 
@@ -1347,7 +1352,7 @@ __global__ __launch_bounds__(NT, 1) void level_sep_pl(LevelArgs a) {
 template <typename TIn, int TH, int NT>
 constexpr int sep_pl_lds_floats(bool interior) {
     using G = SepGeom<TH, NT>;
-    return (interior ? G::lds_floats((int)sizeof(TIn), true) : G::LDS_FLOATS) + 3 * G::NH * G::NW + 16 + SEP_PL_MAXF;
+    return (interior ? G::lds_floats((int)sizeof(TIn), true) : G::LDS_FLOATS + 3 * G::NH * G::NW) + 16 + SEP_PL_MAXF;
 }
 
 // ================================================================================================

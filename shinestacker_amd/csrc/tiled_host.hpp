@@ -547,7 +547,8 @@ int launch_level_sep(mi_stack* s, int l, int set, const void* src, size_t src_st
     const size_t lds = (size_t)(PM == 3 ? sep_pl_lds_floats<TIn, TH, NT>(false) : PM == 2 ? sep_e_lds_floats<TH, NT>()
                                         : SG::LDS_FLOATS + (PM == 1 ? 3 * SG::NH * SG::NW : 0)) * sizeof(float);   // border tiles
     const size_t lds_in = (size_t)(PM == 3 ? sep_pl_lds_floats<TIn, TH, NT>(true) : PM == 2 ? sep_e_lds_floats<TH, NT>()
-                                           : MF ? SG::lds_floats_mf((int)sizeof(TIn)) : SG::lds_floats((int)sizeof(TIn), true)) * sizeof(float);   // interior tiles
+                                           : MF ? SG::lds_floats_mf((int)sizeof(TIn))
+                                                : SG::lds_floats((int)sizeof(TIn), true) + (PM == 1 && sizeof(TIn) <= 2 ? 3 * SG::NH * SG::NW : 0)) * sizeof(float);   // interior tiles
     void (*kin)(LevelArgs);
     void (*kbd)(LevelArgs);
     if constexpr (PM == 1) { kin = level_sep_pair<TIn, true, TH, NT>; kbd = level_sep_pair<TIn, false, TH, NT>; }
@@ -714,14 +715,16 @@ int launch_payload_pair_tiles(mi_stack* s, int set, const void* src, size_t src_
     if ((rc = launch_payload_pair0<TIn>(s, set, src, src_stride, nb, st, 0, t->tileFlag))) return rc;
     return launch_payload_pair1<TIn>(s, set, src, src_stride, nb, st, 0, t->tileFlag);
 }
-// Does a batch of `nb` frames run its levels 0 and 1 as a pair?  mi_stack_params.pair_levels: 1 = always, 2 = never, 0 = when
-// the batch is long enough for the saved traffic (G_1: 3 + 3.6 of the 24 bytes per pixel and frame) to outweigh the
-// once-per-batch recomputation in the payload passes, whose gathers are three times wider where neighbouring pixels
-// have different winners.
-constexpr int SEP_PAIR_MIN_FRAMES = 32;
+// Does a batch of `nb` frames run its levels 0 and 1 as a pair?  mi_stack_params.pair_levels: 1 = always, 2 = never, 0 = when it
+// measured faster: float-32 frames (level 0's kernel is bound by memory AND issue, the times add: 30 MB less per frame against
+// the G_2 reduce it takes on -- +0.07 ms per launch of 16 frames; the 8- and 16-bit kernels are issue-bound: +0.17 ms, more than
+// level 1's pass saves) in batches long enough for the once-per-batch recomputation in the payload pass (about 1.2 ms more
+// than the passes that read a stored G_1, at 24 MP) to be small beside the 2.9 ms per 256 frames level 1 gets faster by.
+// Interleaved A/B on one box, 256 x 24 MP: float-32 +1.5 to +3 %, 8-bit -3 %, 16-bit -8 % (profiles/r06/pair_ab.txt).
+constexpr int SEP_PAIR_MIN_FRAMES = 64;
 inline bool sep_use_pair(const mi_stack* s, int nb) {
     if (!s->sep || s->L < 2 || s->p.pair_levels == 2) return false;
-    return s->p.pair_levels == 1 || nb >= SEP_PAIR_MIN_FRAMES;
+    return s->p.pair_levels == 1 || (s->p.in_dtype == MI_F32 && nb >= SEP_PAIR_MIN_FRAMES);
 }
 
 // MI_ARITH_EXACT: the same for the reference-order arithmetic (exact_payload, kernels_tiled.hpp)
