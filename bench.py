@@ -561,7 +561,7 @@ def main():
             ent = tj.get(args.arith, {})
             if ent.get("source_sha") != kernel_source_sha():
                 traffic_note = (f"profiles/traffic.json[{args.arith}] was measured on kernel sources {ent.get('source_sha')}, "
-                                f"these are {kernel_source_sha()}: re-run tools/profile_r04.sh")
+                                f"these are {kernel_source_sha()}: re-run tools/profile_r06.sh (its last step writes profiles/traffic.json)")
             elif ent.get("dtype", "f32") != args.dtype or ent.get("frames_per_launch") is None:
                 traffic_note = f"profiles/traffic.json[{args.arith}] is for dtype {ent.get('dtype')}, this run is {args.dtype}"
             else:

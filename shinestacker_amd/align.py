@@ -192,9 +192,21 @@ def have_opencv():
         return False
 
 
+_auto_fallback_logged = False
+
+
 def auto_estimator(device=0):
-    """`estimator="auto"`: the reference's own recipe when OpenCV is importable, the GPU ECC estimator otherwise."""
-    return opencv_estimator if have_opencv() else ecc_estimator(device=device)
+    """`estimator="auto"`: the reference's own recipe when OpenCV is importable, the GPU ECC estimator otherwise -- a different
+    algorithm (the reference matches SIFT features and fits with RANSAC, align.py:90-151), so the swap is logged, once."""
+    global _auto_fallback_logged
+    if have_opencv():
+        return opencv_estimator
+    if not _auto_fallback_logged:
+        _auto_fallback_logged = True
+        logging.getLogger("shinestacker_amd").warning(
+            "estimator='auto': OpenCV (cv2) is not importable, the reference's detector / matcher / RANSAC recipe "
+            "(align.py:90-151) cannot run; frames are registered with the GPU ECC estimator instead (estimator='ecc')")
+    return ecc_estimator(device=device)
 
 
 def resolve_estimator(estimator, device=0):
@@ -238,7 +250,11 @@ def ecc_estimator(min_correlation=0.5, max_iters=60, device=0, phase_init=False)
                         m, cc = ms[0], float(ccs[0])
                     else:
                         m, cc, _iters = al.estimate(buf.ptr + ref.nbytes, max_iters=max_iters)
-                except (DeviceError, ValueError):   # no overlap / constant image, in either motion model: "no matches"
+                except DeviceError as e:
+                    # the estimator's own documented failure (cc == -2: no overlap / constant image / degenerate transform, in
+                    # either motion model) means "no matches"; anything else -- a HIP fault, a bad handle -- is not an alignment result
+                    if not str(e).startswith("ECC:"):
+                        raise
                     return 0, None
             finally:
                 if al is not None:

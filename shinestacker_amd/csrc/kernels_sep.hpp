@@ -21,9 +21,10 @@
 //            (pyramid.py:49-50); the three-channel Laplacian is only needed for the winning frame of a pixel
 //            and is filled in once per batch (sep_payload)
 //
-// This is NOT bit-identical to the exact-order mode (kernels_tiled.hpp, the drop-in default): coefficients agree
-// with a float64 evaluation within the forward-error bound of a 25-term float32 dot product, and the per-pixel
-// arg-max can flip at near ties.  oracle/pyramid_oracle.c restates this arithmetic operation by operation
+// This is NOT bit-identical to the exact-order mode (kernels_tiled.hpp: the C library's default and the audit mode
+// `arith="exact"`; THIS arithmetic is what the Python entry points -- PyramidStack() and pipeline.py -- run by default):
+// coefficients agree with a float64 evaluation within the forward-error bound of a 25-term float32 dot product, and the
+// per-pixel arg-max can flip at near ties.  oracle/separable_oracle.c restates this arithmetic operation by operation
 // (bit-exact parity target of this file); tests/test_sep_tolerance.py holds the tolerance against float64.
 //
 // Workgroup = 512 threads, tile 28 x 56 pixels of level l; per frame, four barrier phases:

@@ -46,7 +46,8 @@ constants = SimpleNamespace(
 def resolve_arith(arith=None, float_type=None):
     """The evaluation order a stack runs with: the caller's choice, else constants.DEFAULT_PY_ARITH ("exact" for float-64
     stacks, which the separable kernels do not serve)."""
-    f64 = float_type in (constants.FLOAT_64, "float64") or getattr(float_type, "__name__", None) == "float64"
+    f64 = (float_type in (constants.FLOAT_64, "float64") or getattr(float_type, "__name__", None) == "float64"
+           or (isinstance(float_type, int) and not isinstance(float_type, bool) and float_type == 3))   # 3 = _lib.MI_F64, Stack's code
     if arith is None:
         return "exact" if f64 else constants.DEFAULT_PY_ARITH
     return arith

@@ -49,7 +49,7 @@ def align_and_stack(frames, ref_idx=-1, estimator=None, alignment_config=None, f
     dt = ref.dtype
     fb = h * w * 3 * dt.itemsize
     lib = _lib.load()
-    stack_kwargs["arith"] = resolve_arith(stack_kwargs.get("arith"))   # one default for every entry point
+    stack_kwargs["arith"] = resolve_arith(stack_kwargs.get("arith"), stack_kwargs.get("float_type"))   # one default for every entry point
     stack = _lib.Stack(h, w, in_dtype=dt, out_dtype=dt, device=device, batch_frames=batch_frames,
                        **stack_kwargs)
     src = _lib.DeviceBuffer(fb, device)            # uploaded moving frame
@@ -308,7 +308,7 @@ def align_and_stack_device(dev_frames, n_frames, height, width, dtype, ref_idx=-
 
     Returns (fused image as ndarray, or None when `out_dev` -- a device address for the result --
     is given; list of 2x3 transforms, None at ref_idx; list of correlation coefficients)."""
-    stack_kwargs["arith"] = resolve_arith(stack_kwargs.get("arith"))   # one default for every entry point
+    stack_kwargs["arith"] = resolve_arith(stack_kwargs.get("arith"), stack_kwargs.get("float_type"))   # one default for every entry point
     _lib.require_device()
     if n_frames < 1:
         raise ValueError("no frames")
@@ -544,7 +544,7 @@ def bunches_then_stack(get_frame, n_frames, height, width, dtype, frames=constan
     on the device) and `stage2_s` (the stack over the bunch results, to its result).  Returns the fused image (or None when `out_dev` is given) and the list of
     bunches (frame indices)."""
     from .actions import get_bunches
-    stack_kwargs["arith"] = resolve_arith(stack_kwargs.get("arith"))   # one default for every entry point
+    stack_kwargs["arith"] = resolve_arith(stack_kwargs.get("arith"), stack_kwargs.get("float_type"))   # one default for every entry point
     _lib.require_device()
     if overlap >= frames:
         raise InvalidOptionError("overlap", overlap, "overlap must be smaller than batch size")

@@ -409,3 +409,38 @@ def test_chain_refinement_guard_measures_the_displacement_at_the_corners():
     assert abs(pipeline._corner_shift(eye, rot, h, w) - 1e-3 * (w - 1)) < 1e-9
     assert pipeline.CHAIN_REFINE_MAX_SHIFT == 2.0
     assert inspect.signature(pipeline.align_and_stack_device).parameters["chain_refine"].default is True
+
+
+def test_default_arith_follows_the_float_type_in_every_spelling(caplog):
+    """defaults.resolve_arith: float-64 stacks run the exact order (the separable kernels are float-32) whichever way the caller
+    names the type -- the reference's constant, NumPy's type, or the C code `_lib.Stack` takes (MI_F64) -- and the entry points of
+    pipeline.py hand it the caller's float_type (round-5 advice: they passed none, so MI_F64 + no arith asked for 'separable'
+    and mi_stack_create refused)."""
+    import inspect
+    from shinestacker_amd import _lib, constants, pipeline
+    from shinestacker_amd.defaults import resolve_arith
+    assert resolve_arith() == constants.DEFAULT_PY_ARITH == "separable"
+    for ft in (constants.FLOAT_64, "float64", np.float64, _lib.MI_F64):
+        assert resolve_arith(None, ft) == "exact", ft
+        assert resolve_arith("separable", ft) == "separable"      # an explicit choice is the caller's (and the library's to refuse)
+    for ft in (None, constants.FLOAT_32, np.float32, _lib.MI_F32, True):
+        assert resolve_arith(None, ft) == "separable", ft
+    for fn in (pipeline.align_and_stack, pipeline.align_and_stack_device, pipeline.bunches_then_stack):
+        assert 'resolve_arith(stack_kwargs.get("arith"), stack_kwargs.get("float_type"))' in inspect.getsource(fn), fn.__name__
+
+
+def test_auto_estimator_says_so_when_it_is_not_the_references(caplog, monkeypatch):
+    """align.auto_estimator: without OpenCV the reference's SIFT + RANSAC recipe (align.py:90-151) cannot run and the GPU ECC
+    estimator registers the frames -- another algorithm, so the swap goes to the log (once)."""
+    import logging
+    from shinestacker_amd import align
+    monkeypatch.setattr(align, "have_opencv", lambda: False)
+    monkeypatch.setattr(align, "_auto_fallback_logged", False)
+    with caplog.at_level(logging.WARNING, logger="shinestacker_amd"):
+        est = align.resolve_estimator("auto")
+        align.resolve_estimator(None)
+    assert callable(est) and est is not align.opencv_estimator
+    msgs = [r.getMessage() for r in caplog.records if "estimator='auto'" in r.getMessage()]
+    assert len(msgs) == 1 and "ECC" in msgs[0] and "align.py:90-151" in msgs[0]
+    monkeypatch.setattr(align, "have_opencv", lambda: True)
+    assert align.resolve_estimator("auto") is align.opencv_estimator
