@@ -9,7 +9,8 @@ combine (N>1), collapse, abs/clip/truncating cast -- result left in HBM.
 Workload at N=1: BASELINE.json configs[1] -- 256 x 24 MP (4000x6000x3) fp32
 frames, 6 Laplacian levels + 63x94 base.
   --scaling weak   (default) every rank holds its own 256-frame shard of a 256*N-frame stack;
-  --scaling strong BASELINE.json configs[2]: the SAME 256 frames, 256/N per rank (contiguous global indices).
+  --scaling strong BASELINE.json configs[2]: the SAME 256 frames, 256/N per rank.
+  --shards interleaved (default): rank r of N holds frames r, r + N, ...; contiguous: the block [r F, (r + 1) F).
   --arith separable (default) north_star's LDS-staged 5-tap separable / polyphase form (MI_ARITH_SEPARABLE,
                     tolerance-tested against float64, bit-exact against oracle/separable_oracle.c);
   --arith exact     the reference-order 25-tap form, bit-identical to the oracle of the reference's own run.
@@ -48,6 +49,10 @@ def parse():
     ap.add_argument("--impl", default="auto", choices=["auto", "simple", "tiled"])
     ap.add_argument("--arith", default="separable", choices=["separable", "exact"])
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--shards", default="interleaved", choices=["interleaved", "contiguous"],
+                    help="how the frames of the stack are dealt to the ranks: rank r of W holds frames r, r + W, ... (default: every "
+                         "rank sees the whole focus range, its winners are as coherent as the whole stack's and its payload pass "
+                         "as cheap) or the contiguous block [r F, (r + 1) F) (rounds 1-5)")
     ap.add_argument("--batch", type=int, default=0, help="frames per fused launch (0 = library default)")
     ap.add_argument("--source", default="device", choices=["device", "host", "host-pinned"],
                     help="host: frames are pushed from host memory one by one (PCIe-inclusive rate; "
@@ -236,9 +241,9 @@ def project_scaling(L, measure, args, H, W, total_frames, t1_s, device, job_byte
       local     the per-rank kernels of the winners-only exchange (winner map over the rank's pixel chunk, plan over the
                 whole map, pack of the rows the rank won, unpack of the other ranks' rows at rank 0), timed on this GPU on a
                 synthetic winner map in which rank r wins the r-th horizontal band of every level;
-      link      bytes that cross rank 0's busiest xGMI link once: 4 (energies, all-to-all) + 1 (winner map, all-gather) +
-                12 (winners' Laplacians to rank 0) bytes per state pixel, divided by N (one peer's share), at
-                XGMI_LINK_GBS x XGMI_EFFICIENCY.
+      link      bytes that cross rank 0's busiest xGMI link once: 4 + 4 (energies and, for the interleaved shards' ties, the
+                winners' frame indices, all-to-all) + 1 (winner map, all-gather) + 12 (winners' Laplacians to rank 0) bytes per
+                state pixel, divided by N (one peer's share), at XGMI_LINK_GBS x XGMI_EFFICIENCY.
     step(N) = compute + local + link with no overlap credited (the implementation exchanges level 0 while the rank's
     coarser levels still run; that saving is listed as `hidden_behind_coarse_levels_ms` and NOT subtracted)."""
     import ctypes as C
@@ -256,12 +261,16 @@ def project_scaling(L, measure, args, H, W, total_frames, t1_s, device, job_byte
         # a shard step is a few milliseconds: enough steps that the timed region is ~0.2 s of steady state, three warm-ups
         # (the first steps after the host-side set-up run at a lower clock)
         k = max(args.steps, int(0.2 / max(t1_s / n, 1e-4)) + 1)
-        st, dt_s, prof, _ = measure(args.arith, k, 3, F=fn)
+        # rank 0's shard of the N-GPU job: frames 0, n, 2n, ... (interleaved: every rank sees the whole focus range)
+        dt_np = {"u8": np.uint8, "u16": np.uint16, "f32": np.float32}[args.dtype]
+        shard = L.DeviceBuffer(H * W * 3 * np.dtype(dt_np).itemsize * fn, device)
+        L.synth_frames_device(shard.ptr, dt_np, H, W, 0, fn, total_frames, device=device, frame_step=n)
+        st, dt_s, prof, _ = measure(args.arith, k, 3, buf=shard, F=fn, index_step=n)
         compute_ms = dt_s / k * 1e3
         coarse_ms = prof["levels"][0] / k
         e_ptr, l_ptr, _i_ptr, npx = st.state_ptrs(-1)
-        # synthetic winner map: rank r wins the r-th band of every level (what frame-sharded focus stacks look like)
-        win_h = np.concatenate([np.repeat((np.arange(h, dtype=np.int64) * n // max(h, 1)).astype(np.uint8), w)
+        # synthetic winner map: the generator's bands, dealt to the ranks like its frames (band b is frame b's: rank b mod n)
+        win_h = np.concatenate([np.repeat(((np.arange(h, dtype=np.int64) * total_frames // max(h, 1)) % n).astype(np.uint8), w)
                                 for (h, w) in list(st.shapes[:-1]) + [st.shapes[-1], st.shapes[-1]]])
         win_h = np.concatenate([win_h, np.zeros(max(0, npx - win_h.size), np.uint8)])[:npx]
         win = L.DeviceBuffer(npx, device)
@@ -291,11 +300,11 @@ def project_scaling(L, measure, args, H, W, total_frames, t1_s, device, job_byte
             for _ in range(5):
                 local(rank)
             t_local[rank] = (time.perf_counter() - t0) / 5 * 1e3
-        for b in (win, cand, wchunk, plan, rows, ptrs):
+        for b in (win, cand, wchunk, plan, rows, ptrs, shard):
             b.free()
         st.close()
         local_ms = max(t_local.values())      # rank 0 unpacks, the others pack: the slower of the two bounds the step
-        link_ms = 17.0 * npx / n / (XGMI_LINK_GBS * XGMI_EFFICIENCY * 1e9) * 1e3
+        link_ms = 21.0 * npx / n / (XGMI_LINK_GBS * XGMI_EFFICIENCY * 1e9) * 1e3
         step_ms = compute_ms + local_ms + link_ms
         out["shard_step"].append({"frames": fn, "ms": compute_ms, "steps": k, "measured": True,
                                   "job_roofline_frac": job_bytes_per_frame * fn / (compute_ms * 1e-3) / (HBM_PEAK_GBS * 1e9),
@@ -325,7 +334,10 @@ def dry_run(args, rank, world):
     if args.scaling == "strong" and total % world:
         raise SystemExit(f"--scaling strong: {total} frames do not split over {world} ranks")
     F = total // world
-    frames = [orc.synth_frame_numpy(H, W, f, total) for f in range(rank * F, (rank + 1) * F)]
+    inter = args.shards == "interleaved" and world > 1
+    mine = range(rank, total, world) if inter else range(rank * F, (rank + 1) * F)
+    frames = [orc.synth_frame_numpy(H, W, f, total) for f in mine]
+    gidx = (lambda a: a * world + rank) if inter else (lambda a: a + rank * F)    # local frame number -> global frame index
     ops = multigpu.TorchWinnerOps()
     phase = {"compute": 0.0, "combine": 0.0, "collapse": 0.0}
     out = None
@@ -336,20 +348,20 @@ def dry_run(args, rank, world):
         so = orc.StreamingOracle(H, W, np.uint8, min_size=16, arith=args.arith)
         for f in frames:
             so.push_frame(f)
-        first = rank * F
         hb, wb = so.shapes[so.levels]
         yy, xx = np.mgrid[0:hb, 0:wb]
         bases = np.stack(so.bases)
-        state = [(so.best_e[lv], so.best_lap[lv], so.best_idx[lv] + first) for lv in range(so.levels)]
-        state += [(so.b_ent, bases[so.idx_e, yy, xx], so.idx_e + first), (so.b_dev, bases[so.idx_d, yy, xx], so.idx_d + first)]
+        state = [(so.best_e[lv], so.best_lap[lv], gidx(so.best_idx[lv])) for lv in range(so.levels)]
+        state += [(so.b_ent, bases[so.idx_e, yy, xx], gidx(so.idx_e)), (so.b_dev, bases[so.idx_d, yy, xx], gidx(so.idx_d))]
         e = torch.cat([torch.from_numpy(np.ascontiguousarray(a, np.float32).ravel()) for a, _, _ in state])
         lp = torch.cat([torch.from_numpy(np.ascontiguousarray(b, np.float32).ravel()) for _, b, _ in state])
         ix = torch.cat([torch.from_numpy(np.ascontiguousarray(c, np.int32).ravel()) for _, _, c in state])
         t1 = time.perf_counter()
         if world > 1:
             n0 = state[0][0].size
-            multigpu.combine_winners(e[:n0], lp[:3 * n0], ix[:n0], dist.group.WORLD, ops, with_index=False, root_energy=False)
-            multigpu.combine_winners(e[n0:], lp[3 * n0:], ix[n0:], dist.group.WORLD, ops, with_index=False, root_energy=False)
+            kw = dict(with_index=False, root_energy=False, tiebreak_index=inter)
+            multigpu.combine_winners(e[:n0], lp[:3 * n0], ix[:n0], dist.group.WORLD, ops, **kw)
+            multigpu.combine_winners(e[n0:], lp[3 * n0:], ix[n0:], dist.group.WORLD, ops, **kw)
         t2 = time.perf_counter()
         if rank == 0:   # collapse from the combined payloads
             off = 0
@@ -389,7 +401,8 @@ def dry_run(args, rank, world):
                 "ms_per_step": dt_s / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
                 "vs_baseline": None, "dtype": "u8", "data": "synthetic",
                 "config": {"workload": f"DRY RUN on CPU (oracle + gloo): {total}x{W}x{H}x3 u8 frames", "frames_per_gpu": F,
-                           "arith": args.arith, "parallelism": f"{total} frames in contiguous blocks of {F} over {world} rank(s)"},
+                           "arith": args.arith, "shards": args.shards if world > 1 else None,
+                           "parallelism": f"{total} frames, {F} per rank ({args.shards if world > 1 else 'one rank'}) over {world} rank(s)"},
                 "roofline": None,
                 "breakdown_ms_per_step": {f"{k}_ms_host": v / args.steps * 1e3 for k, v in phase.items()},
                 "verified": bool(np.array_equal(out, whole.finish())), "dry_run": True}
@@ -453,7 +466,15 @@ def main():
         F, total_frames = args.frames, args.frames * world
     per = H * W * 3 * np.dtype(dt).itemsize
     buf = L.DeviceBuffer(per * F, device)
-    L.synth_frames_device(buf.ptr, dt, H, W, rank * F, F, total_frames, device=device)
+    inter = args.shards == "interleaved" and world > 1
+    if inter:   # rank r: frames r, r + world, ... of the stack
+        L.synth_frames_device(buf.ptr, dt, H, W, rank, F, total_frames, device=device, frame_step=world)
+    else:
+        L.synth_frames_device(buf.ptr, dt, H, W, rank * F, F, total_frames, device=device)
+
+    def index_first(st, F=F, step=None):   # the global frame index of the handle's k-th frame
+        step = (world if inter else 1) if step is None else step
+        st.set_first_index(rank if step > 1 else rank * F, step)
     impl = {"auto": L.IMPL_AUTO, "simple": L.IMPL_SIMPLE, "tiled": L.IMPL_TILED}[args.impl]
     out_dt = np.uint16 if args.dtype == "u16" else np.uint8
 
@@ -474,9 +495,9 @@ def main():
             torch.cuda.synchronize()
         st.sync()
 
-    def measure(arith, steps, warmup, buf=buf, dt=dt, out_dt=out_dt, F=F):
+    def measure(arith, steps, warmup, buf=buf, dt=dt, out_dt=out_dt, F=F, index_step=None):
         st = L.Stack(H, W, in_dtype=dt, out_dtype=out_dt, device=device, impl=impl, batch_frames=args.batch, arith=arith)
-        st.set_first_index(rank * F)
+        index_first(st, F, index_step)
         combiner = None
         if world > 1 or force_dist:
             from shinestacker_amd import multigpu
@@ -487,7 +508,7 @@ def main():
 
         def step(timed=False):
             st.reset()
-            st.set_first_index(rank * F)
+            index_first(st, F, index_step)
             t0 = time.perf_counter()
             if host_frames is not None:
                 for i in range(F):
@@ -599,7 +620,8 @@ def main():
                                         "reference's own recordings pin (cv2.filter2D's real order: unpinned third party)"),
                        "impl": args.impl if args.impl != "auto" else ["auto", "simple", "tiled"][st.params.impl],
                        "device": L.device_name(device),
-                       "parallelism": f"{total_frames} frames in contiguous blocks of {F} over {world} " +
+                       "shards": args.shards if world > 1 else None,
+                       "parallelism": f"{total_frames} frames, {F} per rank" + (f" ({args.shards}: rank r holds " + ("frames r, r + " + str(world) + ", ..." if inter else "the block [r F, (r + 1) F)") + ")" if world > 1 else "") + f" over {world} " +
                                       ("rank(s) SHARING ONE GPU (functional run, collectives over gloo through the host)"
                                        if one_gpu else "GPU(s)")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,

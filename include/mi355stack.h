@@ -157,6 +157,14 @@ MI_API int mi_stack_level_shape(const mi_stack_t* s, int level, int* h, int* w);
 MI_API int mi_stack_frames_pushed(const mi_stack_t* s, int* n);
 /* global index of this handle's first frame (multi-GPU frame sharding); default 0 */
 MI_API int mi_stack_set_first_index(mi_stack_t* s, int first_global_index);
+/* interleaved frame shards (rank r of W holds frames r, r + W, ...: every rank sees the whole focus range, so its winners are
+ * as coherent as the whole stack's): the global index of the handle's k-th frame = first_global_index + k * stride.  The
+ * kernels number the frames consecutively; mi_stack_export_indices rewrites the winner indices of one level (level == levels,
+ * levels + 1: the base twins; -1: all) into the global numbering, in place -- before they leave the handle (the cross-GPU
+ * combine breaks ties by them: np.argmax's first maximum, pyramid.py:51; the index taps call it themselves).  After an export
+ * the handle takes no more frames until mi_stack_reset.  Default stride 1: nothing to export. */
+MI_API int mi_stack_set_index_stride(mi_stack_t* s, int stride);
+MI_API int mi_stack_export_indices(mi_stack_t* s, int level);
 
 /* One frame from host memory (H rows of row_stride_bytes; 0 = tightly packed).
  * Returns after the work is enqueued; the host buffer may be reused on return. */
@@ -238,6 +246,10 @@ MI_API int mi_combine_select(int device, void* stream, int n, const void* cand_e
  * mi_combine_plan_bytes) and the row totals per rank on the host (synchronises the stream).
  * dev_bufs: DEVICE array of n_ranks device pointers, entry r = rank r's packed rows (the entry of `rank` itself unused). */
 MI_API int mi_combine_winner(int device, void* stream, int n_ranks, const void* cand_e, size_t npix, void* win_u8);
+/* the same for interleaved shards (mi_stack_set_index_stride): the candidates' global frame indices travel with their
+ * energies and break ties (the lower index wins) -- the rank order is not the frame order there */
+MI_API int mi_combine_winner_idx(int device, void* stream, int n_ranks, const void* cand_e, const void* cand_idx, size_t npix,
+                                 void* win_u8);
 MI_API size_t mi_combine_plan_bytes(size_t npix, int n_ranks);
 MI_API int mi_combine_plan(int device, void* stream, const void* win_u8, size_t npix, int n_ranks, void* plan,
                            int64_t* totals);

@@ -89,6 +89,8 @@ SIGNATURES = {
                                        C.POINTER(C.c_int)]),
     "mi_stack_frames_pushed": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "mi_stack_set_first_index": (C.c_int, [C.c_void_p, C.c_int]),
+    "mi_stack_set_index_stride": (C.c_int, [C.c_void_p, C.c_int]),
+    "mi_stack_export_indices": (C.c_int, [C.c_void_p, C.c_int]),
     "mi_stack_push_frame": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "mi_stack_push_frame_pinned": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "mi_stack_wait_uploads": (C.c_int, [C.c_void_p, C.c_int]),
@@ -112,6 +114,7 @@ SIGNATURES = {
     "mi_combine_select": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mi_combine_winner": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "mi_combine_winner_idx": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "mi_combine_plan_bytes": (C.c_size_t, [C.c_size_t, C.c_int]),
     "mi_combine_plan": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p,
                                   C.POINTER(C.c_int64)]),
@@ -405,6 +408,7 @@ class Stack:
             raise InvalidOptionError("pair_levels", pair_levels, "0 = automatic, 1 = always, 2 = never")
         p.pair_levels = int(pair_levels)
         self.arith = p.arith
+        self.index_stride = 1
         self.params = p
         self.in_dtype, self.out_dtype = in_dtype, out_dtype
         self.float_type = int(float_type)
@@ -453,8 +457,15 @@ class Stack:
         check(load().mi_stack_frames_pushed(self._h, C.byref(n)))
         return n.value
 
-    def set_first_index(self, idx):
+    def set_first_index(self, idx, stride=1):
+        """global index of this handle's k-th frame = idx + k * stride (stride > 1: interleaved frame shards)"""
         check(load().mi_stack_set_first_index(self._h, int(idx)))
+        check(load().mi_stack_set_index_stride(self._h, int(stride)))
+        self.index_stride = int(stride)
+
+    def export_indices(self, level=-1):
+        """winner indices of `level` (-1: all levels and both base twins) into the global numbering (no-op at stride 1)"""
+        check(load().mi_stack_export_indices(self._h, int(level)))
 
     # -- data path
     def push_frame(self, frame, zero_copy=False):
@@ -642,9 +653,16 @@ class DepthMap:
 
 
 def synth_frames_device(dev_ptr, dtype, height, width, first_frame, n_frames, stack_size,
-                        seed=20250824, device=0):
-    check(load().mi_synth_frames_device(device, dev_ptr, DTYPE_CODE[np.dtype(dtype)], height,
-                                        width, first_frame, n_frames, stack_size, seed))
+                        seed=20250824, device=0, frame_step=1):
+    """frames first_frame, first_frame + frame_step, ... of the `stack_size`-frame generator stack, packed at dev_ptr"""
+    code = DTYPE_CODE[np.dtype(dtype)]
+    if frame_step == 1:
+        check(load().mi_synth_frames_device(device, dev_ptr, code, height, width, first_frame, n_frames, stack_size, seed))
+        return
+    per = height * width * 3 * np.dtype(dtype).itemsize
+    for k in range(n_frames):
+        check(load().mi_synth_frames_device(device, dev_ptr + k * per, code, height, width, first_frame + k * frame_step, 1,
+                                            stack_size, seed))
 
 
 BORDER_CONSTANT, BORDER_REPLICATE, BORDER_REPLICATE_BLUR = 0, 1, 2

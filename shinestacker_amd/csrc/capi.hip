@@ -108,6 +108,9 @@ struct mi_stack {
 
     int n_pushed = 0;
     int first_index = 0;
+    int index_stride = 1;          // global index of the k-th pushed frame = first_index + k * index_stride (interleaved shards)
+    uint64_t idx_exported = 0;     // bit l: the indices of state level l (L, L + 1: the base twins) are in their global form
+    hipStream_t aux = nullptr;     // stream of the index export (not ordered behind the side streams as s->stream is after a push)
     bool finished = false;
 
     bool prof = false;
@@ -1444,6 +1447,7 @@ void mi_stack_destroy(mi_stack_t* s) {
     }
     for (auto e : s->ev_pool) (void)hipEventDestroy(e);
     for (void* p : s->allocs) (void)hipFree(p);
+    if (s->aux) (void)hipStreamDestroy(s->aux);
     if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
 }
@@ -1459,6 +1463,7 @@ int mi_stack_reset(mi_stack_t* s) {
     if (rc) return rc;
     s->n_pushed = 0;
     s->finished = false;
+    s->idx_exported = 0;
     return tiled_reset(s);
 }
 
@@ -1495,9 +1500,50 @@ int mi_stack_set_first_index(mi_stack_t* s, int first_global_index) {
     return MI_OK;
 }
 
+int mi_stack_set_index_stride(mi_stack_t* s, int stride) {
+    int rc = check_handle(s);
+    if (rc) return rc;
+    if (stride < 1) return fail(MI_ERR_INVALID, "index stride must be >= 1");
+    if (s->n_pushed + tiled_pending(s) != 0) return fail(MI_ERR_STATE, "set_index_stride after frames were pushed");
+    s->index_stride = stride;
+    return MI_OK;
+}
+
+// The kernels number the frames of a handle consecutively from first_index; with an index stride the stored winner indices
+// are rewritten once, in place, into the global numbering (first + k * stride), level by level: the level's bit in
+// idx_exported is set, and the handle takes no more frames until it is reset (the payload passes look winners up by the
+// consecutive numbers).
+static int export_level_indices(mi_stack* s, int level) {
+    if (s->index_stride == 1 || ((s->idx_exported >> level) & 1ull)) return MI_OK;
+    int32_t* idx = level < s->L ? s->bestIdx[level] : level == s->L ? s->idxE : s->idxD;
+    const size_t n = (size_t)s->lh[std::min(level, s->L)] * s->lw[std::min(level, s->L)];
+    if (!s->aux) MI_HIP(hipStreamCreateWithFlags(&s->aux, hipStreamNonBlocking));
+    hipLaunchKernelGGL(idx_export, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->aux, idx, n, s->first_index, s->index_stride);
+    MI_HIP(hipGetLastError());
+    s->idx_exported |= 1ull << level;
+    return MI_OK;
+}
+
+int mi_stack_export_indices(mi_stack_t* s, int level) {
+    int rc = check_handle(s);
+    if (rc) return rc;
+    MI_HIP(hipSetDevice(s->p.device));
+    if (level < -1 || level > s->L + 1) return fail(MI_ERR_INVALID, "bad level %d", level);
+    if ((rc = tiled_flush(s))) return rc;
+    // the level's state must be final: level 0 is, once its last payload pass is through; everything else needs all of it
+    if (level == 0) rc = tiled_sync_level0(s);
+    else { rc = tiled_sync_all(s); if (!rc) MI_HIP(hipStreamSynchronize(s->stream)); }
+    if (rc) return rc;
+    for (int l = (level < 0 ? 0 : level); l <= (level < 0 ? s->L + 1 : level); ++l)
+        if ((rc = export_level_indices(s, l))) return rc;
+    if (s->aux) MI_HIP(hipStreamSynchronize(s->aux));
+    return MI_OK;
+}
+
 int mi_stack_push_frames_device(mi_stack_t* s, const void* dev_frames, int n, size_t frame_stride_bytes) {
     int rc = check_handle(s);
     if (rc) return rc;
+    if (s->idx_exported) return fail(MI_ERR_STATE, "the winner indices were exported (index stride > 1): reset the handle before pushing more frames");
     if (!dev_frames || n < 0) return fail(MI_ERR_INVALID, "bad frames argument");
     if (s->finished) return fail(MI_ERR_STATE, "push after finish; call mi_stack_reset first");
     size_t fb = (size_t)s->p.height * s->p.width * 3 * dtype_size(s->p.in_dtype);
@@ -1510,6 +1556,7 @@ int mi_stack_push_frames_device(mi_stack_t* s, const void* dev_frames, int n, si
 int mi_stack_push_frame(mi_stack_t* s, const void* host_bgr, size_t row_stride_bytes) {
     int rc = check_handle(s);
     if (rc) return rc;
+    if (s->idx_exported) return fail(MI_ERR_STATE, "the winner indices were exported (index stride > 1): reset the handle before pushing more frames");
     if (!host_bgr) return fail(MI_ERR_INVALID, "null frame");
     if (s->finished) return fail(MI_ERR_STATE, "push after finish; call mi_stack_reset first");
     MI_HIP(hipSetDevice(s->p.device));
@@ -1521,6 +1568,7 @@ int mi_stack_push_frame_pinned(mi_stack_t* s, const void* host_bgr, size_t row_s
     if (rc) return rc;
     if (!host_bgr) return fail(MI_ERR_INVALID, "null frame");
     if (s->finished) return fail(MI_ERR_STATE, "push after finish; call mi_stack_reset first");
+    if (s->idx_exported) return fail(MI_ERR_STATE, "the winner indices were exported (index stride > 1): reset the handle before pushing more frames");
     if (s->p.impl != MI_IMPL_TILED || s->f64) return mi_stack_push_frame(s, host_bgr, row_stride_bytes);   // synchronous paths
     MI_HIP(hipSetDevice(s->p.device));
     hipPointerAttribute_t at{};
@@ -1637,12 +1685,17 @@ int mi_stack_get_level(mi_stack_t* s, int level, int what, void* host_out, size_
             src = s->bestE[level]; bytes = np(level) * 4; break;
         case MI_TAP_INDEX:
             if (level < 0 || level >= L) return fail(MI_ERR_INVALID, "bad level %d", level);
+            if ((rc = mi_stack_export_indices(s, level))) return rc;   // (index stride > 1: the tap shows global frame numbers)
             src = s->bestIdx[level]; bytes = np(level) * 4; break;
         case MI_TAP_FUSED_BASE:
             if (!s->finished) return fail(MI_ERR_STATE, "fused base is available after finish");
             src = s->fusedBase; bytes = np(L) * 3 * fb; break;
-        case MI_TAP_BASE_IDX_E: src = s->idxE; bytes = np(L) * 4; break;
-        case MI_TAP_BASE_IDX_D: src = s->idxD; bytes = np(L) * 4; break;
+        case MI_TAP_BASE_IDX_E:
+            if ((rc = mi_stack_export_indices(s, L))) return rc;
+            src = s->idxE; bytes = np(L) * 4; break;
+        case MI_TAP_BASE_IDX_D:
+            if ((rc = mi_stack_export_indices(s, L + 1))) return rc;
+            src = s->idxD; bytes = np(L) * 4; break;
         case MI_TAP_BASE_ENT: src = s->bEnt; bytes = np(L) * fb; break;
         case MI_TAP_BASE_DEV: src = s->bDev; bytes = np(L) * fb; break;
         case MI_TAP_COLLAPSED:
@@ -1769,6 +1822,16 @@ int mi_combine_winner(int device, void* stream, int n, const void* cand_e, size_
     MI_HIP(hipSetDevice(device));
     hipLaunchKernelGGL(combine_winner, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n,
                        (const float*)cand_e, npix, (uint8_t*)win);
+    MI_HIP(hipGetLastError());
+    return MI_OK;
+}
+
+int mi_combine_winner_idx(int device, void* stream, int n, const void* cand_e, const void* cand_idx, size_t npix, void* win) {
+    if (npix == 0) return MI_OK;
+    if (n < 1 || n > CB_MAXR || !cand_e || !cand_idx || !win) return fail(MI_ERR_INVALID, "bad argument (1 <= ranks <= %d)", CB_MAXR);
+    MI_HIP(hipSetDevice(device));
+    hipLaunchKernelGGL(combine_winner_idx, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n,
+                       (const float*)cand_e, (const int32_t*)cand_idx, npix, (uint8_t*)win);
     MI_HIP(hipGetLastError());
     return MI_OK;
 }

@@ -480,6 +480,31 @@ __global__ void combine_winner(int n, const float* __restrict__ cand_e, size_t n
     win[p] = (uint8_t)bi;
 }
 
+// The same when the ranks hold INTERLEAVED frames (rank r: frames r, r + W, ...): the rank order is no longer the frame order, so a
+// tie between ranks goes to the candidate with the lower global frame index -- np.argmax's first maximum (pyramid.py:51).
+__global__ void combine_winner_idx(int n, const float* __restrict__ cand_e, const int32_t* __restrict__ cand_idx, size_t npix,
+                                   uint8_t* __restrict__ win) {
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npix) return;
+    float be = cand_e[p];
+    int32_t bf = cand_idx[p];
+    int bi = 0;
+    for (int r = 1; r < n; ++r) {
+        const float e = cand_e[(size_t)r * npix + p];
+        const int32_t f = cand_idx[(size_t)r * npix + p];
+        if (e > be || (e == be && f < bf)) { be = e; bf = f; bi = r; }
+    }
+    win[p] = (uint8_t)bi;
+}
+
+// stored winner index (first + consecutive frame number) -> global index (first + number * stride), in place
+__global__ void idx_export(int32_t* __restrict__ idx, size_t n, int first, int stride) {
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const int32_t v = idx[p];
+    if (v >= first) idx[p] = first + (v - first) * stride;
+}
+
 // Blocks of CB_PX = 1024 pixels, one workgroup of 256 threads each, a thread = 4 consecutive pixels (one 32-bit load of the
 // winner map).  Inside a block the position of a pixel among the pixels of ITS rank comes from one packed prefix scan:
 // the thread's per-rank counts (0..4) sit in 16-bit fields of 64-bit words (4 ranks per word), scanned across the wave by

@@ -137,13 +137,19 @@ def combine_all(states, group, select_fn, width=3, with_index=True, root_energy=
             off += m
 
 
-def first_max_rank(cand_e):
-    """torch form of mi_combine_winner (CPU tests / reference semantics): winning rank per pixel, strict '>' in rank order"""
+def first_max_rank(cand_e, cand_i=None):
+    """torch form of mi_combine_winner[_idx] (CPU tests / reference semantics): winning rank per pixel, strict '>' in rank
+    order; with the candidates' global frame indices `cand_i` (interleaved shards: the rank order is not the frame order) a
+    tie goes to the lower index -- np.argmax's first maximum"""
     world, m = cand_e.shape
     best = torch.zeros(m, dtype=torch.uint8, device=cand_e.device)
     be = cand_e[0].clone()
+    bf = cand_i[0].clone() if cand_i is not None else None
     for r in range(1, world):
         win = cand_e[r] > be
+        if cand_i is not None:
+            win = win | ((cand_e[r] == be) & (cand_i[r] < bf))
+            bf = torch.where(win, cand_i[r], bf)
         be = torch.where(win, cand_e[r], be)
         best = torch.where(win, torch.full_like(best, r), best)
     return best
@@ -153,8 +159,8 @@ class TorchWinnerOps:
     """The four local steps of `combine_winners` in plain torch (CPU tensors under gloo in tests/; on the GPU the
     Combiner uses the library's kernels: boolean-mask indexing of 32 Mpixel states costs milliseconds per call)."""
 
-    def winner(self, cand_e):
-        return first_max_rank(cand_e)
+    def winner(self, cand_e, cand_i=None):
+        return first_max_rank(cand_e, cand_i)
 
     def plan(self, win, world):
         return None, [int((win == r).sum()) for r in range(world)]
@@ -220,7 +226,8 @@ class HostStagedComm(DirectComm):
             b.copy_(h)
 
 
-def combine_winners(e_all, l_all, i_all, group, ops, width=3, with_index=True, root_energy=True, comm=None, force=False):
+def combine_winners(e_all, l_all, i_all, group, ops, width=3, with_index=True, root_energy=True, comm=None, force=False,
+                    tiebreak_index=False):
     """Cross-rank first-max of a flat state (e_all (n,), l_all (n*width,), i_all (n,) or None), result on rank 0.
     Same outcome as `combine_all`, less traffic -- the payload crosses the fabric once, not twice:
 
@@ -230,6 +237,10 @@ def combine_winners(e_all, l_all, i_all, group, ops, width=3, with_index=True, r
       4. every rank packs the payload rows it won (pixel order) and sends them straight to rank 0, which unpacks
          them into place -- 12 B/pixel in total INTO rank 0, spread over its 7 links, instead of 12 B/pixel all-to-all
          plus 12 B/pixel to rank 0.  Optionally the winners' energies / indices travel the same way.
+
+    `tiebreak_index` (interleaved shards -- rank r holds frames r, r + W, ...): the candidates' global frame indices travel with
+    their energies in step 1 (8 instead of 4 B/pixel there) and break ties in step 2, because the rank order is not the
+    frame order then.
 
     `comm`: how the collectives move the tensors (default `DirectComm(group)`; `HostStagedComm` stages device tensors
     through the host).  `force`: run the local steps at world 1 as well -- rank 0 then packs the rows it won and unpacks
@@ -246,12 +257,18 @@ def combine_winners(e_all, l_all, i_all, group, ops, width=3, with_index=True, r
     sizes = [b - a for a, b in bounds]
     per = -(-n // world)
     mine = sizes[rank]
+    cand_i = None
     if world > 1:
         cand = torch.empty(world * mine, dtype=e_all.dtype, device=e_all.device)
         comm.all_to_all(cand, e_all, [mine] * world, sizes)
+        if tiebreak_index:
+            cand_i = torch.empty(world * mine, dtype=i_all.dtype, device=i_all.device)
+            comm.all_to_all(cand_i, i_all, [mine] * world, sizes)
     else:
         cand = e_all
-    win_chunk = ops.winner(cand.view(world, mine))
+        cand_i = i_all if tiebreak_index else None
+    win_chunk = (ops.winner(cand.view(world, mine), cand_i.view(world, mine)) if cand_i is not None
+                 else ops.winner(cand.view(world, mine)))
     if world > 1:
         padded = torch.zeros(per, dtype=torch.uint8, device=e_all.device)
         padded[:mine] = win_chunk
@@ -322,11 +339,15 @@ class Combiner:
         return out_e, out_l, out_i
 
     # ---- the library's kernels behind the TorchWinnerOps protocol
-    def winner(self, cand_e):
+    def winner(self, cand_e, cand_i=None):
         world, m = cand_e.shape
         out = torch.empty(m, dtype=torch.uint8, device=cand_e.device)
         stream = torch.cuda.current_stream(cand_e.device).cuda_stream
-        _lib.check(_lib.load().mi_combine_winner(self.device, C.c_void_p(stream), world, cand_e.data_ptr(), m, out.data_ptr()))
+        if cand_i is not None:
+            _lib.check(_lib.load().mi_combine_winner_idx(self.device, C.c_void_p(stream), world, cand_e.data_ptr(),
+                                                         cand_i.data_ptr(), m, out.data_ptr()))
+        else:
+            _lib.check(_lib.load().mi_combine_winner(self.device, C.c_void_p(stream), world, cand_e.data_ptr(), m, out.data_ptr()))
         return out
 
     def plan(self, win, world):
@@ -370,14 +391,19 @@ class Combiner:
         e, l, i, n0 = self._slabs
         import time
         ts = torch.cuda.current_stream(torch.device("cuda", self.device))
-        kw = dict(with_index=with_index, root_energy=root_energy, comm=self.comm, force=self.force)
+        interleaved = getattr(st, "index_stride", 1) > 1    # the indices break ties, in their global form (export_indices)
+        kw = dict(with_index=with_index, root_energy=root_energy, comm=self.comm, force=self.force, tiebreak_index=interleaved)
         t0 = time.perf_counter()
         st.sync_level(0)
+        if interleaved and n0:
+            st.export_indices(0)
         t1 = time.perf_counter()
         if n0:
             combine_winners(e[:n0], l[:3 * n0], i[:n0], self.group, self, **kw)
         t2 = time.perf_counter()
         st.sync()       # the coarser levels + base of this rank: they ran on the stacker's streams beside the exchange above
+        if interleaved:
+            st.export_indices(-1)
         t3 = time.perf_counter()
         combine_winners(e[n0:], l[3 * n0:], i[n0:], self.group, self, **kw)
         ts.synchronize()

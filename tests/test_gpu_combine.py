@@ -120,6 +120,44 @@ for arith in ("exact", "separable"):
         assert np.array_equal(st2.finish(), ref.finish()), arith
         ref.close()
     st.close(); st2.close()
+# INTERLEAVED shards (rank r holds frames r, r + world, ...: set_first_index(r, world)): the rank order is not the frame order
+# any more, ties go by the global frame index -- frame 6 (rank 0) repeats frame 5 (rank 1): 5 must win although its rank is higher
+frames[6] = frames[5].copy()
+for arith in ("exact", "separable"):
+    for kw in (dict(with_index=True, root_energy=True), dict(with_index=False, root_energy=False)):
+        st = L.Stack(H, W, arith=arith)
+        st.set_first_index(rank, world)
+        for f in frames[rank::world]:
+            st.push_frame(f)
+        Combiner(st, comm=HostStagedComm(dist.group.WORLD)).combine_winners(**kw)
+        if rank == 0:
+            whole = L.Stack(H, W, arith=arith)
+            for f in frames:
+                whole.push_frame(f)
+            if kw["with_index"]:
+                for lv in range(st.levels):
+                    for tap in (L.TAP_ENERGY, L.TAP_INDEX, L.TAP_FUSED_LAP):
+                        assert np.array_equal(st.tap(tap, lv), whole.tap(tap, lv)), ("interleaved", arith, lv, tap)
+                for tap in (L.TAP_BASE_IDX_E, L.TAP_BASE_IDX_D):
+                    assert np.array_equal(st.tap(tap, st.levels), whole.tap(tap, st.levels)), ("interleaved", arith, tap)
+            assert np.array_equal(st.finish(), whole.finish()), ("interleaved", arith)
+            whole.close()
+        st.close()
+# a rank's own view: the index taps show global frame numbers, and an exported handle takes no more frames until reset
+st = L.Stack(H, W, arith="separable")
+st.set_first_index(rank, world)
+for f in frames[rank::world]:
+    st.push_frame(f)
+own = st.tap(L.TAP_INDEX, 0)
+assert set(np.unique(own)) <= set(range(rank, N, world))
+try:
+    st.push_frame(frames[0])
+    raise SystemExit("push after export did not fail")
+except RuntimeError:
+    pass
+st.reset()
+st.push_frame(frames[0])
+st.close()
 dist.barrier()
 dist.destroy_process_group()
 if rank == 0:
@@ -131,7 +169,8 @@ def test_device_combine_with_two_ranks_on_one_gpu(tmp_path):
     """`Combiner.combine_winners` with world == 2 and the library's HIP kernels (mi_combine_winner / plan / pack / unpack on
     the device-resident slabs): two processes share the one GPU, the collectives travel over gloo through the host
     (`HostStagedComm`) because RCCL refuses two ranks on one device.  Cross-rank duplicate frames: the first maximum in
-    global frame order must win (pyramid.py:48-55).  Both arithmetics, both exchange variants."""
+    global frame order must win (pyramid.py:48-55).  Both arithmetics, both exchange variants; contiguous frame blocks and
+    interleaved shards (set_first_index(rank, world): ties by the global frame index, mi_combine_winner_idx)."""
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]

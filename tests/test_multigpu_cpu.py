@@ -154,6 +154,68 @@ def test_two_rank_combine_equals_single_stack(oracle):
     assert np.array_equal(fused.astype(np.float32), so.fused_base().ravel())
 
 
+def _worker_interleaved(rank, world, port, ret):
+    """rank r holds frames r, r + world, ...: the winners-only protocol with the frame indices as tie-breakers"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import oracle as orc
+        from shinestacker_amd import multigpu
+        frames = _frames()            # 3 == 1 (both on rank 1), 6 == 0 (both on rank 0) ...
+        frames[4] = frames[1].copy()  # ... and 4 (rank 0) == 1 (rank 1): the LOWER index lives on the HIGHER rank
+        so = orc.StreamingOracle(72, 104, np.uint8, min_size=8)
+        for f in frames[rank::world]:
+            so.push_frame(f)
+        g = lambda a: a * world + rank                      # local frame number -> global frame index
+        levels = [(so.best_e[lv], so.best_lap[lv], g(so.best_idx[lv])) for lv in range(so.levels)]
+        bases = np.stack(so.bases)
+        hb, wb = so.shapes[so.levels]
+        yy, xx = np.mgrid[0:hb, 0:wb]
+        levels.append((so.b_ent, bases[so.idx_e, yy, xx], g(so.idx_e)))
+        levels.append((so.b_dev, bases[so.idx_d, yy, xx], g(so.idx_d)))
+        t = [(torch.from_numpy(np.ascontiguousarray(e).ravel().copy()), torch.from_numpy(np.ascontiguousarray(l).ravel().copy()),
+              torch.from_numpy(np.ascontiguousarray(i, np.int32).ravel().copy())) for e, l, i in levels]
+        e_all, l_all, i_all = (torch.cat([a for a, _, _ in t]), torch.cat([b for _, b, _ in t]), torch.cat([c for _, _, c in t]))
+        n0 = t[0][0].numel()
+        ops = multigpu.TorchWinnerOps()
+        multigpu.combine_winners(e_all[:n0], l_all[:3 * n0], i_all[:n0], dist.group.WORLD, ops, tiebreak_index=True)
+        multigpu.combine_winners(e_all[n0:], l_all[3 * n0:], i_all[n0:], dist.group.WORLD, ops, tiebreak_index=True)
+        if rank == 0:
+            ret["state"] = (e_all.numpy(), l_all.numpy(), i_all.numpy(), [a.numel() for a, _, _ in t])
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_combine_of_interleaved_shards_equals_single_stack(oracle):
+    """SURVEY 8(e) with the frames dealt round-robin (rank r: frames r, r + W, ...): np.argmax's first maximum
+    (pyramid.py:51) across ranks needs the candidates' global frame indices -- a tie goes to the lower index, whichever rank
+    holds it."""
+    port = _free_port()
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_worker_interleaved, args=(2, port, ret), nprocs=2, join=True)
+        e_all, l_all, i_all, sizes = ret["state"]
+    frames = _frames()
+    frames[4] = frames[1].copy()
+    so = oracle.StreamingOracle(72, 104, np.uint8, min_size=8)
+    for f in frames:
+        so.push_frame(f)
+    hb, wb = so.shapes[so.levels]
+    yy, xx = np.mgrid[0:hb, 0:wb]
+    bases = np.stack(so.bases)
+    want = [(so.best_e[lv], so.best_lap[lv], so.best_idx[lv]) for lv in range(so.levels)]
+    want += [(so.b_ent, bases[so.idx_e, yy, xx], so.idx_e), (so.b_dev, bases[so.idx_d, yy, xx], so.idx_d)]
+    off = 0
+    for (e, l, i), n in zip(want, sizes):
+        assert np.array_equal(e_all[off:off + n], np.asarray(e, np.float32).ravel())
+        assert np.array_equal(i_all[off:off + n], np.asarray(i, np.int32).ravel())
+        assert np.array_equal(l_all[3 * off:3 * (off + n)], np.asarray(l, np.float32).ravel())
+        off += n
+    assert not np.isin(i_all, [3, 4, 6]).any()       # every duplicate lost to its earlier copy
+
+
 def test_chunk_bounds_cover_everything():
     from shinestacker_amd.multigpu import chunk_bounds
     for n in (0, 1, 7, 8, 9, 1000003):
@@ -164,8 +226,9 @@ def test_chunk_bounds_cover_everything():
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("scaling,nproc", [("strong", 2), ("weak", 2), ("strong", 8)])
-def test_bench_dry_run_under_torch_distributed_run(scaling, nproc):
+@pytest.mark.parametrize("scaling,nproc,shards", [("strong", 2, "interleaved"), ("weak", 2, "interleaved"), ("strong", 8, "interleaved"),
+                                                  ("strong", 2, "contiguous")])
+def test_bench_dry_run_under_torch_distributed_run(scaling, nproc, shards):
     """bench.py's distributed skeleton the way the driver starts it (python -m torch.distributed.run, one process per
     rank), on CPU: --dry-run replaces the HIP path by the oracle and RCCL by gloo; the strong split (BASELINE configs[2]:
     the SAME stack, frames / N per rank), the winners-only combine and the JSON contract are the real ones."""
@@ -175,12 +238,13 @@ def test_bench_dry_run_under_torch_distributed_run(scaling, nproc):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", str(nproc), "--steps", "2", "--warmup", "1",
-           "--frames", "6" if nproc == 2 else "16", "--scaling", scaling, "--dry-run"]   # 8 ranks: the driver's configs[2] launch
+           "--frames", "6" if nproc == 2 else "16", "--scaling", scaling, "--shards", shards, "--dry-run"]   # 8 ranks: the driver's configs[2] launch
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=280, cwd=root)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert r.returncode == 0 and lines, r.stdout[-1500:] + r.stderr[-3000:]
     d = json.loads(lines[-1])
     assert d["n_gpus"] == nproc and d["scaling"] == scaling and d["verified"] is True and d["steps"] == 2
+    assert d["config"]["shards"] == shards
     assert d["config"]["frames_per_gpu"] == ((3 if scaling == "strong" else 6) if nproc == 2 else 2)
     assert {"compute_ms_host", "combine_ms_host", "collapse_ms_host"} <= set(d["breakdown_ms_per_step"])
     for k in ("metric", "value", "unit", "ms_per_step", "higher_is_better", "vs_baseline", "dtype", "data"):
