@@ -113,7 +113,7 @@ typedef struct mi_stack_params {
     int32_t pair_levels;   /* MI_ARITH_SEPARABLE: pyramid levels 0 and 1 as one pair -- level 0's kernel hands level 1 gray(G_1) and
                             * G_2, the three-channel G_1 of the batch never reaches HBM (pyramid.py:27-46, :125-139: the
                             * reduce -> expand dependency), the winners' pixels of it are recomputed once per batch.  Results
-                            * are bit-identical either way.  0 = automatic (float-32 frames, batches of 64 and more: where it
+                            * are bit-identical either way.  0 = automatic (float-32 frames, batches of 192 and more: where it
                             * measured faster), 1 = always, 2 = never                              */
     int32_t reserved[3];
 } mi_stack_params_t;

@@ -47,6 +47,11 @@ struct TiledState {
     float* logp[2] = {nullptr, nullptr};
     float* feat[2] = {nullptr, nullptr};    // (entropy, deviation) of every (frame, pixel) of the batch
     hipStream_t st1 = nullptr, st2 = nullptr;
+    // st3 (round 6): the payload passes.  A level's payload pass only needs that level's arg-max; the next level's energy pass
+    // does not need the payload -- gather-bound kernel beside streaming kernel instead of one after the other.
+    hipStream_t st3 = nullptr;
+    std::vector<hipEvent_t> evPayIn;   // [set][level]: the level's energy pass (all streams) is through
+    hipEvent_t evPay[2] = {nullptr, nullptr};   // the batch's payload passes are through
     hipEvent_t evL0i[2] = {nullptr, nullptr}, evL0b[2] = {nullptr, nullptr}, evRest[2] = {nullptr, nullptr};
     hipEvent_t evL0done[2] = {nullptr, nullptr};   // level-0 state of the batch is final (separable: after its payload pass)
     std::vector<hipEvent_t> evLvl;  // [set][level][interior|border]: per-level joins of st2 and st1
@@ -133,11 +138,13 @@ int tiled_create(mi_stack* s) {
     // they run beside; otherwise they starve and become the critical path.
     int prio_lo = 0, prio_hi = 0;
     MI_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-    if (study_env("MI_SERIAL", 0)) t->st1 = t->st2 = s->stream;   // -DMI_STUDY: every kernel alone on the GPU
+    if (study_env("MI_SERIAL", 0)) t->st1 = t->st2 = t->st3 = s->stream;   // -DMI_STUDY: every kernel alone on the GPU
     else {
         const int bd = study_env("MI_BD_PRIO", 0), co = study_env("MI_CO_PRIO", 0);   // 0 high, 1 normal, 2 low
         MI_HIP(hipStreamCreateWithPriority(&t->st1, hipStreamNonBlocking, bd == 0 ? prio_hi : bd == 1 ? 0 : prio_lo));
         MI_HIP(hipStreamCreateWithPriority(&t->st2, hipStreamNonBlocking, co == 0 ? prio_hi : co == 1 ? 0 : prio_lo));
+        if (study_env("MI_PAYLOAD_STREAM", 1)) MI_HIP(hipStreamCreateWithPriority(&t->st3, hipStreamNonBlocking, co == 0 ? prio_hi : co == 1 ? 0 : prio_lo));
+        else t->st3 = t->st2;   // -DMI_STUDY: the payload passes in line with the levels (rounds 2-5)
         if (study_env("MI_BD_PRIO", 0)) fprintf(stderr, "priority range lo=%d hi=%d\n", prio_lo, prio_hi);
     }
     t->gstride.assign(L + 1, 0);
@@ -147,6 +154,12 @@ int tiled_create(mi_stack* s) {
         MI_HIP(hipEventCreateWithFlags(&t->evL0b[set], hipEventDisableTiming));
         MI_HIP(hipEventCreateWithFlags(&t->evRest[set], hipEventDisableTiming));
         MI_HIP(hipEventCreateWithFlags(&t->evL0done[set], hipEventDisableTiming));
+        MI_HIP(hipEventCreateWithFlags(&t->evPay[set], hipEventDisableTiming));
+        for (int i = 0; i <= L; ++i) {
+            hipEvent_t e;
+            MI_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            t->evPayIn.push_back(e);
+        }
         for (int i = 0; i < 2 * (L + 1); ++i) {
             hipEvent_t e;
             MI_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -175,6 +188,7 @@ int tiled_sync_all(mi_stack* s) {
     if (t->stc) MI_HIP(hipStreamSynchronize(t->stc));
     if (t->st1) MI_HIP(hipStreamSynchronize(t->st1));
     if (t->st2) MI_HIP(hipStreamSynchronize(t->st2));
+    if (t->st3 && t->st3 != t->st2) MI_HIP(hipStreamSynchronize(t->st3));
     t->streams_dirty = false;
     return MI_OK;
 }
@@ -187,8 +201,10 @@ void tiled_destroy(mi_stack* s) {
         if (t->evL0b[set]) (void)hipEventDestroy(t->evL0b[set]);
         if (t->evRest[set]) (void)hipEventDestroy(t->evRest[set]);
         if (t->evL0done[set]) (void)hipEventDestroy(t->evL0done[set]);
+        if (t->evPay[set]) (void)hipEventDestroy(t->evPay[set]);
     }
     for (auto e : t->evLvl) (void)hipEventDestroy(e);
+    for (auto e : t->evPayIn) (void)hipEventDestroy(e);
     for (int i = 0; i < TiledState::NUP; ++i)
         if (t->evUp[i]) (void)hipEventDestroy(t->evUp[i]);
     for (int i = 0; i < TiledState::NPIN; ++i) {
@@ -200,6 +216,7 @@ void tiled_destroy(mi_stack* s) {
     if (t->evInput) (void)hipEventDestroy(t->evInput);
     if (t->stc) (void)hipStreamDestroy(t->stc);
     if (t->st1 && t->st1 != s->stream) (void)hipStreamDestroy(t->st1);
+    if (t->st3 && t->st3 != s->stream && t->st3 != t->st2) (void)hipStreamDestroy(t->st3);
     if (t->st2 && t->st2 != s->stream) (void)hipStreamDestroy(t->st2);
     delete t;
     tstate(s) = nullptr;
@@ -719,9 +736,10 @@ int launch_payload_pair_tiles(mi_stack* s, int set, const void* src, size_t src_
 // measured faster: float-32 frames (level 0's kernel is bound by memory AND issue, the times add: 30 MB less per frame against
 // the G_2 reduce it takes on -- +0.07 ms per launch of 16 frames; the 8- and 16-bit kernels are issue-bound: +0.17 ms, more than
 // level 1's pass saves) in batches long enough for the once-per-batch recomputation in the payload pass (about 1.2 ms more
-// than the passes that read a stored G_1, at 24 MP) to be small beside the 2.9 ms per 256 frames level 1 gets faster by.
+// than the passes that read a stored G_1, at 24 MP) to be small beside the 2.9 ms per 256 frames level 1 gets faster by
+// (a 64-frame shard measured 11.0 ms with the pair, ~8.5 without).
 // Interleaved A/B on one box, 256 x 24 MP: float-32 +1.5 to +3 %, 8-bit -3 %, 16-bit -8 % (profiles/r06/pair_ab.txt).
-constexpr int SEP_PAIR_MIN_FRAMES = 64;
+constexpr int SEP_PAIR_MIN_FRAMES = 192;
 inline bool sep_use_pair(const mi_stack* s, int nb) {
     if (!s->sep || s->L < 2 || s->p.pair_levels == 2) return false;
     return s->p.pair_levels == 1 || (s->p.in_dtype == MI_F32 && nb >= SEP_PAIR_MIN_FRAMES);
@@ -760,9 +778,19 @@ int run_batch(mi_stack* s, const void* frames, size_t stride, int nb) {
     TiledState* t = tstate(s);
     const int L = s->L;
     const int set = (int)(t->batch_no & 1);
-    hipStream_t st0 = s->stream, st1 = t->st1, st2 = t->st2;
+    hipStream_t st0 = s->stream, st1 = t->st1, st2 = t->st2, st3 = t->st3;
     int rc;
     if ((rc = tiled_reserve(s, set, nb))) return rc;
+    // the previous batch's payload passes (st3) fold chunk partials into the running state and read what this batch's level
+    // kernels are about to overwrite
+    for (hipStream_t st : {st0, st1, st2}) MI_HIP(hipStreamWaitEvent(st, t->evPay[set ^ 1], 0));
+    // level `l`'s energy pass is through on st2 (its border tiles joined): its payload pass may start on st3
+    auto payload_after = [&](int l) -> int {
+        hipEvent_t e = t->evPayIn[set * (L + 1) + l];
+        MI_HIP(hipEventRecord(e, st2));
+        MI_HIP(hipStreamWaitEvent(st3, e, 0));
+        return MI_OK;
+    };
     // Gb[set] is free once st2 finished batch k-2 (no-op for the first two batches)
     MI_HIP(hipStreamWaitEvent(st0, t->evRest[set], 0));
     MI_HIP(hipStreamWaitEvent(st1, t->evRest[set], 0));
@@ -811,12 +839,14 @@ int run_batch(mi_stack* s, const void* frames, size_t stride, int nb) {
     // a pair whose levels both run unchunked fills in the Laplacians of levels 0 and 1 in one tile-by-tile pass behind level
     // 1's energy pass (below); level 0's state is final only then
     bool tile_payload = pair && li0.nparts == 0 && nb <= 256;
+    MI_HIP(hipStreamWaitEvent(st3, t->evL0i[set], 0));
+    MI_HIP(hipStreamWaitEvent(st3, t->evL0b[set], 0));
     if (!tile_payload) {
-        if ((rc = pair ? launch_payload_pair0<TIn>(s, set, frames, stride, nb, st2, li0.nparts)
-                 : s->sep ? launch_payload_sep<TIn>(s, 0, set, frames, stride, nb, st2, li0.nparts)
-                          : launch_payload_exact<TIn, FMA>(s, 0, set, frames, stride, nb, st2)))
+        if ((rc = pair ? launch_payload_pair0<TIn>(s, set, frames, stride, nb, st3, li0.nparts)
+                 : s->sep ? launch_payload_sep<TIn>(s, 0, set, frames, stride, nb, st3, li0.nparts)
+                          : launch_payload_exact<TIn, FMA>(s, 0, set, frames, stride, nb, st3)))
             return rc;
-        MI_HIP(hipEventRecord(t->evL0done[set], st2));   // st2 waited for both level-0 kernels above
+        MI_HIP(hipEventRecord(t->evL0done[set], st3));   // st3 waited for both level-0 kernels above
     }
     // coarser levels: interior tiles on st2, border tiles on st1 (disjoint tiles of one level run
     // side by side); both streams join after every level because level l+1 reads all of G_{l+1}
@@ -838,15 +868,16 @@ int run_batch(mi_stack* s, const void* frames, size_t stride, int nb) {
                 MI_HIP(hipEventRecord(eb, st1));
                 MI_HIP(hipStreamWaitEvent(st2, eb, 0));
             }
+            if ((rc = payload_after(1))) return rc;
             if (tile_payload && li.nparts == 0) {
-                if ((rc = launch_payload_pair_tiles<TIn>(s, set, frames, stride, nb, st2))) return rc;
-                MI_HIP(hipEventRecord(t->evL0done[set], st2));
+                if ((rc = launch_payload_pair_tiles<TIn>(s, set, frames, stride, nb, st3))) return rc;
+                MI_HIP(hipEventRecord(t->evL0done[set], st3));
             } else {
                 if (tile_payload) {   // (level 1 ran in chunks after all: level 0's payload on its own, late)
-                    if ((rc = launch_payload_pair0<TIn>(s, set, frames, stride, nb, st2, 0))) return rc;
-                    MI_HIP(hipEventRecord(t->evL0done[set], st2));
+                    if ((rc = launch_payload_pair0<TIn>(s, set, frames, stride, nb, st3, 0))) return rc;
+                    MI_HIP(hipEventRecord(t->evL0done[set], st3));
                 }
-                if ((rc = launch_payload_pair1<TIn>(s, set, frames, stride, nb, st2, li.nparts))) return rc;
+                if ((rc = launch_payload_pair1<TIn>(s, set, frames, stride, nb, st3, li.nparts))) return rc;
             }
             continue;
         }
@@ -861,7 +892,8 @@ int run_batch(mi_stack* s, const void* frames, size_t stride, int nb) {
                 MI_HIP(hipEventRecord(eb, st1));
                 MI_HIP(hipStreamWaitEvent(st2, eb, 0));
             }
-            if ((rc = launch_payload_sep<float>(s, l, set, t->Gb[set][l], t->gstride[l] * sizeof(float), nb, st2, li.nparts))) return rc;
+            if ((rc = payload_after(l))) return rc;
+            if ((rc = launch_payload_sep<float>(s, l, set, t->Gb[set][l], t->gstride[l] * sizeof(float), nb, st3, li.nparts))) return rc;
             continue;
         }
         if (s->sep && il && l == 1)
@@ -878,8 +910,9 @@ int run_batch(mi_stack* s, const void* frames, size_t stride, int nb) {
         MI_HIP(hipEventRecord(eb, st1));
         MI_HIP(hipStreamWaitEvent(st2, eb, 0));
         MI_HIP(hipStreamWaitEvent(st1, ei, 0));
-        if ((rc = s->sep ? launch_payload_sep<float>(s, l, set, t->Gb[set][l], t->gstride[l] * sizeof(float), nb, st2)
-                         : launch_payload_exact<float, FMA>(s, l, set, t->Gb[set][l], t->gstride[l] * sizeof(float), nb, st2)))
+        if ((rc = payload_after(l))) return rc;
+        if ((rc = s->sep ? launch_payload_sep<float>(s, l, set, t->Gb[set][l], t->gstride[l] * sizeof(float), nb, st3)
+                         : launch_payload_exact<float, FMA>(s, l, set, t->Gb[set][l], t->gstride[l] * sizeof(float), nb, st3)))
             return rc;
     }
     MI_HIP(hipGetLastError());
@@ -909,6 +942,8 @@ int run_batch(mi_stack* s, const void* frames, size_t stride, int nb) {
                                s->idxE, s->idxD, s->baseE, s->baseD);
         MI_HIP(hipGetLastError());
     }
+    MI_HIP(hipEventRecord(t->evPay[set], st3));
+    MI_HIP(hipStreamWaitEvent(st2, t->evPay[set], 0));   // evRest covers the payload passes too (they read Gb[set])
     MI_HIP(hipEventRecord(t->evRest[set], st2));
     t->streams_dirty = true;
     s->n_pushed += nb;
