@@ -330,6 +330,12 @@ MI_API int mi_aligner_estimate(mi_aligner_t al, void* stream, const void* dev_mo
 MI_API int mi_aligner_estimate_batch(mi_aligner_t al, void* stream, const void* const* dev_movs, int n, int max_iters,
                               double eps, double* M_out, double* cc_out, int* iters_out);
 
+/* Every frame of a batch against ANOTHER FRAME OF THE BATCH (ref_of[k] = index of frame k's reference; a frame may name itself:
+ * identity, correlation 1): the pyramids of the n frames are built once, frame k's template is frame ref_of[k]'s pyramid.  The
+ * chained order of the reference's jobs (stack_framework.py:214-232: frame f against frame f - 1) as ONE batched Gauss-Newton
+ * -- the steps are then composed by the caller.  M_out[k]: frame k -> frame ref_of[k], full-resolution pixels. */
+MI_API int mi_aligner_estimate_pairs(mi_aligner_t al, void* stream, const void* const* dev_frames, int n_frames, const int* ref_of,
+                                     int max_iters, double eps, double* M_out, double* cc_out, int* iters_out);
 /* The same iteration started from given transforms instead of from the identity: `M_init` (n x 6, moving -> reference,
  * full-resolution pixels: what an earlier estimate returned) is refined on the `levels` finest pyramid levels (1 = the
  * finest alone).  The chained order of the reference's jobs (step_process, stack_framework.py:214-232) uses it to pull

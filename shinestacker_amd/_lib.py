@@ -167,6 +167,8 @@ SIGNATURES = {
     "mi_aligner_estimate_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int,
                                             C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                             C.POINTER(C.c_int)]),
+    "mi_aligner_estimate_pairs": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int), C.c_int,
+                                            C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "mi_aligner_refine_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_double),
                                           C.c_int, C.c_int, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                           C.POINTER(C.c_int)]),
@@ -773,6 +775,19 @@ class Aligner:
         cc = (C.c_double * n)()
         it = (C.c_int * n)()
         check(load().mi_aligner_estimate_batch(self._h, stream, ptrs, n, int(max_iters), float(eps), m, cc, it))
+        return (np.array(list(m), dtype=np.float64).reshape(n, 2, 3), np.array(list(cc), dtype=np.float64),
+                np.array(list(it), dtype=np.int32))
+
+    def estimate_pairs(self, dev_ptrs, ref_of, max_iters=60, eps=1e-9, stream=None):
+        """Every frame against another frame of the batch: ref_of[k] = index (into dev_ptrs) of frame k's reference
+        (mi_aligner_estimate_pairs).  -> (M n x 2 x 3, frame k -> frame ref_of[k]; cc n; iterations n)"""
+        n = len(dev_ptrs)
+        ptrs = (C.c_void_p * n)(*dev_ptrs)
+        refs = (C.c_int * n)(*[int(r) for r in ref_of])
+        m = (C.c_double * (6 * n))()
+        cc = (C.c_double * n)()
+        it = (C.c_int * n)()
+        check(load().mi_aligner_estimate_pairs(self._h, stream, ptrs, n, refs, int(max_iters), float(eps), m, cc, it))
         return (np.array(list(m), dtype=np.float64).reshape(n, 2, 3), np.array(list(cc), dtype=np.float64),
                 np.array(list(it), dtype=np.int32))
 

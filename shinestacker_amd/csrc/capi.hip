@@ -940,8 +940,11 @@ inline int ecc_sample_step(size_t np) {
 // `M_init` (n x 6, moving -> reference in full-resolution pixels, what a previous estimate returned) + `start_level`: the
 // iteration starts from that transform on pyramid level `start_level` instead of from the identity on the coarsest level
 // (mi_aligner_refine_batch).
+// `tslots` (n, optional): frame k is registered against the pyramid of the batch's frame tslots[k] instead of the handle's
+// reference (mi_aligner_estimate_pairs; no phase-correlation start there).
 int aligner_solve(mi_aligner* al, hipStream_t st, int n, int max_iters, double eps, double* M_out, double* cc_out,
-                  int* iters_out, double* M9_out = nullptr, const double* M_init = nullptr, int start_level = -1) {
+                  int* iters_out, double* M9_out = nullptr, const double* M_init = nullptr, int start_level = -1,
+                  const int* tslots = nullptr) {
     if (max_iters < 1) max_iters = 50;
     if (!(eps > 0)) eps = 1e-8;
     auto& lv = al->lv;
@@ -952,6 +955,7 @@ int aligner_solve(mi_aligner* al, hipStream_t st, int n, int max_iters, double e
         hs[k].a = 1.0;
         hs[k].rho = -1.0;
         hs[k].last_rho = -2.0;
+        hs[k].tslot = tslots ? tslots[k] : -1;
         if (M_init) {
             // W = M^-1 (reference -> moving, what the iteration works on): A = [a -b; b a], T in origin coordinates of level
             // l_first (sub-sampled pixels / 2^l_first) -- the inverse of the read-out at the end of this function
@@ -965,7 +969,7 @@ int aligner_solve(mi_aligner* al, hipStream_t st, int n, int max_iters, double e
             hs[k].T1 = -(b * M[2] + a * M[5]) / sc;
         }
     }
-    if (al->phase_init && !M_init) {
+    if (al->phase_init && !M_init && !tslots) {
         // coarse initialiser: the translation phase correlation finds on level pc_level (<= 512 pixels per side) becomes
         // the starting translation of the Gauss-Newton iteration at the coarsest level
         const EccLevel& PL = lv[al->pc_level];
@@ -2219,6 +2223,31 @@ int mi_aligner_estimate_batch(mi_aligner_t al, void* stream, const void* const* 
     }
     MI_HIP(hipGetLastError());
     return aligner_solve(al, st, n, max_iters, eps, M_out, cc_out, iters_out);
+}
+
+int mi_aligner_estimate_pairs(mi_aligner_t al, void* stream, const void* const* dev_frames, int n, const int* ref_of,
+                              int max_iters, double eps, double* M_out, double* cc_out, int* iters_out) {
+    if (!al || !dev_frames || !ref_of || !M_out) return fail(MI_ERR_INVALID, "null argument");
+    if (n < 1 || n > ECC_MAXF) return fail(MI_ERR_INVALID, "batch of %d frames (1..%d)", n, ECC_MAXF);
+    for (int k = 0; k < n; ++k) {
+        if (!dev_frames[k]) return fail(MI_ERR_INVALID, "null frame %d", k);
+        if (ref_of[k] < 0 || ref_of[k] >= n) return fail(MI_ERR_INVALID, "frame %d: reference %d is not a frame of the batch", k, ref_of[k]);
+    }
+    MI_HIP(hipSetDevice(al->device));
+    hipStream_t st = stream ? (hipStream_t)stream : al->own;
+    int rc = aligner_reserve(al, n);
+    if (rc) return rc;
+    const int split = n > 1 ? 2 : 1 << 30;   // (as mi_aligner_estimate_batch)
+    for (int k = 0; k < n; ++k)
+        if ((rc = aligner_build(al, st, dev_frames[k], false, k, split))) return rc;
+    for (size_t l = (size_t)split; l < al->lv.size(); ++l) {
+        const auto& a = al->lv[l - 1];
+        const auto& b = al->lv[l];
+        hipLaunchKernelGGL((ecc_blur_tile<1>), dim3(cdiv(b.w, 64), cdiv(b.h, 16), n), dim3(256), 0, st, (const float*)a.img, a.h, a.w,
+                           b.img, b.h, b.w);
+    }
+    MI_HIP(hipGetLastError());
+    return aligner_solve(al, st, n, max_iters, eps, M_out, cc_out, iters_out, nullptr, nullptr, -1, ref_of);
 }
 
 int mi_aligner_refine_batch(mi_aligner_t al, void* stream, const void* const* dev_movs, int n, const double* M_init, int levels,

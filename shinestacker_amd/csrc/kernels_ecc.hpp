@@ -448,7 +448,9 @@ struct EccState {
     double a, b, tx, ty;     // similarity about the image centre of the current level
     double T0, T1;           // translation in origin coordinates (carried from level to level)
     double rho, last_rho;
-    int iters, failed, active, pad_;
+    int iters, failed, active;
+    int tslot;               // the frame's template: -1 = the handle's reference, s >= 0 = the pyramid of the batch's frame s
+                             // (mi_aligner_estimate_pairs: every frame against a neighbour of the same batch)
 };
 
 // H d = r for the symmetric 4 x 4 H (10 values, row-major upper triangle): column-scaled Gaussian elimination with
@@ -553,6 +555,7 @@ __global__ __launch_bounds__(256) void ecc_accumulate(const float* __restrict__ 
     const int f = blockIdx.y;
     if (!state[f].active) return;
     const EccParams p = {state[f].a, state[f].b, state[f].tx, state[f].ty};
+    if (state[f].tslot >= 0) tmpl = img + (size_t)state[f].tslot * fstride;
     img += (size_t)f * fstride;
     partial += (size_t)f * ECC_MAX_BLOCKS * ECC_NSUM;
     ticket += f;

@@ -120,6 +120,155 @@ def _corner_shift(m0, m1, height, width):
     return float(np.abs(np.asarray(m0) @ pts - np.asarray(m1) @ pts).max())
 
 
+CHAIN_PAIR_WORKERS = 4   # estimator handles (one host thread each) that share the chain's neighbour pairs
+
+
+def _to33(m):
+    m = np.asarray(m, np.float64)
+    return m if m.shape == (3, 3) else np.vstack([m, [0.0, 0.0, 1.0]])
+
+
+def _align_chains_pairs_device(lib, dev_frames, aligned, n_frames, height, width, dt, ref_idx, cfg, min_correlation, max_iters,
+                               device, corr=None, chain_refine=True, reuse=None):
+    """`step_process=True` without its serial dependency (round 6).  The reference registers frame f against the ALIGNED frame
+    f - 1 (stack_framework.py:214-232): neighbours look alike, so the estimate is easy, and the aligned neighbour carries the
+    transform found so far.  The same chain, factored: every frame is registered against its UNWARPED neighbour -- independent
+    estimates: ALIGN_RIGID as batched Gauss-Newton over up to 127 pairs at once (mi_aligner_estimate_pairs), ALIGN_HOMOGRAPHY
+    pair by pair on CHAIN_PAIR_WORKERS estimator handles --, the steps are composed along each chain in
+    float64 (frame -> neighbour -> ... -> reference), and, as in the serial form, every composed estimate is refined against
+    the GLOBAL reference frame (one batched call for all frames: the datum that keeps the steps' errors from adding up,
+    `chain_refine`); then all frames are warped.  No step waits for a warp, nothing synchronises the device per frame.
+    Differences from the serial form: a step's reference has not been resampled (its estimate sees the sharper image) and,
+    with `corr`, has not been balanced yet (the ECC criterion is invariant to gain and offset); the balanced, aligned frames
+    the stack sees are produced exactly as before.  `reuse` (ALIGN_RIGID): (pair estimator, global-reference estimator, frame
+    scratch, mask scratch) of an earlier call -- nothing is allocated then.  Returns (transforms, correlation coefficients
+    -- the refinement's where it was accepted)."""
+    import threading
+    fb = height * width * 3 * dt.itemsize
+    mode = _BORDER_CODE[cfg['border_mode']]
+    bv = (C.c_double * 4)(*(list(cfg['border_value']) + [0, 0, 0, 0])[:4])
+    homography = cfg['transform'] == constants.ALIGN_HOMOGRAPHY
+    sub = max(1, int(cfg['subsample']))
+    transforms, ccs = [None] * n_frames, [1.0] * n_frames
+    _lib.check(lib.mi_memcpy_d2d(device, aligned + ref_idx * fb, dev_frames + ref_idx * fb, fb))   # align.py:279-280
+    chains = [list(range(ref_idx + 1, n_frames)), list(range(ref_idx - 1, -1, -1))]
+    pairs = []                      # (frame, its neighbour towards the reference frame)
+    for ch in chains:
+        prev = ref_idx
+        for i in ch:
+            pairs.append((i, prev))
+            prev = i
+    if not pairs:
+        return transforms, ccs
+    step_m, step_cc, errors = {}, {}, []
+    import os, time
+    _t = [time.perf_counter()]
+    def _lap(label):
+        if os.environ.get("MI_CHAIN_TIMING"):
+            lib.mi_device_synchronize(device)
+            _t.append(time.perf_counter())
+            print(f"[chain] {label}: {(_t[-1] - _t[-2]) * 1e3:.1f} ms", flush=True)
+
+    if not homography:
+        # ALIGN_RIGID: the pairs of a chain as batches of ONE Gauss-Newton each (mi_aligner_estimate_pairs: the pyramids of the
+        # batch's frames are built once, a frame's template is its neighbour's pyramid).  A batch = a run of up to MAX_BATCH
+        # frames along a chain, led by the frame the run's first step refers to (the reference frame, or the last frame of
+        # the run before), which is registered against itself.
+        al = None
+        try:
+            al = reuse[0] if reuse else _lib.Aligner(height, width, dt, subsample=sub, device=device, fast=bool(cfg['fast_subsampling']))
+            for ch in chains:
+                lead = ref_idx
+                for b0 in range(0, len(ch), _lib.Aligner.MAX_BATCH - 1):
+                    run = ch[b0:b0 + _lib.Aligner.MAX_BATCH - 1]
+                    frames_b = [lead] + run
+                    ms, cs, _ = al.estimate_pairs([dev_frames + i * fb for i in frames_b], [0] + list(range(len(run))),
+                                                  max_iters=max_iters)
+                    for k, i in enumerate(run, start=1):
+                        if not cs[k] >= min_correlation:
+                            raise AlignmentError(i, f"correlation {cs[k]:.3f} < {min_correlation}")
+                        step_m[i], step_cc[i] = _to33(ms[k]), float(cs[k])
+                    lead = run[-1]
+        finally:
+            if al is not None and not reuse:
+                al.close()
+    else:
+        nw = max(1, min(CHAIN_PAIR_WORKERS, len(pairs)))
+
+        def worker(k):
+            al = None
+            try:
+                al = _lib.Aligner(height, width, dt, subsample=sub, device=device, fast=bool(cfg['fast_subsampling']))
+                lo, hi = k * len(pairs) // nw, (k + 1) * len(pairs) // nw
+                for i, prev in pairs[lo:hi]:
+                    al.set_reference(dev_frames + prev * fb)
+                    ms, cs, _ = al.estimate_homography_batch([dev_frames + i * fb], max_iters=max_iters)
+                    if not cs[0] >= min_correlation:
+                        raise AlignmentError(i, f"correlation {cs[0]:.3f} < {min_correlation}")
+                    step_m[i], step_cc[i] = _to33(ms[0]), float(cs[0])
+            except Exception as e:  # noqa: BLE001  re-raised on the calling thread
+                errors.append(e)
+            finally:
+                if al is not None:
+                    al.close()
+
+        threads = [threading.Thread(target=worker, args=(k,)) for k in range(nw)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if errors:
+            raise errors[0]
+    _lap("pair estimates")
+    # frame -> reference: the steps composed along the chain (x_ref = M_prev_total M_step x_frame)
+    for ch in chains:
+        total = np.eye(3)
+        for i in ch:
+            total = total @ step_m[i]
+            transforms[i] = total.copy() if homography else total[:2].copy()
+            ccs[i] = step_cc[i]
+    if chain_refine and not homography:
+        gref = None
+        try:
+            gref = reuse[1] if reuse else _lib.Aligner(height, width, dt, subsample=sub, device=device, fast=bool(cfg['fast_subsampling']))
+            gref.set_reference(dev_frames + ref_idx * fb)
+            todo = [i for ch in chains for i in ch[1:]]     # (a chain's first step IS an estimate against the global reference)
+            for b0 in range(0, len(todo), _lib.Aligner.MAX_BATCH):
+                idx = todo[b0:b0 + _lib.Aligner.MAX_BATCH]
+                try:
+                    m2, c2, _ = gref.refine_batch([dev_frames + i * fb for i in idx], np.stack([transforms[i] for i in idx]),
+                                                  levels=2, max_iters=max_iters)
+                except (_lib.DeviceError, ValueError):
+                    continue
+                for j, i in enumerate(idx):
+                    if c2[j] >= min_correlation and _corner_shift(transforms[i], m2[j], height, width) <= CHAIN_REFINE_MAX_SHIFT:
+                        transforms[i], ccs[i] = m2[j], float(c2[j])
+        finally:
+            if gref is not None and not reuse:
+                gref.close()
+    _lap("refine")
+    tmp = mask = None
+    try:
+        tmp = reuse[2] if reuse else _lib.DeviceBuffer(fb, device)
+        mask = reuse[3] if reuse else _lib.DeviceBuffer(height * width, device)
+        warp = lib.mi_warp_perspective_device if homography else lib.mi_warp_affine_device
+        for ch in chains:
+            for i in ch:
+                m = np.asarray(transforms[i], np.float64)
+                arr = (C.c_double * m.size)(*m.reshape(-1))
+                _lib.check(warp(device, None, dev_frames + i * fb, aligned + i * fb, tmp.ptr, mask.ptr, height, width,
+                                _lib.DTYPE_CODE[dt], arr, mode, bv, 21, float(cfg['border_blur'])))
+                if corr is not None:
+                    corr.apply_correction_device(i, aligned + i * fb, None)
+        _lib.check(lib.mi_device_synchronize(device))
+        _lap("warps")
+    finally:
+        for b in (tmp, mask):
+            if b is not None and not reuse:
+                b.free()
+    return transforms, ccs
+
+
 def _align_chains_device(lib, dev_frames, aligned, n_frames, height, width, dt, ref_idx, cfg, min_correlation, max_iters,
                          device, corr=None, chain_refine=True):
     """`step_process=True` (stack_framework.py:214-232, the documented default of the reference's jobs): frame ref+1 is
@@ -172,7 +321,7 @@ def _align_chains_device(lib, dev_frames, aligned, n_frames, height, width, dt, 
                     try:
                         m2, c2, _ = gref.refine_batch([dev_frames + i * fb], m[None], levels=2, max_iters=max_iters)
                         if c2[0] >= min_correlation and _corner_shift(m, m2[0], height, width) <= CHAIN_REFINE_MAX_SHIFT:
-                            m = m2[0]
+                            m, cc = m2[0], c2[0]     # (the coefficient reported is that of the transform that is used)
                     except (_lib.DeviceError, ValueError):
                         pass
                 transforms[i], ccs[i] = m, float(cc)
@@ -211,8 +360,9 @@ class StackHandles:
     the scratch buffers of ONE geometry.  The library never sees the sizes of `batches` / `tmp` / `mask`, so the geometry
     they were made for travels with them and a later call is checked against it (`matches`)."""
 
-    def __init__(self, stack, aligner, batches, tmp, mask, **geometry):
+    def __init__(self, stack, aligner, batches, tmp, mask, gref=None, **geometry):
         self.stack, self.aligner, self.batches, self.tmp, self.mask = stack, aligner, batches, tmp, mask
+        self.gref = gref    # step_process: the estimator that holds the GLOBAL reference frame (chain_refine)
         self.geometry = geometry
 
     def __iter__(self):    # (stack, aligner, batches, tmp, mask), as rounds 2-3 returned them
@@ -224,6 +374,8 @@ class StackHandles:
 
     def close(self):
         self.aligner.close()
+        if self.gref is not None:
+            self.gref.close()
         self.stack.close()
         for b in (self.batches, self.tmp, self.mask):
             b.free()
@@ -267,7 +419,7 @@ def auto_batch_frames(n_frames, height, width, dtype, device=0, share=0.25):
 def align_and_stack_device(dev_frames, n_frames, height, width, dtype, ref_idx=-1, alignment_config=None,
                            min_correlation=0.5, max_iters=60, device=0, batch_frames=None, out_dev=None,
                            balance=None, ecc_batch=16, step_process=False, native_loop=True, handles=None,
-                           keep_handles=False, info=None, chain_refine=True, **stack_kwargs):
+                           keep_handles=False, info=None, chain_refine=True, chain_serial=False, **stack_kwargs):
     """BASELINE config 4 with every frame resident in HBM: `dev_frames` is the device address of
     `n_frames` contiguous H x W x 3 frames.  Each frame is registered against frames[ref_idx] by
     the device ECC estimator (mi_aligner_*), warped with the blurred replicate border of
@@ -305,6 +457,9 @@ def align_and_stack_device(dev_frames, n_frames, height, width, dtype, ref_idx=-
     file order afterwards, so that the stack sees them exactly as the reference's FocusStack reads the aligned files.
     `chain_refine` (default True; ALIGN_RIGID): every chain estimate is refined against the global reference frame before the
     frame is warped, so that the steps' errors do not add up (`_align_chains_device`); False = the plain chain.
+    `chain_serial` (default False): the chain as rounds 3-5 ran it -- every step registered against the WARPED neighbour, one
+    device synchronisation per frame (`_align_chains_device`); the default factors the chain into independent
+    neighbour estimates + composition (`_align_chains_pairs_device`).
 
     Returns (fused image as ndarray, or None when `out_dev` -- a device address for the result --
     is given; list of 2x3 transforms, None at ref_idx; list of correlation coefficients)."""
@@ -324,19 +479,50 @@ def align_and_stack_device(dev_frames, n_frames, height, width, dtype, ref_idx=-
     dt = np.dtype(dtype)
     fb = height * width * 3 * dt.itemsize
     lib = _lib.load()
-    if step_process and (handles is not None or keep_handles):
-        raise InvalidOptionError("handles", "reuse", ": handle reuse is implemented for the non-chained native loop, not for "
-                                 "step_process")
     if step_process:
-        aligned = _lib.DeviceBuffer(fb * n_frames, device)
-        corr = None
-        if balance is not None:
-            corr = _make_correction(balance, device)
-            corr.begin_device(dev_frames + ref_idx * fb, height, width, dt, n_frames)
-        transforms, ccs = _align_chains_device(lib, dev_frames, aligned.ptr, n_frames, height, width, dt, ref_idx, cfg,
-                                               min_correlation, max_iters, device, corr, chain_refine=chain_refine)
-        stack = _lib.Stack(height, width, in_dtype=dt, out_dtype=dt, device=device, **stack_kwargs)
+        reusing = handles is not None or keep_handles
+        if reusing and (chain_serial or homography):
+            raise InvalidOptionError("handles", "reuse", ": with step_process, handle reuse is implemented for the factored ALIGN_RIGID "
+                                     "chain (not chain_serial, not ALIGN_HOMOGRAPHY)")
+        sub = max(1, int(cfg['subsample']))
+        geometry = dict(height=int(height), width=int(width), dtype=dt.name, step_process=True, frames=int(n_frames), subsample=sub,
+                        fast=bool(cfg['fast_subsampling']), device=int(device),
+                        stack_kwargs=tuple(sorted((k, repr(v)) for k, v in stack_kwargs.items())))
+        created = []
+        if handles is not None:
+            bad = handles.mismatch(**geometry)
+            if bad:
+                raise InvalidOptionError("handles", {k: geometry[k] for k in bad},
+                                         f": these handles were created for {({k: handles.geometry.get(k) for k in bad})}")
+            stack, aligner, aligned, tmp, mask = handles
+            gref = handles.gref
+            stack.reset()
+        else:
+            aligned = _lib.DeviceBuffer(fb * n_frames, device)
+            created.append(aligned.free)
+            aligner = gref = tmp = mask = None
+            if reusing:
+                aligner = _lib.Aligner(height, width, dt, subsample=sub, device=device, fast=bool(cfg['fast_subsampling']))
+                gref = _lib.Aligner(height, width, dt, subsample=sub, device=device, fast=bool(cfg['fast_subsampling']))
+                tmp, mask = _lib.DeviceBuffer(fb, device), _lib.DeviceBuffer(height * width, device)
+                created += [aligner.close, gref.close, tmp.free, mask.free]
+            stack = None
+        done = False
         try:
+            corr = None
+            if balance is not None:
+                corr = _make_correction(balance, device)
+                corr.begin_device(dev_frames + ref_idx * fb, height, width, dt, n_frames)
+            if chain_serial:
+                transforms, ccs = _align_chains_device(lib, dev_frames, aligned.ptr, n_frames, height, width, dt, ref_idx, cfg,
+                                                       min_correlation, max_iters, device, corr, chain_refine=chain_refine)
+            else:
+                transforms, ccs = _align_chains_pairs_device(lib, dev_frames, aligned.ptr, n_frames, height, width, dt, ref_idx, cfg,
+                                                             min_correlation, max_iters, device, corr, chain_refine=chain_refine,
+                                                             reuse=(aligner, gref, tmp, mask) if reusing else None)
+            if stack is None:
+                stack = _lib.Stack(height, width, in_dtype=dt, out_dtype=dt, device=device, **stack_kwargs)
+                created.append(stack.close)
             stack.push_frames_device(aligned.ptr, n_frames, fb)
             if out_dev is not None:
                 stack.finish_device(out_dev)
@@ -344,9 +530,14 @@ def align_and_stack_device(dev_frames, n_frames, height, width, dtype, ref_idx=-
                 out = None
             else:
                 out = stack.finish()
+            done = True
         finally:
-            stack.close()
-            aligned.free()
+            if not (keep_handles and done):
+                for release in reversed(created):
+                    release()
+        if keep_handles:
+            return out, transforms, ccs, (handles if handles is not None else
+                                          StackHandles(stack, aligner, aligned, tmp, mask, gref=gref, **geometry))
         return out, transforms, ccs
     ecc_batch = max(1, min(int(ecc_batch), _lib.Aligner.MAX_BATCH))
     if batch_frames is None:   # handles of an earlier call fix it; else as many frames per push as memory allows

@@ -55,6 +55,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="warped frames per push into the stacker (resident mode; 0 = the pipeline's choice: as many as memory allows, up to 128)")
     ap.add_argument("--step-process", action="store_true", help="the reference's chained order (resident mode)")
     ap.add_argument("--no-chain-refine", action="store_true", help="with --step-process: the plain chain (no refinement against the global reference frame)")
+    ap.add_argument("--chain-serial", action="store_true", help="with --step-process: every step against the WARPED neighbour, one device synchronisation per frame (rounds 3-5)")
     ap.add_argument("--arith", default="exact", choices=["exact", "separable"], help="stacker arithmetic (resident mode)")
     ap.add_argument("--ecc-batch", type=int, default=0, help="frames per batched Gauss-Newton (0 = the pipeline's default)")
     ap.add_argument("--reuse-handles", action="store_true", help="time a second stack on the handles of a first one (no allocation in the timed region)")
@@ -98,12 +99,14 @@ def main():
         out = L.DeviceBuffer(fb)
         bal = {'channel': 'LUMI', 'corr_map': 'LINEAR', 'subsample': 8} if args.balance else None
         acfg = {'transform': 'ALIGN_HOMOGRAPHY'} if args.homography else None
-        align_and_stack_device(buf.ptr, min(N, 4), H, W, np.uint8, out_dev=out.ptr, balance=bal, arith=args.arith, step_process=args.step_process, chain_refine=not args.no_chain_refine, batch_frames=(args.batch or None), alignment_config=acfg, native_loop=not args.python_loop, **({'ecc_batch': args.ecc_batch} if args.ecc_batch else {}))   # warm-up
+        align_and_stack_device(buf.ptr, min(N, 4), H, W, np.uint8, out_dev=out.ptr, balance=bal, arith=args.arith, step_process=args.step_process, chain_refine=not args.no_chain_refine, chain_serial=args.chain_serial, batch_frames=(args.batch or None), alignment_config=acfg, native_loop=not args.python_loop, **({'ecc_batch': args.ecc_batch} if args.ecc_batch else {}))   # warm-up
         if args.reuse_handles:   # what a job of many stacks pays per stack: the handles exist already
-            if args.step_process or args.python_loop:
+            if args.python_loop or (args.step_process and (args.chain_serial or args.homography)):
                 # (round 3 dropped these flags silently here and wrote a non-chained run into config4_resident_step.json)
-                raise SystemExit("--reuse-handles times the native non-chained loop; it cannot be combined with --step-process / --python-loop")
+                raise SystemExit("--reuse-handles times the native non-chained loop or the factored step_process chain; it cannot be combined with --python-loop / --chain-serial")
             kw = dict(balance=bal, arith=args.arith, batch_frames=(args.batch or None), alignment_config=acfg, **({'ecc_batch': args.ecc_batch} if args.ecc_batch else {}))
+            if args.step_process:
+                kw = dict(balance=bal, arith=args.arith, alignment_config=acfg, step_process=True, chain_refine=not args.no_chain_refine)
             from shinestacker_amd.pipeline import close_handles
             *_, hd = align_and_stack_device(buf.ptr, N, H, W, np.uint8, ref_idx=ref, out_dev=out.ptr, keep_handles=True, **kw)
             t0 = time.perf_counter()
@@ -113,15 +116,15 @@ def main():
             recovered = {k: m.copy() for k, m in enumerate(t for t in tr if t is not None)}
             for m in recovered.values():
                 m[:, 2] /= 2
-            report(N, H, W, dt, recovered, truth, ref, cx, cy, "resident, handles reused", list(out.download((H, W, 3), np.uint8).shape))
+            report(N, H, W, dt, recovered, truth, ref, cx, cy, ("resident, step_process (chained, neighbour pairs + composition" + (", plain" if args.no_chain_refine else ", refined against the global reference") + "), handles reused") if args.step_process else "resident, handles reused", list(out.download((H, W, 3), np.uint8).shape))
             return
         t0 = time.perf_counter()
-        _, tr, ccs = align_and_stack_device(buf.ptr, N, H, W, np.uint8, ref_idx=ref, out_dev=out.ptr, balance=bal, arith=args.arith, step_process=args.step_process, chain_refine=not args.no_chain_refine, batch_frames=(args.batch or None), alignment_config=acfg, native_loop=not args.python_loop, **({'ecc_batch': args.ecc_batch} if args.ecc_batch else {}))
+        _, tr, ccs = align_and_stack_device(buf.ptr, N, H, W, np.uint8, ref_idx=ref, out_dev=out.ptr, balance=bal, arith=args.arith, step_process=args.step_process, chain_refine=not args.no_chain_refine, chain_serial=args.chain_serial, batch_frames=(args.batch or None), alignment_config=acfg, native_loop=not args.python_loop, **({'ecc_batch': args.ecc_batch} if args.ecc_batch else {}))
         dt = time.perf_counter() - t0
         recovered = {k: m.copy() for k, m in enumerate(t for t in tr if t is not None)}
         for m in recovered.values():
             m[:, 2] /= 2    # compare at the sub-sampled scale like the host path below
-        report(N, H, W, dt, recovered, truth, ref, cx, cy, ("resident, step_process (chained" + (", plain" if args.no_chain_refine else ", refined against the global reference") + ")" if args.step_process else "resident") + (" + balance" if args.balance else ""), list(out.download((H, W, 3), np.uint8).shape))
+        report(N, H, W, dt, recovered, truth, ref, cx, cy, ("resident, step_process (chained" + (", serial" if args.chain_serial else ", neighbour pairs + composition") + (", plain" if args.no_chain_refine else ", refined against the global reference") + ")" if args.step_process else "resident") + (" + balance" if args.balance else ""), list(out.download((H, W, 3), np.uint8).shape))
         return
     est = ecc_estimator()
     recovered = {}
