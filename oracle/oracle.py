@@ -151,8 +151,10 @@ def red_taps_f32(a=0.4):
     integral, else float32(k) and 1 (separable_oracle.c; the same rule as csrc/common.hpp::red_taps)."""
     k = gen_kernel_1d(a)[:3].astype(np.float64)
     w = 20.0 * np.array([0.25 - a / 2.0, 0.25, a])
-    r = np.round(w)
-    if np.all(np.abs(w - r) < 1e-9):
+    r = np.round(w)      # (the library rounds half away from zero: the two differ on exact halves only, which are not integral)
+    # integral taps whose partial sums stay exact for 16-bit input: (2 |w0| + |w2|) * 65535 < 2^24 (w1 = 5 comes last, the one
+    # operation that may round); a = 0.4: 1 5 8; a = 0.7: -2 5 14 (a negative outer tap is fine); a = 6.7: -62 5 134 is over the bound
+    if np.all(np.abs(w - r) < 1e-9) and 2 * abs(r[0]) + abs(r[2]) <= 255:
         return np.ascontiguousarray(np.array([r[0], 5.0, r[2], 1.0 / 400.0]).astype(np.float32))
     return np.ascontiguousarray(np.array([k[0], k[1], k[2], 1.0]).astype(np.float32))
 

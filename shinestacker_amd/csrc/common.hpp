@@ -106,7 +106,13 @@ inline bool red_taps(double a, float rk[4]) {
     const double k0 = 0.25 - a / 2.0, k1 = 0.25, k2 = a;
     const double w0 = 20.0 * k0, w1 = 20.0 * k1, w2 = 20.0 * k2;
     const double r0 = (double)(long long)(w0 + (w0 < 0 ? -0.5 : 0.5)), r2 = (double)(long long)(w2 + (w2 < 0 ? -0.5 : 0.5));
-    const bool integral = (w0 - r0 < 1e-9 && r0 - w0 < 1e-9) && (w2 - r2 < 1e-9 && r2 - w2 < 1e-9) && w1 == 5.0;
+    // integral, and small enough for the partial sums w0 (a + e) + w2 c of 16-bit input to stay exact:
+    // (2 |w0| + |w2|) * 65535 < 2^24 -- only the last fma (w1 = 5) may round then (kernels_sep.hpp header).  A negative outer
+    // tap (a > 0.5: a = 0.7 gives -2 5 14) is fine; oracle.red_taps_f32 is the same rule (np.round against this
+    // round-half-away: they differ on exact halves only, which are not integral).
+    const double a0 = r0 < 0 ? -r0 : r0, a2 = r2 < 0 ? -r2 : r2;
+    const bool integral = (w0 - r0 < 1e-9 && r0 - w0 < 1e-9) && (w2 - r2 < 1e-9 && r2 - w2 < 1e-9) && w1 == 5.0 &&
+                          2.0 * a0 + a2 <= 255.0;
     if (!integral) {
         rk[0] = (float)k0; rk[1] = (float)k1; rk[2] = (float)k2; rk[3] = 1.0f;
         return false;

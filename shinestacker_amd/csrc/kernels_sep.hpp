@@ -629,7 +629,7 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
             bE[p] = st_e[px];
             bI[p] = -1;      // the running arg-max is not read: -1 = "no frame of this launch has won (yet)"
         } else {
-            bE[p] = -1.0f;   // every energy is >= 0: the first frame always wins
+            bE[p] = -__builtin_inff();   // the first frame always wins (energies can be negative: a generating kernel with a > 0.5 has negative taps)
             bI[p] = -1;
         }
     }
@@ -1404,7 +1404,7 @@ __device__ __forceinline__ void level_sep_e_body(const LevelArgs& a) {
     for (int p = 0; p < 4; ++p) {
         const int y = oy + (p >> 1), x = ox + (p & 1);
         const bool valid = own_tile && y < h && x < w;
-        bE[p] = (!fresh && valid) ? st_e[(size_t)y * w + x] : -1.0f;
+        bE[p] = (!fresh && valid) ? st_e[(size_t)y * w + x] : -__builtin_inff();   // (the first frame always wins, whatever the sign of its energy)
         bI[p] = -1;
     }
 

@@ -419,7 +419,7 @@ __device__ __forceinline__ void level_fused_body(const LevelArgs& a) {
         for (int p = 0; p < 4; ++p) {
             const int y = y0 + 2 * oy + (p >> 1), x = x0 + 2 * ox + (p & 1);
             const bool valid = INTERIOR || (y < h && x < w);
-            bE[q][p] = (!fresh && valid) ? st_e[(size_t)y * w + x] : -1.0f;  // every energy is >= 0: the first frame always wins
+            bE[q][p] = (!fresh && valid) ? st_e[(size_t)y * w + x] : -__builtin_inff();  // the first frame always wins (a > 0.5: negative taps, negative energies)
             bI[q][p] = -1;
         }
     }

@@ -29,7 +29,9 @@ def main():
         kw = {"min_size": int(rng.choice([8, 16, 32])), "use_fma": bool(rng.integers(0, 2)),
               "kernel_size": int(rng.choice([3, 5, 7])),
               # generating kernels with integer reduce taps (0.4, 0.3, 0.5: 20 k integral) and without (separable spec v2)
-              "gen_kernel": float(rng.choice([0.4, 0.4, 0.3, 0.5, 0.35, 0.375]))}
+              # ... a negative integer outer tap (0.7: -2 5 14), taps too large for the integer form (6.7: -62 5 134: integral,
+              # over the bound)
+              "gen_kernel": float(rng.choice([0.4, 0.4, 0.3, 0.5, 0.35, 0.375, 0.7, 6.7]))}
         batch = int(rng.integers(0, 5))
         frames = make_frames(rng, (h, w), dt, n)
         arith = ["exact", "separable"][case % 2]

@@ -72,6 +72,10 @@ CASES = [
     (1000, 70, np.uint8, 2, {"min_size": 16}, 0, True, None),
     (40, 52, np.uint8, 4, {}, 0, False, None),                       # smaller than 2*min_size: base only, no levels
     (33, 47, np.uint16, 3, {}, 2, True, None),                       # same, 16-bit, device frames
+    # a generating kernel with NEGATIVE outer taps (a > 0.5): the blurred energies can be negative, the first frame must win all
+    # the same (round 6: the running maximum started at -1, "every energy is >= 0")
+    (150, 226, np.uint8, 4, {"min_size": 8, "gen_kernel": 0.7}, 0, False, None),
+    (150, 226, np.uint16, 3, {"min_size": 8, "gen_kernel": 0.7}, 0, True, None),
 ]
 
 

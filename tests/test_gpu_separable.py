@@ -52,6 +52,11 @@ CASES = [
     (30, 58, 3, np.uint16, 8, 0.4, 0),
     (256, 64, 5, np.uint8, 8, 0.35, 0),
     (230, 342, 4, np.uint8, 8, 0.4, 0),       # even / odd alternate down the levels: edge and border tiles side by side
+    # reduce taps (red_taps): a negative integer outer tap (a = 0.7: -2 5 14), integer taps over the exactness bound
+    # (a = 6.7: -62 5 134 -> the float taps), both on 16-bit input where the bound matters
+    (150, 226, 3, np.uint16, 8, 0.7, 0),
+    (150, 226, 3, np.uint16, 8, 6.7, 0),
+    (133, 201, 3, np.uint8, 8, 0.7, 0),
 ]
 
 
