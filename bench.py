@@ -590,8 +590,14 @@ def main():
                 traffic_note = f"{ent.get('kernel')}; {ent.get('dispatches')} dispatches; {ent.get('note', '')}"
         except (OSError, AttributeError, ValueError) as e:
             traffic_note = f"profiles/traffic.json unreadable: {e}"
-        kernel = {"separable": "level_sep<level 0> (stage + separable reduce + gray Laplacian + separable energy + "
-                               "select; one launch = 16 frames of the resident push)",
+        pair_on = (args.arith == "separable" and args.dtype == "f32" and F >= 192 and st.levels >= 2
+                   and os.environ.get("SHINESTACKER_AMD_PAIR_LEVELS", "0") in ("0", "1")) or \
+                  (args.arith == "separable" and st.levels >= 2 and os.environ.get("SHINESTACKER_AMD_PAIR_LEVELS") == "1")
+        kernel = {"separable": ("level_sep_pair<level 0> (levels 0 / 1 as a pair: stage + separable reduce + gray Laplacian + separable "
+                                "energy + select of level 0, AND gray(G_1) + the tile's pixels of G_2 for level 1; one launch = 16 "
+                                "frames of the resident push; `achieved` counts level 0's algorithmic bytes only)" if pair_on else
+                                "level_sep<level 0> (stage + separable reduce + gray Laplacian + separable energy + "
+                                "select; one launch = 16 frames of the resident push)"),
                   "exact": "level_fused<level 0> (stage+reduce+laplacian+energy+select, one launch per frame batch)"}
         breakdown = {k: v[0] / args.steps for k, v in prof.items()}
         if world > 1 or force_dist:
@@ -611,6 +617,9 @@ def main():
                                    f"{st.levels}-level Laplacian pyramid fusion "
                                    f"(BASELINE.json configs[{1 if world == 1 or args.scaling == 'weak' else 2}])",
                        "frames_per_gpu": F, "source": args.source, "arith": args.arith,
+                       "pair_levels": ("levels 0 / 1 run as a pair (mi_stack_params.pair_levels, automatic: float-32 batches of 192 "
+                                       "frames and more): G_1 never through HBM, same bits" if pair_on else
+                                       "off for this run (level-by-level kernels)") if args.arith == "separable" else None,
                        "arith_parity": ("separable: bit-identical to oracle/separable_oracle.c (its specification); against the "
                                         "reference's evaluation order the stated bound is 32 u maxv per convolution (u = 2^-24; "
                                         "SURVEY 7), not north_star's 1 ULP: measured Gaussian / energy differences <= 8 % / 1.5 % of "

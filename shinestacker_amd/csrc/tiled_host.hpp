@@ -52,6 +52,7 @@ struct TiledState {
     hipStream_t st3 = nullptr;
     std::vector<hipEvent_t> evPayIn;   // [set][level]: the level's energy pass (all streams) is through
     hipEvent_t evPay[2] = {nullptr, nullptr};   // the batch's payload passes are through
+    std::vector<hipEvent_t> evGrp;     // pair, piped: level 0's launch of frame group g is through (level 1's energy launch of g waits)
     hipEvent_t evL0i[2] = {nullptr, nullptr}, evL0b[2] = {nullptr, nullptr}, evRest[2] = {nullptr, nullptr};
     hipEvent_t evL0done[2] = {nullptr, nullptr};   // level-0 state of the batch is final (separable: after its payload pass)
     std::vector<hipEvent_t> evLvl;  // [set][level][interior|border]: per-level joins of st2 and st1
@@ -205,6 +206,7 @@ void tiled_destroy(mi_stack* s) {
     }
     for (auto e : t->evLvl) (void)hipEventDestroy(e);
     for (auto e : t->evPayIn) (void)hipEventDestroy(e);
+    for (auto e : t->evGrp) (void)hipEventDestroy(e);
     for (int i = 0; i < TiledState::NUP; ++i)
         if (t->evUp[i]) (void)hipEventDestroy(t->evUp[i]);
     for (int i = 0; i < TiledState::NPIN; ++i) {
@@ -740,6 +742,9 @@ int launch_payload_pair_tiles(mi_stack* s, int set, const void* src, size_t src_
 // (a 64-frame shard measured 11.0 ms with the pair, ~8.5 without).
 // Interleaved A/B on one box, 256 x 24 MP: float-32 +1.5 to +3 %, 8-bit -3 %, 16-bit -8 % (profiles/r06/pair_ab.txt).
 constexpr int SEP_PAIR_MIN_FRAMES = 192;
+#ifndef MI_L1E_PIPE_DEFAULT
+#define MI_L1E_PIPE_DEFAULT 0
+#endif
 inline bool sep_use_pair(const mi_stack* s, int nb) {
     if (!s->sep || s->L < 2 || s->p.pair_levels == 2) return false;
     return s->p.pair_levels == 1 || (s->p.in_dtype == MI_F32 && nb >= SEP_PAIR_MIN_FRAMES);
@@ -811,6 +816,16 @@ int run_batch(mi_stack* s, const void* frames, size_t stride, int nb) {
     bool il = false;
     SepLevelInfo li0;
     const bool pair = sep_use_pair(s, nb);
+    // pair: pipe level 1's energy pass behind level 0's launches, group by group -- when both levels run as consecutive
+    // launches and have no border tiles (even sizes)
+    bool l1e_pipe = false;
+    if (pair) {
+        static const int pipe_on = study_env("MI_L1E_PIPE", MI_L1E_PIPE_DEFAULT);
+        bool p0 = false, p1 = false;
+        level_chunk_frames(nb, cdiv(s->lw[0], 56) * cdiv(s->lh[0], MI_SEP_TH), &p0);
+        level_chunk_frames(nb, cdiv(s->lw[1], 56) * cdiv(s->lh[1], MI_SEP_TH), &p1);
+        l1e_pipe = pipe_on && !p0 && !p1 && !(s->lh[0] & 1) && !(s->lw[0] & 1) && !(s->lh[1] & 1) && !(s->lw[1] & 1);
+    }
     if (s->sep && !pair && interleave01 && L >= 2 && nb > SEP_LAUNCH_FRAMES) {
         bool p0 = false, p1 = false;
         const int nt0 = cdiv(s->lw[0], 56) * cdiv(s->lh[0], MI_SEP_TH), nt1 = cdiv(s->lw[1], 56) * cdiv(s->lh[1], MI_SEP_TH);
@@ -824,6 +839,25 @@ int run_batch(mi_stack* s, const void* frames, size_t stride, int nb) {
             rc = launch_level0_sep<TIn>(s, set, frames, stride, nb, st0, st1, t->evL0b[set], f0, f1);
             if (!rc) rc = launch_level_sep<float, false>(s, 1, set, t->Gb[set][1], t->gstride[1] * sizeof(float), nb, st0, st1,
                                                          t->evLvl[(set * (L + 1) + 1) * 2 + 1], f0, f1);
+        }
+    } else if (pair && l1e_pipe) {
+        // level 1's energy launch of a frame group right behind level 0's launch of that group, on st2 (it needs the group's
+        // gray(G_1) and G_2 only): the light kernel beside the heavy one
+        const int ngrp = cdiv(nb, SEP_LAUNCH_FRAMES);
+        while ((int)t->evGrp.size() < ngrp) {
+            hipEvent_t e;
+            MI_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            t->evGrp.push_back(e);
+        }
+        for (int g = 0; g < ngrp && !rc; ++g) {
+            const int f0 = g * SEP_LAUNCH_FRAMES, f1 = std::min(nb, f0 + SEP_LAUNCH_FRAMES);
+            rc = launch_level_sep<TIn, true, false, 1>(s, 0, set, frames, stride, nb, st0, st1, t->evL0b[set], f0, f1, &li0);
+            if (rc) break;
+            MI_HIP(hipEventRecord(t->evGrp[g], st0));
+            MI_HIP(hipStreamWaitEvent(st2, t->evGrp[g], 0));
+            SepLevelInfo li1;
+            rc = launch_level_sep<float, false, false, 2>(s, 1, set, t->Gb[set][1], (size_t)s->lh[1] * s->lw[1] * sizeof(float), nb,
+                                                          st2, st1, t->evLvl[(set * (L + 1) + 1) * 2 + 1], f0, f1, &li1);
         }
     } else if (pair) rc = launch_level_sep<TIn, true, false, 1>(s, 0, set, frames, stride, nb, st0, st1, t->evL0b[set], 0, -1, &li0);
     else if (s->sep) rc = launch_level0_sep<TIn>(s, set, frames, stride, nb, st0, st1, t->evL0b[set], 0, -1, &li0);
@@ -861,7 +895,8 @@ int run_batch(mi_stack* s, const void* frames, size_t stride, int nb) {
             // the second level of the pair: energy only, from gray(G_1) and G_2 (both written by level 0's kernel); its
             // payload pass recomputes the winners' G_1 from the frames
             SepLevelInfo li;
-            if ((rc = launch_level_sep<float, false, false, 2>(s, 1, set, t->Gb[set][1], (size_t)s->lh[1] * s->lw[1] * sizeof(float), nb,
+            if (l1e_pipe) ;   // (launched group by group behind level 0, above: no chunks, no border tiles)
+            else if ((rc = launch_level_sep<float, false, false, 2>(s, 1, set, t->Gb[set][1], (size_t)s->lh[1] * s->lw[1] * sizeof(float), nb,
                                                                st2, st1, eb, 0, -1, &li, ei)))
                 return rc;
             if (li.border) {
