@@ -110,11 +110,12 @@ typedef struct mi_stack_params {
                             * > 0: batches of exactly this many frames, buffers allocated by mi_stack_create (for
                             * callers that push batch after batch and must not stall on an allocation)           */
     int32_t arith;         /* MI_ARITH_*; 0 = exact (the C default, see the enum's comment)     */
-    int32_t pair_levels;   /* MI_ARITH_SEPARABLE: pyramid levels 0 and 1 as one pair -- level 0's kernel hands level 1 gray(G_1) and
-                            * G_2, the three-channel G_1 of the batch never reaches HBM (pyramid.py:27-46, :125-139: the
-                            * reduce -> expand dependency), the winners' pixels of it are recomputed once per batch.  Results
-                            * are bit-identical either way.  0 = automatic (float-32 frames, batches of 192 and more: where it
-                            * measured faster), 1 = always, 2 = never                              */
+    int32_t pair_levels;   /* MI_ARITH_SEPARABLE: pyramid levels as pass PAIRS (l, l + 1) -- level l's kernel hands level l + 1
+                            * gray(G_{l+1}) and G_{l+2}, the three-channel G_{l+1} of the batch never reaches HBM (pyramid.py:27-46,
+                            * :125-139: the reduce -> expand dependency), the winners' pixels of it are recomputed once per batch.
+                            * Results are bit-identical either way.  0 = automatic = where it measured faster: the pair (0, 1)
+                            * for float-32 frames in batches of 192 and more; 1 = pairs (0, 1), (2, 3), ...; 2 = none;
+                            * 3 = pairs (1, 2), (3, 4), ...                                                */
     int32_t reserved[3];
 } mi_stack_params_t;
 

@@ -406,8 +406,8 @@ class Stack:
         p.arith = ARITH_CODE[arith]
         if pair_levels is None:   # (test runs: SHINESTACKER_AMD_PAIR_LEVELS=1 sends every separable stack down the pair kernels)
             pair_levels = int(os.environ.get("SHINESTACKER_AMD_PAIR_LEVELS", "0"))
-        if pair_levels not in (0, 1, 2):
-            raise InvalidOptionError("pair_levels", pair_levels, "0 = automatic, 1 = always, 2 = never")
+        if pair_levels not in (0, 1, 2, 3):
+            raise InvalidOptionError("pair_levels", pair_levels, "0 = automatic, 1 = pairs from level 0 on, 2 = none, 3 = pairs from level 1 on")
         p.pair_levels = int(pair_levels)
         self.arith = p.arith
         self.index_stride = 1

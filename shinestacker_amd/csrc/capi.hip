@@ -1307,7 +1307,7 @@ int mi_stack_create(mi_stack_t** out, const mi_stack_params_t* params) {
     if (p.arith != MI_ARITH_EXACT && p.arith != MI_ARITH_SEPARABLE) return fail(MI_ERR_INVALID, "bad arith %d", p.arith);
     if (p.arith == MI_ARITH_SEPARABLE && p.float_type != MI_F32)
         return fail(MI_ERR_INVALID, "MI_ARITH_SEPARABLE needs float_type MI_F32");
-    if (p.pair_levels < 0 || p.pair_levels > 2) return fail(MI_ERR_INVALID, "pair_levels must be 0 (automatic), 1 (always) or 2 (never)");
+    if (p.pair_levels < 0 || p.pair_levels > 3) return fail(MI_ERR_INVALID, "pair_levels must be 0 (automatic), 1 (pairs from level 0 on), 2 (none) or 3 (pairs from level 1 on)");
     int ndev = 0;
     int rc = mi_device_count(&ndev);
     if (rc) return rc;

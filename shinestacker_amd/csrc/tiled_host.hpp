@@ -31,11 +31,12 @@ struct TiledState {
     std::vector<uint16_t*> sbOrder; // [l] super-block order of the level's interior launch (LevelArgs::sb_order), device
     std::vector<int> sbGroups;      // [l] entries of sbOrder[l] (a multiple of 8)
     std::vector<size_t> gstride;    // floats between frames in Gb[.][l]
-    // MI_ARITH_SEPARABLE, level pairs (kernels_sep.hpp "PAIR", run_batch): a batch that runs levels 0 and 1 as a pair keeps
-    // gray(G_1) -- one float per pixel -- in Gb[set][1] and the three-channel G_1 of its LAST frame in G1keep[set] (the tap)
-    float* G1keep[2] = {nullptr, nullptr};
-    bool last_pair = false;         // the most recent batch ran as a pair
-    uint8_t* tileFlag = nullptr;    // [level-0 tile] the pair's tile-by-tile payload pass left this tile to the per-quad kernels
+    // MI_ARITH_SEPARABLE, level pairs (kernels_sep.hpp "PAIR", run_batch): a batch that runs levels l and l + 1 as a pair keeps
+    // gray(G_{l+1}) -- one float per pixel -- in Gb[set][l+1] and the three-channel G_{l+1} of its LAST frame in
+    // Gkeep[set][l+1] (the tap; allocated when the first such batch runs)
+    std::vector<float*> Gkeep[2];
+    unsigned last_kept = 0;         // bit l: the most recent batch kept level l's Gaussian images as gray + one frame
+    std::vector<uint8_t*> tileFlag; // [l][level-l tile] the pair's tile-by-tile payload pass left this tile to the per-quad kernels
     void* ring = nullptr;           // staging ring for host-pushed frames (bcap frames, in_dtype)
     size_t frame_bytes = 0;
     int pending = 0;                // frames staged in the ring, not yet processed
@@ -114,7 +115,6 @@ int tiled_reserve(mi_stack* s, int set, int nb) {
     }
     for (int l = 1; l <= s->L; ++l)
         if ((rc = dev_alloc_t(s, &t->Gb[set][l], t->gstride[l] * nb))) return rc;
-    if (s->sep && s->L >= 2 && !t->G1keep[set] && (rc = dev_alloc_t(s, &t->G1keep[set], t->gstride[1]))) return rc;
     const size_t npb = (size_t)s->lh[s->L] * s->lw[s->L];
     if ((rc = dev_alloc_t(s, &t->lev[set], npb * nb))) return rc;
     if ((rc = dev_alloc_t(s, &t->cnt[set], (size_t)s->nlevels_hist * nb))) return rc;
@@ -167,6 +167,7 @@ int tiled_create(mi_stack* s) {
             t->evLvl.push_back(e);
         }
         t->Gb[set].assign(L + 1, nullptr);
+        t->Gkeep[set].assign(L + 1, nullptr);
         for (int l = 1; l <= L; ++l) t->gstride[l] = (size_t)s->lh[l] * s->lw[l] * 3;
         // The per-batch buffers are allocated by the first batch that needs them (tiled_reserve in run_batch): a stack
         // that arrives as one resident push never uses the second set, and growing a set later (free + allocate behind a
@@ -177,6 +178,7 @@ int tiled_create(mi_stack* s) {
             if (rc) return rc;
         }
     }
+    t->tileFlag.assign(L + 1, nullptr);
     t->partE.assign(L + 1, nullptr);
     t->partI.assign(L + 1, nullptr);
     t->part_cap.assign(L + 1, 0);
@@ -238,7 +240,7 @@ const float* tiled_last_gauss(mi_stack* s, int level) {
     TiledState* t = tstate(s);
     if (s->p.impl != MI_IMPL_TILED) return s->G[level];
     int last = t->last_nb > 0 ? t->last_nb - 1 : 0;
-    if (level == 1 && t->last_pair) return t->G1keep[t->last_set];   // (Gb[.][1] holds gray(G_1) then)
+    if ((t->last_kept >> level) & 1u) return t->Gkeep[t->last_set][level];   // (Gb[.][level] holds gray(G_level) then)
     return t->Gb[t->last_set][level] + (size_t)last * t->gstride[level];
 }
 
@@ -469,7 +471,7 @@ int launch_level(mi_stack* s, int l, int set, const void* src, size_t src_stride
 // (optional): recorded on st_in and waited for on st_bd in front of a border launch (everything st_in has done so far).
 // `PM` (level pairs, kernels_sep.hpp "PAIR"): 0 = a level on its own; 1 = the first level of a pair (level_sep_pair: writes
 // gray(G_{l+1}) into Gb[set][l+1] -- one float per pixel --, G_{l+2} into Gb[set][l+2] and the three-channel G_{l+1} of the
-// batch's last frame into G1keep[set]); 2 = the second level of a pair (level_sep_e: `src` = that gray, reads G_{l+1});
+// batch's last frame into Gkeep[set][l+1]); 2 = the second level of a pair (level_sep_e: `src` = that gray, reads G_{l+1});
 // 3 = the pair's payload pass tile by tile (level_sep_pl, one launch over the whole batch: fills bestLap[l] and bestLap[l+1]
 // of the tiles with few distinct winners, flags the others in tileFlag).
 struct SepLevelInfo { int nparts = 0; bool border = false; };
@@ -498,8 +500,12 @@ int launch_level_sep(mi_stack* s, int l, int set, const void* src, size_t src_st
     const size_t gray_stride = (size_t)a.hn * a.wn;
     if constexpr (PM == 1 || PM == 3) {
         static_assert(!MF, "the matrix-pipe reduce has no pair form");
-        if (l != 0 || l + 2 > s->L) return fail(MI_ERR_INVALID, "level pair at level %d of %d", l, s->L);
-        a.gnext = t->G1keep[set];
+        if (l + 2 > s->L) return fail(MI_ERR_INVALID, "level pair at level %d of %d", l, s->L);
+        if (!t->Gkeep[set][l + 1]) {   // (first pair batch of this level and set: one image)
+            int rc = dev_alloc_t(s, &t->Gkeep[set][l + 1], t->gstride[l + 1]);
+            if (rc) return rc;
+        }
+        a.gnext = t->Gkeep[set][l + 1];
         a.gnext_stride = 0;
         a.gray1_stride = gray_stride;
         a.g2_stride = t->gstride[l + 2];
@@ -510,7 +516,7 @@ int launch_level_sep(mi_stack* s, int l, int set, const void* src, size_t src_st
         a.g2 = t->Gb[set][l + 2];
         a.idx1 = s->bestIdx[l + 1];
         a.lap1 = s->bestLap[l + 1];
-        a.tile_flag = t->tileFlag;
+        a.tile_flag = t->tileFlag[l];
     }
     // The "interior" launch covers every tile whose staged patch may be mirrored into place (kernels_sep.hpp, edge tiles):
     // all of the grid, except the tile rows / columns that reach an ODD far edge (those stay with the border kernel), and
@@ -690,64 +696,85 @@ int launch_payload_sep(mi_stack* s, int l, int set, const void* src, size_t src_
     return MI_OK;
 }
 
-// Level pair (0, 1): the payload passes that recompute the winners' G_1 from the frames (sep_payload_pair0 / 1)
+// Level pair (l, l + 1): the payload passes that recompute the winners' G_{l+1} from level l's images `src` (l = 0: the frames,
+// TIn; else Gb[set][l], float) -- sep_payload_pair0 / 1
 template <typename TIn>
-int launch_payload_pair0(mi_stack* s, int set, const void* src, size_t src_stride, int nb, hipStream_t st, int nparts,
+int launch_payload_pair0(mi_stack* s, int l, int set, const void* src, size_t src_stride, int nb, hipStream_t st, int nparts,
                          const uint8_t* tile_flag = nullptr) {
     TiledState* t = tstate(s);
     const dim3 blk(32, 8);
-    const dim3 grd(cdiv(cdiv(s->lw[0], 2), blk.x), cdiv(cdiv(s->lh[0], 2), blk.y));
+    const dim3 grd(cdiv(cdiv(s->lw[l], 2), blk.x), cdiv(cdiv(s->lh[l], 2), blk.y));
     ProfScope ps(s, MI_PROF_LEVEL, 0.0, st);
-    hipLaunchKernelGGL((sep_payload_pair0<TIn>), grd, blk, 0, st, src, src_stride, nb, s->lh[0], s->lw[0], s->lh[1], s->lw[1],
-                       s->bestIdx[0], s->first_index + s->n_pushed, s->bestLap[0], s->k1d[0], s->k1d[1], s->k1d[2], s->rk[0],
-                       s->rk[1], s->rk[2], s->rk[3], s->bestE[0], (const float*)(nparts > 0 ? t->partE[0] : nullptr),
-                       (const int32_t*)(nparts > 0 ? t->partI[0] : nullptr), (size_t)s->lh[0] * s->lw[0], nparts, tile_flag,
+    hipLaunchKernelGGL((sep_payload_pair0<TIn>), grd, blk, 0, st, src, src_stride, nb, s->lh[l], s->lw[l], s->lh[l + 1], s->lw[l + 1],
+                       s->bestIdx[l], s->first_index + s->n_pushed, s->bestLap[l], s->k1d[0], s->k1d[1], s->k1d[2], s->rk[0],
+                       s->rk[1], s->rk[2], s->rk[3], s->bestE[l], (const float*)(nparts > 0 ? t->partE[l] : nullptr),
+                       (const int32_t*)(nparts > 0 ? t->partI[l] : nullptr), (size_t)s->lh[l] * s->lw[l], nparts, tile_flag,
                        MI_SEP_TH, 56);
     return MI_OK;
 }
 template <typename TIn>
-int launch_payload_pair1(mi_stack* s, int set, const void* src, size_t src_stride, int nb, hipStream_t st, int nparts,
+int launch_payload_pair1(mi_stack* s, int l, int set, const void* src, size_t src_stride, int nb, hipStream_t st, int nparts,
                          const uint8_t* tile_flag = nullptr) {
     TiledState* t = tstate(s);
     const dim3 blk(32, 8);
-    const dim3 grd(cdiv(cdiv(s->lw[1], 2), blk.x), cdiv(cdiv(s->lh[1], 2), blk.y));
+    const dim3 grd(cdiv(cdiv(s->lw[l + 1], 2), blk.x), cdiv(cdiv(s->lh[l + 1], 2), blk.y));
     ProfScope ps(s, MI_PROF_LEVEL, 0.0, st);
-    hipLaunchKernelGGL((sep_payload_pair1<TIn>), grd, blk, 0, st, src, src_stride, (const float*)t->Gb[set][2], t->gstride[2], nb,
-                       s->lh[0], s->lw[0], s->lh[1], s->lw[1], s->lh[2], s->lw[2], s->bestIdx[1], s->first_index + s->n_pushed,
-                       s->bestLap[1], s->k1d[0], s->k1d[1], s->k1d[2], s->rk[0], s->rk[1], s->rk[2], s->rk[3], s->bestE[1],
-                       (const float*)(nparts > 0 ? t->partE[1] : nullptr), (const int32_t*)(nparts > 0 ? t->partI[1] : nullptr),
-                       (size_t)s->lh[1] * s->lw[1], nparts, tile_flag, MI_SEP_TH, 56);
+    hipLaunchKernelGGL((sep_payload_pair1<TIn>), grd, blk, 0, st, src, src_stride, (const float*)t->Gb[set][l + 2], t->gstride[l + 2], nb,
+                       s->lh[l], s->lw[l], s->lh[l + 1], s->lw[l + 1], s->lh[l + 2], s->lw[l + 2], s->bestIdx[l + 1],
+                       s->first_index + s->n_pushed, s->bestLap[l + 1], s->k1d[0], s->k1d[1], s->k1d[2], s->rk[0], s->rk[1], s->rk[2],
+                       s->rk[3], s->bestE[l + 1], (const float*)(nparts > 0 ? t->partE[l + 1] : nullptr),
+                       (const int32_t*)(nparts > 0 ? t->partI[l + 1] : nullptr), (size_t)s->lh[l + 1] * s->lw[l + 1], nparts, tile_flag,
+                       MI_SEP_TH, 56);
     return MI_OK;
 }
-// The pair's payload, tile by tile (level_sep_pl) + the per-quad kernels on the tiles it flags: levels 0 and 1 at once, behind
-// both levels' energy passes.  Needs unchunked levels (the per-quad kernels alone fold chunk partials) and frame numbers
-// that fit the 256-bit winner map.
-inline bool sep_pair_tile_payload(int nb, int nparts0, int nparts1) { return nparts0 == 0 && nparts1 == 0 && nb <= 256; }
+// The pair's payload, tile by tile (level_sep_pl) + the per-quad kernels on the tiles it flags: levels l and l + 1 at once,
+// behind both levels' energy passes.  Needs unchunked levels (the per-quad kernels alone fold chunk partials) and frame
+// numbers that fit the 256-bit winner map.
 template <typename TIn>
-int launch_payload_pair_tiles(mi_stack* s, int set, const void* src, size_t src_stride, int nb, hipStream_t st) {
+int launch_payload_pair_tiles(mi_stack* s, int l, int set, const void* src, size_t src_stride, int nb, hipStream_t st) {
     TiledState* t = tstate(s);
-    const size_t ntiles = (size_t)cdiv(s->lw[0], 56) * cdiv(s->lh[0], MI_SEP_TH);
+    const size_t ntiles = (size_t)cdiv(s->lw[l], 56) * cdiv(s->lh[l], MI_SEP_TH);
     int rc;
-    if (!t->tileFlag && (rc = dev_alloc_t(s, &t->tileFlag, ntiles))) return rc;
-    MI_HIP(hipMemsetAsync(t->tileFlag, 0, ntiles, st));
-    if ((rc = launch_level_sep<TIn, false, false, 3>(s, 0, set, src, src_stride, nb, st, st, nullptr))) return rc;
-    if ((rc = launch_payload_pair0<TIn>(s, set, src, src_stride, nb, st, 0, t->tileFlag))) return rc;
-    return launch_payload_pair1<TIn>(s, set, src, src_stride, nb, st, 0, t->tileFlag);
+    if (!t->tileFlag[l] && (rc = dev_alloc_t(s, &t->tileFlag[l], ntiles))) return rc;
+    MI_HIP(hipMemsetAsync(t->tileFlag[l], 0, ntiles, st));
+    if ((rc = launch_level_sep<TIn, false, false, 3>(s, l, set, src, src_stride, nb, st, st, nullptr))) return rc;
+    if ((rc = launch_payload_pair0<TIn>(s, l, set, src, src_stride, nb, st, 0, t->tileFlag[l]))) return rc;
+    return launch_payload_pair1<TIn>(s, l, set, src, src_stride, nb, st, 0, t->tileFlag[l]);
 }
-// Does a batch of `nb` frames run its levels 0 and 1 as a pair?  mi_stack_params.pair_levels: 1 = always, 2 = never, 0 = when it
-// measured faster: float-32 frames (level 0's kernel is bound by memory AND issue, the times add: 30 MB less per frame against
-// the G_2 reduce it takes on -- +0.07 ms per launch of 16 frames; the 8- and 16-bit kernels are issue-bound: +0.17 ms, more than
-// level 1's pass saves) in batches long enough for the once-per-batch recomputation in the payload pass (about 1.2 ms more
-// than the passes that read a stored G_1, at 24 MP) to be small beside the 2.9 ms per 256 frames level 1 gets faster by
-// (a 64-frame shard measured 11.0 ms with the pair, ~8.5 without).
-// Interleaved A/B on one box, 256 x 24 MP: float-32 +1.5 to +3 %, 8-bit -3 %, 16-bit -8 % (profiles/r06/pair_ab.txt).
+// The batch's pair plan: pm[l] = 1: level l is the first level of a pair, 2: the second, 0: on its own.  pair_levels 1 = pairs
+// from level 0 on -- (0, 1), (2, 3), ... --, 3 = from level 1 on, 2 = none (both forced plans exist for the tests: every pair
+// gives the same bits); 0 = automatic = where it measured faster: the pair (0, 1) for float-32 frames in batches of
+// SEP_PAIR_MIN_FRAMES and more.
+//  * float-32, level 0: the kernel is bound by memory AND issue, the times add: 30 MB less per frame against the G_2 reduce it
+//    takes on -- +0.05 ms per launch of 16 frames; level 1's pass 0.33 -> 0.15 ms per launch; the payload recomputation
+//    (1.56 ms per batch at 24 MP) hides behind levels 2+ on its own stream.  Interleaved A/B on three boxes, 256 x 24 MP:
+//    +2.5 to +4.5 % (profiles/r06/pair_ab_box*.txt).
+//  * 8- / 16-bit frames, level 0: issue-bound kernels, +0.17 / +0.24 ms per launch -- more than level 1 saves: -3 % / -8 %.
+//  * deeper pairs -- (2, 3) behind (0, 1) for float-32, (1, 2) and (3, 4) for 8- / 16-bit frames -- measured no gain or a
+//    loss (27.5-27.8 -> 27.7-28.1 ms; 22.2 -> 22.7 ms; 24.1 -> 24.9 ms): those levels run in frame chunks, their pairs'
+//    payload is the per-quad recomputation, and it ends up as the tail of the batch.
+//  * short batches: the once-per-batch payload recomputation outweighs level 1's gain (a 64-frame shard: 11.0 against 8.1 ms).
 constexpr int SEP_PAIR_MIN_FRAMES = 192;
 #ifndef MI_L1E_PIPE_DEFAULT
 #define MI_L1E_PIPE_DEFAULT 0
 #endif
-inline bool sep_use_pair(const mi_stack* s, int nb) {
-    if (!s->sep || s->L < 2 || s->p.pair_levels == 2) return false;
-    return s->p.pair_levels == 1 || (s->p.in_dtype == MI_F32 && nb >= SEP_PAIR_MIN_FRAMES);
+inline void sep_pair_plan(const mi_stack* s, int nb, std::vector<int>& pm) {
+    pm.assign(std::max(s->L, 1), 0);
+    if (!s->sep || s->p.pair_levels == 2) return;
+    static const int plan = study_env("MI_PAIR_PLAN", -1);   // -DMI_STUDY: bit l = level l is the first level of a pair
+    int l0;
+    if (plan >= 0) {
+        for (int l = 0; l + 2 <= s->L; ++l)
+            if (((plan >> l) & 1) && pm[l] == 0) { pm[l] = 1; pm[l + 1] = 2; }
+        return;
+    }
+    if (s->p.pair_levels == 1) l0 = 0;
+    else if (s->p.pair_levels == 3) l0 = 1;
+    else {
+        if (nb >= SEP_PAIR_MIN_FRAMES && s->p.in_dtype == MI_F32 && s->L >= 2) { pm[0] = 1; pm[1] = 2; }
+        return;
+    }
+    for (int l = l0; l + 2 <= s->L; l += 2) { pm[l] = 1; pm[l + 1] = 2; }
 }
 
 // MI_ARITH_EXACT: the same for the reference-order arithmetic (exact_payload, kernels_tiled.hpp)
@@ -815,7 +842,9 @@ int run_batch(mi_stack* s, const void* frames, size_t stride, int nb) {
     static const int interleave01 = study_env("MI_INTERLEAVE01", 0);
     bool il = false;
     SepLevelInfo li0;
-    const bool pair = sep_use_pair(s, nb);
+    std::vector<int> pm;   // the batch's pair plan (sep_pair_plan): 1 = first level of a pair, 2 = second
+    sep_pair_plan(s, nb, pm);
+    const bool pair = pm[0] == 1;
     // pair: pipe level 1's energy pass behind level 0's launches, group by group -- when both levels run as consecutive
     // launches and have no border tiles (even sizes)
     bool l1e_pipe = false;
@@ -870,18 +899,30 @@ int run_batch(mi_stack* s, const void* frames, size_t stride, int nb) {
     MI_HIP(hipStreamWaitEvent(st2, t->evL0i[set], 0));
     MI_HIP(hipStreamWaitEvent(st2, t->evL0b[set], 0));
     MI_HIP(hipStreamWaitEvent(st1, t->evL0i[set], 0));
-    // a pair whose levels both run unchunked fills in the Laplacians of levels 0 and 1 in one tile-by-tile pass behind level
-    // 1's energy pass (below); level 0's state is final only then
-    bool tile_payload = pair && li0.nparts == 0 && nb <= 256;
+    // the first level of a pair gets its payload together with the second level's, behind that level's energy pass (below);
+    // level 0's state is final only then
     MI_HIP(hipStreamWaitEvent(st3, t->evL0i[set], 0));
     MI_HIP(hipStreamWaitEvent(st3, t->evL0b[set], 0));
-    if (!tile_payload) {
-        if ((rc = pair ? launch_payload_pair0<TIn>(s, set, frames, stride, nb, st3, li0.nparts)
-                 : s->sep ? launch_payload_sep<TIn>(s, 0, set, frames, stride, nb, st3, li0.nparts)
-                          : launch_payload_exact<TIn, FMA>(s, 0, set, frames, stride, nb, st3)))
+    if (!pair) {
+        if ((rc = s->sep ? launch_payload_sep<TIn>(s, 0, set, frames, stride, nb, st3, li0.nparts)
+                         : launch_payload_exact<TIn, FMA>(s, 0, set, frames, stride, nb, st3)))
             return rc;
         MI_HIP(hipEventRecord(t->evL0done[set], st3));   // st3 waited for both level-0 kernels above
     }
+    int nparts_first = li0.nparts;   // chunk partials of the pending pair's first level
+    // The payload of the pair (l - 1, l), on st3 behind level l's energy pass: tile by tile when both levels ran unchunked,
+    // else the per-quad kernels (which fold the chunks' partial maxima).  `src` = the images of level l - 1.
+    auto pair_payload = [&](int l, int nparts_second, auto tag, const void* src, size_t src_stride) -> int {
+        using T = decltype(tag);
+        int r;
+        if (nparts_first == 0 && nparts_second == 0 && nb <= 256) r = launch_payload_pair_tiles<T>(s, l - 1, set, src, src_stride, nb, st3);
+        else {
+            r = launch_payload_pair0<T>(s, l - 1, set, src, src_stride, nb, st3, nparts_first);
+            if (!r) r = launch_payload_pair1<T>(s, l - 1, set, src, src_stride, nb, st3, nparts_second);
+        }
+        if (!r && l == 1) MI_HIP(hipEventRecord(t->evL0done[set], st3));
+        return r;
+    };
     // coarser levels: interior tiles on st2, border tiles on st1 (disjoint tiles of one level run
     // side by side); both streams join after every level because level l+1 reads all of G_{l+1}
     static const int only_l0 = study_env("MI_ONLY_L0", 0);   // -DMI_STUDY: level 0 alone on the GPU (results are wrong)
@@ -891,29 +932,36 @@ int run_batch(mi_stack* s, const void* frames, size_t stride, int nb) {
         static const int wide_levels = study_env("MI_WIDE_LEVELS", -1);
         const bool wide = wide_levels >= 0 ? l <= wide_levels : (size_t)s->lh[l] * s->lw[l] >= ((size_t)4 << 20);
         hipEvent_t ei = t->evLvl[(set * (L + 1) + l) * 2], eb = t->evLvl[(set * (L + 1) + l) * 2 + 1];
-        if (pair && l == 1) {
-            // the second level of the pair: energy only, from gray(G_1) and G_2 (both written by level 0's kernel); its
-            // payload pass recomputes the winners' G_1 from the frames
+        if (pm[l] == 2) {
+            // the second level of a pair: energy only, from gray(G_l) and G_{l+1} (both written by level l - 1's kernel);
+            // the pair's payload pass recomputes the winners' G_l from level l - 1's images
             SepLevelInfo li;
-            if (l1e_pipe) ;   // (launched group by group behind level 0, above: no chunks, no border tiles)
-            else if ((rc = launch_level_sep<float, false, false, 2>(s, 1, set, t->Gb[set][1], (size_t)s->lh[1] * s->lw[1] * sizeof(float), nb,
-                                                               st2, st1, eb, 0, -1, &li, ei)))
+            if (l == 1 && l1e_pipe) ;   // (launched group by group behind level 0, above: no chunks, no border tiles)
+            else if ((rc = launch_level_sep<float, false, false, 2>(s, l, set, t->Gb[set][l], (size_t)s->lh[l] * s->lw[l] * sizeof(float), nb,
+                                                                    st2, st1, eb, 0, -1, &li, ei)))
                 return rc;
             if (li.border) {
                 MI_HIP(hipEventRecord(eb, st1));
                 MI_HIP(hipStreamWaitEvent(st2, eb, 0));
             }
-            if ((rc = payload_after(1))) return rc;
-            if (tile_payload && li.nparts == 0) {
-                if ((rc = launch_payload_pair_tiles<TIn>(s, set, frames, stride, nb, st3))) return rc;
-                MI_HIP(hipEventRecord(t->evL0done[set], st3));
-            } else {
-                if (tile_payload) {   // (level 1 ran in chunks after all: level 0's payload on its own, late)
-                    if ((rc = launch_payload_pair0<TIn>(s, set, frames, stride, nb, st3, 0))) return rc;
-                    MI_HIP(hipEventRecord(t->evL0done[set], st3));
-                }
-                if ((rc = launch_payload_pair1<TIn>(s, set, frames, stride, nb, st3, li.nparts))) return rc;
+            if ((rc = payload_after(l))) return rc;
+            if ((rc = l == 1 ? pair_payload(l, li.nparts, TIn{}, frames, stride)
+                             : pair_payload(l, li.nparts, float{}, t->Gb[set][l - 1], t->gstride[l - 1] * sizeof(float))))
+                return rc;
+            continue;
+        }
+        if (pm[l] == 1) {
+            // the first level of a pair beyond level 0: level_sep_pair on the float images of level l (gray(G_{l+1}) and G_{l+2}
+            // out); its payload waits for level l + 1
+            SepLevelInfo li;
+            if ((rc = launch_level_sep<float, false, false, 1>(s, l, set, t->Gb[set][l], t->gstride[l] * sizeof(float), nb, st2, st1, eb,
+                                                               0, -1, &li, ei)))
+                return rc;
+            if (li.border) {
+                MI_HIP(hipEventRecord(eb, st1));
+                MI_HIP(hipStreamWaitEvent(st2, eb, 0));
             }
+            nparts_first = li.nparts;
             continue;
         }
         if (s->sep && !(il && l == 1)) {
@@ -984,7 +1032,9 @@ int run_batch(mi_stack* s, const void* frames, size_t stride, int nb) {
     s->n_pushed += nb;
     t->last_nb = nb;
     t->last_set = set;
-    t->last_pair = pair;
+    t->last_kept = 0;
+    for (int l = 0; l + 1 < L; ++l)
+        if (pm[l] == 1) t->last_kept |= 1u << (l + 1);
     t->batch_no++;
     return MI_OK;
 }

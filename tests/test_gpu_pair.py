@@ -18,8 +18,9 @@ def L(hiplib):
     return hiplib
 
 
+@pytest.mark.parametrize("pl", [1, 3])       # pairs (0, 1), (2, 3), ... / (1, 2), (3, 4), ...
 @pytest.mark.parametrize("h,w,n,dt,min_size,a,batch", CASES)
-def test_pair_equals_oracle(L, oracle, h, w, n, dt, min_size, a, batch):
+def test_pair_equals_oracle(L, oracle, h, w, n, dt, min_size, a, batch, pl):
     rng = np.random.default_rng(h * 7 + w)
     hi = 65536 if dt == np.uint16 else 256
     frames = [rng.integers(0, hi, (h, w, 3)).astype(dt) for _ in range(n)]
@@ -27,24 +28,25 @@ def test_pair_equals_oracle(L, oracle, h, w, n, dt, min_size, a, batch):
         frames[2] = frames[0].copy()     # exact ties: the first maximum must win
     so, gs = run_oracle(oracle, frames, min_size=min_size, gen_kernel=a)
     st = L.Stack(h, w, in_dtype=dt, out_dtype=np.uint16 if dt == np.uint16 else np.uint8, impl=2, arith="separable",
-                 min_size=min_size, gen_kernel=a, batch_frames=batch, pair_levels=1)
+                 min_size=min_size, gen_kernel=a, batch_frames=batch, pair_levels=pl)
     for f in frames:
         st.push_frame(f)
-    compare(L, st, so, gs[-1])      # (gs[-1][1]: the three-channel G_1 of the last frame -- the pair keeps exactly that one)
+    compare(L, st, so, gs[-1])      # (gs[-1][l + 1]: the three-channel G_{l+1} of the last frame -- a pair keeps exactly that one)
     st.close()
 
 
+@pytest.mark.parametrize("pl", [1, 3])
 @pytest.mark.parametrize("dt", [np.uint8, np.uint16, np.float32])
 @pytest.mark.parametrize("h,w", [(420, 620), (421, 619), (338, 458), (1000, 1500)])
-def test_pair_sizes_and_types(L, oracle, dt, h, w):
+def test_pair_sizes_and_types(L, oracle, dt, h, w, pl):
     """natural-ish content (the generator), sizes whose levels 0 / 1 / 2 are even / odd in every combination, a size with many
     interior tiles; host pushes in batches of 3 (state reloaded, the kept frame changes) and one resident push"""
     n = 7
     hi = 257 if dt == np.uint16 else 1
     frames = [(oracle.synth_frame_numpy(h, w, f, n).astype(np.uint16) * hi).astype(dt) for f in range(n)]
-    so, gs = run_oracle(oracle, frames)
+    so, gs = run_oracle(oracle, frames, min_size=16)     # (one level more than the default: pairs at two depths)
     od = np.uint16 if dt == np.uint16 else np.uint8
-    st = L.Stack(h, w, in_dtype=dt, out_dtype=od, arith="separable", batch_frames=3, pair_levels=1)
+    st = L.Stack(h, w, in_dtype=dt, out_dtype=od, arith="separable", batch_frames=3, pair_levels=pl, min_size=16)
     for f in frames:
         st.push_frame(f)
     compare(L, st, so, gs[-1])
@@ -53,8 +55,8 @@ def test_pair_sizes_and_types(L, oracle, dt, h, w):
     buf = L.DeviceBuffer(fb * n)
     for i, f in enumerate(frames):
         buf.upload(f, i * fb)
-    so, gs = run_oracle(oracle, frames)
-    st = L.Stack(h, w, in_dtype=dt, out_dtype=od, arith="separable", pair_levels=1)
+    so, gs = run_oracle(oracle, frames, min_size=16)
+    st = L.Stack(h, w, in_dtype=dt, out_dtype=od, arith="separable", pair_levels=pl, min_size=16)
     st.push_frames_device(buf.ptr, n)
     compare(L, st, so, gs[-1])
     st.close()
@@ -100,7 +102,7 @@ def test_pair_is_bit_identical_to_the_unpaired_kernels(L, oracle):
     for i, f in enumerate(frames):
         buf.upload(f, i * fb)
     taps = []
-    for pl in (1, 2, 0):
+    for pl in (1, 2, 0, 3):
         st = L.Stack(h, w, in_dtype=np.uint8, arith="separable", pair_levels=pl)
         st.push_frames_device(buf.ptr, n)
         t = [st.tap(k, lv) for lv in range(st.levels) for k in (L.TAP_ENERGY, L.TAP_INDEX, L.TAP_FUSED_LAP)]
@@ -128,11 +130,12 @@ def test_pair_needs_two_levels(L, oracle):
     compare(L, st, so, gs[-1])
     st.close()
     with pytest.raises(Exception):
-        L.Stack(h, w, in_dtype=np.uint8, arith="separable", pair_levels=3)
+        L.Stack(h, w, in_dtype=np.uint8, arith="separable", pair_levels=4)
 
 
+@pytest.mark.parametrize("pl", [1, 3])
 @pytest.mark.parametrize("kind", ["coherent", "noise", "mixed"])
-def test_pair_tile_payload(L, oracle, kind):
+def test_pair_tile_payload(L, oracle, kind, pl):
     """frames large enough for levels 0 AND 1 to run unchunked (> 1536 tiles each): the pair's payload is the tile-by-tile pass
     (level_sep_pl) -- `coherent`: few winners per tile, no tile is flagged; `noise`: 36 frames of noise, every tile has more
     than 32 winners and goes to the per-quad kernels; `mixed`: both kinds of tile in one image"""
@@ -150,7 +153,7 @@ def test_pair_tile_payload(L, oracle, kind):
     buf = L.DeviceBuffer(fb * n)
     for i, f in enumerate(frames):
         buf.upload(f, i * fb)
-    st = L.Stack(h, w, in_dtype=np.uint8, arith="separable", pair_levels=1)
+    st = L.Stack(h, w, in_dtype=np.uint8, arith="separable", pair_levels=pl)
     st.push_frames_device(buf.ptr, n)
     compare(L, st, so, gs[-1])
     st.close()
