@@ -48,8 +48,12 @@ struct TiledState {
     float* logp[2] = {nullptr, nullptr};
     float* feat[2] = {nullptr, nullptr};    // (entropy, deviation) of every (frame, pixel) of the batch
     hipStream_t st1 = nullptr, st2 = nullptr;
-    // st3 (round 6): the payload passes.  A level's payload pass only needs that level's arg-max; the next level's energy pass
-    // does not need the payload -- gather-bound kernel beside streaming kernel instead of one after the other.
+    // st3 (round 6): the stream of the payload passes.  A level's payload pass only needs that level's arg-max; the next level's
+    // energy pass does not need the payload -- gather-bound kernel beside streaming kernel instead of one after the other.
+    // It IS st1, the border tiles' stream (idle behind level 0 but for a few short launches), not a stream of its own: the
+    // runtime maps streams onto four hardware queues, and a fifth stream in the process shares one -- config 4 (stacker +
+    // estimator) went from 34.6 to 41.6 ms with a separate payload stream because the estimator's stream then queued behind
+    // the warps'; the 256-frame job measures the same either way (docs/studies.md, round 6).
     hipStream_t st3 = nullptr;
     std::vector<hipEvent_t> evPayIn;   // [set][level]: the level's energy pass (all streams) is through
     hipEvent_t evPay[2] = {nullptr, nullptr};   // the batch's payload passes are through
@@ -144,8 +148,9 @@ int tiled_create(mi_stack* s) {
         const int bd = study_env("MI_BD_PRIO", 0), co = study_env("MI_CO_PRIO", 0);   // 0 high, 1 normal, 2 low
         MI_HIP(hipStreamCreateWithPriority(&t->st1, hipStreamNonBlocking, bd == 0 ? prio_hi : bd == 1 ? 0 : prio_lo));
         MI_HIP(hipStreamCreateWithPriority(&t->st2, hipStreamNonBlocking, co == 0 ? prio_hi : co == 1 ? 0 : prio_lo));
-        if (study_env("MI_PAYLOAD_STREAM", 1)) MI_HIP(hipStreamCreateWithPriority(&t->st3, hipStreamNonBlocking, co == 0 ? prio_hi : co == 1 ? 0 : prio_lo));
-        else t->st3 = t->st2;   // -DMI_STUDY: the payload passes in line with the levels (rounds 2-5)
+        const int ps = study_env("MI_PAYLOAD_STREAM", 2);   // -DMI_STUDY: 0 = in line with the levels (rounds 2-5), 1 = a stream of their own
+        if (ps == 1) MI_HIP(hipStreamCreateWithPriority(&t->st3, hipStreamNonBlocking, co == 0 ? prio_hi : co == 1 ? 0 : prio_lo));
+        else t->st3 = ps == 2 ? t->st1 : t->st2;
         if (study_env("MI_BD_PRIO", 0)) fprintf(stderr, "priority range lo=%d hi=%d\n", prio_lo, prio_hi);
     }
     t->gstride.assign(L + 1, 0);
@@ -191,7 +196,7 @@ int tiled_sync_all(mi_stack* s) {
     if (t->stc) MI_HIP(hipStreamSynchronize(t->stc));
     if (t->st1) MI_HIP(hipStreamSynchronize(t->st1));
     if (t->st2) MI_HIP(hipStreamSynchronize(t->st2));
-    if (t->st3 && t->st3 != t->st2) MI_HIP(hipStreamSynchronize(t->st3));
+    if (t->st3 && t->st3 != t->st2 && t->st3 != t->st1) MI_HIP(hipStreamSynchronize(t->st3));
     t->streams_dirty = false;
     return MI_OK;
 }
@@ -220,7 +225,7 @@ void tiled_destroy(mi_stack* s) {
     if (t->evInput) (void)hipEventDestroy(t->evInput);
     if (t->stc) (void)hipStreamDestroy(t->stc);
     if (t->st1 && t->st1 != s->stream) (void)hipStreamDestroy(t->st1);
-    if (t->st3 && t->st3 != s->stream && t->st3 != t->st2) (void)hipStreamDestroy(t->st3);
+    if (t->st3 && t->st3 != s->stream && t->st3 != t->st2 && t->st3 != t->st1) (void)hipStreamDestroy(t->st3);
     if (t->st2 && t->st2 != s->stream) (void)hipStreamDestroy(t->st2);
     delete t;
     tstate(s) = nullptr;
