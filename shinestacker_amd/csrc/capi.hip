@@ -35,6 +35,7 @@ int tiled_create(mi_stack* s);
 void tiled_destroy(mi_stack* s);
 int tiled_reset(mi_stack* s);
 int tiled_pending(const mi_stack* s);
+void tiled_side_streams(const mi_stack* s, hipStream_t out[2]);
 int tiled_push(mi_stack* s, const void* dev_frames, int n, size_t stride);
 int tiled_push_host(mi_stack* s, const void* host_bgr, size_t row_stride_bytes, bool pinned = false);
 int tiled_wait_uploads(mi_stack* s, int max_outstanding);
@@ -745,7 +746,7 @@ struct mi_aligner {
     // stream and on WARP_LANES - 1 streams of the handle, each with its own border-blur scratch, so that one frame's short,
     // latency-bound kernels (tables, tile list, border blur of a few hundred tiles, scatter) run beside the next frame's warp
     // instead of in front of it.
-    hipStream_t wst[3] = {nullptr, nullptr, nullptr};
+    hipStream_t wst[3] = {nullptr, nullptr, nullptr};   // (the stacker's side streams: borrowed per call, never destroyed here)
     hipEvent_t wev[3] = {nullptr, nullptr, nullptr}, wstart = nullptr;
     void *wtmp[3] = {nullptr, nullptr, nullptr}, *wmask[3] = {nullptr, nullptr, nullptr};
     // optional coarse initialiser (mi_aligner_set_phase_init): phase correlation on pyramid level `pc_level`
@@ -798,7 +799,6 @@ void aligner_free(mi_aligner* al) {
     if (al->own) (void)hipStreamDestroy(al->own);
     al->own = nullptr;
     for (int j = 0; j < 3; ++j) {
-        if (al->wst[j]) (void)hipStreamDestroy(al->wst[j]);
         if (al->wev[j]) (void)hipEventDestroy(al->wev[j]);
         (void)hipFree(al->wtmp[j]);
         (void)hipFree(al->wmask[j]);
@@ -808,18 +808,19 @@ void aligner_free(mi_aligner* al) {
     al->wstart = nullptr;
 }
 
-// the side lanes of mi_align_stack_device's warp stage (created on first use; one frame + one mask of scratch each)
-// Measured (round 5, config 4, interleaved A/B of 1 against 4 lanes): 0.0371 vs 0.0369 s -- the job is bound by the summed work
-// of its kernels, not by the order they are enqueued in.  1 = every warp on the stacker's stream; -DMI_WARP_LANES=4 builds the lanes.
+// The side lanes of mi_align_stack_device's warp stage (scratch created on first use; one frame + one mask each).
+// Round 5 built them on streams of their own (1 against 4 lanes: 0.0371 vs 0.0369 s) -- with the stacker's three streams and
+// the estimator's that made seven streams on the runtime's four hardware queues, so the lanes queued behind each
+// other anyway.  Round 6: the lanes ARE the stacker's side streams (border tiles / levels >= 1), which carry nothing while a
+// batch buffer fills: no stream is added.
 #ifndef MI_WARP_LANES
-#define MI_WARP_LANES 1
+#define MI_WARP_LANES 2
 #endif
 constexpr int WARP_LANES = MI_WARP_LANES;
 int aligner_warp_lanes(mi_aligner* al, size_t frame_bytes, size_t mask_bytes) {
     if (al->wstart) return MI_OK;
-    static_assert(WARP_LANES >= 1 && WARP_LANES <= 4, "lanes");
+    static_assert(WARP_LANES >= 1 && WARP_LANES <= 3, "lanes: the stacker's own stream and its two side streams");
     for (int j = 0; j < WARP_LANES - 1; ++j) {
-        MI_HIP(hipStreamCreateWithFlags(&al->wst[j], hipStreamNonBlocking));
         MI_HIP(hipEventCreateWithFlags(&al->wev[j], hipEventDisableTiming));
         if (hipMalloc(&al->wtmp[j], frame_bytes) != hipSuccess || hipMalloc(&al->wmask[j], mask_bytes) != hipSuccess)
             return fail(MI_ERR_NOMEM, "out of device memory");
@@ -907,6 +908,39 @@ int aligner_build(mi_aligner* al, hipStream_t st, const void* dev_img, bool is_t
         const dim3 gt(cdiv(lv[l].w, 64), cdiv(lv[l].h, 16));
         if (l == 0) hipLaunchKernelGGL((ecc_blur_tile<0>), gt, dim3(256), 0, st, src, sh, sw, dst, lv[l].h, lv[l].w);
         else hipLaunchKernelGGL((ecc_blur_tile<1>), gt, dim3(256), 0, st, src, sh, sw, dst, lv[l].h, lv[l].w);
+    }
+    MI_HIP(hipGetLastError());
+    return MI_OK;
+}
+
+// gray + pyramid of the n moving frames of a batch (slots 0 .. n-1): levels 0 and 1 of all frames in one launch where
+// ecc_pyramid2 applies (sub-sampling 2, n > 1), frame by frame otherwise; the levels from `split` on, one launch per level
+int aligner_build_batch(mi_aligner* al, hipStream_t st, const void* const* dev_movs, int n) {
+    static_assert(ECC_MAXF <= 128, "EccFramePtrs holds 128 frames");
+    auto& lv = al->lv;
+    const int split = n > 1 ? 2 : 1 << 30;
+    int rc;
+    if (n > 1 && al->subsample == 2 && lv.size() >= 2) {
+        EccFramePtrs fr{};
+        for (int k = 0; k < n; ++k) fr.p[k] = dev_movs[k];
+        const dim3 gp(cdiv(al->w, 64), cdiv(al->h, 32), n);
+        float *d0 = lv[0].img, *d1 = lv[1].img;
+        if (al->dtype == MI_U8) {
+            if (al->area) hipLaunchKernelGGL((ecc_pyramid2_batch<uint8_t, true>), gp, dim3(256), 0, st, fr, al->height, al->width, al->h, al->w, d0, lv[1].h, lv[1].w, d1);
+            else hipLaunchKernelGGL((ecc_pyramid2_batch<uint8_t, false>), gp, dim3(256), 0, st, fr, al->height, al->width, al->h, al->w, d0, lv[1].h, lv[1].w, d1);
+        } else {
+            if (al->area) hipLaunchKernelGGL((ecc_pyramid2_batch<uint16_t, true>), gp, dim3(256), 0, st, fr, al->height, al->width, al->h, al->w, d0, lv[1].h, lv[1].w, d1);
+            else hipLaunchKernelGGL((ecc_pyramid2_batch<uint16_t, false>), gp, dim3(256), 0, st, fr, al->height, al->width, al->h, al->w, d0, lv[1].h, lv[1].w, d1);
+        }
+    } else {
+        for (int k = 0; k < n; ++k)
+            if ((rc = aligner_build(al, st, dev_movs[k], false, k, split))) return rc;
+    }
+    for (size_t l = (size_t)split; l < lv.size(); ++l) {
+        const auto& a = lv[l - 1];
+        const auto& b = lv[l];
+        hipLaunchKernelGGL((ecc_blur_tile<1>), dim3(cdiv(b.w, 64), cdiv(b.h, 16), n), dim3(256), 0, st, (const float*)a.img, a.h, a.w,
+                           b.img, b.h, b.w);
     }
     MI_HIP(hipGetLastError());
     return MI_OK;
@@ -2209,19 +2243,7 @@ int mi_aligner_estimate_batch(mi_aligner_t al, void* stream, const void* const* 
     hipStream_t st = stream ? (hipStream_t)stream : al->own;
     int rc = aligner_reserve(al, n);
     if (rc) return rc;
-    // gray + the two large levels frame by frame (each gray image is still in L2 when its blur reads it: batching those
-    // was 10 % slower); the small levels (1.5 MP and below at 24 MP / sub-sample 2) are launch-latency-bound, so one
-    // launch per level builds them for the whole batch (blockIdx.z = frame).  Same kernel, same values.
-    const int split = n > 1 ? 2 : 1 << 30;
-    for (int k = 0; k < n; ++k)
-        if ((rc = aligner_build(al, st, dev_movs[k], false, k, split))) return rc;
-    for (size_t l = (size_t)split; l < al->lv.size(); ++l) {
-        const auto& a = al->lv[l - 1];
-        const auto& b = al->lv[l];
-        hipLaunchKernelGGL((ecc_blur_tile<1>), dim3(cdiv(b.w, 64), cdiv(b.h, 16), n), dim3(256), 0, st, (const float*)a.img, a.h, a.w,
-                           b.img, b.h, b.w);
-    }
-    MI_HIP(hipGetLastError());
+    if ((rc = aligner_build_batch(al, st, dev_movs, n))) return rc;   // gray + pyramids of the batch's frames
     return aligner_solve(al, st, n, max_iters, eps, M_out, cc_out, iters_out);
 }
 
@@ -2237,16 +2259,7 @@ int mi_aligner_estimate_pairs(mi_aligner_t al, void* stream, const void* const* 
     hipStream_t st = stream ? (hipStream_t)stream : al->own;
     int rc = aligner_reserve(al, n);
     if (rc) return rc;
-    const int split = n > 1 ? 2 : 1 << 30;   // (as mi_aligner_estimate_batch)
-    for (int k = 0; k < n; ++k)
-        if ((rc = aligner_build(al, st, dev_frames[k], false, k, split))) return rc;
-    for (size_t l = (size_t)split; l < al->lv.size(); ++l) {
-        const auto& a = al->lv[l - 1];
-        const auto& b = al->lv[l];
-        hipLaunchKernelGGL((ecc_blur_tile<1>), dim3(cdiv(b.w, 64), cdiv(b.h, 16), n), dim3(256), 0, st, (const float*)a.img, a.h, a.w,
-                           b.img, b.h, b.w);
-    }
-    MI_HIP(hipGetLastError());
+    if ((rc = aligner_build_batch(al, st, dev_frames, n))) return rc;   // gray + pyramids of the batch's frames
     return aligner_solve(al, st, n, max_iters, eps, M_out, cc_out, iters_out, nullptr, nullptr, -1, ref_of);
 }
 
@@ -2262,16 +2275,7 @@ int mi_aligner_refine_batch(mi_aligner_t al, void* stream, const void* const* de
     hipStream_t st = stream ? (hipStream_t)stream : al->own;
     int rc = aligner_reserve(al, n);
     if (rc) return rc;
-    const int split = n > 1 ? 2 : 1 << 30;
-    for (int k = 0; k < n; ++k)
-        if ((rc = aligner_build(al, st, dev_movs[k], false, k, split))) return rc;
-    for (size_t l = (size_t)split; l < al->lv.size(); ++l) {
-        const auto& a = al->lv[l - 1];
-        const auto& b = al->lv[l];
-        hipLaunchKernelGGL((ecc_blur_tile<1>), dim3(cdiv(b.w, 64), cdiv(b.h, 16), n), dim3(256), 0, st, (const float*)a.img, a.h, a.w,
-                           b.img, b.h, b.w);
-    }
-    MI_HIP(hipGetLastError());
+    if ((rc = aligner_build_batch(al, st, dev_movs, n))) return rc;   // gray + pyramids of the batch's frames
     return aligner_solve(al, st, n, max_iters, eps, M_out, cc_out, iters_out, nullptr, M_init, levels - 1);
 }
 
@@ -2286,16 +2290,7 @@ int mi_aligner_estimate_homography_batch(mi_aligner_t al, void* stream, const vo
     hipStream_t st = stream ? (hipStream_t)stream : al->own;
     int rc = aligner_reserve(al, n);
     if (rc) return rc;
-    const int split = n > 1 ? 2 : 1 << 30;
-    for (int k = 0; k < n; ++k)
-        if ((rc = aligner_build(al, st, dev_movs[k], false, k, split))) return rc;
-    for (size_t l = (size_t)split; l < al->lv.size(); ++l) {
-        const auto& a = al->lv[l - 1];
-        const auto& b = al->lv[l];
-        hipLaunchKernelGGL((ecc_blur_tile<1>), dim3(cdiv(b.w, 64), cdiv(b.h, 16), n), dim3(256), 0, st, (const float*)a.img, a.h, a.w,
-                           b.img, b.h, b.w);
-    }
-    MI_HIP(hipGetLastError());
+    if ((rc = aligner_build_batch(al, st, dev_movs, n))) return rc;   // gray + pyramids of the batch's frames
     return aligner_solve(al, st, n, max_iters, eps, nullptr, cc_out, iters_out, M9_out);
 }
 
@@ -2335,8 +2330,11 @@ int mi_align_stack_device(mi_stack_t* st, mi_aligner_t al, const void* dev_frame
         cc_out[i] = 1.0;
     }
     // warp lanes (see mi_aligner): not with the in-place balance, whose histogram / table scratch is one per call
-    const int lanes = bal ? 1 : WARP_LANES;
+    hipStream_t side[2] = {nullptr, nullptr};
+    tiled_side_streams(st, side);
+    const int lanes = bal || !side[0] || !side[1] ? 1 : WARP_LANES;
     if (lanes > 1 && (rc = aligner_warp_lanes(al, fb, (size_t)H * W))) return rc;
+    for (int j = 0; j < lanes - 1; ++j) al->wst[j] = side[j];
     unsigned lanes_used = 0;
     int cur = 0, filled = 0;
     auto flush = [&]() -> int {

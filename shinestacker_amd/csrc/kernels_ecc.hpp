@@ -297,8 +297,8 @@ __device__ __forceinline__ void ecc_pyramid2_interior(const T* __restrict__ img,
 }
 
 template <typename T, bool AREA>
-__global__ __launch_bounds__(256) void ecc_pyramid2(const T* __restrict__ img, int src_h, int src_w, int h, int w,
-                                                    float* __restrict__ L0, int h1, int w1, float* __restrict__ L1) {
+__device__ __forceinline__ void ecc_pyramid2_body(const T* __restrict__ img, int src_h, int src_w, int h, int w,
+                                                  float* __restrict__ L0, int h1, int w1, float* __restrict__ L1) {
     constexpr int TW = 64, TH = 32;
     constexpr int GW = TW + 8, GH = TH + 8, GS = ECC_P2_GS;   // gray patch: level coordinates x0-4 .., y0-4 ..
     constexpr int PW = TW + 4, PH = TH + 4, PS = PW + 1;      // level-0 patch: x0-2 .., y0-2 ..
@@ -373,6 +373,22 @@ __global__ __launch_bounds__(256) void ecc_pyramid2(const T* __restrict__ img, i
         for (int t = 0; t < 5; ++t) acc += k[t] * sR1[(min(max(2 * yi - 2 + t, 0), h - 1) - (y0 - 2)) * R1S + j];
         L1[(size_t)yi * w1 + xj] = acc;
     }
+}
+
+template <typename T, bool AREA>
+__global__ __launch_bounds__(256) void ecc_pyramid2(const T* __restrict__ img, int src_h, int src_w, int h, int w,
+                                                    float* __restrict__ L0, int h1, int w1, float* __restrict__ L1) {
+    ecc_pyramid2_body<T, AREA>(img, src_h, src_w, h, w, L0, h1, w1, L1);
+}
+
+// the frames of a batch in ONE launch (blockIdx.z = frame k: its source anywhere in memory, its levels in slot k of the
+// batch's level images): a single frame's 2961 workgroups are 1.4 rounds of the chip, a batch of 16 fills it 23 times over
+struct EccFramePtrs { const void* p[128]; };
+template <typename T, bool AREA>
+__global__ __launch_bounds__(256) void ecc_pyramid2_batch(EccFramePtrs fr, int src_h, int src_w, int h, int w,
+                                                          float* __restrict__ L0, int h1, int w1, float* __restrict__ L1) {
+    const int k = blockIdx.z;
+    ecc_pyramid2_body<T, AREA>((const T*)fr.p[k], src_h, src_w, h, w, L0 + (size_t)k * h * w, h1, w1, L1 + (size_t)k * h1 * w1);
 }
 
 // ecc_blur_tile: ecc_blur_down through LDS -- a workgroup stages the source patch of a 64 x 16 output tile (replicate

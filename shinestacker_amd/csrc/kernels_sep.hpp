@@ -1255,7 +1255,7 @@ __device__ __forceinline__ void level_sep_body(const LevelArgs& a) {
             // H2: the tile's N2H x N2W pixels of G_{l+2}, one per lane on the first and the last wave (their quad rows are
             // halo: half idle in P4); G_{l+1} columns through REFLECT101
             constexpr int H2N = N2H * N2W, H2W = (H2N + 1) / 2;
-            static_assert(H2W <= 64, "H2 items");
+            static_assert(H2W <= 64 || MI_SEP_TH != 28, "H2 items");   // (taller-tile study builds never launch the pair kernels)
             const int wv = lt >> 6, wl = lt & 63;
             if ((wv == 0 || wv == NT / 64 - 1) && wl < H2W && (wv == 0 ? wl : H2W + wl) < H2N) {
                 const int item = wv == 0 ? wl : H2W + wl, m = item / N2W, k = item - m * N2W;

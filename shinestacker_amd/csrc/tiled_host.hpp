@@ -240,6 +240,13 @@ int tiled_reset(mi_stack* s) {
 }
 
 int tiled_pending(const mi_stack* s) { return tstate(s) ? tstate(s)->pending : 0; }
+// the side streams of a tiled handle (null for the simple implementation): mi_align_stack_device borrows them as warp lanes
+// while a batch buffer fills -- they are idle then, and the process stays inside its four hardware queues
+void tiled_side_streams(const mi_stack* s, hipStream_t out[2]) {
+    const TiledState* t = tstate(s);
+    out[0] = t && t->st1 != s->stream ? t->st1 : nullptr;
+    out[1] = t && t->st2 != s->stream ? t->st2 : nullptr;
+}
 
 const float* tiled_last_gauss(mi_stack* s, int level) {
     TiledState* t = tstate(s);
