@@ -3,16 +3,17 @@
 //
 // Batch pipeline over three HIP streams (all work of one handle):
 //   st0 = s->stream : level-0 interior kernel of batch k      (the big one)
-//   st1             : level-0 border kernel of batch k, then the border kernels of levels 1..L-1
+//   st1             : level-0 border kernel of batch k, then the border kernels of levels 1..L-1, and the payload passes
+//                     (`st3` below is an alias of st1: a level's payload pass beside the next level's energy pass)
 //   st2             : interior kernels of levels 1..L-1 (joined with st1 after every level) and
 //                     the base features of batch k
 // MI_ARITH_EXACT: batches of 32 frames; level 0 of batch k+1 runs while st2 still works on batch k, so the
 // latency-bound small levels hide behind the level-0 kernel.  MI_ARITH_SEPARABLE: a resident push is ONE batch
 // (up to 256 frames), processed level after level -- many-tile levels as consecutive launches of 16 frames,
-// few-tile levels as parallel frame chunks + merge (launch_level_sep), the payload pass of a level behind it on st2.
+// few-tile levels as parallel frame chunks + merge (launch_level_sep), the payload pass of a level behind it on st1.
 // The per-batch Gaussian images Gb[set][l] are double-buffered (set = k & 1) and allocated on demand; events
 // order producers and consumers.  Selection state is only ever touched by one stream per level (level 0: st0/st1
-// on disjoint pixels; levels >= 1 and base: st2), so stream order alone keeps the first-max semantics.
+// on disjoint pixels; levels >= 1 and base: st2; payload passes: events per level), so stream order keeps the first-max semantics.
 #pragma once
 
 namespace mi {
@@ -759,7 +760,7 @@ int launch_payload_pair_tiles(mi_stack* s, int l, int set, const void* src, size
 // SEP_PAIR_MIN_FRAMES and more.
 //  * float-32, level 0: the kernel is bound by memory AND issue, the times add: 30 MB less per frame against the G_2 reduce it
 //    takes on -- +0.05 ms per launch of 16 frames; level 1's pass 0.33 -> 0.15 ms per launch; the payload recomputation
-//    (1.56 ms per batch at 24 MP) hides behind levels 2+ on its own stream.  Interleaved A/B on three boxes, 256 x 24 MP:
+//    (1.56 ms per batch at 24 MP) hides behind levels 2+ (off the levels' stream).  Interleaved A/B on three boxes, 256 x 24 MP:
 //    +2.5 to +4.5 % (profiles/r06/pair_ab_box*.txt).
 //  * 8- / 16-bit frames, level 0: issue-bound kernels, +0.17 / +0.24 ms per launch -- more than level 1 saves: -3 % / -8 %.
 //  * deeper pairs -- (2, 3) behind (0, 1) for float-32, (1, 2) and (3, 4) for 8- / 16-bit frames -- measured no gain or a
