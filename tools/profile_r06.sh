@@ -8,7 +8,7 @@
 #   5. gpurun_out/traffic.json with provenance (kernel sources' sha256, dtype, frames per launch) -- tools/promote_r06.sh copies it to
 #      profiles/traffic.json, which bench.py reads (tests/test_records.py fails while its sha is not the sources');
 #   6. kernel timelines of the 256-frame step and of rank 0's interleaved 32-frame shard;
-#   7. interleaved A/B of the pair against the level-by-level kernels (fp32 / u8 / u16), config 4 (non-chained, chained).
+#   7. interleaved A/B of the shipped pair plan against the level-by-level kernels (fp32), config 4 (non-chained, chained) + its kernel summary.
 # Everything lands under gpurun_out/; tools/promote_r06.sh (run where the repository is) copies what is kept into profiles/r06/.
 set -u
 cd "$(dirname "$0")/.."
@@ -43,11 +43,13 @@ tools/timeline_run.sh r06
 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/tl_r06_shard -o t -- python tools/shard_step.py 8 256 --trace > gpurun_out/r06/shard_step.txt 2>&1
 python tools/timeline_all.py gpurun_out/tl_r06_shard/t_kernel_trace.csv 4.9 > gpurun_out/tl_r06_shard/timeline.txt
 {
-  echo "# interleaved A/B on ONE box: levels 0 / 1 as a pair (SHINESTACKER_AMD_PAIR_LEVELS=1) against the level-by-level kernels (=2); 256 x 24 MP"
-  for dt in f32 u8 u16; do tools/ab.sh 3 "SHINESTACKER_AMD_PAIR_LEVELS=2" "SHINESTACKER_AMD_PAIR_LEVELS=1" -- --steps 5 --warmup 1 --dtype $dt; done
-} > gpurun_out/r06/pair_ab_$(hostname | tr -c 'a-zA-Z0-9\n' '_').txt 2>&1
+  echo "# interleaved A/B on ONE box: the shipped plan (SHINESTACKER_AMD_PAIR_LEVELS=0: float-32, >= 192 frames: levels 0 / 1 as a pair) against the level-by-level kernels (=2); 256 x 24 MP fp32"
+  tools/ab.sh 3 "SHINESTACKER_AMD_PAIR_LEVELS=2" "SHINESTACKER_AMD_PAIR_LEVELS=0" -- --steps 5 --warmup 1 --dtype f32
+} > gpurun_out/r06/pair_ab_final.txt 2>&1
+rocprofv3 --kernel-trace --output-format csv -d gpurun_out/tl_r06_c4 -o t -- python tools/config4.py --frames 128 --resident --arith separable --reuse-handles > /dev/null 2>&1
+python tools/timeline_all.py gpurun_out/tl_r06_c4/t_kernel_trace.csv 45 --summary > gpurun_out/r06/config4_timeline_summary.txt 2>&1
 python tools/config4.py --frames 128 --resident --arith separable --reuse-handles > gpurun_out/r06/config4_resident_separable.json 2> /dev/null
 python tools/config4.py --frames 128 --resident --arith separable --step-process --reuse-handles > gpurun_out/r06/config4_resident_step_refined.json 2> /dev/null
 python tools/config4.py --frames 128 --resident --arith separable --step-process --chain-serial > gpurun_out/r06/config4_resident_step_serial.json 2> /dev/null
-python bench.py > gpurun_out/r06/bench_default.json 2> gpurun_out/r06/bench_default.err
+python bench.py --traffic-json gpurun_out/traffic.json > gpurun_out/r06/bench_default.json 2> gpurun_out/r06/bench_default.err   # (the file promote_r06.sh copies to profiles/traffic.json)
 for t in r06 r06_nopair r06_u8 r06_u16 r06_exact; do echo "=== $t"; head -45 gpurun_out/prof_$t/summary.txt; done

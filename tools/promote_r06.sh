@@ -13,5 +13,9 @@ cp gpurun_out/calib/FETCH_SIZE/*counter_collection.csv profiles/r06/calib_FETCH_
 cp gpurun_out/calib/WRITE_SIZE/*counter_collection.csv profiles/r06/calib_WRITE_SIZE.csv 2>/dev/null
 cp gpurun_out/tl_r06/timeline.txt profiles/r06/timeline.txt
 cp gpurun_out/tl_r06_shard/timeline.txt profiles/r06/timeline_32_frames_interleaved.txt
-cp gpurun_out/r06/* profiles/r06/ 2>/dev/null
+for f in pair_ab_final.txt config4_resident_separable.json config4_resident_step_refined.json config4_resident_step_serial.json \
+         config4_timeline_summary.txt bench_default.json; do
+  cp gpurun_out/r06/$f profiles/r06/$f
+done
+grep -v "^[EWI][0-9]\{8\}" gpurun_out/r06/shard_step.txt > profiles/r06/shard_step.txt   # (without rocprofv3's own log lines)
 ls profiles/r06
