@@ -26,7 +26,9 @@ lib = L.load()
 bv = (C.c_double * 4)(0, 0, 0, 0)
 cx, cy = (W - 1) / 2, (H - 1) / 2
 for name, (deg, s, tx, ty) in {"shift 3.4/-2.2": (0, 1, 3.4, -2.2), "0.2 deg": (0.2, 1.001, 5, -3), "1.3 deg": (1.3, 1.006, 24, -13),
-                               "5 deg": (5, 1.0, 0, 0), "30 deg": (30, 1.0, 0, 0)}.items():
+                               "5 deg": (5, 1.0, 0, 0), "30 deg": (30, 1.0, 0, 0),
+                               # no tile's source window leaves the frame with one of these two (no per-pixel ring tiles):
+                               "zoom 1.02": (0, 1.02, 0, 0), "zoom 0.98": (0, 0.98, 0, 0)}.items():
     if a.only and a.only not in name:
         continue
     t = np.deg2rad(deg)
