@@ -115,9 +115,11 @@ def cpu_baseline(args, total_frames):
 
     def frame(f):   # generated one at a time, outside the timed sections
         fr = orc.synth_frame_u8(H, W, f, total_frames)
+        if args.dtype == "f32":   # the workload's own type: float-32 frames holding the generator's 8-bit values
+            return fr.astype(np.float32)
         return fr.astype(np.uint16) * 257 if args.dtype == "u16" else fr
     first = frame(0)
-    so = orc.StreamingOracle(H, W, first.dtype, keep_gauss=False, arith=args.arith)
+    so = orc.StreamingOracle(H, W, np.uint8 if first.dtype == np.float32 else first.dtype, keep_gauss=False, arith=args.arith)   # (the result's type)
     dt = 0.0
     for f in range(n):
         fr = first if f == 0 else frame(f)
@@ -129,8 +131,8 @@ def cpu_baseline(args, total_frames):
     dt += time.perf_counter() - t0
     out = {"value": n * H * W / dt / 1e6, "unit": "Mpixels/s", "cores": orc.lib().orc_num_threads(),
            "kind": "port", "cpu_model": cpu_model(), "os_cpu_count": os.cpu_count(),
-           "sample": f"{n} of {total_frames} frames of {W}x{H} (same generator, values as {first.dtype}; the GPU leg "
-                     f"holds the same values as {args.dtype}), oracle.StreamingOracle(arith={args.arith}) push+finish, "
+           "sample": f"{n} of {total_frames} frames of {W}x{H} (same generator, the same values as {first.dtype} frames -- "
+                     f"the GPU leg's type is {args.dtype}), oracle.StreamingOracle(arith={args.arith}) push+finish, "
                      f"OpenMP on {orc.lib().orc_num_threads()} threads, {dt:.1f} s"}
     if args.cpu_refshaped > 0:
         # SURVEY 8(d) leg (i): the reference's own structure (per-channel full-size 25-tap filters, zero-stuffed

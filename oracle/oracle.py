@@ -392,6 +392,8 @@ class StreamingOracle:
             lib().orc_to_f32_u8(src, src.size, g[0])
         elif src.dtype == np.uint16:
             lib().orc_to_f32_u16(src, src.size, g[0])
+        elif src.dtype == np.float32:
+            g = [src] + g[1:]     # float-32 frames are level 0 as they are (read only from here on): no copy
         else:
             g[0][...] = src
         for lv in range(self.levels):
