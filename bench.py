@@ -138,7 +138,10 @@ def cpu_baseline(args, total_frames):
         # SURVEY 8(d) leg (i): the reference's own structure (per-channel full-size 25-tap filters, zero-stuffed
         # expand, every frame's pyramid resident, argmax over the frame axis) on a reduced stack
         m = args.cpu_refshaped
-        frames = [first] + [frame(f) for f in range(1, m)]
+        # (8- / 16-bit frames, as the reference reads them from files: its base rule takes the histogram of the integer image)
+        frames = [orc.synth_frame_u8(H, W, f, total_frames) for f in range(m)]
+        if args.dtype == "u16":
+            frames = [fr.astype(np.uint16) * 257 for fr in frames]
         t0 = time.perf_counter()
         orc.RefShaped().stack(frames)
         dr = time.perf_counter() - t0

@@ -32,3 +32,19 @@ def test_round_profiles_are_tracked():
               "rocprofv3_summary_exact.txt", "kernel_stats.csv", "timeline.txt", "bench_default.json"):
         assert f in have, f
     assert any(f.startswith("pair_ab_") for f in have)
+
+
+def test_cpu_baseline_leg_runs_for_every_input_type():
+    """bench.py's cpu_baseline on a tiny sample (CPU only): the streaming port on the GPU leg's own frame type (float-32 frames are
+    level 0 as they are), the reference-shaped leg on the integer frames the reference reads -- the default line must not
+    die in its side measurements"""
+    import types
+    import bench
+    vals = {}
+    for dt in ("f32", "u8", "u16"):
+        a = types.SimpleNamespace(cpu_frames=3, height=96, width=160, dtype=dt, arith="separable", cpu_refshaped=2)
+        out = bench.cpu_baseline(a, 6)
+        assert out["value"] > 0 and out["kind"] == "port" and out["cores"] >= 1
+        assert out["reference_shaped"]["value"] > 0 and out["reference_shaped"]["frames"] == 2
+        vals[dt] = out
+    assert "float32" in vals["f32"]["sample"] and "uint8" in vals["u8"]["sample"] and "uint16" in vals["u16"]["sample"]
