@@ -1,9 +1,10 @@
-"""GPU: MI_ARITH_SEPARABLE with pyramid levels 0 and 1 run as a PAIR (csrc/kernels_sep.hpp: level_sep_pair hands level 1
-gray(G_1) and G_2, level_sep_e is level 1's energy pass, sep_payload_pair0 / 1 recompute the winners' G_1; the three-channel
-G_1 of the batch never reaches HBM -- reference: the reduce -> expand dependency of algorithms/pyramid.py:27-46, :125-139).
-The pair must give the SAME BITS as the level-by-level kernels, i.e. equal oracle/separable_oracle.c on every tap: the cases
-of tests/test_gpu_separable.py with pair_levels = 1 (forced: small test stacks stay below the automatic threshold), frame
-chunks, batch boundaries, the automatic choice, and the kept-frame tap."""
+"""GPU: MI_ARITH_SEPARABLE with pyramid levels run as PAIRS (csrc/kernels_sep.hpp: the first level's kernel -- level_sep_pair --
+hands the second gray(G_{l+1}) and G_{l+2}, level_sep_e is the second level's energy pass, level_sep_pl / sep_payload_pair0 / 1
+recompute the winners' G_{l+1}; the three-channel G_{l+1} of the batch never reaches HBM -- reference: the reduce -> expand
+dependency of algorithms/pyramid.py:27-46, :125-139).  A pair must give the SAME BITS as the level-by-level kernels, i.e. equal
+oracle/separable_oracle.c on every tap: the cases of tests/test_gpu_separable.py with the pair plans forced (pair_levels = 1:
+(0, 1), (2, 3), ...; 3: (1, 2), (3, 4), ... -- small test stacks stay below the automatic plan's threshold), frame chunks, batch
+boundaries, the automatic choice, the kept-frame tap, and the tile-by-tile payload pass."""
 import numpy as np
 import pytest
 
